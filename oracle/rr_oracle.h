@@ -1,0 +1,116 @@
+/*
+ * rr_oracle.h — CPU ORACLE for the rustradio streaming-DSP hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product (rustradio_amd/, include/rustradio_amd.h) never links, imports or
+ * calls anything in oracle/.
+ *
+ * It is a plain-C restatement (not a copy: the reference is Rust) of the
+ * algorithms in /root/reference/src/{fir,fft_filter,rational_resampler,
+ * quadrature_demod,hilbert,window}.rs, in the reference's operation order,
+ * in IEEE f32 without FMA contraction or reassociation (build flags in
+ * oracle/Makefile).  Every function cites the reference lines it follows.
+ *
+ * Parity pinning (see tests/test_oracle_golden.py, tests/golden/):
+ *   - FIR / tap designers / windows / resampler / quadrature-demod(exact) /
+ *     FftFilter bookkeeping: PINNED against every known-answer test the
+ *     reference holds for this path (transcribed as data in
+ *     tests/golden/reference_known_answers.json).
+ *   - Hilbert: the reference has no unit test; pinned only by reading
+ *     src/hilbert.rs:72-128 and by an f64 cross-check.  "parity unpinned".
+ *   - FFT arithmetic inside FftFilter: the reference delegates to the crate
+ *     rustfft 6.4.1 (Cargo.lock:2299), which is not vendored; this oracle uses
+ *     its own f32 Stockham FFT with f64-computed twiddles (what rustfft does
+ *     for twiddles).  Bit-level FFT parity is "unpinned"; the reference's own
+ *     tests for it (filter_a_signal, tag_propagation) are reproduced.
+ *   - fast-math atan2 (crate fast-math 0.1.1, not vendored): restated from
+ *     its published algorithm; "parity unpinned" beyond the reference's 1e-3
+ *     tests.  The exact libm atan2f path is the parity oracle.
+ */
+#ifndef RR_ORACLE_H
+#define RR_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } orc_c32;
+
+/* Status codes, same numbering as include/rustradio_amd.h (BlockRet,
+ * src/block.rs:12-70). */
+enum { ORC_AGAIN = 0, ORC_WAIT_SRC = 1, ORC_WAIT_DST = 2, ORC_EOF = 3, ORC_PENDING = 4, ORC_ERR = -1 };
+
+/* Window types (src/window.rs:42-60). */
+enum { ORC_WIN_HAMMING = 0, ORC_WIN_BLACKMAN = 1, ORC_WIN_BLACKMAN_HARRIS = 2, ORC_WIN_HAMMING_PARM = 3 };
+
+/* quadrature demod atan2 flavour (src/quadrature_demod.rs:77-109). */
+enum { ORC_ATAN2_EXACT = 0, ORC_ATAN2_FAST = 1 };
+
+/* ---- tap design (setup-time) ------------------------------------------------ */
+float  orc_max_attenuation(int wtype);                                    /* window.rs:67-75 */
+int    orc_make_window(int wtype, float parm, size_t ntaps, float *out);  /* window.rs:79-185 */
+size_t orc_compute_ntaps(float samp_rate, float twidth, int wtype);       /* fir.rs:606-610 */
+/* returns ntaps (writes min(ntaps,cap) taps); fir.rs:617-656 */
+size_t orc_low_pass(float samp_rate, float cutoff, float twidth, int wtype, float parm,
+                    float *out, size_t cap);
+void   orc_hilbert_taps(const float *window, size_t ntaps, float *out);   /* fir.rs:660-680 */
+
+/* ---- single-shot kernels (whole-window, no stream bookkeeping) ---------------- */
+/* Fir::filter_n_inplace, fir.rs:166-197.  taps in caller order (NOT reversed). */
+void orc_fir_c32_n(const orc_c32 *taps, size_t ntaps, size_t deci,
+                   const orc_c32 *in, orc_c32 *out, size_t n_out);
+void orc_fir_f32_n(const float *taps, size_t ntaps, size_t deci,
+                   const float *in, float *out, size_t n_out);
+/* in-place forward/inverse unnormalised FFT (power-of-two n); stands in for rustfft. */
+void orc_fft(orc_c32 *buf, size_t n, int inverse);
+float orc_fast_atan2(float y, float x);
+
+/* ---- streaming blocks: restatement of each Block::work() ---------------------- */
+typedef struct orc_block orc_block;
+
+/* FirFilter<Complex> incl. decimation and frequency translation
+ * (fir.rs:303-386, 415-486, 488-551).  translate=0 disables. */
+orc_block *orc_fir_c32_new(const orc_c32 *taps, size_t ntaps, size_t deci,
+                           int translate, float samp_rate, float freq);
+/* FirFilter<Float> (same generic code path, no translation). */
+orc_block *orc_fir_f32_new(const float *taps, size_t ntaps, size_t deci);
+/* FftFilter<RustFftEngine> (fft_filter.rs:131-181, 210-355). */
+orc_block *orc_fftfilter_new(const orc_c32 *taps, size_t ntaps);
+/* FftFilterFloat (fft_filter.rs:365-491); inner stream capacity = 512,000 Complex. */
+orc_block *orc_fftfilter_float_new(const float *taps, size_t ntaps);
+/* RationalResampler<T> for any Copy T of elem_size bytes (rational_resampler.rs:100-213). */
+orc_block *orc_resampler_new(size_t interp, size_t deci, size_t elem_size);
+/* QuadratureDemod (quadrature_demod.rs:32-114). */
+orc_block *orc_quaddemod_new(float gain, int atan2_mode);
+/* Hilbert (hilbert.rs:22-129). */
+orc_block *orc_hilbert_new(size_t ntaps, int wtype, float parm);
+
+void orc_block_free(orc_block *b);
+
+/* One Block::work() call over the stream windows [in, in+in_len) and
+ * [out, out+out_cap) (element counts, not bytes).  Returns a status; on
+ * ORC_WAIT_* `*need` is the WaitForStream amount.  `*consumed`/`*produced`
+ * are what the block passed to consume()/produce() during this call. */
+int orc_block_work(orc_block *b, const void *in, size_t in_len, void *out, size_t out_cap,
+                   size_t *consumed, size_t *produced, size_t *need);
+
+/* BlockEOF::eof(): all inputs eof (+ resampler: pending empty; rational_resampler.rs:209-213). */
+int orc_block_eof(orc_block *b, int src_eof);
+
+/* Introspection used by tests. */
+size_t orc_block_in_elem_size(const orc_block *b);
+size_t orc_block_out_elem_size(const orc_block *b);
+/* FIR: translated taps + rotator state, for tests (fir.rs:441-461). */
+size_t orc_fir_get_taps(const orc_block *b, orc_c32 *out, size_t cap);
+void   orc_fir_get_rotator(const orc_block *b, orc_c32 *phase, orc_c32 *step, int *enabled);
+/* FftFilter: fft_size and nsamples (fft_filter.rs:261-262). */
+void   orc_fftfilter_dims(const orc_block *b, size_t *fft_size, size_t *nsamples);
+const char *orc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

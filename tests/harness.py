@@ -1,0 +1,112 @@
+"""Shared test harness: a minimal restatement of the reference's stream windows
+and single-threaded Graph loop (src/stream.rs:105,208-217,301-310; src/graph.rs:99-160),
+so the oracle blocks and the HIP blocks are driven through IDENTICAL work()
+call sequences and their (status, consumed, produced, need) can be compared
+exactly and their samples within tolerance."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+AGAIN, WAIT_SRC, WAIT_DST, EOF, PENDING = 0, 1, 2, 3, 4
+DEFAULT_STREAM_SIZE = 4_096_000  # bytes, src/stream.rs:105
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden():
+    with open(os.path.join(GOLDEN_DIR, "reference_known_answers.json")) as f:
+        return json.load(f)
+
+
+def cplx(pairs):
+    a = np.asarray(pairs, np.float64)
+    return (a[:, 0] + 1j * a[:, 1]).astype(np.complex64)
+
+
+def max_norm_err(got, ref, scale=None) -> float:
+    """SURVEY §8d parity metric: max|got-ref| / max|ref| (scale overrides the denominator)."""
+    got = np.asarray(got); ref = np.asarray(ref)
+    assert got.shape == ref.shape, f"length mismatch {got.shape} vs {ref.shape}"
+    if ref.size == 0:
+        return 0.0
+    den = float(np.max(np.abs(ref))) if scale is None else float(scale)
+    if den == 0.0:
+        den = 1.0
+    return float(np.max(np.abs(got.astype(np.complex128) - ref.astype(np.complex128)))) / den
+
+
+class Ring:
+    """A stream as the blocks see it: `buf` = readable window, `free()` = writable window."""
+
+    def __init__(self, dtype, nbytes=DEFAULT_STREAM_SIZE):
+        self.dtype = np.dtype(dtype)
+        self.cap = nbytes // self.dtype.itemsize
+        self.buf = np.zeros(0, self.dtype)
+
+    def free(self):
+        return self.cap - len(self.buf)
+
+    def push(self, a):
+        assert len(a) <= self.free()
+        self.buf = np.concatenate([self.buf, np.asarray(a, self.dtype)])
+
+    def consume(self, n):
+        assert n <= len(self.buf)
+        self.buf = self.buf[n:]
+
+
+def run_chain(blocks, x, stream_bytes=DEFAULT_STREAM_SIZE, log=None, max_rounds=1_000_000):
+    """VectorSource(x) -> blocks... -> VectorSink, scheduled like Graph::run:
+    round-robin, each block's work() once per round, until a full round makes no progress.
+    Returns the concatenated sink contents."""
+    rings = [Ring(blocks[0].in_dtype, stream_bytes)] + [Ring(b.out_dtype, stream_bytes) for b in blocks]
+    x = np.asarray(x, blocks[0].in_dtype)
+    pos = 0
+    sink = []
+    for _ in range(max_rounds):
+        progress = False
+        take = min(rings[0].free(), len(x) - pos)  # VectorSource::work, src/vector_source.rs:101-146
+        if take:
+            rings[0].push(x[pos:pos + take]); pos += take; progress = True
+        for i, b in enumerate(blocks):
+            st, c, p, need, out = b.work(rings[i].buf, rings[i + 1].free())
+            if log is not None:
+                log.append((i, st, c, p, need))
+            rings[i].consume(c)
+            rings[i + 1].push(out)
+            if c or p or st == AGAIN:
+                progress = True
+        if len(rings[-1].buf):
+            sink.append(rings[-1].buf.copy()); rings[-1].consume(len(rings[-1].buf)); progress = True
+        if not progress:
+            break
+    else:
+        raise RuntimeError("run_chain did not terminate")
+    dt = blocks[-1].out_dtype
+    return np.concatenate(sink) if sink else np.zeros(0, dt)
+
+
+def signal_source_complex(samp_rate, freq, amplitude, n, state=None):
+    """SignalSourceComplex iterator (src/signal_source.rs:39-52); test-side source restatement.
+    `state` = [current] carried between calls."""
+    rad = 2.0 * np.pi * float(np.float32(freq)) / float(np.float32(samp_rate))
+    cur = 0.0 if state is None else state[0]
+    out = np.zeros(n, np.complex64)
+    twopi = 2.0 * np.pi
+    for i in range(n):
+        cur = (cur + rad) % twopi
+        out[i] = np.float32(amplitude) * np.complex64(complex(np.float32(np.sin(cur)), np.float32(np.sin(cur - np.pi / 2.0))))
+    if state is not None:
+        state[0] = cur
+    return out
+
+
+def signal_source_complex_fast(samp_rate, freq, amplitude, n):
+    """Vectorised variant for big windows (phase accumulated in f64 without the per-sample
+    fmod; differs from the iterator only by f64 rounding of the phase)."""
+    rad = 2.0 * np.pi * float(np.float32(freq)) / float(np.float32(samp_rate))
+    cur = np.mod(rad * np.arange(1, n + 1, dtype=np.float64), 2.0 * np.pi)
+    return (np.float32(amplitude) * (np.sin(cur).astype(np.float32) + 1j * np.sin(cur - np.pi / 2).astype(np.float32))).astype(np.complex64)
