@@ -1,0 +1,145 @@
+/*
+ * rustradio_amd.h — C ABI of the MI355X-native rustradio hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Each entry point cites the interface of ThomasHabets/rustradio (v0.18.2) it
+ * replaces; INTEGRATION.md shows the Rust `impl Block` shim that binds them.
+ *
+ * One opaque `rr_block` per block instance (the reference's struct fields:
+ * taps, carry state).  A handle is not thread-safe but may move between
+ * threads (`Block: Send`, src/block.rs:115); it owns a HIP stream and its
+ * device buffers, and there is no global mutable state, so N handles can run
+ * on N host threads or N GPUs.
+ *
+ * The library is GPU-only: every entry point that computes fails (NULL /
+ * RR_ERR, message in rr_last_error()) when no HIP device is usable.  There is
+ * no CPU fallback.
+ */
+#ifndef RUSTRADIO_AMD_H
+#define RUSTRADIO_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_ABI_VERSION 1
+
+/* Complex<f32>: interleaved [re, im], 8 bytes (src/lib.rs:268-271). */
+typedef struct { float re, im; } rr_c32;
+
+typedef struct rr_block rr_block;
+
+/* BlockRet (src/block.rs:12-70).  RR_WAIT_SRC / RR_WAIT_DST are
+ * WaitForStream(&self.src, need) / WaitForStream(&self.dst, need). */
+enum rr_status {
+    RR_AGAIN = 0,
+    RR_WAIT_SRC = 1,
+    RR_WAIT_DST = 2,
+    RR_EOF = 3,
+    RR_PENDING = 4,
+    RR_ERR = -1
+};
+
+/* WindowType (src/window.rs:42-60). */
+enum rr_window { RR_WIN_HAMMING = 0, RR_WIN_BLACKMAN = 1, RR_WIN_BLACKMAN_HARRIS = 2, RR_WIN_HAMMING_PARM = 3 };
+
+/* QuadratureDemod atan2 flavour: RR_ATAN2_EXACT = `f32::atan2`
+ * (--no-default-features build, src/quadrature_demod.rs:96-109);
+ * RR_ATAN2_FAST = `fast_math::atan2` (default Cargo feature, :77-81). */
+enum rr_atan2 { RR_ATAN2_EXACT = 0, RR_ATAN2_FAST = 1 };
+
+/* Rotator evaluation for FirFilter::translate (src/fir.rs:464-473):
+ * RR_ROT_MODEL  = closed form phase0 * step^m evaluated in f64 from the SAME
+ *                 f32-rounded phase0/step the reference uses (parallel, default);
+ * RR_ROT_REPLAY = bit-faithful replay of the reference's sequential f32
+ *                 recurrence on the host (slow; for parity over long streams). */
+enum rr_rotator { RR_ROT_MODEL = 0, RR_ROT_REPLAY = 1 };
+
+/* ---- library / device ------------------------------------------------------ */
+int         rr_abi_version(void);
+const char *rr_last_error(void);            /* thread-local message of the last failure */
+int         rr_device_count(void);          /* number of visible HIP devices (0 if none) */
+int         rr_set_device(int ordinal);     /* device used by blocks created afterwards on this thread */
+
+/* ---- tap designers (setup time; host f32, same operation order as the reference) */
+float  rr_max_attenuation(int window);                                   /* src/window.rs:67-75 */
+int    rr_make_window(int window, float parm, size_t ntaps, float *out); /* src/window.rs:79-185 */
+size_t rr_compute_ntaps(float samp_rate, float twidth, int window);      /* src/fir.rs:606-610 */
+/* low_pass (src/fir.rs:617-656): returns ntaps, writes min(ntaps, cap) taps; 0 on bad args. */
+size_t rr_low_pass(float samp_rate, float cutoff, float twidth, int window, float parm,
+                   float *out, size_t cap);
+/* low_pass_complex (src/fir.rs:594-604). */
+size_t rr_low_pass_complex(float samp_rate, float cutoff, float twidth, int window, float parm,
+                           rr_c32 *out, size_t cap);
+/* hilbert(window) (src/fir.rs:660-680). */
+int    rr_hilbert_taps(const float *window, size_t ntaps, float *out);
+
+/* ---- block constructors ------------------------------------------------------ */
+/* FirFilter::<Complex>::builder(taps).deci(deci)[.translate(samp_rate, freq)].build(src)
+ * (src/fir.rs:303-386, 476-486).  translate != 0 requests frequency translation
+ * (freq == 0 disables it, fir.rs:438-440).  NULL on invalid args (the reference asserts). */
+rr_block *rr_fir_c32_create(const rr_c32 *taps, size_t ntaps, size_t deci,
+                            int translate, float samp_rate, float freq);
+/* FirFilter::<Float> (same generic block, src/fir.rs:343-386). */
+rr_block *rr_fir_f32_create(const float *taps, size_t ntaps, size_t deci);
+/* FftFilter::new(src, taps) (src/fft_filter.rs:242-279). */
+rr_block *rr_fftfilter_create(const rr_c32 *taps, size_t ntaps);
+/* FftFilterFloat::new(src, taps) (src/fft_filter.rs:391-426). */
+rr_block *rr_fftfilter_float_create(const float *taps, size_t ntaps);
+/* RationalResampler::<T>::new(src, interp, deci) for any Copy T of elem_size
+ * bytes, elem_size in {1,2,4,8,16} (src/rational_resampler.rs:125-151).
+ * NULL (reference: Err) when interp or deci is 0. */
+rr_block *rr_resampler_create(size_t interp, size_t deci, size_t elem_size);
+/* QuadratureDemod::new(src, gain) (src/quadrature_demod.rs:32-43). */
+rr_block *rr_quaddemod_create(float gain, int atan2_mode);
+/* Hilbert::new(src, ntaps, &window_type) (src/hilbert.rs:38-61); ntaps odd > 1. */
+rr_block *rr_hilbert_create(size_t ntaps, int window, float window_parm);
+
+void rr_block_destroy(rr_block *b);
+
+/* ---- Block trait -------------------------------------------------------------- */
+/* Block::work() (src/block.rs:115-126) over the stream windows the Rust shim
+ * obtained from `self.src.read_buf()` / `self.dst.write_buf()`
+ * (src/stream.rs:208-217, 301-310): `in`/`out` are HOST pointers to contiguous
+ * windows of in_len / out_cap ELEMENTS.  The block copies the window to the
+ * GPU, runs its HIP kernels and copies the produced samples back before
+ * returning.  `*consumed` / `*produced` are what the shim must pass to
+ * `consume()` / `produce()`; on RR_WAIT_* `*need` is the WaitForStream amount.
+ * Thresholds and return codes follow each block's reference `work()` exactly
+ * (src/fir.rs:492-550, src/fft_filter.rs:290-354,
+ * src/rational_resampler.rs:155-206, src/quadrature_demod.rs:46-113,
+ * src/hilbert.rs:72-128). */
+int rr_block_work(rr_block *b, const void *in, size_t in_len, void *out, size_t out_cap,
+                  size_t *consumed, size_t *produced, size_t *need);
+
+/* Same contract with DEVICE pointers (device-resident streams between GPU
+ * blocks: no PCIe hop).  Kernels are enqueued on `hip_stream` (a hipStream_t,
+ * NULL = the block's own stream) and the call returns without waiting;
+ * counts are final on return (they depend on lengths only). */
+int rr_block_work_dev(rr_block *b, const void *d_in, size_t in_len, void *d_out, size_t out_cap,
+                      size_t *consumed, size_t *produced, size_t *need, void *hip_stream);
+
+/* BlockEOF::eof() (src/block.rs:103-110): `src_eof` = all input streams are at
+ * EOF; the resampler additionally requires no pending sample
+ * (src/rational_resampler.rs:209-213). */
+int         rr_block_eof(rr_block *b, int src_eof);
+/* BlockName::block_name() (src/block.rs:91-97). */
+const char *rr_block_name(const rr_block *b);
+size_t      rr_block_in_elem_size(const rr_block *b);
+size_t      rr_block_out_elem_size(const rr_block *b);
+/* Wait for everything the block enqueued on its own stream. */
+int         rr_block_sync(rr_block *b);
+
+/* ---- per-block knobs / introspection ------------------------------------------- */
+/* FftFilter: reference fft_size and nsamples (src/fft_filter.rs:261-262) and the
+ * internal overlap-save tile the GPU kernel uses. */
+int rr_fftfilter_dims(const rr_block *b, size_t *fft_size, size_t *nsamples, size_t *gpu_fft_size);
+/* FirFilter translate: rotator mode (default RR_ROT_MODEL). */
+int rr_fir_set_rotator_mode(rr_block *b, int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTRADIO_AMD_H */

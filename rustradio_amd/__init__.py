@@ -1,0 +1,187 @@
+"""rustradio_amd — MI355X-native implementation of rustradio's streaming-DSP hot path.
+
+Host-side mirror (Python, over the C ABI of include/rustradio_amd.h) of the reference's
+block interface for this path: the constructors take what `X::new(src, ...)` / the
+builders take (minus the stream, which the caller owns), and `work()` is
+`Block::work()` over explicit stream windows, returning the BlockRet variant plus
+what the reference would pass to `consume()`/`produce()`.
+
+    FirFilter            src/fir.rs:303-551      (builder: taps, .deci(), .translate())
+    FftFilter            src/fft_filter.rs:210-355
+    FftFilterFloat       src/fft_filter.rs:365-491
+    RationalResampler    src/rational_resampler.rs:100-213
+    QuadratureDemod      src/quadrature_demod.rs:32-114
+    Hilbert              src/hilbert.rs:22-129
+    low_pass / low_pass_complex / hilbert_taps / make_window   src/fir.rs:594-680, src/window.rs
+
+All sample arithmetic runs in HIP kernels on the GPU; nothing here computes samples.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, last_error, LIB_PATH  # noqa: F401
+
+# BlockRet (src/block.rs:12-70)
+AGAIN, WAIT_SRC, WAIT_DST, EOF, PENDING, ERR = 0, 1, 2, 3, 4, -1
+# WindowType (src/window.rs:42-60)
+WIN_HAMMING, WIN_BLACKMAN, WIN_BLACKMAN_HARRIS, WIN_HAMMING_PARM = 0, 1, 2, 3
+ATAN2_EXACT, ATAN2_FAST = 0, 1
+ROT_MODEL, ROT_REPLAY = 0, 1
+DEFAULT_STREAM_SIZE = 4_096_000  # bytes, src/stream.rs:105
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    return lib().rr_device_count()
+
+
+def set_device(ordinal: int) -> None:
+    if lib().rr_set_device(ordinal) != 0:
+        raise ValueError(last_error())
+
+
+# ---- tap designers --------------------------------------------------------------------
+def make_window(wtype: int, ntaps: int, parm: float = 0.0) -> np.ndarray:
+    out = np.zeros(ntaps, np.float32)
+    if lib().rr_make_window(wtype, parm, ntaps, _ptr(out)) != 0:
+        raise ValueError(last_error())
+    return out
+
+
+def compute_ntaps(samp_rate, twidth, wtype=WIN_HAMMING) -> int:
+    return lib().rr_compute_ntaps(samp_rate, twidth, wtype)
+
+
+def low_pass(samp_rate, cutoff, twidth, wtype=WIN_HAMMING, parm=0.0) -> np.ndarray:
+    n = lib().rr_low_pass(samp_rate, cutoff, twidth, wtype, parm, None, 0)
+    if n == 0:
+        raise ValueError(last_error())
+    out = np.zeros(n, np.float32)
+    lib().rr_low_pass(samp_rate, cutoff, twidth, wtype, parm, _ptr(out), n)
+    return out
+
+
+def low_pass_complex(samp_rate, cutoff, twidth, wtype=WIN_HAMMING, parm=0.0) -> np.ndarray:
+    n = lib().rr_low_pass_complex(samp_rate, cutoff, twidth, wtype, parm, None, 0)
+    if n == 0:
+        raise ValueError(last_error())
+    out = np.zeros(n, np.complex64)
+    lib().rr_low_pass_complex(samp_rate, cutoff, twidth, wtype, parm, _ptr(out), n)
+    return out
+
+
+def hilbert_taps(window: np.ndarray) -> np.ndarray:
+    w = np.ascontiguousarray(window, np.float32)
+    out = np.zeros(len(w), np.float32)
+    if lib().rr_hilbert_taps(_ptr(w), len(w), _ptr(out)) != 0:
+        raise ValueError(last_error())
+    return out
+
+
+# ---- blocks ---------------------------------------------------------------------------
+class Block:
+    """One block instance (an opaque `rr_block`)."""
+
+    def __init__(self, handle, in_dtype, out_dtype):
+        if not handle:
+            raise ValueError(last_error())
+        self._h = handle
+        self.in_dtype = np.dtype(in_dtype)
+        self.out_dtype = np.dtype(out_dtype)
+        assert lib().rr_block_in_elem_size(handle) == self.in_dtype.itemsize
+        assert lib().rr_block_out_elem_size(handle) == self.out_dtype.itemsize
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().rr_block_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def name(self) -> str:
+        """BlockName::block_name (src/block.rs:91-97)."""
+        return lib().rr_block_name(self._h).decode()
+
+    def work(self, inp: np.ndarray, out_cap: int):
+        """Block::work() over host windows -> (status, consumed, produced, need, out[:produced])."""
+        inp = np.ascontiguousarray(inp, self.in_dtype)
+        out = np.zeros(max(out_cap, 1), self.out_dtype)
+        c, p, n = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        st = lib().rr_block_work(self._h, _ptr(inp), len(inp), _ptr(out), out_cap,
+                                 C.byref(c), C.byref(p), C.byref(n))
+        if st == ERR:
+            raise RuntimeError(last_error())
+        return st, c.value, p.value, n.value, out[:p.value]
+
+    def work_dev(self, d_in: int, in_len: int, d_out: int, out_cap: int, stream: int = 0):
+        """Block::work() over DEVICE windows (raw device pointers, e.g. tensor.data_ptr());
+        asynchronous on `stream` (0 = the block's own) -> (status, consumed, produced, need)."""
+        c, p, n = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        st = lib().rr_block_work_dev(self._h, C.c_void_p(d_in), in_len, C.c_void_p(d_out), out_cap,
+                                     C.byref(c), C.byref(p), C.byref(n), C.c_void_p(stream))
+        if st == ERR:
+            raise RuntimeError(last_error())
+        return st, c.value, p.value, n.value
+
+    def eof(self, src_eof: bool) -> bool:
+        """BlockEOF::eof (src/block.rs:103-110)."""
+        return bool(lib().rr_block_eof(self._h, int(src_eof)))
+
+    def sync(self) -> None:
+        if lib().rr_block_sync(self._h) != 0:
+            raise RuntimeError(last_error())
+
+
+def FirFilter(taps, deci: int = 1, translate=None, rotator: int = ROT_MODEL) -> Block:
+    """FirFilter::builder(taps).deci(deci).translate(samp_rate, freq).build(src)."""
+    if np.iscomplexobj(np.asarray(taps)):
+        t = np.ascontiguousarray(taps, np.complex64)
+        fs, f = translate if translate is not None else (0.0, 0.0)
+        h = lib().rr_fir_c32_create(_ptr(t), len(t), deci, 1 if translate is not None else 0, fs, f)
+        b = Block(h, np.complex64, np.complex64)
+        if translate is not None and lib().rr_fir_set_rotator_mode(b._h, rotator) != 0:
+            raise ValueError(last_error())
+        return b
+    if translate is not None:
+        raise ValueError("FirFilter asked to translate on non-Complex")  # fir.rs:401
+    t = np.ascontiguousarray(taps, np.float32)
+    return Block(lib().rr_fir_f32_create(_ptr(t), len(t), deci), np.float32, np.float32)
+
+
+def FftFilter(taps) -> Block:
+    t = np.ascontiguousarray(taps, np.complex64)
+    return Block(lib().rr_fftfilter_create(_ptr(t), len(t)), np.complex64, np.complex64)
+
+
+def FftFilterFloat(taps) -> Block:
+    t = np.ascontiguousarray(taps, np.float32)
+    return Block(lib().rr_fftfilter_float_create(_ptr(t), len(t)), np.float32, np.float32)
+
+
+def fftfilter_dims(block: Block):
+    """-> (reference fft_size, reference nsamples, GPU tile size)."""
+    a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    if lib().rr_fftfilter_dims(block._h, C.byref(a), C.byref(b), C.byref(c)) != 0:
+        raise ValueError(last_error())
+    return a.value, b.value, c.value
+
+
+def RationalResampler(interp: int, deci: int, dtype=np.complex64) -> Block:
+    dt = np.dtype(dtype)
+    return Block(lib().rr_resampler_create(interp, deci, dt.itemsize), dt, dt)
+
+
+def QuadratureDemod(gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
+    return Block(lib().rr_quaddemod_create(gain, mode), np.complex64, np.float32)
+
+
+def Hilbert(ntaps: int, wtype: int = WIN_HAMMING, parm: float = 0.0) -> Block:
+    return Block(lib().rr_hilbert_create(ntaps, wtype, parm), np.float32, np.complex64)

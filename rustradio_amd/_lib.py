@@ -1,0 +1,70 @@
+"""Loader of librustradio_amd.so (the C ABI in include/rustradio_amd.h).
+
+The library is the product; this module only binds it.  Import fails loudly when
+the shared object is missing — there is no Python or CPU fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librustradio_amd.so")
+
+# every symbol include/rustradio_amd.h declares (checked by tests/test_abi_symbols.py)
+SYMBOLS = [
+    "rr_abi_version", "rr_last_error", "rr_device_count", "rr_set_device",
+    "rr_max_attenuation", "rr_make_window", "rr_compute_ntaps", "rr_low_pass", "rr_low_pass_complex",
+    "rr_hilbert_taps",
+    "rr_fir_c32_create", "rr_fir_f32_create", "rr_fftfilter_create", "rr_fftfilter_float_create",
+    "rr_resampler_create", "rr_quaddemod_create", "rr_hilbert_create", "rr_block_destroy",
+    "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_in_elem_size",
+    "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_set_rotator_mode",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C rustradio_amd/csrc` (hipcc --offload-arch=gfx950). rustradio_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    sz, f32, vp, i32 = C.c_size_t, C.c_float, C.c_void_p, C.c_int
+    psz = C.POINTER(sz)
+    L.rr_abi_version.restype = i32
+    L.rr_last_error.restype = C.c_char_p
+    L.rr_device_count.restype = i32
+    L.rr_set_device.argtypes = [i32]; L.rr_set_device.restype = i32
+    L.rr_max_attenuation.argtypes = [i32]; L.rr_max_attenuation.restype = f32
+    L.rr_make_window.argtypes = [i32, f32, sz, vp]; L.rr_make_window.restype = i32
+    L.rr_compute_ntaps.argtypes = [f32, f32, i32]; L.rr_compute_ntaps.restype = sz
+    L.rr_low_pass.argtypes = [f32, f32, f32, i32, f32, vp, sz]; L.rr_low_pass.restype = sz
+    L.rr_low_pass_complex.argtypes = [f32, f32, f32, i32, f32, vp, sz]; L.rr_low_pass_complex.restype = sz
+    L.rr_hilbert_taps.argtypes = [vp, sz, vp]; L.rr_hilbert_taps.restype = i32
+    L.rr_fir_c32_create.argtypes = [vp, sz, sz, i32, f32, f32]; L.rr_fir_c32_create.restype = vp
+    L.rr_fir_f32_create.argtypes = [vp, sz, sz]; L.rr_fir_f32_create.restype = vp
+    L.rr_fftfilter_create.argtypes = [vp, sz]; L.rr_fftfilter_create.restype = vp
+    L.rr_fftfilter_float_create.argtypes = [vp, sz]; L.rr_fftfilter_float_create.restype = vp
+    L.rr_resampler_create.argtypes = [sz, sz, sz]; L.rr_resampler_create.restype = vp
+    L.rr_quaddemod_create.argtypes = [f32, i32]; L.rr_quaddemod_create.restype = vp
+    L.rr_hilbert_create.argtypes = [sz, i32, f32]; L.rr_hilbert_create.restype = vp
+    L.rr_block_destroy.argtypes = [vp]; L.rr_block_destroy.restype = None
+    L.rr_block_work.argtypes = [vp, vp, sz, vp, sz, psz, psz, psz]; L.rr_block_work.restype = i32
+    L.rr_block_work_dev.argtypes = [vp, vp, sz, vp, sz, psz, psz, psz, vp]; L.rr_block_work_dev.restype = i32
+    L.rr_block_eof.argtypes = [vp, i32]; L.rr_block_eof.restype = i32
+    L.rr_block_name.argtypes = [vp]; L.rr_block_name.restype = C.c_char_p
+    L.rr_block_in_elem_size.argtypes = [vp]; L.rr_block_in_elem_size.restype = sz
+    L.rr_block_out_elem_size.argtypes = [vp]; L.rr_block_out_elem_size.restype = sz
+    L.rr_block_sync.argtypes = [vp]; L.rr_block_sync.restype = i32
+    L.rr_fftfilter_dims.argtypes = [vp, psz, psz, psz]; L.rr_fftfilter_dims.restype = i32
+    L.rr_fir_set_rotator_mode.argtypes = [vp, i32]; L.rr_fir_set_rotator_mode.restype = i32
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().rr_last_error().decode()

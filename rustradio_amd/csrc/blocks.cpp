@@ -1,0 +1,446 @@
+// blocks.cpp — host side of each block: the reference's work() bookkeeping (thresholds,
+// consumed/produced, WaitForStream amounts, carry state) restated over explicit windows,
+// with the sample arithmetic handed to the HIP kernels.  Citations are to
+// /root/reference/src.  There is no CPU compute path here: every branch that produces
+// samples launches a kernel.
+#include "blocks.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+
+#include "taps.hpp"
+
+namespace rr {
+
+static thread_local int g_device = 0;
+void set_thread_device(int d) { g_device = d; }
+int thread_device() { return g_device; }
+
+// ---- Block base ---------------------------------------------------------------------------
+Block::Block(const char* nm, size_t ies, size_t oes) : name(nm), in_es(ies), out_es(oes) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        throw Error("rustradio_amd: no usable HIP device (this library has no CPU fallback)");
+    if (g_device < 0 || g_device >= n) throw Error("rustradio_amd: device ordinal out of range");
+    device = g_device;
+    RR_HIP(hipSetDevice(device));
+    RR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+}
+Block::~Block() {
+    if (stream) {
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(stream);
+        (void)hipStreamDestroy(stream);
+    }
+}
+void Block::sync() {
+    RR_HIP(hipSetDevice(device));
+    RR_HIP(hipStreamSynchronize(stream));
+}
+bool Block::eof(bool src_eof) { return src_eof; }   // rustradio_macros_code/src/lib.rs:596-623
+
+// Host-window work(): stage the windows through device memory around work_dev().
+int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                     size_t* produced, size_t* need) {
+    RR_HIP(hipSetDevice(device));
+    const size_t in_use = std::min(in_len, host_in_limit(in_len, out_cap));
+    st_in.reserve(std::max<size_t>(in_use * in_es, 16));
+    st_out.reserve(std::max<size_t>(out_cap * out_es, 16));
+    if (in_use) RR_HIP(hipMemcpyAsync(st_in.p, in, in_use * in_es, hipMemcpyHostToDevice, stream));
+    int st = work_dev(st_in.p, in_use, st_out.p, out_cap, consumed, produced, need, stream);
+    if (*produced) RR_HIP(hipMemcpyAsync(out, st_out.p, *produced * out_es, hipMemcpyDeviceToHost, stream));
+    RR_HIP(hipStreamSynchronize(stream));
+    return st;
+}
+
+// ---- FirFilter<T> (fir.rs:303-551) -----------------------------------------------------------
+template <class TapT> static void build_poly(const std::vector<TapT>& rev, int d, int& qpad, std::vector<TapT>& tp) {
+    const int L = (int)rev.size();
+    const int qmax = (L + d - 1) / d;
+    qpad = (qmax + 7) / 8 * 8;
+    tp.assign((size_t)d * qpad, TapT{});
+    for (int k = 0; k < L; k++) tp[(size_t)(k % d) * qpad + k / d] = rev[k];
+}
+
+FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq)
+    : Block("FirFilter<Complex>", 8, 8) {
+    if (ntaps == 0) throw Error("FirFilter: empty taps");            // fir.rs:372
+    if (deci == 0) throw Error("FirFilter: decimation 0");           // fir.rs:319
+    if (ntaps > 0x3fffffff || deci > 0x3fffffff) throw Error("FirFilter: taps/deci too large");
+    std::vector<std::complex<float>> t(ntaps);
+    for (size_t i = 0; i < ntaps; i++) t[i] = {taps[i].re, taps[i].im};
+    if (translate) {                                                 // fir.rs:430-462
+        if (!(samp_rate > 0.0f)) throw Error("FirFilter::translate: samp_rate must be > 0");
+        if (freq != 0.0f) {
+            const double input_step = 2.0 * 3.14159265358979323846 * (double)freq / (double)samp_rate;
+            const float sr = (float)std::cos(input_step), si = (float)std::sin(input_step);
+            float pr = 1.0f, pi = 0.0f;
+            for (size_t k = 0; k < ntaps; k++) {                      // f32 recurrence, num-complex order
+                const float ar = t[k].real(), ai = t[k].imag();
+                t[k] = {ar * pr - ai * pi, ar * pi + ai * pr};
+                const float nr = pr * sr - pi * si, ni = pr * si + pi * sr;
+                pr = nr; pi = ni;
+            }
+            const double first = -input_step * (double)(ntaps - 1);
+            const double ostep = -input_step * (double)deci;
+            rot_on = true;
+            ph0x = (float)std::cos(first); ph0y = (float)std::sin(first);
+            stx = (float)std::cos(ostep); sty = (float)std::sin(ostep);
+            cur_x = ph0x; cur_y = ph0y;
+        }
+    }
+    pl.L = (int)ntaps; pl.d = (int)deci;
+    bool real_taps = true;
+    for (auto& c : t) if (c.imag() != 0.0f) real_taps = false;
+    pl.complex_taps = !real_taps;
+    if (real_taps) {   // Complex::new(t, 0) taps: 2 FMA per tap instead of 4
+        std::vector<float> rev(ntaps), tp;
+        for (size_t j = 0; j < ntaps; j++) rev[j] = t[ntaps - 1 - j].real();   // fir.rs:160
+        build_poly(rev, pl.d, pl.qpad, tp);
+        d_rev.upload(reinterpret_cast<unsigned char*>(rev.data()), rev.size() * 4, stream);
+        d_tp.upload(reinterpret_cast<unsigned char*>(tp.data()), tp.size() * 4, stream);
+    } else {
+        std::vector<cf> rev(ntaps), tp;
+        for (size_t j = 0; j < ntaps; j++) rev[j] = mk(t[ntaps - 1 - j].real(), t[ntaps - 1 - j].imag());
+        build_poly(rev, pl.d, pl.qpad, tp);
+        d_rev.upload(reinterpret_cast<unsigned char*>(rev.data()), rev.size() * 8, stream);
+        d_tp.upload(reinterpret_cast<unsigned char*>(tp.data()), tp.size() * 8, stream);
+    }
+    RR_HIP(hipStreamSynchronize(stream));
+}
+
+size_t FirC32::host_in_limit(size_t in_len, size_t out_cap) const {
+    // only n + ntaps - 1 samples are read (fir.rs:507)
+    const size_t L = pl.L, d = pl.d;
+    if (in_len < L + d - 1 || out_cap == 0) return 0;
+    size_t n = d * ((in_len - L + 1) / d);
+    n = std::min(n, out_cap * d);
+    return n + L - 1;
+}
+
+int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                     size_t* produced, size_t* need, hipStream_t s) {
+    const size_t L = pl.L, d = pl.d;
+    *consumed = *produced = *need = 0;
+    const size_t absolute_minimum = L + d - 1;                       // fir.rs:498-501
+    if (in_len < absolute_minimum) { *need = absolute_minimum; return RR_WAIT_SRC; }
+    size_t n = d * ((in_len - L + 1) / d);                           // fir.rs:502
+    if (out_cap < 1) { *need = 1; return RR_WAIT_DST; }              // fir.rs:511-515
+    n = std::min(n, out_cap * d);                                    // fir.rs:518
+    const size_t out_n = n / d;
+    VSrc<cf> src{nullptr, 0, static_cast<const cf*>(in), (long)in_len};
+    launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
+    if (rot_on) {                                                    // fir.rs:531, 464-473
+        if (rot_mode == RR_ROT_REPLAY) {
+            h_tab.resize(out_n);
+            for (size_t i = 0; i < out_n; i++) {                     // the reference's f32 recurrence
+                h_tab[i] = mk(cur_x, cur_y);
+                const float nx = cur_x * stx - cur_y * sty, ny = cur_x * sty + cur_y * stx;
+                cur_x = nx; cur_y = ny;
+            }
+            d_tab.reserve(out_n * sizeof(cf));
+            RR_HIP(hipMemcpyAsync(d_tab.p, h_tab.data(), out_n * sizeof(cf), hipMemcpyHostToDevice, s));
+            launch_rotate_table(static_cast<cf*>(out), (long)out_n, reinterpret_cast<const cf*>(d_tab.p), s);
+            RR_HIP(hipStreamSynchronize(s));                         // h_tab is reused by the next call
+        } else {
+            launch_rotate_model(static_cast<cf*>(out), (long)out_n, ph0x, ph0y, stx, sty, (long)n_rot, s);
+        }
+        n_rot += out_n;
+    }
+    *consumed = n; *produced = out_n;
+    return RR_AGAIN;                                                 // fir.rs:549
+}
+
+FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<Float>", 4, 4) {
+    if (ntaps == 0) throw Error("FirFilter: empty taps");
+    if (deci == 0) throw Error("FirFilter: decimation 0");
+    if (ntaps > 0x3fffffff || deci > 0x3fffffff) throw Error("FirFilter: taps/deci too large");
+    pl.L = (int)ntaps; pl.d = (int)deci; pl.complex_taps = false;
+    std::vector<float> rev(ntaps), tp;
+    for (size_t j = 0; j < ntaps; j++) rev[j] = taps[ntaps - 1 - j];
+    build_poly(rev, pl.d, pl.qpad, tp);
+    d_rev.upload(rev.data(), rev.size(), stream);
+    d_tp.upload(tp.data(), tp.size(), stream);
+    RR_HIP(hipStreamSynchronize(stream));
+}
+size_t FirF32::host_in_limit(size_t in_len, size_t out_cap) const {
+    const size_t L = pl.L, d = pl.d;
+    if (in_len < L + d - 1 || out_cap == 0) return 0;
+    size_t n = d * ((in_len - L + 1) / d);
+    n = std::min(n, out_cap * d);
+    return n + L - 1;
+}
+int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                     size_t* produced, size_t* need, hipStream_t s) {
+    const size_t L = pl.L, d = pl.d;
+    *consumed = *produced = *need = 0;
+    if (in_len < L + d - 1) { *need = L + d - 1; return RR_WAIT_SRC; }
+    size_t n = d * ((in_len - L + 1) / d);
+    if (out_cap < 1) { *need = 1; return RR_WAIT_DST; }
+    n = std::min(n, out_cap * d);
+    VSrc<float> src{nullptr, 0, static_cast<const float*>(in), (long)in_len};
+    launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
+    *consumed = n; *produced = n / d;
+    return RR_AGAIN;
+}
+
+// ---- FftFilter (fft_filter.rs:131-181, 210-355) --------------------------------------------------
+static size_t calc_fft_size(size_t from) {   // fft_filter.rs:36-42
+    size_t n = 1;
+    while (n < from) n <<= 1;
+    return 2 * n;
+}
+
+// Host f64 radix-2 FFT for the one-time taps transform (setup only).
+static void fft64(std::vector<std::complex<double>>& a) {
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; k++) {
+                const std::complex<double> w = std::polar(1.0, -2.0 * 3.14159265358979323846 * (double)k / (double)len);
+                const auto u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+template <int LOG2F> static void fill_hpos(const std::vector<std::complex<double>>& H, std::vector<cf>& hpos) {
+    const int F = 1 << LOG2F;
+    hpos.resize(F);
+    for (int p = 0; p < F; p++) {
+        const auto h = H[bin_of_pos<LOG2F>(p)];
+        hpos[p] = mk((float)h.real(), (float)h.imag());
+    }
+}
+
+FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8) {
+    if (ntaps == 0) throw Error("FftFilter: empty taps");            // fft_filter.rs:146
+    L = ntaps;
+    fft_size = calc_fft_size(ntaps);                                  // fft_filter.rs:261
+    nsamples = fft_size - ntaps;                                      // fft_filter.rs:262
+    // GPU tile: overlap-save, F >= 1024 and at least the reference's fft_size so that at
+    // least ~half of every tile is new output (S' = F - L + 1).
+    log2f = 10;
+    while (((size_t)1 << log2f) < fft_size) log2f++;
+    if (!fftfilt_supported(log2f))
+        throw Error("FftFilter: more than 8192 taps is not supported by the LDS-resident tile kernel");
+    const size_t F = (size_t)1 << log2f;
+    // H = FFT(taps || 0) / F (fft_filter.rs:151-162), computed in f64 and rounded once
+    std::vector<std::complex<double>> H(F, 0.0);
+    for (size_t i = 0; i < ntaps; i++) H[i] = {taps[i].re, taps[i].im};
+    fft64(H);
+    for (auto& h : H) h /= (double)F;
+    std::vector<cf> hpos, tw(F);
+    switch (log2f) {
+    case 10: fill_hpos<10>(H, hpos); break;
+    case 11: fill_hpos<11>(H, hpos); break;
+    case 12: fill_hpos<12>(H, hpos); break;
+    case 13: fill_hpos<13>(H, hpos); break;
+    default: fill_hpos<14>(H, hpos); break;
+    }
+    for (size_t k = 0; k < F; k++) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)F;
+        tw[k] = mk((float)std::cos(a), (float)std::sin(a));
+    }
+    d_hpos.upload(hpos.data(), F, stream);
+    d_tw.upload(tw.data(), F, stream);
+    // prefix = [L-1 history samples][pending < nsamples]; zero history at stream start (A.4)
+    const size_t pcap = (L - 1) + nsamples + 1;
+    for (auto& p : prefix) {
+        p.reserve(pcap);
+        RR_HIP(hipMemsetAsync(p.p, 0, pcap * sizeof(cf), stream));
+    }
+    RR_HIP(hipStreamSynchronize(stream));
+}
+
+int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                        size_t* produced, size_t* need, hipStream_t s) {
+    *consumed = *produced = *need = 0;
+    const size_t S = nsamples;
+    if (S > out_cap) { *need = S; return RR_WAIT_DST; }               // fft_filter.rs:294-303
+    const size_t total = pend_len + in_len;
+    const size_t k_in = total / S, k_out = out_cap / S;
+    size_t k, new_pend;
+    int st;
+    if (k_in >= k_out) {               // output space runs out first: the loop stops before reading more
+        k = k_out; *consumed = k * S - pend_len; new_pend = 0;
+        st = RR_WAIT_DST; *need = S;
+    } else {                           // input runs out: everything is taken into `buf` (:306-314)
+        k = k_in; *consumed = in_len; new_pend = total - k * S;
+        st = RR_WAIT_SRC; *need = S - new_pend;                        // :323-326
+    }
+    const size_t n_out = k * S;
+    const long plen = (long)(L - 1 + pend_len);
+    VSrc<cf> src{prefix[cur].p, plen, static_cast<const cf*>(in), (long)in_len};
+    if (k) launch_fftfilt_os(log2f, src, static_cast<cf*>(out), (long)n_out, (int)L, d_tw.p, d_hpos.p, s);
+    if (*consumed) {
+        // new carry = last L-1 samples before the first unprocessed one, then the unprocessed tail
+        launch_vcopy_c32(src, (long)n_out, prefix[cur ^ 1].p, (long)(L - 1 + new_pend), s);
+        cur ^= 1;
+        pend_len = new_pend;
+    }
+    *produced = n_out;
+    return st;
+}
+
+// ---- FftFilterFloat (fft_filter.rs:365-491) ---------------------------------------------------------
+FftFilterFloat::FftFilterFloat(const float* taps, size_t ntaps) : Block("FftFilterFloat", 4, 4) {
+    if (ntaps == 0) throw Error("FftFilterFloat: empty taps");
+    std::vector<rr_c32> ct(ntaps);
+    for (size_t i = 0; i < ntaps; i++) ct[i] = rr_c32{taps[i], 0.0f};  // fft_filter.rs:398
+    inner.reset(new FftFilter(ct.data(), ntaps));
+    cap = 4096000 / sizeof(cf);                                         // inner streams: stream.rs:105,336-339
+    for (auto& b : iin) b.reserve(cap);
+    for (auto& b : iout) b.reserve(cap);
+}
+
+int FftFilterFloat::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                             size_t* produced, size_t* need, hipStream_t s) {
+    *consumed = *produced = *need = 0;
+    // outer input -> inner_in as Complex(x, 0)   (fft_filter.rs:431-445)
+    const size_t n = std::min(in_len, cap - iin_len);
+    launch_f32_to_c32(static_cast<const float*>(in), iin[ci].p + iin_len, (long)n, s);
+    iin_len += n;
+    *consumed = n;
+    // inner complex filter (fft_filter.rs:450)
+    size_t ic = 0, ip = 0, ineed = 0;
+    const int st = inner->work_dev(iin[ci].p, iin_len, iout[co].p + iout_len, cap - iout_len, &ic, &ip, &ineed, s);
+    if (ic) {
+        VSrc<cf> v{nullptr, 0, iin[ci].p, (long)iin_len};
+        launch_vcopy_c32(v, (long)ic, iin[ci ^ 1].p, (long)(iin_len - ic), s);
+        ci ^= 1; iin_len -= ic;
+    }
+    iout_len += ip;
+    // inner_out -> outer output, real part   (fft_filter.rs:453-470)
+    const size_t m = std::min(iout_len, out_cap);
+    if (m == 0 && iout_len != 0) { *need = 1; return RR_WAIT_DST; }   // :457-459
+    launch_c32_re(iout[co].p, static_cast<float*>(out), (long)m, s);
+    if (m) {
+        VSrc<cf> v{nullptr, 0, iout[co].p, (long)iout_len};
+        launch_vcopy_c32(v, (long)m, iout[co ^ 1].p, (long)(iout_len - m), s);
+        co ^= 1; iout_len -= m;
+    }
+    *produced = m;
+    *need = ineed;                                                      // :474-489
+    return st;
+}
+
+// ---- RationalResampler (rational_resampler.rs:100-213) -------------------------------------------------
+static int64_t gcd64(int64_t a, int64_t b) {
+    while (b != 0) { const int64_t t = b; b = a % b; a = t; }
+    return a;
+}
+Resampler::Resampler(size_t interp, size_t deci, size_t es) : Block("RationalResampler", es, es) {
+    if (deci == 0) throw Error("RationalResampler created using deci 0");      // :130-132
+    if (interp == 0) throw Error("RationalResampler created using interp 0");  // :133-135
+    if (!(es == 1 || es == 2 || es == 4 || es == 8 || es == 16)) throw Error("RationalResampler: element size must be 1,2,4,8 or 16");
+    if (interp > (size_t)INT64_MAX || deci > (size_t)INT64_MAX) throw Error("RationalResampler: ratio out of range");  // i64::try_from :142-143
+    const int64_t g = gcd64((int64_t)deci, (int64_t)interp);
+    D = (int64_t)deci / g; I = (int64_t)interp / g;
+    d_pending.reserve(16);
+}
+bool Resampler::eof(bool src_eof) { return !has_pending && src_eof; }        // :209-213
+
+int Resampler::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                        size_t* produced, size_t* need, hipStream_t s) {
+    *consumed = *produced = 0; *need = 1;
+    if (out_cap == 0) return RR_WAIT_DST;                                      // :158-160
+    int64_t r = 0;
+    if (has_pending) {                                                         // :162-173
+        const int64_t r_full = counter > 0 ? (counter + D - 1) / D : 0;
+        if (r_full >= (int64_t)out_cap) {
+            r = (int64_t)out_cap; counter -= r * D;
+            launch_resample(in, out, in_es, r, d_pending.p, 0, I, D, 0, s);
+            *produced = (size_t)r;
+            return RR_WAIT_DST;
+        }
+        r = r_full; counter -= r * D; has_pending = false;
+    }
+    if (in_len == 0) {                                                         // :176-179
+        if (r) launch_resample(in, out, in_es, r, d_pending.p, 0, I, D, 0, s);
+        *produced = (size_t)r;
+        return RR_WAIT_SRC;
+    }
+    const int64_t c0 = counter, capp = (int64_t)out_cap - r, n = (int64_t)in_len;
+    const __int128 a = (__int128)c0 + (__int128)n * I;
+    const int64_t m_total = a <= 0 ? 0 : (int64_t)((a + D - 1) / D);
+    if (m_total < capp) {                                                      // all input taken
+        launch_resample(in, out, in_es, r, d_pending.p, m_total, I, D, c0, s);
+        counter = (int64_t)(a - (__int128)m_total * D);
+        *consumed = in_len; *produced = (size_t)(r + m_total);
+        return RR_WAIT_SRC;                                                    // :204
+    }
+    // output fills at emit number capp (:190-196)
+    const int64_t kstar = (int64_t)((((__int128)(capp - 1)) * D - c0) / I);
+    launch_resample(in, out, in_es, r, d_pending.p, capp, I, D, c0, s);
+    counter = (int64_t)((__int128)c0 + (__int128)(kstar + 1) * I - (__int128)capp * D);
+    if (counter > 0) {
+        RR_HIP(hipMemcpyAsync(d_pending.p, static_cast<const unsigned char*>(in) + (size_t)kstar * in_es, in_es,
+                              hipMemcpyDeviceToDevice, s));
+        has_pending = true;
+    }
+    *consumed = (size_t)(kstar + 1); *produced = out_cap;
+    return RR_WAIT_DST;                                                        // :202
+}
+
+// ---- QuadratureDemod (quadrature_demod.rs:32-114) ---------------------------------------------------------
+QuadDemod::QuadDemod(float g, int m) : Block("QuadratureDemod", 8, 4), gain(g), mode(m) {
+    if (m != RR_ATAN2_EXACT && m != RR_ATAN2_FAST) throw Error("QuadratureDemod: bad atan2 mode");
+}
+int QuadDemod::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                        size_t* produced, size_t* need, hipStream_t s) {
+    *consumed = *produced = *need = 0;
+    if (in_len < 2) { *need = 2; return RR_WAIT_SRC; }                         // :49-51
+    if (out_cap == 0) { *need = 1; return RR_WAIT_DST; }                       // :53-55
+    const size_t n1 = std::min(in_len - 1, out_cap);                           // :56
+    launch_quaddemod(static_cast<const cf*>(in), static_cast<float*>(out), (long)n1, gain, mode, s);
+    *consumed = *produced = n1;                                                // :110-111
+    // the reference loops: the next iteration returns the wait
+    if (in_len - n1 < 2) { *need = 2; return RR_WAIT_SRC; }
+    *need = 1; return RR_WAIT_DST;
+}
+
+// ---- Hilbert (hilbert.rs:22-129) -------------------------------------------------------------------------------
+Hilbert::Hilbert(size_t ntaps, int window, float parm) : Block("Hilbert", 4, 8) {
+    if (!(ntaps > 1 && (ntaps & 1) == 1)) throw Error("hilbert filter len must be odd and greater than 1");  // :44-47
+    if (ntaps > 0x3fffffff) throw Error("Hilbert: too many taps");
+    std::vector<float> win, taps;
+    if (!make_window(window, parm, ntaps, win)) throw Error("Hilbert: unknown window type");
+    hilbert_taps(win.data(), ntaps, taps);                                      // :48
+    pl.L = (int)ntaps; pl.d = 1; pl.complex_taps = false;
+    std::vector<float> rev(ntaps), tp;
+    for (size_t j = 0; j < ntaps; j++) rev[j] = taps[ntaps - 1 - j];           // Fir::new, fir.rs:160
+    build_poly(rev, 1, pl.qpad, tp);
+    d_rev.upload(rev.data(), rev.size(), stream);
+    d_tp.upload(tp.data(), tp.size(), stream);
+    for (auto& h : hist) {                                                      // :55 — ntaps zeros
+        h.reserve(ntaps);
+        RR_HIP(hipMemsetAsync(h.p, 0, ntaps * sizeof(float), stream));
+    }
+    RR_HIP(hipStreamSynchronize(stream));
+}
+int Hilbert::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                      size_t* produced, size_t* need, hipStream_t s) {
+    *consumed = *produced = 0; *need = 1;
+    if (in_len == 0) return RR_WAIT_SRC;                                        // :76-78
+    if (out_cap == 0) return RR_WAIT_DST;                                       // :81-83
+    const size_t n = std::min(in_len, out_cap);                                 // :85-87
+    VSrc<float> src{hist[cur].p, (long)pl.L, static_cast<const float*>(in), (long)in_len};
+    launch_hilbert(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)n, s);
+    launch_vcopy_f32(src, (long)n, hist[cur ^ 1].p, (long)pl.L, s);            // :125
+    cur ^= 1;
+    *consumed = *produced = n; *need = 0;
+    return RR_AGAIN;                                                            // :127
+}
+
+}  // namespace rr

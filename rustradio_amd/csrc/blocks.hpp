@@ -1,0 +1,104 @@
+// blocks.hpp — host-side block objects behind the C ABI (include/rustradio_amd.h).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "../../include/rustradio_amd.h"
+#include "kernels.hpp"
+
+namespace rr {
+
+void set_thread_device(int d);
+int thread_device();
+
+struct Block {
+    const char* name;
+    size_t in_es, out_es;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<unsigned char> st_in, st_out;   // staging for host-window work()
+
+    Block(const char* nm, size_t ies, size_t oes);
+    virtual ~Block();
+    Block(const Block&) = delete;
+    Block& operator=(const Block&) = delete;
+
+    virtual int work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                         size_t* produced, size_t* need, hipStream_t s) = 0;
+    virtual bool eof(bool src_eof);
+    // how much of the input window a host-window call must upload
+    virtual size_t host_in_limit(size_t in_len, size_t /*out_cap*/) const { return in_len; }
+    int work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                  size_t* produced, size_t* need);
+    void sync();
+};
+
+struct FirC32 : Block {
+    FirPlan pl;
+    DevBuf<unsigned char> d_tp, d_rev, d_tab;
+    bool rot_on = false;
+    int rot_mode = RR_ROT_MODEL;
+    float ph0x = 1, ph0y = 0, stx = 1, sty = 0;   // f32-rounded phase0 / step (fir.rs:453-461)
+    float cur_x = 1, cur_y = 0;                   // REPLAY state
+    size_t n_rot = 0;                             // outputs rotated so far
+    std::vector<cf> h_tab;
+    FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq);
+    size_t host_in_limit(size_t in_len, size_t out_cap) const override;
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
+struct FirF32 : Block {
+    FirPlan pl;
+    DevBuf<float> d_tp, d_rev;
+    FirF32(const float* taps, size_t ntaps, size_t deci);
+    size_t host_in_limit(size_t in_len, size_t out_cap) const override;
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
+struct FftFilter : Block {
+    size_t L = 0, fft_size = 0, nsamples = 0;
+    int log2f = 10;
+    DevBuf<cf> d_tw, d_hpos;
+    DevBuf<cf> prefix[2];
+    int cur = 0;
+    size_t pend_len = 0;
+    FftFilter(const rr_c32* taps, size_t ntaps);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
+struct FftFilterFloat : Block {
+    std::unique_ptr<FftFilter> inner;
+    size_t cap = 0;
+    DevBuf<cf> iin[2], iout[2];
+    int ci = 0, co = 0;
+    size_t iin_len = 0, iout_len = 0;
+    FftFilterFloat(const float* taps, size_t ntaps);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
+struct Resampler : Block {
+    int64_t I = 1, D = 1, counter = 0;
+    bool has_pending = false;
+    DevBuf<unsigned char> d_pending;
+    Resampler(size_t interp, size_t deci, size_t es);
+    bool eof(bool src_eof) override;
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
+struct QuadDemod : Block {
+    float gain;
+    int mode;
+    QuadDemod(float gain, int mode);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
+struct Hilbert : Block {
+    FirPlan pl;
+    DevBuf<float> d_tp, d_rev;
+    DevBuf<float> hist[2];
+    int cur = 0;
+    Hilbert(size_t ntaps, int window, float parm);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
+}  // namespace rr

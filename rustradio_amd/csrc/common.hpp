@@ -1,0 +1,66 @@
+// common.hpp — error plumbing and small RAII helpers shared by the host side of the library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "fft_core.hpp"
+
+namespace rr {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+void set_last_error(const std::string& m);
+
+#define RR_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            throw ::rr::Error(std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+// Device buffer that only grows.
+template <class T> struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        if (p) RR_HIP(hipFree(p));
+        p = nullptr; cap = 0;
+        RR_HIP(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+        cap = n;
+    }
+    void upload(const T* h, size_t n, hipStream_t s) {
+        reserve(n);
+        if (n) RR_HIP(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+};
+
+// A stream window that may be preceded by a small handle-owned prefix (carry state):
+// virtual index v < plen -> prefix[v]; else in[v - plen] (zero beyond in_len).
+template <class T> struct VSrc {
+    const T* prefix;
+    long plen;
+    const T* in;
+    long in_len;
+#if defined(__HIPCC__)
+    __device__ __forceinline__ T load(long v) const {
+        if (v < plen) return prefix[v];
+        long i = v - plen;
+        if (i < in_len) return in[i];
+        T z{};
+        return z;
+    }
+#endif
+};
+
+}  // namespace rr

@@ -1,0 +1,52 @@
+// kernels.hpp — host-callable launchers of the HIP kernels (one TU per kernel family).
+#pragma once
+#include "common.hpp"
+
+namespace rr {
+
+// ---- kernels_fft.hip ---------------------------------------------------------------
+// Overlap-save FFT filter.  xx = virtual stream whose index 0 is the first of the
+// (L-1) history samples.  Writes y[n] = sum_k t[k] * x[n - k], n < n_out, where x[i] = xx[i + L - 1].
+//   log2f      : internal tile size F = 2^log2f (10..14), F >= 2*(L-1) recommended
+//   tw         : device table of w_F^k, k < F
+//   hpos       : device table of H (scaled by 1/F) in digit-reversed position order
+bool fftfilt_supported(int log2f);
+void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw,
+                       const cf* hpos, hipStream_t s);
+
+// ---- kernels_fir.hip ---------------------------------------------------------------
+struct FirPlan {             // host-prepared polyphase tap table
+    int L = 0, d = 1;
+    int qpad = 0;            // taps per phase, padded to a multiple of 8
+    bool complex_taps = false;
+};
+// y[m] = sum_k rev[k] * x[m*d + k], m < n_out  (rev = reversed taps), x = virtual stream.
+// tp = device polyphase table [d][qpad] (float if real taps else cf), rev = device reversed taps.
+void launch_fir_c32(const FirPlan& pl, const void* tp, const void* rev, VSrc<cf> src, cf* out,
+                    long n_out, hipStream_t s);
+void launch_fir_f32(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src,
+                    float* out, long n_out, hipStream_t s);
+// Hilbert: out[k] = (xp[k + L/2], sum_j rev[j] xp[k + j]), xp = virtual stream (history ++ in).
+void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, cf* out,
+                    long n_out, hipStream_t s);
+// y[m] *= phase0 * step^(m0 + m) evaluated in f64 (RR_ROT_MODEL)
+void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, double sy, long m0,
+                         hipStream_t s);
+// y[m] *= table[m]
+void launch_rotate_table(cf* y, long n, const cf* table, hipStream_t s);
+
+// ---- kernels_misc.hip --------------------------------------------------------------
+// out[r + m] = in[floor((m*D - c0) / I)], m < n_gather; out[0..r) = *pending
+void launch_resample(const void* in, void* out, size_t es, long r, const void* pending,
+                     long n_gather, long I, long D, long c0, hipStream_t s);
+// out[n] = gain * atan2(Im z, Re z), z = conj(x[n]) x[n+1], n < n_out
+void launch_quaddemod(const cf* in, float* out, long n_out, float gain, int mode, hipStream_t s);
+// dst[i] = src.load(v0 + i), i < n   (carry-state update)
+void launch_vcopy_c32(VSrc<cf> src, long v0, cf* dst, long n, hipStream_t s);
+void launch_vcopy_f32(VSrc<float> src, long v0, float* dst, long n, hipStream_t s);
+void launch_f32_to_c32(const float* in, cf* out, long n, hipStream_t s);
+void launch_c32_re(const cf* in, float* out, long n, hipStream_t s);
+
+int device_cu_count();
+
+}  // namespace rr

@@ -1,0 +1,226 @@
+// kernels_fir.hip — direct-form FIR on gfx950: FirFilter<Complex>/<Float> incl. decimation
+// (/root/reference/src/fir.rs:166-197, 492-550) and the Hilbert block's inner filter
+// (/root/reference/src/hilbert.rs:113-116).
+//
+// y[m] = sum_k rev[k] * x[m*d + k]  is evaluated polyphase: for phase p < d the taps
+// rev[q*d + p] run over the decimated sequence x_p[n] = x[n*d + p] as a d=1 FIR, so every
+// thread keeps a sliding window of R inputs in VGPRs and needs ONE new LDS value per tap
+// for R multiply-adds.  The input tile is staged in LDS transposed ([n % R][n / R]) so
+// that lane t's window read x_p[t*R + c] is lane-consecutive (conflict-free).  Taps are
+// wave-uniform and come through the scalar cache.  No MFMA: a FIR is a vector
+// contraction, VALU (FP32) bound for long filters — see DESIGN.md for the roofline.
+#include "kernels.hpp"
+
+namespace rr {
+
+constexpr int FIR_R = 8;
+
+__device__ __forceinline__ void mac(cf& acc, float tap, cf w) {   // real tap (2 FMA)
+    acc.x = fmaf(tap, w.x, acc.x);
+    acc.y = fmaf(tap, w.y, acc.y);
+}
+__device__ __forceinline__ void mac(cf& acc, cf tap, cf w) {      // complex tap (4 FMA)
+    acc.x = fmaf(tap.x, w.x, acc.x);
+    acc.x = fmaf(-tap.y, w.y, acc.x);
+    acc.y = fmaf(tap.x, w.y, acc.y);
+    acc.y = fmaf(tap.y, w.x, acc.y);
+}
+__device__ __forceinline__ void mac(float& acc, float tap, float w) { acc = fmaf(tap, w, acc); }
+
+template <class T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
+template <> __device__ __forceinline__ cf zero_of<cf>() { return mk(0.0f, 0.0f); }
+
+// geometry shared by host and device
+struct FirGeom {
+    int np;        // samples per phase staged in LDS
+    int rstride;   // row stride (elements) of the transposed tile
+    int pstride;   // phase stride
+    size_t lds_bytes;
+};
+static FirGeom fir_geom(int NT, int d, int qpad, size_t es) {
+    FirGeom g;
+    g.np = NT * FIR_R + qpad;
+    int rs = NT + qpad / FIR_R;
+    const int mod = es == 8 ? 16 : 32, want = es == 8 ? 2 : 4;   // bank-friendly residue (see header)
+    while (rs % mod != want) rs++;
+    g.rstride = rs;
+    g.pstride = FIR_R * rs + 1;
+    g.lds_bytes = (size_t)d * g.pstride * es;
+    return g;
+}
+
+template <class T, class TapT, class OutT, int NT, bool HILBERT>
+__global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
+                                            int qpad, int np, int rstride, int pstride,
+                                            const TapT* __restrict__ tp) {
+    constexpr int R = FIR_R;
+    constexpr int NOUT = NT * R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    const int t = threadIdx.x;
+    const long ntiles = (n_out + NOUT - 1) / NOUT;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long m0 = tile * NOUT;
+        const long gi0 = m0 * d;
+        __syncthreads();
+        const int total = np * d;
+        if (d == 1) {
+            for (int i = t; i < total; i += NT)
+                lds[(i % R) * rstride + i / R] = src.load(gi0 + i);
+        } else {
+            for (int i = t; i < total; i += NT) {
+                const int p = i % d, n = i / d;
+                lds[p * pstride + (n % R) * rstride + n / R] = src.load(gi0 + i);
+            }
+        }
+        __syncthreads();
+
+        T acc[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) acc[j] = zero_of<T>();
+        for (int p = 0; p < d; p++) {
+            const T* lp = lds + p * pstride + t;
+            const TapT* tpp = tp + (long)p * qpad;
+            T w[R];
+#pragma unroll
+            for (int j = 0; j < R; j++) w[j] = lp[j * rstride];
+            for (int q0 = 0; q0 < qpad; q0 += R) {
+                const T* lq = lp + q0 / R + 1;
+#pragma unroll
+                for (int kk = 0; kk < R; kk++) {
+                    const TapT tap = tpp[q0 + kk];
+#pragma unroll
+                    for (int j = 0; j < R; j++) mac(acc[j], tap, w[(kk + j) % R]);
+                    w[kk] = lq[kk * rstride];
+                }
+            }
+        }
+        const long mb = m0 + (long)t * R;
+        if constexpr (HILBERT) {
+            // re = xp[k + L/2]  (hilbert.rs:115)
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const int n = t * R + j + L / 2;
+                if (mb + j < n_out) out[mb + j] = mk(lds[(n % R) * rstride + n / R], acc[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                if (mb + j < n_out) out[mb + j] = acc[j];
+        }
+    }
+}
+
+// Fallback for shapes whose tile does not fit LDS (very large d or L): one output per thread,
+// inputs through L1/L2.
+template <class T, class TapT, class OutT, bool HILBERT>
+__global__ __launch_bounds__(256) void k_fir_direct(VSrc<T> src, OutT* __restrict__ out, long n_out, int L,
+                                                    int d, const TapT* __restrict__ rev) {
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < n_out; m += (long)gridDim.x * blockDim.x) {
+        T acc = zero_of<T>();
+        const long b = m * d;
+        for (int k = 0; k < L; k++) mac(acc, rev[k], src.load(b + k));
+        if constexpr (HILBERT) out[m] = mk(src.load(b + L / 2), acc);
+        else out[m] = acc;
+    }
+}
+
+template <class T, class TapT, class OutT, bool HILBERT>
+static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, VSrc<T> src, OutT* out,
+                           long n_out, hipStream_t s) {
+    if (n_out <= 0) return;
+    const int cus = device_cu_count();
+    const size_t LDS_LIMIT = 64 * 1024;
+    int NT = 0;
+    FirGeom g{};
+    for (int cand : {256, 128, 64}) {
+        g = fir_geom(cand, pl.d, pl.qpad, sizeof(T));
+        if (g.lds_bytes <= LDS_LIMIT) { NT = cand; break; }
+    }
+    if (NT == 0) {
+        long grid = (n_out + 255) / 256;
+        if (grid > (long)cus * 16) grid = (long)cus * 16;
+        hipLaunchKernelGGL((k_fir_direct<T, TapT, OutT, HILBERT>), dim3((unsigned)grid), dim3(256), 0, s, src, out,
+                           n_out, pl.L, pl.d, rev);
+        RR_HIP(hipGetLastError());
+        return;
+    }
+    const long ntiles = (n_out + (long)NT * FIR_R - 1) / ((long)NT * FIR_R);
+    long grid = ntiles;
+    const long cap = (long)cus * (long)((160 * 1024) / (g.lds_bytes ? g.lds_bytes : 1) > 8 ? 8 : (160 * 1024) / g.lds_bytes);
+    if (grid > cap && cap > 0) grid = cap;
+#define RR_FIR_LAUNCH(NTV)                                                                                    \
+    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, s, \
+                       src, out, n_out, pl.L, pl.d, pl.qpad, g.np, g.rstride, g.pstride, tp)
+    if (NT == 256) RR_FIR_LAUNCH(256);
+    else if (NT == 128) RR_FIR_LAUNCH(128);
+    else RR_FIR_LAUNCH(64);
+#undef RR_FIR_LAUNCH
+    RR_HIP(hipGetLastError());
+}
+
+void launch_fir_c32(const FirPlan& pl, const void* tp, const void* rev, VSrc<cf> src, cf* out, long n_out,
+                    hipStream_t s) {
+    if (pl.complex_taps)
+        launch_fir_any<cf, cf, cf, false>(pl, (const cf*)tp, (const cf*)rev, src, out, n_out, s);
+    else
+        launch_fir_any<cf, float, cf, false>(pl, (const float*)tp, (const float*)rev, src, out, n_out, s);
+}
+void launch_fir_f32(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, float* out,
+                    long n_out, hipStream_t s) {
+    launch_fir_any<float, float, float, false>(pl, tp, rev, src, out, n_out, s);
+}
+void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, cf* out,
+                    long n_out, hipStream_t s) {
+    launch_fir_any<float, float, cf, true>(pl, tp, rev, src, out, n_out, s);
+}
+
+// ---- frequency-translation rotator (src/fir.rs:464-473) ---------------------------------
+// RR_ROT_MODEL: phi_m = phase0 * step^m with the f32-rounded phase0/step of the reference,
+// evaluated in f64 by binary powering per element (log2(m) complex multiplies).
+__device__ __forceinline__ void zmul(double& ax, double& ay, double bx, double by) {
+    const double x = ax * bx - ay * by, y = ax * by + ay * bx;
+    ax = x; ay = y;
+}
+__global__ __launch_bounds__(256) void k_rotate_model(cf* __restrict__ y, long n, double p0x, double p0y,
+                                                      double sx, double sy, long m0) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned long e = (unsigned long)(m0 + i);
+        double rx = p0x, ry = p0y, bx = sx, by = sy;
+        while (e) {
+            if (e & 1) zmul(rx, ry, bx, by);
+            zmul(bx, by, bx, by);
+            e >>= 1;
+        }
+        const cf v = y[i];
+        const double ox = (double)v.x * rx - (double)v.y * ry;
+        const double oy = (double)v.x * ry + (double)v.y * rx;
+        y[i] = mk((float)ox, (float)oy);
+    }
+}
+__global__ __launch_bounds__(256) void k_rotate_table(cf* __restrict__ y, long n, const cf* __restrict__ tab) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const cf v = y[i], p = tab[i];
+        // sample * phase, un-contracted num-complex order (fir.rs:469)
+        y[i] = mk(__fsub_rn(__fmul_rn(v.x, p.x), __fmul_rn(v.y, p.y)),
+                  __fadd_rn(__fmul_rn(v.x, p.y), __fmul_rn(v.y, p.x)));
+    }
+}
+static unsigned rot_grid(long n) {
+    long g = (n + 255) / 256;
+    const long cap = (long)device_cu_count() * 8;
+    return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, double sy, long m0, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rotate_model, dim3(rot_grid(n)), dim3(256), 0, s, y, n, p0x, p0y, sx, sy, m0);
+    RR_HIP(hipGetLastError());
+}
+void launch_rotate_table(cf* y, long n, const cf* table, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rotate_table, dim3(rot_grid(n)), dim3(256), 0, s, y, n, table);
+    RR_HIP(hipGetLastError());
+}
+
+}  // namespace rr

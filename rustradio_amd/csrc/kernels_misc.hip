@@ -1,0 +1,133 @@
+// kernels_misc.hip — RationalResampler gather, QuadratureDemod, and the small
+// carry-state copies.  All are pure HBM-streaming kernels.
+#include "kernels.hpp"
+
+namespace rr {
+
+static inline unsigned grid_for(long n, int block, int per_thread = 1) {
+    long g = (n + (long)block * per_thread - 1) / ((long)block * per_thread);
+    const long cap = (long)device_cu_count() * 8;  // grid-stride above ~8 blocks/CU
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ---- RationalResampler (src/rational_resampler.rs:183-198 in closed form) -----------
+// The reference's counter loop emits input k while counter > 0; with counter c0 at the
+// start of the window, output m comes from input floor((m*D - c0) / I)  (SURVEY F3/A.6).
+template <class E>
+__global__ __launch_bounds__(256) void k_resample(const E* __restrict__ in, E* __restrict__ out, long r,
+                                                  const E* __restrict__ pending, long n_gather,
+                                                  long I, long D, long c0) {
+    const long total = r + n_gather;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        if (o < r) {
+            out[o] = pending[0];
+        } else {
+            const long m = o - r;
+            const long k = (I == 1) ? (m * D - c0) : (m * D - c0) / I;
+            out[o] = in[k];
+        }
+    }
+}
+
+struct alignas(16) e16 { unsigned int a, b, c, d; };
+
+void launch_resample(const void* in, void* out, size_t es, long r, const void* pending, long n_gather,
+                     long I, long D, long c0, hipStream_t s) {
+    const long total = r + n_gather;
+    if (total <= 0) return;
+    const unsigned g = grid_for(total, 256);
+#define RR_RS(E)                                                                                          \
+    hipLaunchKernelGGL(k_resample<E>, dim3(g), dim3(256), 0, s, (const E*)in, (E*)out, r, (const E*)pending, \
+                       n_gather, I, D, c0)
+    switch (es) {
+    case 1: RR_RS(unsigned char); break;
+    case 2: RR_RS(unsigned short); break;
+    case 4: RR_RS(unsigned int); break;
+    case 8: RR_RS(unsigned long long); break;
+    case 16: RR_RS(e16); break;
+    default: throw Error("resampler: unsupported element size");
+    }
+#undef RR_RS
+    RR_HIP(hipGetLastError());
+}
+
+// ---- QuadratureDemod (src/quadrature_demod.rs:65-109) ---------------------------------
+// fast-math 0.1.1 atan2 restated from its published algorithm (crate not vendored: parity-unpinned flavour).
+__device__ __forceinline__ float flip_sign(float v, float s) {
+    return __uint_as_float(__float_as_uint(v) ^ (__float_as_uint(s) & 0x80000000u));
+}
+__device__ __forceinline__ float fm_atan_raw(float x) {
+    return __fmul_rn(__fsub_rn(__fadd_rn(0.78539816339744830962f, 0.273f), __fmul_rn(0.273f, fabsf(x))), x);
+}
+__device__ __forceinline__ float fm_atan2(float y, float x) {
+    if (fabsf(y) < fabsf(x)) {
+        const float bias = x > 0.0f ? 0.0f : 3.14159265358979323846f;
+        return __fadd_rn(flip_sign(bias, y), fm_atan_raw(__fdiv_rn(y, x)));
+    } else if (x == 0.0f) {
+        if (y == 0.0f) return 0.0f;
+        return flip_sign(1.57079632679489661923f, y);
+    }
+    return __fsub_rn(flip_sign(1.57079632679489661923f, y), fm_atan_raw(__fdiv_rn(x, y)));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_quaddemod(const cf* __restrict__ in, float* __restrict__ out,
+                                                   long n_out, float gain) {
+    for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < n_out; n += (long)gridDim.x * blockDim.x) {
+        const cf a = in[n], b = in[n + 1];
+        // conj(a) * b in num-complex order, un-contracted so that signed zeros behave as on the CPU
+        const float na = -a.y;
+        const float re = __fsub_rn(__fmul_rn(a.x, b.x), __fmul_rn(na, b.y));
+        const float im = __fadd_rn(__fmul_rn(a.x, b.y), __fmul_rn(na, b.x));
+        const float ang = MODE == 0 ? atan2f(im, re) : fm_atan2(im, re);
+        out[n] = __fmul_rn(gain, ang);
+    }
+}
+
+void launch_quaddemod(const cf* in, float* out, long n_out, float gain, int mode, hipStream_t s) {
+    if (n_out <= 0) return;
+    const unsigned g = grid_for(n_out, 256);
+    if (mode == 0) hipLaunchKernelGGL(k_quaddemod<0>, dim3(g), dim3(256), 0, s, in, out, n_out, gain);
+    else hipLaunchKernelGGL(k_quaddemod<1>, dim3(g), dim3(256), 0, s, in, out, n_out, gain);
+    RR_HIP(hipGetLastError());
+}
+
+// ---- carry-state copies -----------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_vcopy(VSrc<T> src, long v0, T* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = src.load(v0 + i);
+}
+void launch_vcopy_c32(VSrc<cf> src, long v0, cf* dst, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_vcopy<cf>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, v0, dst, n);
+    RR_HIP(hipGetLastError());
+}
+void launch_vcopy_f32(VSrc<float> src, long v0, float* dst, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_vcopy<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, v0, dst, n);
+    RR_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_f32_to_c32(const float* __restrict__ in, cf* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = mk(in[i], 0.0f);
+}
+__global__ __launch_bounds__(256) void k_c32_re(const cf* __restrict__ in, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = in[i].x;
+}
+void launch_f32_to_c32(const float* in, cf* out, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_f32_to_c32, dim3(grid_for(n, 256)), dim3(256), 0, s, in, out, n);
+    RR_HIP(hipGetLastError());
+}
+void launch_c32_re(const cf* in, float* out, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_c32_re, dim3(grid_for(n, 256)), dim3(256), 0, s, in, out, n);
+    RR_HIP(hipGetLastError());
+}
+
+}  // namespace rr

@@ -1,0 +1,11 @@
+#pragma once
+#include <cstddef>
+#include <vector>
+
+namespace rr {
+float max_attenuation(int window);
+bool make_window(int window, float parm, size_t n, std::vector<float>& out);
+size_t compute_ntaps(float samp_rate, float twidth, int window);
+bool low_pass(float samp_rate, float cutoff, float twidth, int window, float parm, std::vector<float>& taps);
+bool hilbert_taps(const float* window, size_t ntaps, std::vector<float>& taps);
+}  // namespace rr

@@ -1,0 +1,205 @@
+"""GPU parity: every HIP block against the CPU oracle on identical seeded input, driven
+through identical work() call sequences.  Bar (BASELINE.json north_star / SURVEY §8d):
+    max|y_gpu - y_ref| / max|y_ref| <= 1e-5   (QuadDemod: scale = pi*|gain|),
+lengths and the (status, consumed, produced, need) protocol must match exactly;
+RationalResampler is a pure copy and must be bit-exact."""
+import numpy as np
+import pytest
+
+from harness import AGAIN, WAIT_DST, WAIT_SRC, max_norm_err, run_chain
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def rr():
+    import rustradio_amd
+    return rustradio_amd
+
+
+def rnd_c(n, seed):
+    r = np.random.default_rng(seed)
+    return (r.uniform(-1, 1, n) + 1j * r.uniform(-1, 1, n)).astype(np.complex64)
+
+
+def rnd_f(n, seed):
+    return np.random.default_rng(seed).uniform(-1, 1, n).astype(np.float32)
+
+
+def both(rr, make, x, stream_bytes=4_096_000, scale=None, exact=False):
+    lo, lg = [], []
+    yo = run_chain(make(orc), x, stream_bytes=stream_bytes, log=lo)
+    yg = run_chain(make(rr), x, stream_bytes=stream_bytes, log=lg)
+    assert lo == lg, "work() protocol differs from the reference restatement"
+    assert len(yo) == len(yg)
+    if exact:
+        assert np.array_equal(yo, yg)
+        return 0.0
+    e = max_norm_err(yg, yo, scale)
+    assert e <= TOL, e
+    return e
+
+
+@pytest.mark.parametrize("L,deci,cplx", [(1, 1, False), (1, 7, False), (2, 1, True), (33, 3, True), (127, 1, False),
+                                         (127, 1, True), (255, 8, False), (255, 8, True), (64, 5, False),
+                                         (401, 2, False), (3, 40, True), (1000, 1, False), (9000, 16, False)])
+def test_fir_complex(rr, L, deci, cplx):
+    x = rnd_c(60000, L * 7 + deci)
+    taps = rnd_c(L, L) / max(1, L // 8)
+    if not cplx:
+        taps = taps.real.astype(np.complex64)
+    both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x)
+
+
+def test_fir_complex_chunked(rr):
+    x = rnd_c(50000, 3)
+    taps = orc.low_pass_complex(10e6, 1e6, 190e3)
+    both(rr, lambda m: [m.FirFilter(taps)], x, stream_bytes=8 * 3000)
+    both(rr, lambda m: [m.FirFilter(taps, deci=4)], x, stream_bytes=8 * 1111)
+
+
+@pytest.mark.parametrize("L,deci", [(1, 1), (65, 1), (128, 3), (463, 6)])
+def test_fir_float(rr, L, deci):
+    x = rnd_f(70000, L)
+    taps = rnd_f(L, L + 1) / max(1, L // 8)
+    both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x)
+
+
+def test_fir_cfg1_tone_and_noise(rr):
+    # BASELINE configs[0]: 127 real taps, 1M samples
+    taps = orc.low_pass_complex(10e6, 1e6, 190e3)
+    assert len(taps) == 127
+    n = 1_000_000
+    ph = (np.arange(n, dtype=np.float32) * np.float32(0.013))
+    tone = (np.sin(ph) + 1j * np.cos(ph)).astype(np.complex64)   # rustradio-ui/tests/fir_filter_bench.rs:40-45
+    for x in (tone, rnd_c(n, 0x5EED0001)):
+        yo = run_chain([orc.FirFilter(taps)], x)
+        yg = run_chain([rr.FirFilter(taps)], x)
+        assert len(yo) == len(yg) == 999_874
+        assert max_norm_err(yg, yo) <= TOL
+
+
+@pytest.mark.parametrize("mode", ["replay", "model"])
+def test_fir_translate(rr, mode):
+    x = rnd_c(40000, 21)
+    taps = orc.low_pass_complex(100e6, 5e6, 943e3 * 4)
+    rot = rr.ROT_REPLAY if mode == "replay" else rr.ROT_MODEL
+    for deci, f in ((1, 1.7e6), (8, -12.5e6), (3, 0.0)):
+        lo, lg = [], []
+        yo = run_chain([orc.FirFilter(taps, deci=deci, translate=(100e6, f))], x, log=lo, stream_bytes=8 * 9000)
+        yg = run_chain([rr.FirFilter(taps, deci=deci, translate=(100e6, f), rotator=rot)], x, log=lg, stream_bytes=8 * 9000)
+        assert lo == lg and len(yo) == len(yg)
+        assert max_norm_err(yg, yo) <= TOL
+
+
+@pytest.mark.parametrize("L", [1, 2, 5, 193, 401, 463, 512, 513, 1025, 2467, 5000])
+def test_fftfilter(rr, L):
+    n = 200_000 if L < 1025 else 400_000
+    x = rnd_c(n, L)
+    taps = rnd_c(L, 300 + L) / max(1, L // 4)
+    e = both(rr, lambda m: [m.FftFilter(taps)], x)
+    f_ref, s_ref, _ = rr.fftfilter_dims(rr.FftFilter(taps))
+    assert (f_ref, s_ref) == orc.fftfilter_dims(orc.FftFilter(taps))
+
+
+def test_fftfilter_chunked_and_small_outputs(rr):
+    taps = orc.low_pass_complex(10e6, 1e6, 60e3)
+    x = rnd_c(150_000, 77)
+    both(rr, lambda m: [m.FftFilter(taps)], x, stream_bytes=8 * 700)      # one block per call
+    both(rr, lambda m: [m.FftFilter(taps)], x, stream_bytes=8 * 5000)
+    # direct protocol probes
+    for impl in (orc, rr):
+        b = impl.FftFilter(taps)
+        assert b.work(x[:100], 622)[:4] == (WAIT_DST, 0, 0, 623)
+        assert b.work(x[:100], 10_000)[:4] == (WAIT_SRC, 100, 0, 523)
+        st, c, p, need, out = b.work(x[100:5000], 1300)
+        assert (st, c, p, need) == (WAIT_DST, 2 * 623 - 100, 2 * 623, 623)
+
+
+def test_fftfilter_rejects_too_many_taps(rr):
+    with pytest.raises(ValueError):
+        rr.FftFilter(np.ones(8193, np.complex64))
+    with pytest.raises(ValueError):
+        rr.FftFilter(np.ones(0, np.complex64))
+
+
+def test_fftfilter_float(rr):
+    x = rnd_f(300_000, 5)
+    taps = orc.low_pass(200e3, 44.1e3, 500.0)
+    both(rr, lambda m: [m.FftFilterFloat(taps)], x)
+    both(rr, lambda m: [m.FftFilterFloat(taps)], x, stream_bytes=4 * 30_000)
+
+
+@pytest.mark.parametrize("I,D", [(1, 1), (1, 6), (25, 128), (3, 2), (200000, 1024000), (48, 200), (7, 3), (1, 1000)])
+@pytest.mark.parametrize("dtype", [np.complex64, np.uint32, np.uint8, np.uint16])
+def test_resampler_bit_exact(rr, I, D, dtype):
+    n = 100_003
+    if np.dtype(dtype) == np.complex64:
+        x = rnd_c(n, I + D)
+    else:
+        x = (np.arange(n) * 2654435761 % (1 << 32)).astype(np.uint64).astype(dtype)
+    both(rr, lambda m: [m.RationalResampler(I, D, dtype)], x, exact=True)
+    both(rr, lambda m: [m.RationalResampler(I, D, dtype)], x, exact=True, stream_bytes=np.dtype(dtype).itemsize * 4001)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_quaddemod(rr, mode):
+    x = rnd_c(300_000, 8)
+    x[100:110] = 0          # zero runs: atan2(0,0) must be exactly 0 (quadrature_demod.rs:211-219)
+    gain = 0.7
+    both(rr, lambda m: [m.QuadratureDemod(gain, mode)], x, scale=np.pi * gain)
+    yg = run_chain([rr.QuadratureDemod(gain, mode)], x)
+    assert np.all(yg[100:109] == 0.0)
+
+
+@pytest.mark.parametrize("L,w", [(65, 0), (3, 0), (129, 1), (255, 2)])
+def test_hilbert(rr, L, w):
+    x = rnd_f(200_000, L)
+    both(rr, lambda m: [m.Hilbert(L, w)], x)
+    both(rr, lambda m: [m.Hilbert(L, w)], x, stream_bytes=4 * 7777)
+
+
+def test_hilbert_rejects_even(rr):
+    for n in (0, 1, 2, 64):
+        with pytest.raises(ValueError):
+            rr.Hilbert(n)
+
+
+def test_fm_chain_cfg3(rr):
+    """BASELINE configs[2]: FftFilter(463 taps) -> RationalResampler(1:6) -> QuadratureDemod @2.4 Msps."""
+    fs = 2.4e6
+    n = 1_200_000
+    t = np.arange(n, dtype=np.float64)
+    phi = 2 * np.pi * np.cumsum(150e3 + 75e3 * np.sin(2 * np.pi * 1e3 * t / fs)) / fs
+    r = np.random.default_rng(0x5EED0003)
+    x = (np.exp(1j * phi) + 0.01 * (r.standard_normal(n) + 1j * r.standard_normal(n))).astype(np.complex64)
+    taps = orc.low_pass_complex(fs, 100e3, 12.5e3)
+    assert len(taps) == 463
+    both(rr, lambda m: [m.FftFilter(taps), m.RationalResampler(1, 6), m.QuadratureDemod(1.0)], x, scale=np.pi)
+
+
+def test_channelizer_cfg5(rr):
+    """BASELINE configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8)."""
+    x = rnd_f(800_000, 0x5EED0005)
+    taps = orc.low_pass_complex(100e6, 5e6, 943e3)
+    assert len(taps) == 255
+    both(rr, lambda m: [m.Hilbert(65), m.FirFilter(taps, deci=8)], x)
+
+
+def test_device_window_api(rr):
+    """rr_block_work_dev: device-resident windows (torch tensors only provide the memory)."""
+    import torch
+    taps = orc.low_pass_complex(10e6, 1e6, 60e3)
+    x = rnd_c(1_000_000, 9)
+    yo = run_chain([orc.FftFilter(taps)], x, stream_bytes=8 * len(x))
+    dx = torch.from_numpy(x.view(np.float32)).cuda()
+    dy = torch.zeros(2 * len(x), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    b = rr.FftFilter(taps)
+    st, c, p, need = b.work_dev(dx.data_ptr(), len(x), dy.data_ptr(), len(x))
+    b.sync()
+    assert st == WAIT_SRC and c == len(x) and p == len(yo)
+    yg = dy.cpu().numpy().view(np.complex64)[:p]
+    assert max_norm_err(yg, yo) <= TOL
