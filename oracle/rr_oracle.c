@@ -644,7 +644,7 @@ static int work_hilbert(orc_block *b, const float *in, size_t in_len, orc_c32 *o
     }
     memcpy(b->history, iv + n, sizeof(float) * b->ntaps); /* :125 */
     free(iv);
-    *consumed = n; *produced = n;
+    *consumed = n; *produced = n; *need = 0;
     return ORC_AGAIN;
 }
 
