@@ -1,0 +1,392 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the rustradio hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]:
+    FftFilter, 401 taps (low_pass_complex(10e6, 1e6, 60e3) => reference fft_size 1024,
+    nsamples 623), 10 Msps synthetic Complex<f32>, 10 s = 100,000,000 samples per step.
+Other workloads (--workload, also summarised under "others" in the JSON line):
+    fir          configs[0]: FirFilter<Complex> 127 real taps, 1,000,000 samples
+    fm_chain     configs[2]: FftFilter(463) -> RationalResampler(1:6) -> QuadratureDemod, 2.4 Msps x 10 s
+    channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in)
+
+Multi-GPU (one process per GPU, weak scaling): the path shards by channel — every rank
+filters its own channel of a shared IQ source (channel c uses the low-pass taps shifted to
+f_c, i.e. complex taps, same kernel).  The only collective is the fan-out broadcast of the
+source from rank 0 over RCCL, done before the timed region (inputs resident in HBM).
+
+Prints ONE JSON line (rank 0).  `value` counts input samples entering the first block,
+summed over ranks, per second of max-over-ranks wall time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import rustradio_amd as rr  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+METRIC = "Msamples/s through FIR+FftFilter+Resampler+QuadDemod chain; % HBM roofline"
+
+
+# ---- synthetic inputs (generated on the GPU; torch is plumbing only) -----------------------
+def synth_complex(n, fs, tones_hz, seed, device, chunk=8_000_000):
+    """uniform[-1,1) noise per component + unit tones, Complex<f32> interleaved -> float32[2n]."""
+    out = torch.empty(2 * n, dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        v = torch.rand(m, 2, generator=g, device=device, dtype=torch.float32) * 2 - 1
+        t = torch.arange(s, s + m, device=device, dtype=torch.float64)
+        for f in tones_hz:
+            ph = (2 * math.pi * f / fs) * t
+            v[:, 0] += torch.cos(ph).float() * 0.25
+            v[:, 1] += torch.sin(ph).float() * 0.25
+        out[2 * s:2 * (s + m)] = v.reshape(-1)
+    return out
+
+
+def synth_real(n, fs, tones_hz, seed, device, chunk=16_000_000):
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        v = torch.rand(m, generator=g, device=device, dtype=torch.float32) * 2 - 1
+        t = torch.arange(s, s + m, device=device, dtype=torch.float64)
+        for f in tones_hz:
+            v += torch.cos((2 * math.pi * f / fs) * t).float() * 0.25
+        out[s:s + m] = v
+    return out
+
+
+def synth_fm(n, fs, device, seed, chunk=4_000_000):
+    """Broadcast-FM-like station centred in the channel: 75 kHz deviation, 1 kHz tone, sigma=0.01 noise."""
+    out = torch.empty(2 * n, dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        t = torch.arange(s, s + m, device=device, dtype=torch.float64)
+        # phase = integral of 2 pi * 75e3 * sin(2 pi 1e3 t): closed form
+        ph = -(75e3 / 1e3) * torch.cos(2 * math.pi * 1e3 * t / fs)
+        v = torch.stack([torch.cos(ph), torch.sin(ph)], dim=1).float()
+        v += 0.01 * torch.randn(m, 2, generator=g, device=device, dtype=torch.float32)
+        out[2 * s:2 * (s + m)] = v.reshape(-1)
+    return out
+
+
+# ---- workloads ------------------------------------------------------------------------------
+class Workload:
+    """blocks = device-resident chain; bufs[i] feeds blocks[i]; bufs[-1] is the sink."""
+    name = ""
+    dtype = "f32"
+    alg_bytes_per_sample = 0.0     # SURVEY §8d compulsory traffic per INPUT sample of the chain
+    dominant = 0                   # index of the block whose kernel the roofline object describes
+    dominant_bytes_per_unit = 0.0  # algorithmic bytes of that kernel per sample it consumes
+
+    def step(self, stream):
+        """one pass over the resident batch; returns input samples consumed by the first block"""
+        n_in = self.n
+        for i, b in enumerate(self.blocks):
+            es_out = b.out_dtype.itemsize
+            cap = self.caps[i]
+            st, c, p, need = b.work_dev(self.bufs[i].data_ptr(), n_in, self.bufs[i + 1].data_ptr(), cap, stream)
+            if i == 0:
+                consumed0 = c
+            if i == self.dominant:
+                self.dom_units += c
+            n_in = p
+        return consumed0
+
+
+def chan_taps(taps, fs, f_c):
+    """channel c of a shared source: the low-pass prototype shifted to f_c (complex band-pass)."""
+    if f_c == 0.0:
+        return taps
+    k = np.arange(len(taps), dtype=np.float64)
+    return (taps.astype(np.complex128) * np.exp(2j * np.pi * f_c * k / fs)).astype(np.complex64)
+
+
+def make_fftfilter(dev, rank, world, shared_src):
+    w = Workload()
+    w.name = "FftFilter 401 taps (ref fft_size 1024, nsamples 623), 10 Msps Complex<f32>, 100,000,000 samples/step"
+    w.dtype = "f32"
+    fs, n = 10e6, 100_000_000
+    taps = rr.low_pass_complex(fs, 1e6, 60e3)
+    assert len(taps) == 401
+    f_c = 0.0 if world == 1 else (rank - world // 2) * 250e3
+    blk = rr.FftFilter(chan_taps(taps, fs, f_c))
+    w.blocks = [blk]
+    w.n = n
+    w.bufs = [shared_src(lambda: synth_complex(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0002, dev)),
+              torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev)]
+    w.caps = [n + 1024]
+    w.alg_bytes_per_sample = 16.0
+    w.dominant, w.dominant_bytes_per_unit = 0, 16.0
+    w.fs = fs
+    w.cpu = ("FftFilter", taps)
+    return w
+
+
+def make_fir(dev, rank, world, shared_src):
+    w = Workload()
+    w.name = "FirFilter<Complex> 127 real taps, 1,000,000 samples/step"
+    fs, n = 10e6, 1_000_000
+    taps = rr.low_pass_complex(fs, 1e6, 190e3)
+    assert len(taps) == 127
+    w.blocks = [rr.FirFilter(taps)]
+    w.n = n
+    w.bufs = [shared_src(lambda: synth_complex(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0001, dev)),
+              torch.empty(2 * n, dtype=torch.float32, device=dev)]
+    w.caps = [n]
+    w.alg_bytes_per_sample = 16.0
+    w.dominant, w.dominant_bytes_per_unit = 0, 16.0
+    w.cpu = ("FirFilter", taps)
+    return w
+
+
+def make_fm_chain(dev, rank, world, shared_src):
+    w = Workload()
+    w.name = "FftFilter(463 taps)->RationalResampler(1:6)->QuadratureDemod(exact atan2), 2.4 Msps x 10 s = 24,000,000 samples/step"
+    fs, n = 2.4e6, 24_000_000
+    taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
+    assert len(taps) == 463
+    w.blocks = [rr.FftFilter(taps), rr.RationalResampler(1, 6, np.complex64), rr.QuadratureDemod(1.0, rr.ATAN2_EXACT)]
+    w.n = n
+    w.bufs = [shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0003)),
+              torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev),
+              torch.empty(2 * (n // 6 + 1024), dtype=torch.float32, device=dev),
+              torch.empty(n // 6 + 1024, dtype=torch.float32, device=dev)]
+    w.caps = [n + 1024, n // 6 + 1024, n // 6 + 1024]
+    w.alg_bytes_per_sample = 8.0 + 4.0 / 6.0
+    w.dominant, w.dominant_bytes_per_unit = 0, 16.0
+    w.cpu = ("fm_chain", taps)
+    return w
+
+
+def make_channelizer(dev, rank, world, shared_src):
+    w = Workload()
+    w.name = "Hilbert(65)->FirFilter<Complex>(255 real taps, deci 8), 100 Msps f32 x 1 s = 100,000,000 samples/step"
+    fs, n = 100e6, 100_000_000
+    taps = rr.low_pass_complex(fs, 5e6, 943e3)
+    assert len(taps) == 255
+    w.blocks = [rr.Hilbert(65), rr.FirFilter(taps, deci=8)]
+    w.n = n
+    w.bufs = [shared_src(lambda: synth_real(n, fs, (3e6, 12e6, 37e6), 0x5EED0005, dev)),
+              torch.empty(2 * n, dtype=torch.float32, device=dev),
+              torch.empty(2 * (n // 8 + 8), dtype=torch.float32, device=dev)]
+    w.caps = [n, n // 8 + 8]
+    w.alg_bytes_per_sample = 5.0
+    w.dominant, w.dominant_bytes_per_unit = 0, 12.0
+    w.cpu = ("channelizer", taps)
+    return w
+
+
+WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain, "channelizer": make_channelizer}
+
+
+# ---- measurement ------------------------------------------------------------------------------
+def run_timed(w, steps, warmup, dist, stream):
+    for b in w.blocks:
+        b.set_profiling(False)
+    w.dom_units = 0
+    for _ in range(warmup):
+        w.step(stream.cuda_stream)
+    torch.cuda.synchronize()
+    w.blocks[w.dominant].set_profiling(True)
+    w.dom_units = 0
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(steps):
+        units += w.step(stream.cuda_stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms, launches = w.blocks[w.dominant].profile(reset=True)
+    w.blocks[w.dominant].set_profiling(False)
+    return units, dt, kms, launches, w.dom_units
+
+
+def cpu_baseline(w, seconds=10.0):
+    """The oracle (strict-order C restatement of the reference blocks, oracle/rr_oracle.c)
+    timed on ONE host core over 512,000-sample work() windows (src/stream.rs:105) of the
+    same synthetic input, for about `seconds` of CPU time."""
+    from oracle import pyoracle as orc
+    kind, taps = w.cpu
+    win = 512_000
+    nwin = 16
+    if kind == "channelizer":
+        host = w.bufs[0][:win * 2 * nwin].cpu().numpy()
+        chain = [orc.Hilbert(65), orc.FirFilter(taps, deci=8)]
+        win = 1_024_000
+    else:
+        host = w.bufs[0][:2 * win * nwin].cpu().numpy().view(np.complex64)
+        chain = {"FftFilter": lambda: [orc.FftFilter(taps)],
+                 "FirFilter": lambda: [orc.FirFilter(taps)],
+                 "fm_chain": lambda: [orc.FftFilter(taps), orc.RationalResampler(1, 6), orc.QuadratureDemod(1.0)]}[kind]()
+    nwin = len(host) // win
+    rings = [np.zeros(0, b.in_dtype) for b in chain]
+    t0 = time.perf_counter()
+    fed = 0
+    i = 0
+    while time.perf_counter() - t0 < seconds:
+        chunk = host[(i % nwin) * win:(i % nwin + 1) * win]
+        i += 1
+        rings[0] = np.concatenate([rings[0], chunk])
+        fed += len(chunk)
+        for j, b in enumerate(chain):
+            while True:
+                st, c, p, need, out = b.work(rings[j], 4_096_000 // b.out_dtype.itemsize)
+                rings[j] = rings[j][c:]
+                if j + 1 < len(chain):
+                    rings[j + 1] = np.concatenate([rings[j + 1], out])
+                if st != 0 or (c == 0 and p == 0):
+                    break
+    dt = time.perf_counter() - t0
+    return {"value": round(fed / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{fed} input samples of the same synthetic stream in {win}-sample work() windows, {dt:.1f} s, 1 thread, gcc -O2 strict f32"}
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/pmc_traffic.py); None when not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fftfilter", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other workloads")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (rustradio_amd has no CPU path)")
+    ndev = torch.cuda.device_count()
+    dev_idx = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_idx)
+    rr.set_device(dev_idx)
+    dev = torch.device("cuda", dev_idx)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist = dist_mod
+
+    def shared_src(gen):
+        """fan-out of the shared IQ source: rank 0 synthesises it, RCCL broadcasts it."""
+        if dist is None:
+            return gen()
+        if rank == 0:
+            t = gen()
+            meta = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
+        else:
+            meta = torch.zeros(1, dtype=torch.int64, device=dev)
+        dist.broadcast(meta, src=0)
+        if rank != 0:
+            t = torch.empty(int(meta.item()), dtype=torch.float32, device=dev)
+        tb0 = time.perf_counter()
+        dist.broadcast(t, src=0)
+        torch.cuda.synchronize()
+        shared_src.bcast_gbs = t.numel() * 4 / (time.perf_counter() - tb0) / 1e9
+        return t
+    shared_src.bcast_gbs = None
+
+    stream = torch.cuda.current_stream()
+    w = WORKLOADS[args.workload](dev, rank, world, shared_src)
+    units, dt, kms, launches, dom_units = run_timed(w, args.steps, args.warmup, dist, stream)
+
+    # max over ranks of the wall time, sum over ranks of the units
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        uu = torch.tensor([units], dtype=torch.float64, device=dev)
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+        dt, units_all = float(tt.item()), float(uu.item())
+    else:
+        units_all = float(units)
+
+    others = {}
+    if not args.no_others and world == 1:
+        for name in WORKLOADS:
+            if name == args.workload:
+                continue
+            wo = WORKLOADS[name](dev, rank, world, lambda gen: gen())
+            k = max(3, min(args.steps, 10)) if name != "fir" else 200
+            u, t, km, ln, du = run_timed(wo, k, 2, None, stream)
+            ach = (wo.dominant_bytes_per_unit * du / max(ln, 1)) / (km / max(ln, 1) * 1e-3) / 1e9 if km > 0 else None
+            others[name] = {"workload": wo.name, "msamples_per_s": round(u / t / 1e6, 1),
+                            "ms_per_step": round(t / k * 1e3, 4),
+                            "chain_alg_gbs": round(wo.alg_bytes_per_sample * u / t / 1e9, 1),
+                            "dominant_kernel_alg_gbs": None if ach is None else round(ach, 1)}
+            del wo
+            torch.cuda.empty_cache()
+
+    if rank == 0:
+        value = units_all / dt / 1e6
+        avg_kernel_s = (kms / max(launches, 1)) * 1e-3
+        alg_bytes_per_launch = w.dominant_bytes_per_unit * dom_units / max(launches, 1)
+        achieved = alg_bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        line = {
+            "metric": METRIC, "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": w.dtype, "data": "synthetic",
+            "config": {"workload": w.name, "samples_per_step_per_gpu": w.n,
+                       "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
+                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain") else ("k_fir" if args.workload != "channelizer" else "k_fir<hilbert>"),
+                         "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
+                         "alg_bytes_per_launch": alg_bytes_per_launch},
+            "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),
+        }
+        if shared_src.bcast_gbs is not None:
+            line["source_broadcast_gbs"] = round(shared_src.bcast_gbs, 1)
+        if others:
+            line["others"] = others
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+            line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,12 @@ size_t      rr_block_out_elem_size(const rr_block *b);
 /* Wait for everything the block enqueued on its own stream. */
 int         rr_block_sync(rr_block *b);
 
+/* Measurement aid: when enabled, every work call brackets the block's dominant kernel
+ * with HIP events on the stream it is launched on; rr_block_profile waits for them and
+ * returns the summed kernel time and the number of launches (reset != 0 clears them). */
+int rr_block_set_profiling(rr_block *b, int on);
+int rr_block_profile(rr_block *b, double *total_ms, size_t *launches, int reset);
+
 /* ---- per-block knobs / introspection ------------------------------------------- */
 /* FftFilter: reference fft_size and nsamples (src/fft_filter.rs:261-262) and the
  * internal overlap-save tile the GPU kernel uses. */

@@ -139,6 +139,16 @@ class Block:
         if lib().rr_block_sync(self._h) != 0:
             raise RuntimeError(last_error())
 
+    def set_profiling(self, on: bool) -> None:
+        lib().rr_block_set_profiling(self._h, int(on))
+
+    def profile(self, reset: bool = True):
+        """-> (summed dominant-kernel time in ms, launches), from HIP events on the launch stream."""
+        ms, n = C.c_double(0), C.c_size_t(0)
+        if lib().rr_block_profile(self._h, C.byref(ms), C.byref(n), int(reset)) != 0:
+            raise RuntimeError(last_error())
+        return ms.value, n.value
+
 
 def FirFilter(taps, deci: int = 1, translate=None, rotator: int = ROT_MODEL) -> Block:
     """FirFilter::builder(taps).deci(deci).translate(samp_rate, freq).build(src)."""

@@ -135,6 +135,17 @@ int rr_block_sync(rr_block* b) {
     try { b->b->sync(); return 0; } catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
 }
 
+int rr_block_set_profiling(rr_block* b, int on) {
+    if (!b) return RR_ERR;
+    b->b->prof_on = on != 0;
+    return 0;
+}
+int rr_block_profile(rr_block* b, double* total_ms, size_t* launches, int reset) {
+    if (!b) return RR_ERR;
+    try { RR_HIP(hipSetDevice(b->b->device)); b->b->prof_read(total_ms, launches, reset != 0); return 0; }
+    catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
+}
+
 int rr_fftfilter_dims(const rr_block* b, size_t* fft_size, size_t* nsamples, size_t* gpu_fft_size) {
     if (!b) return RR_ERR;
     const rr::FftFilter* f = dynamic_cast<const rr::FftFilter*>(b->b.get());

@@ -30,6 +30,7 @@ Block::Block(const char* nm, size_t ies, size_t oes) : name(nm), in_es(ies), out
     RR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 }
 Block::~Block() {
+    for (auto& e : prof_evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (stream) {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
@@ -40,17 +41,44 @@ void Block::sync() {
     RR_HIP(hipSetDevice(device));
     RR_HIP(hipStreamSynchronize(stream));
 }
+void Block::prof_begin(hipStream_t s) {
+    if (!prof_on) return;
+    if (prof_used == prof_evs.size()) {
+        hipEvent_t a, b;
+        RR_HIP(hipEventCreate(&a));
+        RR_HIP(hipEventCreate(&b));
+        prof_evs.emplace_back(a, b);
+    }
+    RR_HIP(hipEventRecord(prof_evs[prof_used].first, s));
+}
+void Block::prof_end(hipStream_t s) {
+    if (!prof_on) return;
+    RR_HIP(hipEventRecord(prof_evs[prof_used].second, s));
+    prof_used++;
+}
+void Block::prof_read(double* total_ms, size_t* launches, bool reset) {
+    double t = 0;
+    for (size_t i = 0; i < prof_used; i++) {
+        RR_HIP(hipEventSynchronize(prof_evs[i].second));
+        float ms = 0;
+        RR_HIP(hipEventElapsedTime(&ms, prof_evs[i].first, prof_evs[i].second));
+        t += ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = prof_used;
+    if (reset) prof_used = 0;
+}
 bool Block::eof(bool src_eof) { return src_eof; }   // rustradio_macros_code/src/lib.rs:596-623
 
 // Host-window work(): stage the windows through device memory around work_dev().
 int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                      size_t* produced, size_t* need) {
     RR_HIP(hipSetDevice(device));
-    const size_t in_use = std::min(in_len, host_in_limit(in_len, out_cap));
+    const size_t in_use = in_len;   // whole window: kernels may touch (zero-weighted) samples past the consumed range
     st_in.reserve(std::max<size_t>(in_use * in_es, 16));
     st_out.reserve(std::max<size_t>(out_cap * out_es, 16));
     if (in_use) RR_HIP(hipMemcpyAsync(st_in.p, in, in_use * in_es, hipMemcpyHostToDevice, stream));
-    int st = work_dev(st_in.p, in_use, st_out.p, out_cap, consumed, produced, need, stream);
+    int st = work_dev(st_in.p, in_len, st_out.p, out_cap, consumed, produced, need, stream);
     if (*produced) RR_HIP(hipMemcpyAsync(out, st_out.p, *produced * out_es, hipMemcpyDeviceToHost, stream));
     RR_HIP(hipStreamSynchronize(stream));
     return st;
@@ -112,15 +140,6 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     RR_HIP(hipStreamSynchronize(stream));
 }
 
-size_t FirC32::host_in_limit(size_t in_len, size_t out_cap) const {
-    // only n + ntaps - 1 samples are read (fir.rs:507)
-    const size_t L = pl.L, d = pl.d;
-    if (in_len < L + d - 1 || out_cap == 0) return 0;
-    size_t n = d * ((in_len - L + 1) / d);
-    n = std::min(n, out_cap * d);
-    return n + L - 1;
-}
-
 int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                      size_t* produced, size_t* need, hipStream_t s) {
     const size_t L = pl.L, d = pl.d;
@@ -132,7 +151,9 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     n = std::min(n, out_cap * d);                                    // fir.rs:518
     const size_t out_n = n / d;
     VSrc<cf> src{nullptr, 0, static_cast<const cf*>(in), (long)in_len};
+    prof_begin(s);
     launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
+    prof_end(s);
     if (rot_on) {                                                    // fir.rs:531, 464-473
         if (rot_mode == RR_ROT_REPLAY) {
             h_tab.resize(out_n);
@@ -166,13 +187,6 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
     d_tp.upload(tp.data(), tp.size(), stream);
     RR_HIP(hipStreamSynchronize(stream));
 }
-size_t FirF32::host_in_limit(size_t in_len, size_t out_cap) const {
-    const size_t L = pl.L, d = pl.d;
-    if (in_len < L + d - 1 || out_cap == 0) return 0;
-    size_t n = d * ((in_len - L + 1) / d);
-    n = std::min(n, out_cap * d);
-    return n + L - 1;
-}
 int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                      size_t* produced, size_t* need, hipStream_t s) {
     const size_t L = pl.L, d = pl.d;
@@ -182,7 +196,9 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     if (out_cap < 1) { *need = 1; return RR_WAIT_DST; }
     n = std::min(n, out_cap * d);
     VSrc<float> src{nullptr, 0, static_cast<const float*>(in), (long)in_len};
+    prof_begin(s);
     launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
+    prof_end(s);
     *consumed = n; *produced = n / d;
     return RR_AGAIN;
 }
@@ -282,7 +298,11 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     const size_t n_out = k * S;
     const long plen = (long)(L - 1 + pend_len);
     VSrc<cf> src{prefix[cur].p, plen, static_cast<const cf*>(in), (long)in_len};
-    if (k) launch_fftfilt_os(log2f, src, static_cast<cf*>(out), (long)n_out, (int)L, d_tw.p, d_hpos.p, s);
+    if (k) {
+        prof_begin(s);
+        launch_fftfilt_os(log2f, src, static_cast<cf*>(out), (long)n_out, (int)L, d_tw.p, d_hpos.p, s);
+        prof_end(s);
+    }
     if (*consumed) {
         // new carry = last L-1 samples before the first unprocessed one, then the unprocessed tail
         launch_vcopy_c32(src, (long)n_out, prefix[cur ^ 1].p, (long)(L - 1 + new_pend), s);
@@ -375,7 +395,9 @@ int Resampler::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     const __int128 a = (__int128)c0 + (__int128)n * I;
     const int64_t m_total = a <= 0 ? 0 : (int64_t)((a + D - 1) / D);
     if (m_total < capp) {                                                      // all input taken
+        prof_begin(s);
         launch_resample(in, out, in_es, r, d_pending.p, m_total, I, D, c0, s);
+        prof_end(s);
         counter = (int64_t)(a - (__int128)m_total * D);
         *consumed = in_len; *produced = (size_t)(r + m_total);
         return RR_WAIT_SRC;                                                    // :204
@@ -403,7 +425,9 @@ int QuadDemod::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     if (in_len < 2) { *need = 2; return RR_WAIT_SRC; }                         // :49-51
     if (out_cap == 0) { *need = 1; return RR_WAIT_DST; }                       // :53-55
     const size_t n1 = std::min(in_len - 1, out_cap);                           // :56
+    prof_begin(s);
     launch_quaddemod(static_cast<const cf*>(in), static_cast<float*>(out), (long)n1, gain, mode, s);
+    prof_end(s);
     *consumed = *produced = n1;                                                // :110-111
     // the reference loops: the next iteration returns the wait
     if (in_len - n1 < 2) { *need = 2; return RR_WAIT_SRC; }
@@ -436,7 +460,9 @@ int Hilbert::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     if (out_cap == 0) return RR_WAIT_DST;                                       // :81-83
     const size_t n = std::min(in_len, out_cap);                                 // :85-87
     VSrc<float> src{hist[cur].p, (long)pl.L, static_cast<const float*>(in), (long)in_len};
+    prof_begin(s);
     launch_hilbert(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)n, s);
+    prof_end(s);
     launch_vcopy_f32(src, (long)n, hist[cur ^ 1].p, (long)pl.L, s);            // :125
     cur ^= 1;
     *consumed = *produced = n; *need = 0;

@@ -26,11 +26,17 @@ struct Block {
     virtual int work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                          size_t* produced, size_t* need, hipStream_t s) = 0;
     virtual bool eof(bool src_eof);
-    // how much of the input window a host-window call must upload
-    virtual size_t host_in_limit(size_t in_len, size_t /*out_cap*/) const { return in_len; }
     int work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                   size_t* produced, size_t* need);
     void sync();
+
+    // optional HIP-event timing of the block's dominant kernel (bench.py's roofline figure)
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_evs;
+    size_t prof_used = 0;
+    void prof_begin(hipStream_t s);
+    void prof_end(hipStream_t s);
+    void prof_read(double* total_ms, size_t* launches, bool reset);
 };
 
 struct FirC32 : Block {
@@ -43,7 +49,6 @@ struct FirC32 : Block {
     size_t n_rot = 0;                             // outputs rotated so far
     std::vector<cf> h_tab;
     FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq);
-    size_t host_in_limit(size_t in_len, size_t out_cap) const override;
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 
@@ -51,7 +56,6 @@ struct FirF32 : Block {
     FirPlan pl;
     DevBuf<float> d_tp, d_rev;
     FirF32(const float* taps, size_t ntaps, size_t deci);
-    size_t host_in_limit(size_t in_len, size_t out_cap) const override;
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 
