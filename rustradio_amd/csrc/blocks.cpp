@@ -132,7 +132,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
         d_tp.upload(reinterpret_cast<unsigned char*>(tp.data()), tp.size() * 4, stream);
     } else {
         std::vector<cf> rev(ntaps), tp;
-        for (size_t j = 0; j < ntaps; j++) rev[j] = mk(t[ntaps - 1 - j].real(), t[ntaps - 1 - j].imag());
+        for (size_t j = 0; j < ntaps; j++) rev[j] = mkcf(t[ntaps - 1 - j].real(), t[ntaps - 1 - j].imag());
         build_poly(rev, pl.d, pl.qpad, tp);
         d_rev.upload(reinterpret_cast<unsigned char*>(rev.data()), rev.size() * 8, stream);
         d_tp.upload(reinterpret_cast<unsigned char*>(tp.data()), tp.size() * 8, stream);
@@ -158,7 +158,7 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
         if (rot_mode == RR_ROT_REPLAY) {
             h_tab.resize(out_n);
             for (size_t i = 0; i < out_n; i++) {                     // the reference's f32 recurrence
-                h_tab[i] = mk(cur_x, cur_y);
+                h_tab[i] = mkcf(cur_x, cur_y);
                 const float nx = cur_x * stx - cur_y * sty, ny = cur_x * sty + cur_y * stx;
                 cur_x = nx; cur_y = ny;
             }
@@ -235,7 +235,7 @@ template <int LOG2F> static void fill_hpos(const std::vector<std::complex<double
     hpos.resize(F);
     for (int p = 0; p < F; p++) {
         const auto h = H[bin_of_pos<LOG2F>(p)];
-        hpos[p] = mk((float)h.real(), (float)h.imag());
+        hpos[p] = mkcf((float)h.real(), (float)h.imag());
     }
 }
 
@@ -266,7 +266,7 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8
     }
     for (size_t k = 0; k < F; k++) {
         const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)F;
-        tw[k] = mk((float)std::cos(a), (float)std::sin(a));
+        tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
     }
     d_hpos.upload(hpos.data(), F, stream);
     d_tw.upload(tw.data(), F, stream);

@@ -24,75 +24,128 @@
 
 namespace rr {
 
-struct cf { float x, y; };
+struct alignas(8) cf { float x, y; };   // Complex<f32>, interleaved (src/lib.rs:268-271)
+RR_HD cf mkcf(float x, float y) { cf r; r.x = x; r.y = y; return r; }
 
-RR_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
-RR_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
-RR_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-RR_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-// a * conj(b)
-RR_HD cf cmulc(cf a, cf b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
-RR_HD cf mul_mj(cf a) { return mk(a.y, -a.x); }   // -j * a
-RR_HD cf mul_pj(cf a) { return mk(-a.y, a.x); }   // +j * a
-template <bool INV> RR_HD cf mul_w4(cf a) { return INV ? mul_pj(a) : mul_mj(a); }  // w4^1 (or conj)
+// Register type of the transform.  On the device a complex value lives in an aligned VGPR
+// pair (ext_vector float2) so that complex add/sub are single v_pk_add_f32 and a complex
+// multiply is v_pk_mul_f32 + v_pk_fma_f32: the +-j rotations and the (-im, re) swizzle of
+// the multiply ride on the VOP3P op_sel / neg modifiers instead of costing instructions.
+// hipcc only emits those modifiers for splats and negation, so the swizzled forms are
+// written as (non-volatile, register-only) inline asm.  On the host (CPU emulation test)
+// the same functions are plain C++.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float creg __attribute__((ext_vector_type(2)));
+RR_HD creg mk(float x, float y) { creg r; r.x = x; r.y = y; return r; }
+RR_HD creg cadd(creg a, creg b) { return a + b; }
+RR_HD creg csub(creg a, creg b) { return a - b; }
+// a + (-j) b = (a.x + b.y, a.y - b.x)
+RR_HD creg add_mj(creg a, creg b) {
+    creg r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + (+j) b = (a.x - b.y, a.y + b.x)
+RR_HD creg add_pj(creg a, creg b) {
+    creg r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * w = a * w.xx + (-a.y, a.x) * w.yy
+RR_HD creg cmul(creg a, creg w) {
+    creg t = a * __builtin_shufflevector(w, w, 0, 0), r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * conj(w) = a * w.xx + (a.y, -a.x) * w.yy
+RR_HD creg cmulc(creg a, creg w) {
+    creg t = a * __builtin_shufflevector(w, w, 0, 0), r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+RR_HD creg to_reg(cf a) { return mk(a.x, a.y); }
+RR_HD cf from_reg(creg a) { cf r; r.x = a.x; r.y = a.y; return r; }
+#else
+typedef cf creg;
+RR_HD creg mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+RR_HD creg cadd(creg a, creg b) { return mk(a.x + b.x, a.y + b.y); }
+RR_HD creg csub(creg a, creg b) { return mk(a.x - b.x, a.y - b.y); }
+RR_HD creg add_mj(creg a, creg b) { return mk(a.x + b.y, a.y - b.x); }
+RR_HD creg add_pj(creg a, creg b) { return mk(a.x - b.y, a.y + b.x); }
+RR_HD creg cmul(creg a, creg b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+RR_HD creg cmulc(creg a, creg b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+RR_HD creg to_reg(cf a) { return a; }
+RR_HD cf from_reg(creg a) { return a; }
+#endif
 
 constexpr float kSqrtHalf = 0.70710678118654752440f;
 constexpr float kCos8 = 0.92387953251128675613f;   // cos(pi/8)
 constexpr float kSin8 = 0.38268343236508977173f;   // sin(pi/8)
 
+// a + w4 b and a - w4 b, w4 = -j (forward) or +j (inverse): the rotation is free
+template <bool INV> RR_HD creg add_w4(creg a, creg b) { return INV ? add_pj(a, b) : add_mj(a, b); }
+template <bool INV> RR_HD creg sub_w4(creg a, creg b) { return INV ? add_mj(a, b) : add_pj(a, b); }
+
 // multiply by w16^M = exp(-2 pi i M / 16) (forward) or its conjugate (INV)
-template <int M, bool INV> RR_HD cf mul_w16(cf a) {
+template <int M, bool INV> RR_HD creg mul_w16(creg a) {
     constexpr int m = ((M % 16) + 16) % 16;
+    const creg zero = mk(0.0f, 0.0f);
     if constexpr (m == 0) return a;
-    else if constexpr (m == 4) return mul_w4<INV>(a);
-    else if constexpr (m == 8) return mk(-a.x, -a.y);
-    else if constexpr (m == 12) return mul_w4<!INV>(a);
-    else if constexpr (m == 2) {  // (1 - j)/sqrt2 fwd
-        return INV ? mk((a.x - a.y) * kSqrtHalf, (a.x + a.y) * kSqrtHalf)
-                   : mk((a.x + a.y) * kSqrtHalf, (a.y - a.x) * kSqrtHalf);
-    } else if constexpr (m == 6) {  // (-1 - j)/sqrt2 fwd
-        return INV ? mk((-a.x - a.y) * kSqrtHalf, (a.x - a.y) * kSqrtHalf)
-                   : mk((a.y - a.x) * kSqrtHalf, (-a.x - a.y) * kSqrtHalf);
-    } else if constexpr (m == 10) { cf t = mul_w16<2, INV>(a); return mk(-t.x, -t.y); }
-    else if constexpr (m == 14) { cf t = mul_w16<6, INV>(a); return mk(-t.x, -t.y); }
-    else {
-        // generic: w = (c, -s) forward
+    else if constexpr (m == 4) return add_w4<INV>(zero, a);
+    else if constexpr (m == 8) return csub(zero, a);
+    else if constexpr (m == 12) return sub_w4<INV>(zero, a);
+    else if constexpr (m == 2) {   // (1 -+ j)/sqrt2 : (a + w4 a) / sqrt2
+        creg t = add_w4<INV>(a, a);
+        return mk(t.x * kSqrtHalf, t.y * kSqrtHalf);
+    } else if constexpr (m == 6) { // (-1 -+ j)/sqrt2 : (w4 a - a) / sqrt2 = -(a - w4 a)/sqrt2
+        creg t = sub_w4<INV>(a, a);
+        return mk(t.x * -kSqrtHalf, t.y * -kSqrtHalf);
+    } else if constexpr (m == 10) {
+        creg t = add_w4<INV>(a, a);
+        return mk(t.x * -kSqrtHalf, t.y * -kSqrtHalf);
+    } else if constexpr (m == 14) {
+        creg t = sub_w4<INV>(a, a);
+        return mk(t.x * kSqrtHalf, t.y * kSqrtHalf);
+    } else {
+        // generic: forward w = (c, -s), s = sin(pi m / 8), c = cos(pi m / 8)
         constexpr float c = (m == 1 || m == 15) ? kCos8 : (m == 3 || m == 13) ? kSin8
                           : (m == 5 || m == 11) ? -kSin8 : -kCos8;            // m == 7, 9
         constexpr float s = (m == 1 || m == 7) ? kSin8 : (m == 3 || m == 5) ? kCos8
                           : (m == 9 || m == 15) ? -kSin8 : -kCos8;            // m == 11, 13
-        const cf w = mk(c, INV ? s : -s);
-        return cmul(a, w);
+        const creg w = mk(c, -s);
+        return INV ? cmulc(a, w) : cmul(a, w);
     }
 }
 
-template <bool INV> RR_HD void bfly2(cf& a, cf& b) {
-    cf t = csub(a, b);
+template <bool INV> RR_HD void bfly2(creg& a, creg& b) {
+    creg t = csub(a, b);
     a = cadd(a, b);
     b = t;
 }
 
 // natural-order 4-point DFT in place
-template <bool INV> RR_HD void bfly4(cf& a0, cf& a1, cf& a2, cf& a3) {
-    cf t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_w4<INV>(csub(a1, a3));
+template <bool INV> RR_HD void bfly4(creg& a0, creg& a1, creg& a2, creg& a3) {
+    creg t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
     a0 = cadd(t0, t2);
     a2 = csub(t0, t2);
-    a1 = cadd(t1, t3);
-    a3 = csub(t1, t3);
+    a1 = add_w4<INV>(t1, t3);
+    a3 = sub_w4<INV>(t1, t3);
 }
 
 // R-point DFT of v[0..R) (stride 1 in the register array), natural order in and out.
 template <int R, bool INV> struct Dft;
 
 template <bool INV> struct Dft<2, INV> {
-    static RR_HD void run(cf* v) { bfly2<INV>(v[0], v[1]); }
+    static RR_HD void run(creg* v) { bfly2<INV>(v[0], v[1]); }
 };
 template <bool INV> struct Dft<4, INV> {
-    static RR_HD void run(cf* v) { bfly4<INV>(v[0], v[1], v[2], v[3]); }
+    static RR_HD void run(creg* v) { bfly4<INV>(v[0], v[1], v[2], v[3]); }
 };
 template <bool INV> struct Dft<8, INV> {
     // n = 2 n1 + n2 (N1 = 4, N2 = 2), k = k1 + 4 k2
-    static RR_HD void run(cf* v) {
+    static RR_HD void run(creg* v) {
         bfly4<INV>(v[0], v[2], v[4], v[6]);
         bfly4<INV>(v[1], v[3], v[5], v[7]);
         v[3] = mul_w16<2, INV>(v[3]);   // w8^1
@@ -100,13 +153,13 @@ template <bool INV> struct Dft<8, INV> {
         v[7] = mul_w16<6, INV>(v[7]);   // w8^3
         bfly2<INV>(v[0], v[1]); bfly2<INV>(v[2], v[3]); bfly2<INV>(v[4], v[5]); bfly2<INV>(v[6], v[7]);
         // v[2 k1 + k2] = X[k1 + 4 k2]  ->  natural order
-        cf t1 = v[1], t2 = v[2], t3 = v[3], t4 = v[4], t5 = v[5], t6 = v[6];
+        creg t1 = v[1], t2 = v[2], t3 = v[3], t4 = v[4], t5 = v[5], t6 = v[6];
         v[1] = t2; v[2] = t4; v[3] = t6; v[4] = t1; v[5] = t3; v[6] = t5;
     }
 };
 template <bool INV> struct Dft<16, INV> {
     // n = 4 n1 + n2, k = k1 + 4 k2
-    static RR_HD void run(cf* v) {
+    static RR_HD void run(creg* v) {
         bfly4<INV>(v[0], v[4], v[8], v[12]);
         bfly4<INV>(v[1], v[5], v[9], v[13]);
         bfly4<INV>(v[2], v[6], v[10], v[14]);
@@ -120,7 +173,7 @@ template <bool INV> struct Dft<16, INV> {
         bfly4<INV>(v[8], v[9], v[10], v[11]);
         bfly4<INV>(v[12], v[13], v[14], v[15]);
         // v[4 k1 + k2] = X[k1 + 4 k2]  -> transpose 4x4 to natural order
-        cf t;
+        creg t;
         t = v[1]; v[1] = v[4]; v[4] = t;
         t = v[2]; v[2] = v[8]; v[8] = t;
         t = v[3]; v[3] = v[12]; v[12] = t;
@@ -176,18 +229,18 @@ constexpr int lds_elems(int F) { return F + (F >> 4); }
 // Per-thread twiddles of pass I: twl[k-1] = w_{R P}^{k lo} = tw[k * lo * TWSTRIDE], k = 1..15.
 // Only radix-16 passes (one group per thread) carry twiddles in every Plan above.
 template <int LOG2F, int I> RR_HD constexpr bool pass_has_twiddles() { return PassGeom<LOG2F, I>::P > 1; }
-template <int LOG2F, int I> RR_HD void load_twiddles(cf* twl, int t, const cf* __restrict__ tw) {
+template <int LOG2F, int I> RR_HD void load_twiddles(creg* twl, int t, const cf* __restrict__ tw) {
     using G = PassGeom<LOG2F, I>;
     static_assert(G::P == 1 || G::U == 1, "twiddled passes must be radix 16");
     if constexpr (G::P > 1) {
         const int lo = G::lo(t);
 #pragma unroll
-        for (int k = 1; k < 16; k++) twl[k - 1] = tw[k * lo * G::TWSTRIDE];
+        for (int k = 1; k < 16; k++) twl[k - 1] = to_reg(tw[k * lo * G::TWSTRIDE]);
     }
 }
 // One forward pass on the 16 registers of a thread.  `v[u*R + n]` = element n of group
 // (t + T u); twl = this thread's twiddles for the pass (unused when P == 1).
-template <int LOG2F, int I> RR_HD void fwd_pass(cf* v, const cf* twl) {
+template <int LOG2F, int I> RR_HD void fwd_pass(creg* v, const creg* twl) {
     using G = PassGeom<LOG2F, I>;
 #pragma unroll
     for (int u = 0; u < G::U; u++) Dft<G::R, false>::run(v + u * G::R);
@@ -197,7 +250,7 @@ template <int LOG2F, int I> RR_HD void fwd_pass(cf* v, const cf* twl) {
     }
 }
 // Mirror: conj twiddle first, then inverse DFT of the digit.
-template <int LOG2F, int I> RR_HD void inv_pass(cf* v, const cf* twl) {
+template <int LOG2F, int I> RR_HD void inv_pass(creg* v, const creg* twl) {
     using G = PassGeom<LOG2F, I>;
     if constexpr (G::P > 1) {
 #pragma unroll
@@ -222,31 +275,31 @@ template <int LOG2F, int I> RR_HD constexpr int lds_off(int u, int n) {
     if (G::P == 1) return n + u * G::R * G::T + ((u * G::R * G::T) >> 4);
     return n * G::P + ((n * G::P) >> 4);
 }
-template <int LOG2F, int I> RR_HD void lds_store(const cf* v, int t, cf* lds) {
+template <int LOG2F, int I> RR_HD void lds_store(const creg* v, int t, creg* lds) {
     using G = PassGeom<LOG2F, I>;
-    cf* b = lds + lds_base<LOG2F, I>(t);
+    creg* b = lds + lds_base<LOG2F, I>(t);
 #pragma unroll
     for (int u = 0; u < G::U; u++)
 #pragma unroll
         for (int n = 0; n < G::R; n++) b[lds_off<LOG2F, I>(u, n)] = v[u * G::R + n];
 }
-template <int LOG2F, int I> RR_HD void lds_load(cf* v, int t, const cf* lds) {
+template <int LOG2F, int I> RR_HD void lds_load(creg* v, int t, const creg* lds) {
     using G = PassGeom<LOG2F, I>;
-    const cf* b = lds + lds_base<LOG2F, I>(t);
+    const creg* b = lds + lds_base<LOG2F, I>(t);
 #pragma unroll
     for (int u = 0; u < G::U; u++)
 #pragma unroll
         for (int n = 0; n < G::R; n++) v[u * G::R + n] = b[lds_off<LOG2F, I>(u, n)];
 }
 // H in position order: this thread's 16 values for the layout of pass I
-template <int LOG2F, int I> RR_HD void load_h(cf* h, int t, const cf* __restrict__ hpos) {
+template <int LOG2F, int I> RR_HD void load_h(creg* h, int t, const cf* __restrict__ hpos) {
     using G = PassGeom<LOG2F, I>;
 #pragma unroll
     for (int u = 0; u < G::U; u++)
 #pragma unroll
-        for (int n = 0; n < G::R; n++) h[u * G::R + n] = hpos[G::pos(t + G::T * u, n)];
+        for (int n = 0; n < G::R; n++) h[u * G::R + n] = to_reg(hpos[G::pos(t + G::T * u, n)]);
 }
-RR_HD void apply_h(cf* v, const cf* h) {
+RR_HD void apply_h(creg* v, const creg* h) {
 #pragma unroll
     for (int n = 0; n < 16; n++) v[n] = cmul(v[n], h[n]);
 }

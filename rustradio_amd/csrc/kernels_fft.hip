@@ -15,13 +15,12 @@ namespace rr {
 // twiddles and H are re-read from L1/L2 per tile.
 template <int LOG2F> struct KCfg {
     static constexpr bool PERSIST = LOG2F <= 12;
-    static constexpr bool PREFETCH = false;
     static constexpr int T = 1 << (LOG2F - 4);
     static constexpr int WAVES_PER_SIMD = PERSIST ? WPS : (T / 64 + 3) / 4;
 };
 
 template <int LOG2F, int I, bool PERSIST>
-__device__ __forceinline__ void get_tw(cf* dst, const cf* persist, int t, const cf* __restrict__ tw) {
+__device__ __forceinline__ void get_tw(creg* dst, const creg* persist, int t, const cf* __restrict__ tw) {
     if constexpr (pass_has_twiddles<LOG2F, I>()) {
         if constexpr (PERSIST) {
 #pragma unroll
@@ -32,6 +31,22 @@ __device__ __forceinline__ void get_tw(cf* dst, const cf* persist, int t, const 
     }
 }
 
+// Workgroup b -> tile sequence.  The dispatcher places workgroup b on XCD b % 8 (observed,
+// used for speed only): each XCD gets one contiguous eighth of the tiles and its
+// workgroups sweep it together, so the L-1 samples two neighbouring tiles share are
+// fetched from HBM once and re-read from that XCD's L2.
+struct TileIter {
+    long tile, end, step;
+    __device__ __forceinline__ TileIter(long ntiles) {
+        const int b = blockIdx.x, g = gridDim.x;
+        const int nx = g < 8 ? g : 8;                  // partitions (XCDs that have a workgroup)
+        const int xcd = b % nx, slot = b / nx;
+        const int gx = (g - xcd + nx - 1) / nx;        // workgroups in this partition
+        const long lo = ntiles * xcd / nx, hi = ntiles * (xcd + 1) / nx;
+        tile = lo + slot; end = hi; step = gx;
+    }
+};
+
 template <int LOG2F>
 __global__ __launch_bounds__(KCfg<LOG2F>::T, KCfg<LOG2F>::WAVES_PER_SIMD)
 void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles,
@@ -41,44 +56,36 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
     constexpr int NP = Plan<LOG2F>::NP;
     constexpr bool PERSIST = KCfg<LOG2F>::PERSIST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf* lds = reinterpret_cast<cf*>(smem_raw);
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
     const int t = threadIdx.x;
     const long S = F - L + 1;
+    const int first = L - 1;                 // first valid position of a tile
 
     // persistent per-thread constants (PERSIST only)
-    cf tw0[15], tw1[15], tw2[15], hreg[16];
+    creg tw0[15], tw1[15], tw2[15], hreg[16];
     if constexpr (PERSIST) {
         load_twiddles<LOG2F, 0>(tw0, t, tw);
         load_twiddles<LOG2F, 1>(tw1, t, tw);
         load_twiddles<LOG2F, 2>(tw2, t, tw);
         load_h<LOG2F, NP - 1>(hreg, t, hpos);
     }
+    const creg* in_reg = reinterpret_cast<const creg*>(src.in);
+    creg* out_reg = reinterpret_cast<creg*>(out);
 
-    constexpr bool PREFETCH = KCfg<LOG2F>::PREFETCH;
-    long tile = blockIdx.x;
-    cf nxt[16];
-    if constexpr (PREFETCH) {
-        if (tile < ntiles) {
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long tile = it.tile;
+        const long v0 = tile * S;            // virtual index of the tile's first sample
+        if constexpr (!PERSIST) asm volatile("" ::: "memory");  // keep per-tile table loads inside the loop
+        creg v[16];
+        if (v0 >= src.plen && v0 - src.plen + F <= src.in_len) {       // interior tile: plain coalesced loads
+            const creg* p = in_reg + (v0 - src.plen) + t;
 #pragma unroll
-            for (int n = 0; n < 16; n++) nxt[n] = src.load(tile * S + n * T + t);
-        }
-    }
-    for (; tile < ntiles; tile += gridDim.x) {
-        cf v[16];
-        if constexpr (PREFETCH) {
-#pragma unroll
-            for (int n = 0; n < 16; n++) v[n] = nxt[n];
-            const long tn = tile + gridDim.x;
-            if (tn < ntiles) {
-#pragma unroll
-                for (int n = 0; n < 16; n++) nxt[n] = src.load(tn * S + n * T + t);
-            }
+            for (int n = 0; n < 16; n++) v[n] = p[n * T];
         } else {
-            if constexpr (!PERSIST) asm volatile("" ::: "memory");  // keep per-tile table loads inside the loop
 #pragma unroll
-            for (int n = 0; n < 16; n++) v[n] = src.load(tile * S + n * T + t);
+            for (int n = 0; n < 16; n++) v[n] = to_reg(src.load(v0 + n * T + t));
         }
-        cf twl[15];
+        creg twl[15];
 
         // ---- forward ----
         get_tw<LOG2F, 0, PERSIST>(twl, tw0, t, tw);
@@ -103,7 +110,7 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
         if constexpr (PERSIST) {
             apply_h(v, hreg);
         } else {
-            cf h[16];
+            creg h[16];
             load_h<LOG2F, NP - 1>(h, t, hpos);
             apply_h(v, h);
         }
@@ -127,12 +134,20 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
         inv_pass<LOG2F, 0>(v, twl);
 
         // tile positions [L-1, F) are valid linear-convolution outputs
-        const long o0 = tile * S - (L - 1);
+        const long o0 = tile * S - first;
+        creg* po = out_reg + o0 + t;
+        if (o0 + F <= n_out) {                                  // whole tile inside the output window
 #pragma unroll
-        for (int n = 0; n < 16; n++) {
-            const int idx = n * T + t;
-            const long o = o0 + idx;
-            if (idx >= L - 1 && o < n_out) out[o] = v[n];
+            for (int n = 0; n < 16; n++) {
+                if (n * T >= first) po[n * T] = v[n];           // wave-uniform
+                else if ((n + 1) * T > first) { if (n * T + t >= first) po[n * T] = v[n]; }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < 16; n++) {
+                const int idx = n * T + t;
+                if (idx >= first && o0 + idx < n_out) po[n * T] = v[n];
+            }
         }
         // next tile's first lds_store touches exactly the slots this thread just read
     }

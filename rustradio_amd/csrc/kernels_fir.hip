@@ -29,7 +29,7 @@ __device__ __forceinline__ void mac(float& acc, float tap, float w) { acc = fmaf
 
 template <class T> __device__ __forceinline__ T zero_of();
 template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
-template <> __device__ __forceinline__ cf zero_of<cf>() { return mk(0.0f, 0.0f); }
+template <> __device__ __forceinline__ cf zero_of<cf>() { return mkcf(0.0f, 0.0f); }
 
 // geometry shared by host and device
 struct FirGeom {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 const int n = t * R + j + L / 2;
-                if (mb + j < n_out) out[mb + j] = mk(lds[(n % R) * rstride + n / R], acc[j]);
+                if (mb + j < n_out) out[mb + j] = mkcf(lds[(n % R) * rstride + n / R], acc[j]);
             }
         } else {
 #pragma unroll
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_fir_direct(VSrc<T> src, OutT* __restric
         T acc = zero_of<T>();
         const long b = m * d;
         for (int k = 0; k < L; k++) mac(acc, rev[k], src.load(b + k));
-        if constexpr (HILBERT) out[m] = mk(src.load(b + L / 2), acc);
+        if constexpr (HILBERT) out[m] = mkcf(src.load(b + L / 2), acc);
         else out[m] = acc;
     }
 }
@@ -196,14 +196,14 @@ __global__ __launch_bounds__(256) void k_rotate_model(cf* __restrict__ y, long n
         const cf v = y[i];
         const double ox = (double)v.x * rx - (double)v.y * ry;
         const double oy = (double)v.x * ry + (double)v.y * rx;
-        y[i] = mk((float)ox, (float)oy);
+        y[i] = mkcf((float)ox, (float)oy);
     }
 }
 __global__ __launch_bounds__(256) void k_rotate_table(cf* __restrict__ y, long n, const cf* __restrict__ tab) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const cf v = y[i], p = tab[i];
         // sample * phase, un-contracted num-complex order (fir.rs:469)
-        y[i] = mk(__fsub_rn(__fmul_rn(v.x, p.x), __fmul_rn(v.y, p.y)),
+        y[i] = mkcf(__fsub_rn(__fmul_rn(v.x, p.x), __fmul_rn(v.y, p.y)),
                   __fadd_rn(__fmul_rn(v.x, p.y), __fmul_rn(v.y, p.x)));
     }
 }

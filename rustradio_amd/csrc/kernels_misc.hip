@@ -113,7 +113,7 @@ void launch_vcopy_f32(VSrc<float> src, long v0, float* dst, long n, hipStream_t 
 
 __global__ __launch_bounds__(256) void k_f32_to_c32(const float* __restrict__ in, cf* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = mk(in[i], 0.0f);
+        out[i] = mkcf(in[i], 0.0f);
 }
 __global__ __launch_bounds__(256) void k_c32_re(const cf* __restrict__ in, float* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
