@@ -259,6 +259,12 @@ template <int LOG2F, int I> RR_HD void inv_pass(creg* v, const creg* twl) {
 #pragma unroll
     for (int u = 0; u < G::U; u++) Dft<G::R, true>::run(v + u * G::R);
 }
+// RR_LDS_Q = volatile keeps hipcc from fusing neighbouring 8-byte LDS accesses into
+// ds_read2_b64 / ds_write2_b64 (a tuning experiment).
+#ifndef RR_LDS_Q
+#define RR_LDS_Q
+#endif
+
 // LDS addressing of a pass layout, split into ONE per-thread base and compile-time
 // offsets so that every ds_read/ds_write uses base VGPR + immediate:
 //   lds_pad(pos(t + T u, n)) == lds_base<I>(t) + lds_off<I>(u, n)
@@ -277,7 +283,7 @@ template <int LOG2F, int I> RR_HD constexpr int lds_off(int u, int n) {
 }
 template <int LOG2F, int I> RR_HD void lds_store(const creg* v, int t, creg* lds) {
     using G = PassGeom<LOG2F, I>;
-    creg* b = lds + lds_base<LOG2F, I>(t);
+    RR_LDS_Q creg* b = lds + lds_base<LOG2F, I>(t);
 #pragma unroll
     for (int u = 0; u < G::U; u++)
 #pragma unroll
@@ -285,7 +291,7 @@ template <int LOG2F, int I> RR_HD void lds_store(const creg* v, int t, creg* lds
 }
 template <int LOG2F, int I> RR_HD void lds_load(creg* v, int t, const creg* lds) {
     using G = PassGeom<LOG2F, I>;
-    const creg* b = lds + lds_base<LOG2F, I>(t);
+    const RR_LDS_Q creg* b = lds + lds_base<LOG2F, I>(t);
 #pragma unroll
     for (int u = 0; u < G::U; u++)
 #pragma unroll
