@@ -1,0 +1,593 @@
+// rustradio.hpp — C++17 host-side mirror of rustradio's operator API for the hot path,
+// layered on the C ABI (include/rustradio_amd.h).  The reference is Rust; this image has no
+// Rust toolchain, so the host side above the C ABI is C++ with the same names, argument
+// meaning and error behaviour as the reference:
+//
+//   Block / BlockRet / BlockName / BlockEOF      src/block.rs:12-126
+//   ReadStream / WriteStream / Tag / new_stream  src/stream.rs:48-93, 105, 187-339
+//   VectorSource / VectorSink / NullSink / Graph  src/vector_source.rs, src/vector_sink.rs,
+//                                                 src/null_sink.rs, src/graph.rs:99-173
+//   FirFilter (+builder .deci() .translate()), Fir::filter_n   src/fir.rs:150-198, 303-551
+//   FftFilter / FftFilterFloat                    src/fft_filter.rs:210-491
+//   RationalResampler (+builder)                  src/rational_resampler.rs:19-213
+//   QuadratureDemod                               src/quadrature_demod.rs:32-114
+//   Hilbert                                       src/hilbert.rs:22-129
+//   fir::low_pass / low_pass_complex / hilbert, window::WindowType   src/fir.rs:594-680, src/window.rs
+//
+// A block's work() does exactly what the Rust shim in INTEGRATION.md does: take the stream
+// windows, hand plain pointers to rr_block_work(), then consume()/produce() what the GPU
+// block reported, re-basing tags the way the reference block does.  No sample arithmetic
+// happens in this file.
+#pragma once
+#include <algorithm>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "../../include/rustradio_amd.h"
+
+namespace rustradio {
+
+using Float = float;                    // src/lib.rs:268
+using Complex = std::complex<float>;    // src/lib.rs:271 (interleaved re, im)
+
+struct Error : std::runtime_error {     // src/lib.rs:276-311
+    using std::runtime_error::runtime_error;
+    static Error msg(const std::string& m) { return Error(m); }
+};
+
+constexpr size_t DEFAULT_STREAM_SIZE = 4'096'000;   // bytes, src/stream.rs:105
+
+// ---- tags (src/stream.rs:48-93) ----------------------------------------------------------------
+using TagValue = std::variant<bool, uint64_t, float, std::string>;
+struct Tag {
+    size_t pos_;
+    std::string key_;
+    TagValue val_;
+    Tag(size_t p, std::string k, TagValue v) : pos_(p), key_(std::move(k)), val_(std::move(v)) {}
+    size_t pos() const { return pos_; }
+    void set_pos(size_t p) { pos_ = p; }
+    const std::string& key() const { return key_; }
+    const TagValue& val() const { return val_; }
+    bool operator==(const Tag& o) const { return pos_ == o.pos_ && key_ == o.key_ && val_ == o.val_; }
+};
+
+namespace detail {
+inline uint64_t& activity() { static thread_local uint64_t a = 0; return a; }   // samples moved (Graph idle detection)
+}
+
+// ---- streams --------------------------------------------------------------------------------------
+// The reference hands out contiguous windows of a double-mapped ring
+// (src/nowasm/circular_buffer.rs:98-128, 572-615).  This harness keeps the same contract —
+// read_buf() = ALL readable samples, write_buf() = ALL free space, fixed capacity — with a
+// compacting vector; only the window semantics matter to the blocks.
+struct StreamWait {
+    virtual ~StreamWait() = default;
+    virtual size_t id() const = 0;
+    virtual bool closed() const = 0;
+};
+
+template <class T> struct StreamState : StreamWait {
+    std::vector<T> buf;           // [rpos, buf.size()) readable; capacity `cap` samples
+    size_t rpos = 0;
+    size_t cap;
+    std::vector<Tag> tags;        // positions relative to rpos
+    bool writer_alive = true, reader_alive = true;
+    size_t id_;
+    explicit StreamState(size_t bytes) : cap(bytes / sizeof(T)) {
+        static size_t next_id = 1;
+        id_ = next_id++;
+        buf.reserve(cap);
+    }
+    size_t used() const { return buf.size() - rpos; }
+    size_t free() const { return cap - used(); }
+    size_t id() const override { return id_; }
+    bool closed() const override { return !writer_alive || !reader_alive; }   // src/stream.rs:148-150
+};
+
+template <class T> class BufferReader {   // circular_buffer.rs:233-251
+    std::shared_ptr<StreamState<T>> s_;
+public:
+    explicit BufferReader(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {}
+    const T* slice() const { return s_->buf.data() + s_->rpos; }
+    size_t len() const { return s_->used(); }
+    bool is_empty() const { return len() == 0; }
+    const T* begin() const { return slice(); }
+    const T* end() const { return slice() + len(); }
+    void consume(size_t n) {               // circular_buffer.rs:472-513
+        if (n > s_->used()) throw Error("consume: n > used");
+        detail::activity() += n;
+        s_->rpos += n;
+        std::vector<Tag> keep;
+        for (auto& t : s_->tags)
+            if (t.pos() >= n) keep.emplace_back(t.pos() - n, t.key(), t.val());
+        s_->tags.swap(keep);
+        if (s_->rpos == s_->buf.size()) { s_->buf.clear(); s_->rpos = 0; }
+    }
+};
+
+template <class T> class BufferWriter {   // circular_buffer.rs:284-310
+    std::shared_ptr<StreamState<T>> s_;
+    size_t base_;
+public:
+    explicit BufferWriter(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {
+        // make the free space contiguous after the readable window
+        if (s_->rpos) {
+            s_->buf.erase(s_->buf.begin(), s_->buf.begin() + (std::ptrdiff_t)s_->rpos);
+            s_->rpos = 0;
+        }
+        base_ = s_->buf.size();
+        s_->buf.resize(s_->cap);
+    }
+    ~BufferWriter() { if (s_ && s_->buf.size() == s_->cap && !produced_) s_->buf.resize(base_); }
+    BufferWriter(BufferWriter&& o) noexcept : s_(std::move(o.s_)), base_(o.base_), produced_(o.produced_) { o.s_.reset(); }
+    BufferWriter(const BufferWriter&) = delete;
+    T* slice() { return s_->buf.data() + base_; }
+    size_t len() const { return s_->cap - base_; }
+    bool is_empty() const { return len() == 0; }
+    void fill_from_slice(const T* src, size_t n) { std::memcpy(slice(), src, n * sizeof(T)); }
+    void produce(size_t n, const std::vector<Tag>& tags) {   // circular_buffer.rs:518-557
+        if (n > len()) throw Error("produce: n > free");
+        if (n == 0) { s_->buf.resize(base_); produced_ = true; return; }   // tags dropped (:528-533)
+        detail::activity() += n;
+        for (auto& t : tags) s_->tags.emplace_back(t.pos() + base_, t.key(), t.val());
+        s_->buf.resize(base_ + n);
+        produced_ = true;
+    }
+private:
+    bool produced_ = false;
+};
+
+template <class T> class ReadStream {      // src/stream.rs:187-246
+    std::shared_ptr<StreamState<T>> s_;
+public:
+    ReadStream() = default;
+    explicit ReadStream(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {}
+    ~ReadStream() { if (s_) s_->reader_alive = false; }
+    ReadStream(ReadStream&&) = default;
+    ReadStream& operator=(ReadStream&&) = default;
+    ReadStream(const ReadStream&) = delete;
+    static ReadStream from_slice(const T* d, size_t n) {    // src/stream.rs:187-195 (test helper)
+        auto st = std::make_shared<StreamState<T>>(DEFAULT_STREAM_SIZE);
+        st->buf.assign(d, d + n);
+        st->writer_alive = false;
+        return ReadStream(st);
+    }
+    std::pair<BufferReader<T>, std::vector<Tag>> read_buf() const {   // :208-217
+        return {BufferReader<T>(s_), s_->tags};
+    }
+    bool eof() const { return !s_->writer_alive && s_->used() == 0; }  // :237-246
+    const StreamWait& wait_handle() const { return *s_; }
+    size_t id() const { return s_->id(); }
+};
+
+template <class T> class WriteStream {     // src/stream.rs:288-310
+    std::shared_ptr<StreamState<T>> s_;
+public:
+    WriteStream() = default;
+    explicit WriteStream(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {}
+    ~WriteStream() { if (s_) s_->writer_alive = false; }
+    WriteStream(WriteStream&&) = default;
+    WriteStream& operator=(WriteStream&&) = default;
+    WriteStream(const WriteStream&) = delete;
+    BufferWriter<T> write_buf() const { return BufferWriter<T>(s_); }  // :301-310
+    size_t free() const { return s_->free(); }
+    const StreamWait& wait_handle() const { return *s_; }
+    size_t id() const { return s_->id(); }
+};
+
+template <class T> std::pair<WriteStream<T>, ReadStream<T>> new_stream(size_t bytes = DEFAULT_STREAM_SIZE) {  // :336-339
+    auto st = std::make_shared<StreamState<T>>(bytes);
+    return {WriteStream<T>(st), ReadStream<T>(st)};
+}
+
+// ---- Block (src/block.rs) -----------------------------------------------------------------------------
+struct BlockRet {
+    enum Kind { Again, Pending, WaitForStream, EOF_ } kind;
+    const StreamWait* stream = nullptr;
+    size_t need = 0;
+    static BlockRet again() { return {Again, nullptr, 0}; }
+    static BlockRet eof() { return {EOF_, nullptr, 0}; }
+    static BlockRet wait(const StreamWait& s, size_t n) { return {WaitForStream, &s, n}; }
+};
+
+struct Block {
+    virtual ~Block() = default;
+    virtual const char* block_name() const = 0;   // BlockName, :91-97
+    virtual bool eof() = 0;                       // BlockEOF, :103-110
+    virtual BlockRet work() = 0;                  // Block::work, :115-126 (throws Error on failure)
+};
+
+// ---- window / tap designers (src/window.rs, src/fir.rs:594-680) -----------------------------------------
+namespace window {
+struct WindowType {
+    int kind; float parm;
+    static WindowType Hamming() { return {RR_WIN_HAMMING, 0}; }
+    static WindowType Blackman() { return {RR_WIN_BLACKMAN, 0}; }
+    static WindowType BlackmanHarris() { return {RR_WIN_BLACKMAN_HARRIS, 0}; }
+    static WindowType HammingParm(float a0) { return {RR_WIN_HAMMING_PARM, a0}; }
+    float max_attenuation() const { return rr_max_attenuation(kind); }
+    std::vector<Float> make_window(size_t ntaps) const {
+        std::vector<Float> w(ntaps);
+        if (rr_make_window(kind, parm, ntaps, w.data()) != 0) throw Error(rr_last_error());
+        return w;
+    }
+};
+}  // namespace window
+
+namespace fir {
+inline std::vector<Float> low_pass(Float samp_rate, Float cutoff, Float twidth, const window::WindowType& w) {
+    const size_t n = rr_low_pass(samp_rate, cutoff, twidth, w.kind, w.parm, nullptr, 0);
+    if (n == 0) throw Error(rr_last_error());       // the reference asserts (fir.rs:623-625)
+    std::vector<Float> t(n);
+    rr_low_pass(samp_rate, cutoff, twidth, w.kind, w.parm, t.data(), n);
+    return t;
+}
+inline std::vector<Complex> low_pass_complex(Float samp_rate, Float cutoff, Float twidth, const window::WindowType& w) {
+    auto t = low_pass(samp_rate, cutoff, twidth, w);
+    return std::vector<Complex>(t.begin(), t.end());   // Complex::new(t, 0.0), fir.rs:602
+}
+inline std::vector<Float> hilbert(const std::vector<Float>& window) {
+    std::vector<Float> t(window.size());
+    if (rr_hilbert_taps(window.data(), window.size(), t.data()) != 0) throw Error(rr_last_error());
+    return t;
+}
+}  // namespace fir
+
+// ---- GPU block plumbing -----------------------------------------------------------------------------------
+namespace detail {
+struct Handle {
+    rr_block* h;
+    explicit Handle(rr_block* p) : h(p) { if (!h) throw Error(rr_last_error()); }
+    ~Handle() { rr_block_destroy(h); }
+    Handle(const Handle&) = delete;
+};
+struct WorkOut { int st; size_t consumed, produced, need; };
+inline WorkOut work(rr_block* h, const void* in, size_t in_len, void* out, size_t out_cap) {
+    WorkOut w{};
+    w.st = rr_block_work(h, in, in_len, out, out_cap, &w.consumed, &w.produced, &w.need);
+    if (w.st == RR_ERR) throw Error(rr_last_error());
+    return w;
+}
+static_assert(sizeof(Complex) == sizeof(rr_c32), "Complex<f32> must be interleaved re, im");
+}  // namespace detail
+
+// ---- FirFilter (src/fir.rs) ---------------------------------------------------------------------------------
+template <class T> class FirFilter;
+
+template <class T> class FirFilterBuilder {      // fir.rs:303-340, 476-486
+    std::vector<T> taps_;
+    size_t deci_ = 1;
+    bool translate_ = false;
+    Float samp_rate_ = 0, freq_ = 0;
+    friend class FirFilter<T>;
+public:
+    explicit FirFilterBuilder(std::vector<T> taps) : taps_(std::move(taps)) {}
+    FirFilterBuilder& deci(size_t d) { if (d == 0) throw Error("FirFilter: deci 0"); deci_ = d; return *this; }
+    FirFilterBuilder& translate(Float samp_rate, Float freq) {
+        static_assert(std::is_same<T, Complex>::value, "FirFilter asked to translate on non-Complex");
+        translate_ = true; samp_rate_ = samp_rate; freq_ = freq; return *this;
+    }
+    std::pair<std::unique_ptr<FirFilter<T>>, ReadStream<T>> build(ReadStream<T> src);
+};
+
+template <class T> class FirFilter : public Block {
+    detail::Handle h_;
+    size_t deci_;
+    ReadStream<T> src_;
+    WriteStream<T> dst_;
+    static rr_block* make(const std::vector<T>& taps, size_t deci, bool tr, Float fs, Float f) {
+        if constexpr (std::is_same<T, Complex>::value)
+            return rr_fir_c32_create(reinterpret_cast<const rr_c32*>(taps.data()), taps.size(), deci, tr, fs, f);
+        else
+            return rr_fir_f32_create(taps.data(), taps.size(), deci);
+    }
+public:
+    FirFilter(ReadStream<T> src, WriteStream<T> dst, const FirFilterBuilder<T>& b)
+        : h_(make(b.taps_, b.deci_, b.translate_, b.samp_rate_, b.freq_)), deci_(b.deci_), src_(std::move(src)), dst_(std::move(dst)) {}
+    static FirFilterBuilder<T> builder(std::vector<T> taps) { return FirFilterBuilder<T>(std::move(taps)); }
+    static std::pair<std::unique_ptr<FirFilter<T>>, ReadStream<T>> new_(ReadStream<T> src, std::vector<T> taps) {
+        return FirFilterBuilder<T>(std::move(taps)).build(std::move(src));
+    }
+    const char* block_name() const override { return rr_block_name(h_.h); }
+    bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
+    BlockRet work() override {                    // fir.rs:492-550
+        auto [input, tags] = src_.read_buf();
+        auto out = dst_.write_buf();
+        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        if (w.st == RR_WAIT_SRC) { out.produce(0, {}); return BlockRet::wait(src_.wait_handle(), w.need); }
+        if (w.st == RR_WAIT_DST) { out.produce(0, {}); return BlockRet::wait(dst_.wait_handle(), w.need); }
+        std::vector<Tag> keep;                    // :536-545
+        for (auto& t : tags)
+            if (t.pos() < w.consumed) keep.emplace_back(t.pos() / deci_, t.key(), t.val());
+        input.consume(w.consumed);
+        out.produce(w.produced, keep);
+        return BlockRet::again();
+    }
+};
+template <class T>
+std::pair<std::unique_ptr<FirFilter<T>>, ReadStream<T>> FirFilterBuilder<T>::build(ReadStream<T> src) {
+    if (taps_.empty()) throw Error("FirFilter: empty taps");
+    auto [w, r] = new_stream<T>();
+    return {std::make_unique<FirFilter<T>>(std::move(src), std::move(w), *this), std::move(r)};
+}
+
+// Fir<T>::filter_n (fir.rs:181-189): `filter()` across an input range; runs the same HIP kernel.
+template <class T> class Fir {
+    std::vector<T> taps_;
+public:
+    explicit Fir(std::vector<T> taps) : taps_(std::move(taps)) { if (taps_.empty()) throw Error("Fir: empty taps"); }
+    std::vector<T> filter_n(const std::vector<T>& input, size_t deci) const {
+        if (deci == 0) throw Error("filter_n: deci 0");
+        if (input.size() < taps_.size()) throw Error("filter_n: input shorter than taps");
+        const size_t n_out = (input.size() - taps_.size()) / deci + 1;
+        // pad so that the block's "consume whole groups of deci" rule (fir.rs:502) covers n_out outputs
+        std::vector<T> in(input);
+        in.resize((n_out - 1) * deci + taps_.size() + deci - 1, T{});
+        detail::Handle h(FirFilterMaker(taps_, deci));
+        std::vector<T> out(n_out);
+        auto w = detail::work(h.h, in.data(), in.size(), out.data(), out.size());
+        if (w.st != RR_AGAIN || w.produced != n_out) throw Error("filter_n: unexpected block state");
+        return out;
+    }
+private:
+    static rr_block* FirFilterMaker(const std::vector<T>& taps, size_t deci) {
+        if constexpr (std::is_same<T, Complex>::value)
+            return rr_fir_c32_create(reinterpret_cast<const rr_c32*>(taps.data()), taps.size(), deci, 0, 0, 0);
+        else
+            return rr_fir_f32_create(taps.data(), taps.size(), deci);
+    }
+};
+
+// ---- FftFilter / FftFilterFloat (src/fft_filter.rs) ---------------------------------------------------------------
+template <class T> class FftFilterBase : public Block {
+protected:
+    detail::Handle h_;
+    ReadStream<T> src_;
+    WriteStream<T> dst_;
+    std::vector<std::pair<uint64_t, Tag>> pending_;   // tags of samples still inside `buf` (:309-313), absolute position
+    uint64_t in_abs_ = 0, out_abs_ = 0;
+public:
+    FftFilterBase(rr_block* h, ReadStream<T> src, WriteStream<T> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)) {}
+    const char* block_name() const override { return rr_block_name(h_.h); }
+    bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
+    BlockRet work() override {                    // fft_filter.rs:290-354 / 429-490
+        auto [input, tags] = src_.read_buf();
+        auto out = dst_.write_buf();
+        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        // a tag travels with its sample: output sample i is input sample i of the stream
+        for (auto& t : tags)
+            if (t.pos() < w.consumed) pending_.emplace_back(in_abs_ + t.pos(), t);
+        std::vector<Tag> emit;
+        std::vector<std::pair<uint64_t, Tag>> keep;
+        for (auto& pt : pending_) {
+            if (pt.first < out_abs_ + w.produced) emit.emplace_back((size_t)(pt.first - out_abs_), pt.second.key(), pt.second.val());
+            else keep.push_back(pt);
+        }
+        pending_.swap(keep);
+        in_abs_ += w.consumed; out_abs_ += w.produced;
+        input.consume(w.consumed);
+        out.produce(w.produced, emit);
+        if (w.st == RR_WAIT_SRC) return BlockRet::wait(src_.wait_handle(), w.need);
+        if (w.st == RR_WAIT_DST) return BlockRet::wait(dst_.wait_handle(), w.need);
+        return BlockRet::again();
+    }
+};
+
+class FftFilter : public FftFilterBase<Complex> {
+public:
+    using FftFilterBase<Complex>::FftFilterBase;
+    static std::pair<std::unique_ptr<FftFilter>, ReadStream<Complex>> new_(ReadStream<Complex> src, const std::vector<Complex>& taps) {
+        auto [w, r] = new_stream<Complex>();
+        rr_block* h = rr_fftfilter_create(reinterpret_cast<const rr_c32*>(taps.data()), taps.size());
+        return {std::make_unique<FftFilter>(h, std::move(src), std::move(w)), std::move(r)};
+    }
+};
+class FftFilterFloat : public FftFilterBase<Float> {
+public:
+    using FftFilterBase<Float>::FftFilterBase;
+    static std::pair<std::unique_ptr<FftFilterFloat>, ReadStream<Float>> new_(ReadStream<Float> src, const std::vector<Float>& taps) {
+        auto [w, r] = new_stream<Float>();
+        rr_block* h = rr_fftfilter_float_create(taps.data(), taps.size());
+        return {std::make_unique<FftFilterFloat>(h, std::move(src), std::move(w)), std::move(r)};
+    }
+};
+
+// ---- RationalResampler (src/rational_resampler.rs) ------------------------------------------------------------------
+template <class T> class RationalResampler : public Block {
+    detail::Handle h_;
+    ReadStream<T> src_;
+    WriteStream<T> dst_;
+public:
+    RationalResampler(rr_block* h, ReadStream<T> src, WriteStream<T> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)) {}
+    // Err (here: throws Error) when interp or deci is 0 (:130-135)
+    static std::pair<std::unique_ptr<RationalResampler<T>>, ReadStream<T>> new_(ReadStream<T> src, size_t interp, size_t deci) {
+        auto [w, r] = new_stream<T>();
+        rr_block* h = rr_resampler_create(interp, deci, sizeof(T));
+        return {std::make_unique<RationalResampler<T>>(h, std::move(src), std::move(w)), std::move(r)};
+    }
+    struct Builder {                              // typestate builder (:19-92), flattened
+        size_t interp_ = 0, deci_ = 0;
+        Builder& interp(size_t i) { interp_ = i; return *this; }
+        Builder& deci(size_t d) { deci_ = d; return *this; }
+        auto build(ReadStream<T> src) { return RationalResampler<T>::new_(std::move(src), interp_, deci_); }
+    };
+    static Builder builder() { return Builder{}; }
+    const char* block_name() const override { return rr_block_name(h_.h); }
+    bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }   // pending.is_none() && src.eof() (:209-213)
+    BlockRet work() override {                    // :155-206 — tags are dropped (:156)
+        auto [input, tags] = src_.read_buf();
+        (void)tags;
+        auto out = dst_.write_buf();
+        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        input.consume(w.consumed);
+        out.produce(w.produced, {});
+        return w.st == RR_WAIT_DST ? BlockRet::wait(dst_.wait_handle(), w.need) : BlockRet::wait(src_.wait_handle(), w.need);
+    }
+};
+
+// ---- QuadratureDemod (src/quadrature_demod.rs) -------------------------------------------------------------------------
+class QuadratureDemod : public Block {
+    detail::Handle h_;
+    ReadStream<Complex> src_;
+    WriteStream<Float> dst_;
+public:
+    QuadratureDemod(rr_block* h, ReadStream<Complex> src, WriteStream<Float> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)) {}
+    // `exact_atan2 = true` is a --no-default-features build (f32::atan2); false = fast-math feature
+    static std::pair<std::unique_ptr<QuadratureDemod>, ReadStream<Float>> new_(ReadStream<Complex> src, Float gain, bool exact_atan2 = true) {
+        auto [w, r] = new_stream<Float>();
+        rr_block* h = rr_quaddemod_create(gain, exact_atan2 ? RR_ATAN2_EXACT : RR_ATAN2_FAST);
+        return {std::make_unique<QuadratureDemod>(h, std::move(src), std::move(w)), std::move(r)};
+    }
+    const char* block_name() const override { return rr_block_name(h_.h); }
+    bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
+    BlockRet work() override {                    // :46-113 — tags dropped
+        auto [input, tags] = src_.read_buf();
+        (void)tags;
+        auto out = dst_.write_buf();
+        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        input.consume(w.consumed);
+        out.produce(w.produced, {});
+        return w.st == RR_WAIT_DST ? BlockRet::wait(dst_.wait_handle(), w.need) : BlockRet::wait(src_.wait_handle(), w.need);
+    }
+};
+
+// ---- Hilbert (src/hilbert.rs) ----------------------------------------------------------------------------------------------
+class Hilbert : public Block {
+    detail::Handle h_;
+    ReadStream<Float> src_;
+    WriteStream<Complex> dst_;
+public:
+    Hilbert(rr_block* h, ReadStream<Float> src, WriteStream<Complex> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)) {}
+    // asserts odd ntaps > 1 in the reference (:44-47); here: throws Error
+    static std::pair<std::unique_ptr<Hilbert>, ReadStream<Complex>> new_(ReadStream<Float> src, size_t ntaps, const window::WindowType& w) {
+        auto [ws, r] = new_stream<Complex>();
+        rr_block* h = rr_hilbert_create(ntaps, w.kind, w.parm);
+        return {std::make_unique<Hilbert>(h, std::move(src), std::move(ws)), std::move(r)};
+    }
+    const char* block_name() const override { return rr_block_name(h_.h); }
+    bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
+    BlockRet work() override {                    // :72-128
+        auto [input, tags] = src_.read_buf();
+        auto out = dst_.write_buf();
+        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        if (w.st == RR_WAIT_SRC) { out.produce(0, {}); return BlockRet::wait(src_.wait_handle(), w.need); }
+        if (w.st == RR_WAIT_DST) { out.produce(0, {}); return BlockRet::wait(dst_.wait_handle(), w.need); }
+        std::vector<Tag> keep;                    // :119-123
+        for (auto& t : tags) if (t.pos() < w.produced) keep.push_back(t);
+        out.produce(w.produced, keep);
+        input.consume(w.consumed);
+        return BlockRet::again();
+    }
+};
+
+// ---- harness blocks (restated from the reference; host-side plumbing only) ----------------------------------------------------
+struct Repeat {                                   // src/lib.rs Repeat
+    uint64_t count; bool infinite;
+    static Repeat finite(uint64_t n) { return {n, false}; }
+    static Repeat infinite_() { return {0, true}; }
+};
+
+template <class T> class VectorSource : public Block {   // src/vector_source.rs:97-146
+    WriteStream<T> dst_;
+    std::vector<T> data_;
+    Repeat repeat_;
+    uint64_t repeat_count_ = 0;
+    size_t pos_ = 0;
+public:
+    VectorSource(WriteStream<T> dst, std::vector<T> d, Repeat r) : dst_(std::move(dst)), data_(std::move(d)), repeat_(r) {}
+    static std::pair<std::unique_ptr<VectorSource<T>>, ReadStream<T>> new_(std::vector<T> data, Repeat r = Repeat::finite(1)) {
+        auto [w, rd] = new_stream<T>();
+        return {std::make_unique<VectorSource<T>>(std::move(w), std::move(data), r), std::move(rd)};
+    }
+    const char* block_name() const override { return "VectorSource"; }
+    bool eof() override { return !repeat_.infinite && repeat_count_ >= repeat_.count; }
+    BlockRet work() override {
+        if (eof() || data_.empty()) return BlockRet::eof();
+        auto out = dst_.write_buf();
+        const size_t n = std::min(out.len(), data_.size() - pos_);
+        if (n == 0) { out.produce(0, {}); return BlockRet::wait(dst_.wait_handle(), 1); }
+        std::vector<Tag> tags;
+        if (pos_ == 0) {
+            tags.emplace_back(0, "VectorSource::start", true);
+            tags.emplace_back(0, "VectorSource::repeat", (uint64_t)repeat_count_);
+            if (repeat_count_ == 0) tags.emplace_back(0, "VectorSource::first", true);
+        }
+        out.fill_from_slice(data_.data() + pos_, n);
+        out.produce(n, tags);
+        pos_ += n;
+        if (pos_ == data_.size()) { pos_ = 0; repeat_count_++; }
+        return eof() ? BlockRet::eof() : BlockRet::again();
+    }
+};
+
+template <class T> class VectorSink : public Block {     // src/vector_sink.rs:113-137
+    ReadStream<T> src_;
+    std::shared_ptr<std::vector<T>> data_ = std::make_shared<std::vector<T>>();
+    std::shared_ptr<std::vector<Tag>> tags_ = std::make_shared<std::vector<Tag>>();
+public:
+    explicit VectorSink(ReadStream<T> src) : src_(std::move(src)) {}
+    std::shared_ptr<std::vector<T>> hook() const { return data_; }           // vector_sink.rs:103-111
+    std::shared_ptr<std::vector<Tag>> tag_hook() const { return tags_; }
+    const char* block_name() const override { return "VectorSink"; }
+    bool eof() override { return src_.eof(); }
+    BlockRet work() override {
+        auto [input, tags] = src_.read_buf();
+        const size_t n = input.len();
+        for (auto& t : tags) tags_->emplace_back(t.pos() + data_->size(), t.key(), t.val());
+        data_->insert(data_->end(), input.begin(), input.end());
+        input.consume(n);
+        return BlockRet::wait(src_.wait_handle(), 1);
+    }
+};
+
+template <class T> class NullSink : public Block {       // src/null_sink.rs:15-25
+    ReadStream<T> src_;
+public:
+    explicit NullSink(ReadStream<T> src) : src_(std::move(src)) {}
+    const char* block_name() const override { return "NullSink"; }
+    bool eof() override { return src_.eof(); }
+    BlockRet work() override {
+        auto [input, tags] = src_.read_buf();
+        (void)tags;
+        input.consume(input.len());
+        return BlockRet::wait(src_.wait_handle(), 1);
+    }
+};
+
+// Single-threaded round-robin runner (src/graph.rs:99-173), minus timing statistics.  A block
+// that reaches EOF is dropped, which closes its output streams (the reference: Arc strong
+// count, src/stream.rs:148-150, 237-246); the run ends when a whole round moves no sample
+// and returns no Again/Pending (src/graph.rs:108-154).
+class Graph {
+    std::vector<std::unique_ptr<Block>> blocks_;
+public:
+    void add(std::unique_ptr<Block> b) { blocks_.push_back(std::move(b)); }
+    void run() {
+        for (;;) {
+            bool done = true;
+            const uint64_t before = detail::activity();
+            for (auto& bp : blocks_) {
+                if (!bp) continue;
+                const BlockRet ret = bp->work();
+                switch (ret.kind) {
+                case BlockRet::Again:
+                case BlockRet::Pending: done = false; break;
+                case BlockRet::EOF_: bp.reset(); done = false; break;
+                case BlockRet::WaitForStream:
+                    if (bp->eof() || ret.stream->closed()) { bp.reset(); done = false; }   // graph.rs:136-143
+                    break;
+                }
+            }
+            if (done && detail::activity() == before) break;
+        }
+    }
+};
+
+}  // namespace rustradio

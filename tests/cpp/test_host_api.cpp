@@ -1,0 +1,190 @@
+// test_host_api.cpp — the reference's unit tests for the hot path, written against the C++
+// host mirror (rustradio_amd/host/rustradio.hpp) the way the reference writes them
+// (VectorSource -> block, work() by hand or Graph, then read_buf()).  Needs a GPU.
+// Build: g++ -O2 -std=c++17 tests/cpp/test_host_api.cpp -L rustradio_amd/lib -lrustradio_amd
+#include <cmath>
+#include <cstdio>
+
+#include "../../rustradio_amd/host/rustradio.hpp"
+
+using namespace rustradio;
+using window::WindowType;
+
+static int g_fail = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #c); g_fail++; } } while (0)
+
+static void assert_almost_equal_complex(const Complex* l, size_t ln, const std::vector<Complex>& r) {   // src/lib.rs:846-861
+    if (ln != r.size()) { printf("FAIL length %zu vs %zu\n", ln, r.size()); g_fail++; return; }
+    for (size_t i = 0; i < ln; i++)
+        if (std::abs(l[i] - r[i]) > 0.001f) { printf("FAIL element %zu: (%g,%g) vs (%g,%g)\n", i, l[i].real(), l[i].imag(), r[i].real(), r[i].imag()); g_fail++; return; }
+}
+static bool is_wait(const BlockRet& r) { return r.kind == BlockRet::WaitForStream; }
+
+static const std::vector<Complex> SIX = {{1, 0}, {2, 0}, {3, 0.2f}, {4.1f, 0}, {5, 0}, {6, 0.2f}};
+
+static void test_complex() {   // src/fir.rs:921-950
+    Fir<Complex> filter({{0.1f, 0}, {1, 0}, {0, 0.2f}});
+    auto a = filter.filter_n(SIX, 1);
+    assert_almost_equal_complex(a.data(), a.size(), {{2.3f, 0.22f}, {3.41f, 0.6f}, {4.56f, 0.6f}, {5.6f, 0.84f}});
+    auto b = filter.filter_n(SIX, 2);
+    assert_almost_equal_complex(b.data(), b.size(), {{2.3f, 0.22f}, {4.56f, 0.6f}});
+}
+
+static void test_identity() {  // src/fir.rs:691-741
+    for (size_t deci = 1; deci <= 3 * SIX.size(); deci++) {
+        auto [src, src_out] = VectorSource<Complex>::new_(SIX, Repeat::finite(2));
+        CHECK(src->work().kind == BlockRet::Again);
+        CHECK(src->work().kind == BlockRet::EOF_);
+        auto [b, os] = FirFilter<Complex>::builder({{1, 0}}).deci(deci).build(std::move(src_out));
+        if (deci <= 2 * SIX.size()) CHECK(b->work().kind == BlockRet::Again);
+        CHECK(is_wait(b->work()));
+        auto [res, tags] = os.read_buf();
+        const size_t max = 2 * SIX.size() / deci;
+        if (!res.is_empty()) {
+            std::vector<Tag> want = {Tag(0, "VectorSource::start", true), Tag(0, "VectorSource::repeat", (uint64_t)0),
+                                     Tag(0, "VectorSource::first", true), Tag(6 / deci, "VectorSource::start", true),
+                                     Tag(6 / deci, "VectorSource::repeat", (uint64_t)1)};
+            CHECK(tags == want);
+        }
+        std::vector<Complex> want;
+        for (size_t i = 0; i < 2 * SIX.size() && want.size() < max; i += deci) want.push_back(SIX[i % SIX.size()]);
+        assert_almost_equal_complex(res.slice(), res.len(), want);
+    }
+}
+
+static void moving_avg() {     // src/fir.rs:880-919
+    const std::vector<Complex> full = {{1.5f, 0}, {2.5f, 0.1f}, {3.55f, 0.1f}, {4.55f, 0}, {5.5f, 0.1f}};
+    for (size_t deci = 1; deci <= SIX.size() + 1; deci++) {
+        auto [src, src_out] = VectorSource<Complex>::new_(SIX);
+        src->work();
+        auto [b, os] = FirFilter<Complex>::builder({{0.5f, 0}, {0.5f, 0}}).deci(deci).build(std::move(src_out));
+        if (deci < SIX.size()) CHECK(b->work().kind == BlockRet::Again);
+        CHECK(is_wait(b->work()));
+        auto [res, tags] = os.read_buf();
+        std::vector<Complex> want;
+        for (size_t i = 0; i < full.size() && want.size() < (SIX.size() - 1) / deci; i += deci) want.push_back(full[i]);
+        assert_almost_equal_complex(res.slice(), res.len(), want);
+    }
+}
+
+static void translate_matches_mixed_input() {   // src/fir.rs:744-789
+    std::vector<Complex> input, mixed;
+    for (int i = 0; i < 32; i++) input.emplace_back((float)i, (float)i * 0.25f);
+    const std::vector<Complex> taps = {{0.5f, -0.1f}, {1.0f, 0.2f}, {-0.25f, 0.05f}, {0.125f, -0.3f}};
+    const double step = -2.0 * M_PI * 2.0 / 8.0;
+    const Complex rot((float)std::cos(step), (float)std::sin(step));
+    Complex phase(1, 0);
+    for (auto& s : input) { mixed.push_back(s * phase); phase *= rot; }
+    auto [sa, sa_out] = VectorSource<Complex>::new_(input);
+    CHECK(sa->work().kind == BlockRet::EOF_);
+    auto [tr, tr_out] = FirFilter<Complex>::builder(taps).deci(3).translate(8.0f, 2.0f).build(std::move(sa_out));
+    CHECK(tr->work().kind == BlockRet::Again);
+    CHECK(is_wait(tr->work()));
+    auto [sb, sb_out] = VectorSource<Complex>::new_(mixed);
+    CHECK(sb->work().kind == BlockRet::EOF_);
+    auto [mn, mn_out] = FirFilter<Complex>::builder(taps).deci(3).build(std::move(sb_out));
+    CHECK(mn->work().kind == BlockRet::Again);
+    CHECK(is_wait(mn->work()));
+    auto [r1, t1] = tr_out.read_buf();
+    auto [r2, t2] = mn_out.read_buf();
+    assert_almost_equal_complex(r1.slice(), r1.len(), std::vector<Complex>(r2.begin(), r2.end()));
+}
+
+static void test_filter_generator() {   // src/fir.rs:952-986 (first/centre taps)
+    auto taps = fir::low_pass_complex(10000.0f, 1000.0f, 1000.0f, WindowType::Hamming());
+    CHECK(taps.size() == 25);
+    CHECK(std::abs(taps[12] - Complex(0.19922684f, 0)) < 1e-3f);
+    CHECK(std::abs(taps[0] - Complex(0.002010403f, 0)) < 1e-3f);
+}
+
+static void fft_tag_propagation() {     // src/fft_filter.rs:551-574
+    auto [src, o] = VectorSource<Complex>::new_(std::vector<Complex>(1024), Repeat::finite(2));
+    auto [fft, out] = FftFilter::new_(std::move(o), {Complex(0, 0)});
+    src->work(); src->work();
+    fft->work();
+    auto [res, tags] = out.read_buf();
+    std::vector<Tag> want = {Tag(0, "VectorSource::start", true), Tag(0, "VectorSource::repeat", (uint64_t)0),
+                             Tag(0, "VectorSource::first", true), Tag(1024, "VectorSource::start", true),
+                             Tag(1024, "VectorSource::repeat", (uint64_t)1)};
+    CHECK(tags == want);
+    CHECK(res.len() == 2048);
+}
+
+static void resampler_examples() {      // src/rational_resampler.rs:249-277, 130-135
+    std::vector<uint32_t> input(50);
+    for (uint32_t i = 0; i < 50; i++) input[i] = i;
+    {
+        auto [src, so] = VectorSource<uint32_t>::new_(input);
+        CHECK(src->work().kind == BlockRet::EOF_);
+        auto [b, os] = RationalResampler<uint32_t>::new_(std::move(so), 25, 64);
+        CHECK(is_wait(b->work()));
+        auto [res, tags] = os.read_buf();
+        const std::vector<uint32_t> want = {0, 2, 5, 7, 10, 12, 15, 17, 20, 23, 25, 28, 30, 33, 35, 38, 40, 43, 46, 48};
+        CHECK(std::vector<uint32_t>(res.begin(), res.end()) == want);
+    }
+    bool threw = false;
+    try { auto [src, so] = VectorSource<uint32_t>::new_(input); RationalResampler<uint32_t>::new_(std::move(so), 0, 1); }
+    catch (const Error&) { threw = true; }
+    CHECK(threw);
+}
+
+static void quad_known() {              // src/quadrature_demod.rs:210-264
+    {
+        auto [b, prev] = VectorSource<Complex>::new_(std::vector<Complex>(4));
+        b->work();
+        auto [q, out] = QuadratureDemod::new_(std::move(prev), 1.0f);
+        q->work();
+        auto [o, tags] = out.read_buf();
+        CHECK(o.len() == 3);
+        for (auto v : o) CHECK(v == 0.0f);
+    }
+    {
+        auto [b, prev] = VectorSource<Complex>::new_({{1, 0}, {0.707f, -0.707f}, {0, -1}, {-1, 0}});
+        b->work();
+        auto [q, out] = QuadratureDemod::new_(std::move(prev), 1.0f);
+        q->work();
+        auto [o, tags] = out.read_buf();
+        const float want[3] = {-(float)M_PI / 4, -(float)M_PI / 4, -(float)M_PI / 2};
+        CHECK(o.len() == 3);
+        for (size_t i = 0; i < 3 && i < o.len(); i++) CHECK(std::fabs(o.slice()[i] - want[i]) < 1e-3f);
+    }
+}
+
+static void hilbert_rejects_even() {    // src/hilbert.rs:44-47
+    bool threw = false;
+    try { auto [s, so] = VectorSource<Float>::new_({1.f, 2.f}); Hilbert::new_(std::move(so), 64, WindowType::Hamming()); }
+    catch (const Error&) { threw = true; }
+    CHECK(threw);
+}
+
+static void graph_fm_chain() {
+    // examples/rtl_fm.rs:381-419 style chain on a Graph: VectorSource -> FftFilter -> RationalResampler
+    // -> QuadratureDemod -> VectorSink; a constant-frequency tone must demodulate to its phase step.
+    const size_t n = 600000;
+    const double w = 2.0 * M_PI * 10e3 / 2.4e6;
+    std::vector<Complex> x(n);
+    for (size_t i = 0; i < n; i++) x[i] = Complex((float)std::cos(w * i), (float)std::sin(w * i));
+    auto taps = fir::low_pass_complex(2.4e6f, 100e3f, 12.5e3f, WindowType::Hamming());
+    CHECK(taps.size() == 463);
+    auto [src, s0] = VectorSource<Complex>::new_(x);
+    auto [fft, s1] = FftFilter::new_(std::move(s0), taps);
+    auto [rs, s2] = RationalResampler<Complex>::new_(std::move(s1), 1, 6);
+    auto [qd, s3] = QuadratureDemod::new_(std::move(s2), 1.0f);
+    auto sink = std::make_unique<VectorSink<Float>>(std::move(s3));
+    auto hook = sink->hook();
+    Graph g;
+    g.add(std::move(src)); g.add(std::move(fft)); g.add(std::move(rs)); g.add(std::move(qd)); g.add(std::move(sink));
+    g.run();
+    const size_t n1 = (n / 561) * 561, n2 = (n1 + 5) / 6;
+    CHECK(hook->size() == n2 - 1);
+    double worst = 0;
+    for (size_t i = 200; i < hook->size(); i++) worst = std::max(worst, std::fabs((double)(*hook)[i] - 6.0 * w));
+    CHECK(worst < 1e-4);
+}
+
+int main() {
+    test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
+    fft_tag_propagation(); resampler_examples(); quad_known(); hilbert_rejects_even(); graph_fm_chain();
+    printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
+    return g_fail ? 1 : 0;
+}
