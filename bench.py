@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import rustradio_amd as rr  # noqa: E402
+from rustradio_amd import multi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "Msamples/s through FIR+FftFilter+Resampler+QuadDemod chain; % HBM roofline"
@@ -130,7 +131,7 @@ def make_fftfilter(dev, rank, world, shared_src):
     fs, n = 10e6, 100_000_000
     taps = rr.low_pass_complex(fs, 1e6, 60e3)
     assert len(taps) == 401
-    f_c = 0.0 if world == 1 else (rank - world // 2) * 250e3
+    f_c = 0.0 if world == 1 else multi.channel_frequency(rank, world, 250e3)
     blk = rr.FftFilter(chan_taps(taps, fs, f_c))
     w.blocks = [blk]
     w.n = n
@@ -308,20 +309,9 @@ def main():
 
     def shared_src(gen):
         """fan-out of the shared IQ source: rank 0 synthesises it, RCCL broadcasts it."""
-        if dist is None:
-            return gen()
-        if rank == 0:
-            t = gen()
-            meta = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
-        else:
-            meta = torch.zeros(1, dtype=torch.int64, device=dev)
-        dist.broadcast(meta, src=0)
-        if rank != 0:
-            t = torch.empty(int(meta.item()), dtype=torch.float32, device=dev)
-        tb0 = time.perf_counter()
-        dist.broadcast(t, src=0)
-        torch.cuda.synchronize()
-        shared_src.bcast_gbs = t.numel() * 4 / (time.perf_counter() - tb0) / 1e9
+        t, gbs = multi.broadcast_source(dist, rank, gen, dev)
+        if gbs is not None:
+            shared_src.bcast_gbs = gbs
         return t
     shared_src.bcast_gbs = None
 
@@ -330,14 +320,7 @@ def main():
     units, dt, kms, launches, dom_units = run_timed(w, args.steps, args.warmup, dist, stream)
 
     # max over ranks of the wall time, sum over ranks of the units
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        uu = torch.tensor([units], dtype=torch.float64, device=dev)
-        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
-        dt, units_all = float(tt.item()), float(uu.item())
-    else:
-        units_all = float(units)
+    units_all, dt = multi.aggregate(dist, units, dt, dev)
 
     others = {}
     if not args.no_others and world == 1:
