@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the PMC passes of tools/pmc_run.sh.
+HBM bytes per launch = FETCH_SIZE[KB]*1024*2 + WRITE_SIZE[KB]*1024: FETCH_SIZE on gfx950 counts a
+coalesced streaming read at half its bytes (MI355X_MICROARCH.md §HBM); WRITE_SIZE matched the
+known output size exactly (800,000,xxx B for 1e8 complex samples)."""
+import json
+import re
+import sys
+
+summary, workload, kernel = sys.argv[1], sys.argv[2], sys.argv[3]
+vals, cur = {}, None
+for line in open(summary):
+    if line.startswith("=="):
+        cur = line[2:].strip()
+    m = re.match(r"\s+(\w+)\s+launches=\s*(\d+)\s+avg/launch=([\d.e+]+)", line)
+    if m and cur and kernel in cur:
+        vals[m.group(1)] = float(m.group(3))
+out_path = "profiles/traffic.json"
+try:
+    d = json.load(open(out_path))
+except Exception:
+    d = {}
+d[workload] = {"hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
+               "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"],
+               "kernel": kernel, "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes"}
+json.dump(d, open(out_path, "w"), indent=1)
+print(d[workload])
