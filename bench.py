@@ -274,7 +274,7 @@ def measured_traffic(workload):
     (profiles/traffic.json, written by tools/pmc_traffic.py); None when not collected."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(workload)
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 

@@ -9,7 +9,8 @@
 #include "kernels.hpp"
 
 // Phase-ablation switches for measurement builds (-DRR_FFT_ABLATE_BUILD): RR_FFT_ABLATE=bits
-// 1: no input loads, 2: no output stores, 4: no LDS exchanges, 8: no butterflies.
+// 1: no input loads, 2: no output stores, 4: no LDS exchanges, 8: no butterflies,
+// 16: inputs re-read from an L2-resident window, 32: outputs written to an L2-resident window.
 #ifdef RR_FFT_ABLATE_BUILD
 #define RR_ABLATE(bit) (ablate & (bit))
 #else
@@ -104,6 +105,7 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
     creg* out_reg = reinterpret_cast<creg*>(out);
 
     auto load_tile = [&](long tile, creg* dst) {
+        if (RR_ABLATE(16)) tile = 8 + (tile & 63);      // measurement only: inputs from an L2-resident window
         const long v0 = tile * S;            // virtual index of the tile's first sample
         if (v0 >= src.plen && v0 - src.plen + F <= src.in_len) {       // interior tile: plain coalesced loads
             const creg* p = in_reg + (v0 - src.plen) + t;
@@ -206,7 +208,7 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
             if (!odd) continue;
         }
         // tile positions [L-1, F) are valid linear-convolution outputs
-        const long o0 = tile * S - first;
+        const long o0 = (RR_ABLATE(32) ? 8 + (tile & 63) : tile) * S - first;   // 32: outputs to an L2-resident window
         creg* po = out_reg + o0 + t;
         if (o0 + F <= n_out) {                                  // whole tile inside the output window
 #pragma unroll
