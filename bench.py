@@ -162,23 +162,37 @@ def make_fir(dev, rank, world, shared_src):
     return w
 
 
-def make_fm_chain(dev, rank, world, shared_src):
+def make_fm_chain(dev, rank, world, shared_src, fused=True):
     w = Workload()
-    w.name = "FftFilter(463 taps)->RationalResampler(1:6)->QuadratureDemod(exact atan2), 2.4 Msps x 10 s = 24,000,000 samples/step"
+    how = "fused into one kernel (rr.FmChain)" if fused else "three blocks, device-resident intermediates"
+    w.name = ("FftFilter(463 taps)->RationalResampler(1:6)->QuadratureDemod(exact atan2), 2.4 Msps x 10 s = "
+              "24,000,000 samples/step, " + how)
     fs, n = 2.4e6, 24_000_000
     taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
     assert len(taps) == 463
-    w.blocks = [rr.FftFilter(taps), rr.RationalResampler(1, 6, np.complex64), rr.QuadratureDemod(1.0, rr.ATAN2_EXACT)]
+    src = shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0003))
+    if fused:
+        w.blocks = [rr.FmChain(taps, 1, 6, 1.0, rr.ATAN2_EXACT)]
+        w.bufs = [src, torch.empty(n // 6 + 1024, dtype=torch.float32, device=dev)]
+        w.caps = [n // 6 + 1024]
+        w.dominant_bytes_per_unit = 8.0 + 4.0 / 6.0
+    else:
+        w.blocks = [rr.FftFilter(taps), rr.RationalResampler(1, 6, np.complex64), rr.QuadratureDemod(1.0, rr.ATAN2_EXACT)]
+        w.bufs = [src,
+                  torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev),
+                  torch.empty(2 * (n // 6 + 1024), dtype=torch.float32, device=dev),
+                  torch.empty(n // 6 + 1024, dtype=torch.float32, device=dev)]
+        w.caps = [n + 1024, n // 6 + 1024, n // 6 + 1024]
+        w.dominant_bytes_per_unit = 16.0
     w.n = n
-    w.bufs = [shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0003)),
-              torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev),
-              torch.empty(2 * (n // 6 + 1024), dtype=torch.float32, device=dev),
-              torch.empty(n // 6 + 1024, dtype=torch.float32, device=dev)]
-    w.caps = [n + 1024, n // 6 + 1024, n // 6 + 1024]
     w.alg_bytes_per_sample = 8.0 + 4.0 / 6.0
-    w.dominant, w.dominant_bytes_per_unit = 0, 16.0
+    w.dominant = 0
     w.cpu = ("fm_chain", taps)
     return w
+
+
+def make_fm_chain_unfused(dev, rank, world, shared_src):
+    return make_fm_chain(dev, rank, world, shared_src, fused=False)
 
 
 def make_channelizer(dev, rank, world, shared_src):
@@ -199,7 +213,8 @@ def make_channelizer(dev, rank, world, shared_src):
     return w
 
 
-WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain, "channelizer": make_channelizer}
+WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
+             "fm_chain_unfused": make_fm_chain_unfused, "channelizer": make_channelizer}
 
 
 # ---- measurement ------------------------------------------------------------------------------
@@ -353,7 +368,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain") else ("k_fir" if args.workload != "channelizer" else "k_fir<hilbert>"),
+                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused") else "k_fm_chain" if args.workload == "fm_chain" else ("k_fir" if args.workload != "channelizer" else "k_fir<hilbert>"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),

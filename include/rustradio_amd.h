@@ -97,6 +97,16 @@ rr_block *rr_quaddemod_create(float gain, int atan2_mode);
 /* Hilbert::new(src, ntaps, &window_type) (src/hilbert.rs:38-61); ntaps odd > 1. */
 rr_block *rr_hilbert_create(size_t ntaps, int window, float window_parm);
 
+/* Graph-level fusion of three reference blocks wired as in examples/rtl_fm.rs:381-419:
+ *   FftFilter::new(src, taps) -> RationalResampler::new(_, interp, deci) -> QuadratureDemod::new(_, gain)
+ * as ONE block (Complex in, f32 out) whose whole-stream output equals that of the three blocks in
+ * sequence (src/fft_filter.rs:290-354, src/rational_resampler.rs:155-206,
+ * src/quadrature_demod.rs:46-113); the filtered and resampled streams never reach HBM.
+ * work(): WAIT_DST(n) when the next filter block's outputs do not fit, else consumes like
+ * FftFilter (whole pending block) and WAIT_SRC(nsamples - pending). */
+rr_block *rr_fm_chain_create(const rr_c32 *taps, size_t ntaps, size_t interp, size_t deci,
+                             float gain, int atan2_mode);
+
 void rr_block_destroy(rr_block *b);
 
 /* ---- Block trait -------------------------------------------------------------- */

@@ -193,5 +193,12 @@ def QuadratureDemod(gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
     return Block(lib().rr_quaddemod_create(gain, mode), np.complex64, np.float32)
 
 
+def FmChain(taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
+    """FftFilter(taps) -> RationalResampler(interp, deci) -> QuadratureDemod(gain) fused into one
+    block / one kernel (examples/rtl_fm.rs:381-419 wiring); Complex in, f32 out."""
+    t = np.ascontiguousarray(taps, np.complex64)
+    return Block(lib().rr_fm_chain_create(_ptr(t), len(t), interp, deci, gain, mode), np.complex64, np.float32)
+
+
 def Hilbert(ntaps: int, wtype: int = WIN_HAMMING, parm: float = 0.0) -> Block:
     return Block(lib().rr_hilbert_create(ntaps, wtype, parm), np.float32, np.complex64)

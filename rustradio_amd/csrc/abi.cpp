@@ -97,6 +97,9 @@ rr_block* rr_quaddemod_create(float gain, int atan2_mode) {
 rr_block* rr_hilbert_create(size_t ntaps, int window, float window_parm) {
     return make_block([&] { return new rr::Hilbert(ntaps, window, window_parm); });
 }
+rr_block* rr_fm_chain_create(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int atan2_mode) {
+    return make_block([&] { return new rr::FmChain(taps, ntaps, interp, deci, gain, atan2_mode); });
+}
 void rr_block_destroy(rr_block* b) { delete b; }
 
 static int guarded(rr_block* b, size_t* consumed, size_t* produced, size_t* need, const char* what,

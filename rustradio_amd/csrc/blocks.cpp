@@ -322,6 +322,70 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     return st;
 }
 
+// ---- fused FM chain ------------------------------------------------------------------------------------
+static int64_t gcd64(int64_t a, int64_t b);
+FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float g, int m)
+    : Block("FftFilter>RationalResampler>QuadratureDemod", 8, 4), gain(g), mode(m) {
+    if (deci == 0) throw Error("RationalResampler created using deci 0");
+    if (interp == 0) throw Error("RationalResampler created using interp 0");
+    if (m != RR_ATAN2_EXACT && m != RR_ATAN2_FAST) throw Error("QuadratureDemod: bad atan2 mode");
+    if (interp > (size_t)1 << 40 || deci > (size_t)1 << 40) throw Error("FmChain: ratio out of range");
+    const int64_t gg = gcd64((int64_t)deci, (int64_t)interp);
+    D = (int64_t)deci / gg; I = (int64_t)interp / gg;
+    f.reset(new FftFilter(taps, ntaps));
+    const int64_t G = (D + I - 1) / I;
+    if (G >= (int64_t)(((size_t)1 << f->log2f) - f->L + 1)) throw Error("FmChain: decimation too large for the FFT tile");
+    for (auto& b : last_r) { b.reserve(1); RR_HIP(hipMemsetAsync(b.p, 0, sizeof(cf), stream)); }
+    RR_HIP(hipStreamSynchronize(stream));
+}
+
+int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                      size_t* produced, size_t* need, hipStream_t s) {
+    *consumed = *produced = *need = 0;
+    const uint64_t S = f->nsamples;
+    auto N2 = [&](uint64_t y) { return (uint64_t)(((__int128)y * I + D - 1) / D); };
+    auto N3 = [&](uint64_t y) { const uint64_t r = N2(y); return r ? r - 1 : 0; };
+    const uint64_t o_old = N3(n1);
+    // like FftFilter::work (fft_filter.rs:294-303): room for one block's worth of output first
+    const uint64_t need_next = N3(n1 + S) - o_old;
+    if (need_next > out_cap) { *need = need_next; return RR_WAIT_DST; }
+    const uint64_t total = f->pend_len + in_len;
+    const uint64_t k_in = total / S;
+    // largest k with N3(n1 + k S) - o_old <= out_cap  <=>  ceil((n1+kS) I / D) <= o_old + out_cap + 1
+    const __int128 X = (__int128)(o_old + out_cap + 1) * D / I;        // (n1 + k S) <= X
+    uint64_t k_out = X >= (__int128)n1 ? (uint64_t)((X - n1) / S) : 0;
+    while (k_out > 0 && N3(n1 + k_out * S) - o_old > out_cap) k_out--;
+    uint64_t k, new_pend;
+    int st;
+    if (k_in > k_out) {
+        k = k_out; *consumed = k * S - f->pend_len; new_pend = 0;
+        st = RR_WAIT_DST; *need = N3(n1 + (k + 1) * S) - N3(n1 + k * S);
+    } else {
+        k = k_in; *consumed = in_len; new_pend = total - k * S;
+        st = RR_WAIT_SRC; *need = S - new_pend;
+    }
+    const uint64_t n_y = k * S;
+    VSrc<cf> src{f->prefix[f->cur].p, (long)(f->L - 1 + f->pend_len), static_cast<const cf*>(in), (long)in_len};
+    if (k) {
+        FmChainArgs a;
+        a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
+        a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = gain; a.mode = mode;
+        prof_begin(s);
+        launch_fm_chain(f->log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a,
+                        last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        prof_end(s);
+        if (a.r_hi > a.r_lo) cur_lr ^= 1;
+    }
+    if (*consumed) {
+        launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
+        f->cur ^= 1;
+        f->pend_len = new_pend;
+    }
+    *produced = N3(n1 + n_y) - o_old;
+    n1 += n_y;
+    return st;
+}
+
 // ---- FftFilterFloat (fft_filter.rs:365-491) ---------------------------------------------------------
 FftFilterFloat::FftFilterFloat(const float* taps, size_t ntaps) : Block("FftFilterFloat", 4, 4) {
     if (ntaps == 0) throw Error("FftFilterFloat: empty taps");

@@ -70,6 +70,21 @@ struct FftFilter : Block {
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 
+// Fused FftFilter -> RationalResampler(interp:deci) -> QuadratureDemod (one kernel per call).
+// Whole-stream output = what the three reference blocks produce in sequence: after N input
+// samples, N1 = floor(N/nsamples)*nsamples filtered, N2 = ceil(N1*I/D) resampled, N2-1 demodulated.
+struct FmChain : Block {
+    std::unique_ptr<FftFilter> f;     // owns taps tables, history/pending prefix and tile choice
+    int64_t I = 1, D = 1;
+    float gain;
+    int mode;
+    uint64_t n1 = 0;                  // filtered samples emitted so far
+    DevBuf<cf> last_r[2];
+    int cur_lr = 0;
+    FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
 struct FftFilterFloat : Block {
     std::unique_ptr<FftFilter> inner;
     size_t cap = 0;

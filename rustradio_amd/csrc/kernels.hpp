@@ -14,6 +14,21 @@ bool fftfilt_supported(int log2f);
 void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw,
                        const cf* hpos, hipStream_t s);
 
+// Fused FftFilter -> RationalResampler -> QuadratureDemod over the same virtual stream.
+struct FmChainArgs {
+    long A;            // filtered samples emitted before this call
+    long n_y;          // filtered samples covered by this call (multiple of the reference nsamples)
+    long r_lo, r_hi;   // resampled samples r[m] = y[floor(m*D/I)] whose source lies in [A, A+n_y)
+    long o_base;       // demodulated samples emitted before this call
+    long I, D;         // reduced interp / deci
+    float gain;
+    int mode;          // RR_ATAN2_*
+};
+// out[(u-1) - o_base] = gain * atan2(conj(r[u-1]) r[u]) for u in [max(r_lo,1), r_hi); r[r_lo-1] is
+// *last_in (previous call), r[r_hi-1] is written to *last_out.
+void launch_fm_chain(int log2f, VSrc<cf> src, float* out, int L, const cf* tw, const cf* hpos,
+                     const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+
 // ---- kernels_fir.hip ---------------------------------------------------------------
 struct FirPlan {             // host-prepared polyphase tap table
     int L = 0, d = 1;

@@ -4,11 +4,18 @@
 // regrouping between passes.  Replaces RustFftEngine::run + the overlap-add loop of
 // FftFilter::work (/root/reference/src/fft_filter.rs:172-176, 290-354); results are
 // the same linear convolution, computed tile-independently.
+//
+// Two kernels share the transform body:
+//   k_fftfilt_os : the FftFilter block (tile in -> filtered tile out)
+//   k_fm_chain   : FftFilter -> RationalResampler -> QuadratureDemod fused: the filtered tile
+//                  never leaves the CU; the resampler pick (src/rational_resampler.rs:183-198)
+//                  and the conj-multiply + atan2 (src/quadrature_demod.rs:65-109) run as an
+//                  LDS epilogue and only the demodulated f32 stream is written to HBM.
 #include <cstdlib>
 
 #include "kernels.hpp"
 
-// Phase-ablation switches for measurement builds (-DRR_FFT_ABLATE_BUILD): RR_FFT_ABLATE=bits
+// Phase-ablation switches for measurement builds (make ABLATE=1): RR_FFT_ABLATE=bits
 // 1: no input loads, 2: no output stores, 4: no LDS exchanges, 8: no butterflies,
 // 16: inputs re-read from an L2-resident window, 32: outputs written to an L2-resident window.
 #ifdef RR_FFT_ABLATE_BUILD
@@ -32,30 +39,14 @@ namespace rr {
 // prefetch of the next tile (no gain).
 template <int LOG2F, int VAR> struct KCfg {
     static constexpr int T = 1 << (LOG2F - 4);
-    static constexpr bool TW0_REG = VAR == 0;
-    static constexpr bool TW1_REG = VAR == 0;
-    static constexpr bool H_REG = VAR == 0;
-    static constexpr bool H_LDS = false;
-    static constexpr bool PREFETCH = false;
+    static constexpr bool REG = VAR == 0;
     static constexpr int WAVES_PER_SIMD = VAR == 0 ? 2 : ((T / 64 + 3) / 4 < 2 ? 2 : (T / 64 + 3) / 4);
 };
 
-template <int LOG2F, int I, bool PERSIST>
-__device__ __forceinline__ void get_tw(creg* dst, const creg* persist, int t, const cf* __restrict__ tw) {
-    if constexpr (pass_has_twiddles<LOG2F, I>()) {
-        if constexpr (PERSIST) {
-#pragma unroll
-            for (int k = 0; k < 15; k++) dst[k] = persist[k];
-        } else {
-            load_twiddles<LOG2F, I>(dst, t, tw);
-        }
-    }
-}
-
 // Exchange synchronisation.  __syncthreads() also drains vmcnt (it is a fence), which would
-// serialise the prefetched global loads of the next tile behind every LDS exchange.  A
-// one-wave workgroup needs no barrier at all (a wave's LDS operations execute in order);
-// larger tiles wait for their own LDS writes only and then meet at a raw s_barrier.
+// serialise outstanding global traffic behind every LDS exchange.  A one-wave workgroup needs
+// no barrier at all (a wave's LDS operations execute in order); larger tiles wait for their
+// own LDS writes only and then meet at a raw s_barrier.
 template <int T> __device__ __forceinline__ void tile_sync() {
     if constexpr (T > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("" ::: "memory");
@@ -77,86 +68,60 @@ struct TileIter {
     }
 };
 
-template <int LOG2F, int VAR>
-__global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
-void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles,
-                  const cf* __restrict__ tw, const cf* __restrict__ hpos, int ablate) {
-    constexpr int F = 1 << LOG2F;
-    constexpr int T = F / 16;
-    constexpr int NP = Plan<LOG2F>::NP;
-    using K = KCfg<LOG2F, VAR>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    creg* lds = reinterpret_cast<creg*>(smem_raw);
-    const int t = threadIdx.x;
-    const long S = F - L + 1;
-    const int first = L - 1;                 // first valid position of a tile
-
-    // per-thread constants kept in registers for the whole kernel (per K)
+// Per-thread constants of a kernel instance + the transform of one tile held in v[16]:
+// forward FFT, multiply by H, inverse FFT.  On entry v[n] = x[n*T + t]; on exit
+// v[n] = y[n*T + t] (circular convolution of the tile with the taps, times 1: H carries 1/F).
+template <int LOG2F, int VAR> struct TileXform {
+    static constexpr int F = 1 << LOG2F;
+    static constexpr int T = F / 16;
+    static constexpr int NP = Plan<LOG2F>::NP;
+    static constexpr bool REG = KCfg<LOG2F, VAR>::REG;
     creg tw0[15], tw1[15], hreg[16];
-    if constexpr (K::TW0_REG) load_twiddles<LOG2F, 0>(tw0, t, tw);
-    if constexpr (K::TW1_REG) load_twiddles<LOG2F, 1>(tw1, t, tw);
-    if constexpr (K::H_REG) load_h<LOG2F, NP - 1>(hreg, t, hpos);
-    creg* hlds = lds + lds_elems(F);
-    if constexpr (K::H_LDS) {
-        for (int p = t; p < F; p += T) hlds[lds_pad(p)] = to_reg(hpos[p]);
-        __syncthreads();
-    }
-    const creg* in_reg = reinterpret_cast<const creg*>(src.in);
-    creg* out_reg = reinterpret_cast<creg*>(out);
+    const cf* __restrict__ tw;
+    const cf* __restrict__ hpos;
+    int t;
 
-    auto load_tile = [&](long tile, creg* dst) {
-        if (RR_ABLATE(16)) tile = 8 + (tile & 63);      // measurement only: inputs from an L2-resident window
-        const long v0 = tile * S;            // virtual index of the tile's first sample
-        if (v0 >= src.plen && v0 - src.plen + F <= src.in_len) {       // interior tile: plain coalesced loads
-            const creg* p = in_reg + (v0 - src.plen) + t;
-#pragma unroll
-            for (int n = 0; n < 16; n++) dst[n] = p[n * T];
-        } else {
-#pragma unroll
-            for (int n = 0; n < 16; n++) dst[n] = to_reg(src.load(v0 + n * T + t));
+    __device__ __forceinline__ void init(int t_, const cf* tw_, const cf* hpos_) {
+        t = t_; tw = tw_; hpos = hpos_;
+        if constexpr (REG) {
+            load_twiddles<LOG2F, 0>(tw0, t, tw);
+            load_twiddles<LOG2F, 1>(tw1, t, tw);
+            load_h<LOG2F, NP - 1>(hreg, t, hpos);
         }
-    };
-    TileIter it(ntiles);
-    creg nxt[16];
-    if constexpr (K::PREFETCH) {
-        if (it.tile < it.end) load_tile(it.tile, nxt);
     }
-    for (; it.tile < it.end; it.tile += it.step) {
-        const long tile = it.tile;
-        if constexpr (VAR != 0) asm volatile("" ::: "memory");  // keep per-tile table loads inside the loop
-        creg v[16];
-        if constexpr (K::PREFETCH) {
+    template <int I> __device__ __forceinline__ void get_tw(creg* dst, const creg* persist) const {
+        if constexpr (pass_has_twiddles<LOG2F, I>()) {
+            if constexpr (REG && I < 2) {
 #pragma unroll
-            for (int n = 0; n < 16; n++) v[n] = nxt[n];
-            if (tile + it.step < it.end) load_tile(tile + it.step, nxt);
-        } else {
-            if (RR_ABLATE(1)) {      // measurement only: no input traffic
-#pragma unroll
-                for (int n = 0; n < 16; n++) v[n] = mk((float)(t + n), (float)tile);
-            } else load_tile(tile, v);
+                for (int k = 0; k < 15; k++) dst[k] = persist[k];
+            } else {
+                load_twiddles<LOG2F, I>(dst, t, tw);
+            }
         }
-        RR_PHASE();
+    }
+    __device__ __forceinline__ void run(creg* v, creg* lds, int ablate) const {
+        (void)ablate;
+        if constexpr (!REG) asm volatile("" ::: "memory");   // keep per-tile table loads inside the tile loop
         creg twl[15];
         const bool do_lds = !RR_ABLATE(4), do_math = !RR_ABLATE(8);
 #define lds_store if (do_lds) lds_store
 #define lds_load if (do_lds) lds_load
 #define fwd_pass if (do_math) fwd_pass
 #define inv_pass if (do_math) inv_pass
-
         // ---- forward ----
-        get_tw<LOG2F, 0, K::TW0_REG>(twl, tw0, t, tw);
+        get_tw<0>(twl, tw0);
         fwd_pass<LOG2F, 0>(v, twl);
         lds_store<LOG2F, 0>(v, t, lds);
         tile_sync<T>();
         RR_PHASE();
         lds_load<LOG2F, 1>(v, t, lds);
-        get_tw<LOG2F, 1, K::TW1_REG>(twl, tw1, t, tw);
+        get_tw<1>(twl, tw1);
         fwd_pass<LOG2F, 1>(v, twl);
         lds_store<LOG2F, 1>(v, t, lds);
         tile_sync<T>();
         RR_PHASE();
         lds_load<LOG2F, 2>(v, t, lds);
-        get_tw<LOG2F, 2, false>(twl, tw1, t, tw);
+        get_tw<2>(twl, tw1);
         fwd_pass<LOG2F, 2>(v, twl);
         if constexpr (NP == 4) {
             lds_store<LOG2F, 2>(v, t, lds);
@@ -165,12 +130,8 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
             fwd_pass<LOG2F, 3>(v, twl);
         }
         // ---- frequency response, then the mirror ----
-        if constexpr (K::H_REG) {
+        if constexpr (REG) {
             apply_h(v, hreg);
-        } else if constexpr (K::H_LDS) {
-            creg h[16];
-            lds_load<LOG2F, NP - 1>(h, t, hlds);
-            apply_h(v, h);
         } else {
             creg h[16];
             load_h<LOG2F, NP - 1>(h, t, hpos);
@@ -181,26 +142,88 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
             lds_store<LOG2F, 3>(v, t, lds);
             tile_sync<T>();
             lds_load<LOG2F, 2>(v, t, lds);
-            get_tw<LOG2F, 2, false>(twl, tw1, t, tw);
+            get_tw<2>(twl, tw1);
         }
         inv_pass<LOG2F, 2>(v, twl);
         lds_store<LOG2F, 2>(v, t, lds);
         tile_sync<T>();
         RR_PHASE();
         lds_load<LOG2F, 1>(v, t, lds);
-        get_tw<LOG2F, 1, K::TW1_REG>(twl, tw1, t, tw);
+        get_tw<1>(twl, tw1);
         inv_pass<LOG2F, 1>(v, twl);
         lds_store<LOG2F, 1>(v, t, lds);
         tile_sync<T>();
         RR_PHASE();
         lds_load<LOG2F, 0>(v, t, lds);
-        get_tw<LOG2F, 0, K::TW0_REG>(twl, tw0, t, tw);
+        get_tw<0>(twl, tw0);
         inv_pass<LOG2F, 0>(v, twl);
-
 #undef lds_store
 #undef lds_load
 #undef fwd_pass
 #undef inv_pass
+    }
+};
+
+// Boundary tiles (touching the carry prefix, the start of the stream or the end of the window)
+// are staged through LDS by an out-of-line routine so that their index arithmetic does not
+// cost the steady-state path any registers.
+template <int T>
+__device__ __attribute__((noinline)) void stage_tile_slow(creg* lds, const cf* prefix, long plen, const cf* in,
+                                                          long in_len, long v0, int t) {
+    for (int n = 0; n < 16; n++) {
+        const int p = n * T + t;
+        const long vi = v0 + p;
+        cf x = mkcf(0.0f, 0.0f);
+        if (vi >= 0) {
+            if (vi < plen) x = prefix[vi];
+            else if (vi - plen < in_len) x = in[vi - plen];
+        }
+        lds[lds_pad(p)] = to_reg(x);
+    }
+}
+
+// v[n] = xx[v0 + n*T + t]; interior tiles use plain lane-consecutive loads.
+template <int LOG2F> __device__ __forceinline__ void load_tile16(creg* v, const VSrc<cf>& src, long v0, int t, creg* lds) {
+    constexpr int T = 1 << (LOG2F - 4);
+    if (v0 >= src.plen && v0 - src.plen + 16 * T <= src.in_len) {
+        const creg* p = reinterpret_cast<const creg*>(src.in) + (v0 - src.plen) + t;
+#pragma unroll
+        for (int n = 0; n < 16; n++) v[n] = p[n * T];
+    } else {
+        stage_tile_slow<T>(lds, src.prefix, src.plen, src.in, src.in_len, v0, t);
+        tile_sync<T>();          // (own slots only: each thread reads back what it wrote)
+        lds_load<LOG2F, 0>(v, t, lds);
+    }
+}
+
+// ---- FftFilter -----------------------------------------------------------------------------------
+template <int LOG2F, int VAR>
+__global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
+void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles,
+                  const cf* __restrict__ tw, const cf* __restrict__ hpos, int ablate) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    const int t = threadIdx.x;
+    const long S = F - L + 1;
+    const int first = L - 1;                 // first valid position of a tile
+    TileXform<LOG2F, VAR> X;
+    X.init(t, tw, hpos);
+    creg* out_reg = reinterpret_cast<creg*>(out);
+
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long tile = it.tile;
+        creg v[16];
+        if (RR_ABLATE(1)) {      // measurement only: no input traffic
+#pragma unroll
+            for (int n = 0; n < 16; n++) v[n] = mk((float)(t + n), (float)tile);
+        } else {
+            load_tile16<LOG2F>(v, src, (RR_ABLATE(16) ? 8 + (tile & 63) : tile) * S, t, lds);
+        }
+        RR_PHASE();
+        X.run(v, lds, ablate);
+
         if (RR_ABLATE(2)) {          // measurement only: no output traffic (keeps v live)
             bool odd = false;
 #pragma unroll
@@ -208,7 +231,7 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
             if (!odd) continue;
         }
         // tile positions [L-1, F) are valid linear-convolution outputs
-        const long o0 = (RR_ABLATE(32) ? 8 + (tile & 63) : tile) * S - first;   // 32: outputs to an L2-resident window
+        const long o0 = (RR_ABLATE(32) ? 8 + (tile & 63) : tile) * S - first;
         creg* po = out_reg + o0 + t;
         if (o0 + F <= n_out) {                                  // whole tile inside the output window
 #pragma unroll
@@ -227,35 +250,130 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
     }
 }
 
+// ---- fused FftFilter -> RationalResampler -> QuadratureDemod ------------------------------------------
+// fast-math 0.1.1 atan2 restated from its published algorithm (crate not vendored: parity-unpinned
+// flavour); same code as k_quaddemod in kernels_misc.hip.
+__device__ __forceinline__ float fmc_flip_sign(float v, float s) {
+    return __uint_as_float(__float_as_uint(v) ^ (__float_as_uint(s) & 0x80000000u));
+}
+__device__ __forceinline__ float fmc_atan_raw(float x) {
+    return __fmul_rn(__fsub_rn(__fadd_rn(0.78539816339744830962f, 0.273f), __fmul_rn(0.273f, fabsf(x))), x);
+}
+__device__ __forceinline__ float fmc_atan2(float y, float x) {
+    if (fabsf(y) < fabsf(x)) {
+        const float bias = x > 0.0f ? 0.0f : 3.14159265358979323846f;
+        return __fadd_rn(fmc_flip_sign(bias, y), fmc_atan_raw(__fdiv_rn(y, x)));
+    } else if (x == 0.0f) {
+        if (y == 0.0f) return 0.0f;
+        return fmc_flip_sign(1.57079632679489661923f, y);
+    }
+    return __fsub_rn(fmc_flip_sign(1.57079632679489661923f, y), fmc_atan_raw(__fdiv_rn(x, y)));
+}
+
+struct FmArgs {
+    long A;          // filtered samples emitted before this call (global index of y at tile-space 0)
+    long n_y;        // filtered samples of this call: y[A .. A + n_y)
+    long r_lo, r_hi; // resampled samples whose source lies in this call: r[r_lo .. r_hi)
+    long o_base;     // demod outputs emitted before this call (o index of out[0])
+    long I, D;       // reduced interp / deci: r[m] = y[floor(m*D/I)]
+    int G;           // max distance between the sources of r[m] and r[m+1]
+    float gain;
+    int mode;        // RR_ATAN2_*
+};
+
+// Tile j transforms y[A + j*Sp - G .. + S') and owns every demod output o[u-1] whose UPPER
+// sample r[u] has its source in [A + j*Sp, A + (j+1)*Sp), Sp = S' - G; the lower sample r[u-1]
+// then lies in the same tile — or is the last r of the previous call (`last_r`).
+template <int LOG2F, int VAR>
+__global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
+void k_fm_chain(VSrc<cf> src, float* __restrict__ out, int L, long ntiles, const cf* __restrict__ tw,
+                const cf* __restrict__ hpos, FmArgs a, const cf* __restrict__ last_r_in,
+                cf* __restrict__ last_r_out) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    const int t = threadIdx.x;
+    const int first = L - 1;
+    const long Sp = (F - L + 1) - a.G;
+    TileXform<LOG2F, VAR> X;
+    X.init(t, tw, hpos);
+
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long tile = it.tile;
+        // tile-space position p holds y[ys + p - first] with ys = tile*Sp - G (relative to A);
+        // virtual input index of position 0 = ys (the prefix starts L-1 samples before y[A])
+        const long ys = tile * Sp - a.G;
+        creg v[16];
+        load_tile16<LOG2F>(v, src, ys, t, lds);
+        RR_PHASE();
+        X.run(v, lds, 0);
+        lds_store<LOG2F, 0>(v, t, lds);          // natural order: lds[pad(p)] = tile position p
+        tile_sync<T>();
+
+        // upper samples u with source in [tile*Sp, min((tile+1)*Sp, n_y))  (relative to A)
+        const long y_lo = tile * Sp, y_hi = min((tile + 1) * Sp, a.n_y);
+        // u >= ceil((A + y) * I / D)
+        long u_lo = ((a.A + y_lo) * a.I + a.D - 1) / a.D;
+        long u_hi = ((a.A + y_hi) * a.I + a.D - 1) / a.D;
+        if (u_lo < a.r_lo) u_lo = a.r_lo;
+        if (u_hi > a.r_hi) u_hi = a.r_hi;
+        for (long u = u_lo + t; u < u_hi; u += T) {
+            const long gu = (u * a.D) / a.I - a.A;                 // source of r[u], relative to A
+            const creg ru = lds[lds_pad((int)(gu - ys) + first)];
+            if (u == a.r_hi - 1) last_r_out[0] = from_reg(ru);     // carry for the next call
+            if (u == 0) continue;                                   // r[0] has no lower partner
+            creg rl;
+            if (u == a.r_lo) rl = to_reg(last_r_in[0]);             // lower sample from the previous call
+            else {
+                const long gl = ((u - 1) * a.D) / a.I - a.A;
+                rl = lds[lds_pad((int)(gl - ys) + first)];
+            }
+            // conj(rl) * ru in num-complex order, un-contracted (quadrature_demod.rs:72)
+            const float na = -rl.y;
+            const float re = __fsub_rn(__fmul_rn(rl.x, ru.x), __fmul_rn(na, ru.y));
+            const float im = __fadd_rn(__fmul_rn(rl.x, ru.y), __fmul_rn(na, ru.x));
+            const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+            out[(u - 1) - a.o_base] = __fmul_rn(a.gain, ang);
+        }
+        tile_sync<T>();        // epilogue reads done before the next tile's first exchange
+    }
+}
+
 bool fftfilt_supported(int log2f) { return log2f >= 10 && log2f <= 14; }
 
 int device_cu_count() {
-    int dev = 0, n = 0;
-    RR_HIP(hipGetDevice(&dev));
-    RR_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        RR_HIP(hipGetDevice(&dev));
+        RR_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    }
     return n;
 }
 
+template <class KFn> static long grid_for_tiles(KFn kfn, int T, size_t smem, long ntiles, bool& attr_set, int& per_cu) {
+    if (!attr_set) {
+        RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, T, smem));
+        if (per_cu < 1) per_cu = 1;
+        attr_set = true;
+    }
+    long grid = (long)device_cu_count() * per_cu;
+    return grid > ntiles ? ntiles : grid;
+}
+
 template <int LOG2F, int VAR>
-static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos,
-                       hipStream_t s) {
+static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     const long S = F - L + 1;
     const long ntiles = (n_out + S - 1) / S;
     if (ntiles <= 0) return;
-    const size_t smem = sizeof(cf) * lds_elems(F) * (KCfg<LOG2F, VAR>::H_LDS ? 2 : 1);
+    const size_t smem = sizeof(cf) * lds_elems(F);
     static bool attr_set = false;
     static int per_cu = 0;
-    if (!attr_set) {
-        RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftfilt_os<LOG2F, VAR>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fftfilt_os<LOG2F, VAR>, T, smem));
-        if (per_cu < 1) per_cu = 1;
-        attr_set = true;
-    }
-    long grid = (long)device_cu_count() * per_cu;
-    if (grid > ntiles) grid = ntiles;
+    const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR>, T, smem, ntiles, attr_set, per_cu);
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("RR_FFT_ABLATE"); ablate = e ? atoi(e) : 0; }   // measurement knob
     hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L,
@@ -272,6 +390,39 @@ void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, cons
     case 13: launch_one<13, 3>(src, out, n_out, L, tw, hpos, s); break;
     case 14: launch_one<14, 3>(src, out, n_out, L, tw, hpos, s); break;
     default: throw Error("fftfilt: unsupported tile size");
+    }
+}
+
+template <int LOG2F, int VAR>
+static void launch_fm_one(VSrc<cf> src, float* out, int L, const cf* tw, const cf* hpos, const FmChainArgs& h,
+                          const cf* last_in, cf* last_out, hipStream_t s) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    FmArgs a;
+    a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
+    a.I = h.I; a.D = h.D; a.G = (int)((h.D + h.I - 1) / h.I); a.gain = h.gain; a.mode = h.mode;
+    const long Sp = (F - L + 1) - a.G;
+    if (Sp <= 0) throw Error("fm_chain: decimation too large for the tile");
+    const long ntiles = (h.n_y + Sp - 1) / Sp;
+    if (ntiles <= 0) return;
+    const size_t smem = sizeof(cf) * lds_elems(F);
+    static bool attr_set = false;
+    static int per_cu = 0;
+    const long grid = grid_for_tiles(k_fm_chain<LOG2F, VAR>, T, smem, ntiles, attr_set, per_cu);
+    hipLaunchKernelGGL((k_fm_chain<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, L, ntiles, tw,
+                       hpos, a, last_in, last_out);
+    RR_HIP(hipGetLastError());
+}
+
+void launch_fm_chain(int log2f, VSrc<cf> src, float* out, int L, const cf* tw, const cf* hpos,
+                     const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    switch (log2f) {
+    case 10: launch_fm_one<10, 0>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    case 11: launch_fm_one<11, 0>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    case 12: launch_fm_one<12, 0>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    case 13: launch_fm_one<13, 3>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    case 14: launch_fm_one<14, 3>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    default: throw Error("fm_chain: unsupported tile size");
     }
 }
 

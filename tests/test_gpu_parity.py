@@ -234,3 +234,54 @@ def test_device_window_api(rr):
     assert st == WAIT_SRC and c == len(x) and p == len(yo)
     yg = dy.cpu().numpy().view(np.complex64)[:p]
     assert max_norm_err(yg, yo) <= TOL
+
+
+def _demod_close(yg, yo, ro):
+    """conditioning-aware end-to-end bound (see test_fm_chain_cfg3)."""
+    assert len(yg) == len(yo)
+    eps = TOL * float(np.max(np.abs(ro)))
+    mag = np.abs(ro.astype(np.complex128))
+    bound = TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30)
+    d = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
+    d = np.minimum(d, 2 * np.pi - d)
+    assert np.all(d <= bound[:len(d)]), float(np.max(d - bound[:len(d)]))
+    return d
+
+
+@pytest.mark.parametrize("L,I,D", [(463, 1, 6), (401, 1, 1), (127, 25, 128), (33, 3, 2), (463, 200000, 1024000), (5, 1, 40)])
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 20_000])
+def test_fm_chain_fused_block(rr, L, I, D, stream_bytes):
+    """rr.FmChain (one fused kernel) == FftFilter -> RationalResampler -> QuadratureDemod of the oracle,
+    for whole-stream output and any chunking."""
+    fs = 2.4e6
+    n = 400_000
+    x = fm_signal(n, fs, 0.0, 77 + L)
+    if L == 463:
+        taps = orc.low_pass_complex(fs, 100e3, 12.5e3)
+    else:
+        taps = (rnd_c(L, L) / max(1, L // 4)).astype(np.complex64)
+    gain = 0.9
+    yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D), orc.QuadratureDemod(gain)], x, stream_bytes=stream_bytes)
+    ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D)], x, stream_bytes=stream_bytes)
+    yg = run_chain([rr.FmChain(taps, I, D, gain)], x, stream_bytes=stream_bytes)
+    d = _demod_close(yg / gain, yo / gain, ro)
+    if L == 463 and (I, D) == (1, 6):
+        assert np.max(d[len(taps) // 6 + 2:]) <= TOL * np.pi
+
+
+def test_fm_chain_fused_protocol(rr):
+    taps = orc.low_pass_complex(2.4e6, 100e3, 12.5e3)       # nsamples 561
+    b = rr.FmChain(taps, 1, 6, 1.0)
+    x = fm_signal(10_000, 2.4e6, 0.0, 5)
+    assert b.work(x[:100], 50)[:4] == (WAIT_DST, 0, 0, 93)        # ceil(561/6) - 1 outputs needed
+    assert b.work(x[:100], 1000)[:4] == (WAIT_SRC, 100, 0, 461)
+    st, c, p, need, out = b.work(x[100:5000], 1000)
+    # 100 + 4900 = 5000 = 8 blocks + 512: N1 = 4488, N2 = 748, out 747
+    assert (st, c, p, need) == (WAIT_SRC, 4900, 747, 561 - 512)
+    st, c, p, need, out = b.work(x[5000:], 100)
+    # 512 + 5000 = 9 blocks (5049) + 463; outputs per block ~93.5 -> only one more block fits in 100
+    assert st == WAIT_DST and p <= 100 and c == 561 - 512
+    with pytest.raises(ValueError):
+        rr.FmChain(taps, 0, 6)
+    with pytest.raises(ValueError):
+        rr.FmChain(taps, 1, 100000)
