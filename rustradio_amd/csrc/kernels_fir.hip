@@ -13,9 +13,7 @@
 
 namespace rr {
 
-constexpr int FIR_R = 8;
-
-__device__ __forceinline__ void mac(cf& acc, float tap, cf w) {   // real tap (2 FMA)
+__device__ __forceinline__ void mac(cf& acc, float tap, cf w) {   // real tap (one v_pk_fma_f32)
     acc.x = fmaf(tap, w.x, acc.x);
     acc.y = fmaf(tap, w.y, acc.y);
 }
@@ -31,47 +29,62 @@ template <class T> __device__ __forceinline__ T zero_of();
 template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
 template <> __device__ __forceinline__ cf zero_of<cf>() { return mkcf(0.0f, 0.0f); }
 
-// geometry shared by host and device
+// Tile geometry shared by host and device.  NT threads x R outputs each = NOUT outputs per tile.
+//   input  LDS: per phase p, x_p[n] at  p*pstride + (n % R)*rstride + n / R      (transposed)
+//   output LDS: output i of the tile at (i / R)*(R + 1) + i % R                    (re-coalescing)
 struct FirGeom {
     int np;        // samples per phase staged in LDS
     int rstride;   // row stride (elements) of the transposed tile
     int pstride;   // phase stride
     size_t lds_bytes;
 };
-static FirGeom fir_geom(int NT, int d, int qpad, size_t es) {
+static FirGeom fir_geom(int NT, int R, int d, int qpad, size_t es_in, size_t es_out) {
     FirGeom g;
-    g.np = NT * FIR_R + qpad;
-    int rs = NT + qpad / FIR_R;
-    const int mod = es == 8 ? 16 : 32, want = es == 8 ? 2 : 4;   // bank-friendly residue (see header)
+    g.np = NT * R + qpad;
+    int rs = NT + qpad / R;
+    const int mod = es_in == 8 ? 16 : 32, want = es_in == 8 ? 2 : 4;   // bank-friendly residue
     while (rs % mod != want) rs++;
     g.rstride = rs;
-    g.pstride = FIR_R * rs + 1;
-    g.lds_bytes = (size_t)d * g.pstride * es;
+    g.pstride = R * rs + 1;
+    const size_t in_b = (size_t)d * g.pstride * es_in;
+    const size_t out_b = (size_t)NT * (R + 1) * es_out;
+    g.lds_bytes = in_b > out_b ? in_b : out_b;
     return g;
 }
 
-template <class T, class TapT, class OutT, int NT, bool HILBERT>
+template <class T, class TapT, class OutT, int NT, int R, bool HILBERT>
 __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
                                             int qpad, int np, int rstride, int pstride,
                                             const TapT* __restrict__ tp) {
-    constexpr int R = FIR_R;
     constexpr int NOUT = NT * R;
+    static_assert(R % 2 == 0 && R <= 8, "qpad is padded to a multiple of 8");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
+    OutT* lds_o = reinterpret_cast<OutT*>(smem_raw);
     const int t = threadIdx.x;
     const long ntiles = (n_out + NOUT - 1) / NOUT;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long m0 = tile * NOUT;
         const long gi0 = m0 * d;
-        __syncthreads();
         const int total = np * d;
+        __syncthreads();                       // previous tile's output reads are done
+        // ---- stage the input tile (lane-consecutive global reads, transposed LDS writes) ----
+        const bool interior = gi0 >= src.plen && gi0 - src.plen + total <= src.in_len;
+        const T* gp = src.in + (gi0 - src.plen);
         if (d == 1) {
-            for (int i = t; i < total; i += NT)
-                lds[(i % R) * rstride + i / R] = src.load(gi0 + i);
+            if (interior) {
+                for (int i = t; i < total; i += NT) lds[(i % R) * rstride + i / R] = gp[i];
+            } else {
+                for (int i = t; i < total; i += NT) lds[(i % R) * rstride + i / R] = src.load(gi0 + i);
+            }
         } else {
+            // i = n*d + p: walk n and p incrementally (NT = a*d + b per step) instead of dividing
+            int p = t % d, n = t / d;
+            const int sp = NT % d, sn = NT / d;
             for (int i = t; i < total; i += NT) {
-                const int p = i % d, n = i / d;
-                lds[p * pstride + (n % R) * rstride + n / R] = src.load(gi0 + i);
+                lds[p * pstride + (n % R) * rstride + n / R] = interior ? gp[i] : src.load(gi0 + i);
+                p += sp; n += sn;
+                if (p >= d) { p -= d; n++; }
             }
         }
         __syncthreads();
@@ -96,18 +109,26 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
                 }
             }
         }
-        const long mb = m0 + (long)t * R;
-        if constexpr (HILBERT) {
-            // re = xp[k + L/2]  (hilbert.rs:115)
+        // ---- re-coalesce the outputs through LDS: thread t holds outputs t*R .. t*R+R-1 ----
+        OutT res[R];
+        if constexpr (HILBERT) {               // re = xp[k + L/2]  (hilbert.rs:115)
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 const int n = t * R + j + L / 2;
-                if (mb + j < n_out) out[mb + j] = mkcf(lds[(n % R) * rstride + n / R], acc[j]);
+                res[j] = mkcf(lds[(n % R) * rstride + n / R], acc[j]);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < R; j++)
-                if (mb + j < n_out) out[mb + j] = acc[j];
+            for (int j = 0; j < R; j++) res[j] = acc[j];
+        }
+        __syncthreads();                       // everybody is done reading the input tile
+#pragma unroll
+        for (int j = 0; j < R; j++) lds_o[t * (R + 1) + j] = res[j];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < R; c++) {
+            const int i = c * NT + t;
+            if (m0 + i < n_out) out[m0 + i] = lds_o[(i / R) * (R + 1) + i % R];
         }
     }
 }
@@ -126,19 +147,27 @@ __global__ __launch_bounds__(256) void k_fir_direct(VSrc<T> src, OutT* __restric
     }
 }
 
+// Tile choice: the largest tile whose LDS footprint still lets >= 4 workgroups share a CU and
+// that yields >= 2 tiles per CU (small inputs get small tiles); decimating filters use R = 4
+// so that the d-times larger input tile still fits.
 template <class T, class TapT, class OutT, bool HILBERT>
 static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, VSrc<T> src, OutT* out,
                            long n_out, hipStream_t s) {
     if (n_out <= 0) return;
     const int cus = device_cu_count();
-    const size_t LDS_LIMIT = 64 * 1024;
-    int NT = 0;
+    struct Cfg { int NT, R; };
+    static const Cfg cfgs[] = {{256, 8}, {128, 8}, {64, 8}, {128, 4}, {64, 4}};
+    int pick = -1;
     FirGeom g{};
-    for (int cand : {256, 128, 64}) {
-        g = fir_geom(cand, pl.d, pl.qpad, sizeof(T));
-        if (g.lds_bytes <= LDS_LIMIT) { NT = cand; break; }
+    for (int c = 0; c < 5; c++) {
+        const FirGeom gc = fir_geom(cfgs[c].NT, cfgs[c].R, pl.d, pl.qpad, sizeof(T), sizeof(OutT));
+        if (gc.lds_bytes > 40 * 1024) continue;
+        const long tiles = (n_out + (long)cfgs[c].NT * cfgs[c].R - 1) / ((long)cfgs[c].NT * cfgs[c].R);
+        if (pick < 0) { pick = c; g = gc; }                       // first (largest) that fits
+        if (tiles >= 2L * cus) { pick = c; g = gc; break; }       // ... preferring one that fills the chip
+        pick = c; g = gc;                                         // otherwise keep shrinking
     }
-    if (NT == 0) {
+    if (pick < 0) {
         long grid = (n_out + 255) / 256;
         if (grid > (long)cus * 16) grid = (long)cus * 16;
         hipLaunchKernelGGL((k_fir_direct<T, TapT, OutT, HILBERT>), dim3((unsigned)grid), dim3(256), 0, s, src, out,
@@ -146,16 +175,23 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
         RR_HIP(hipGetLastError());
         return;
     }
-    const long ntiles = (n_out + (long)NT * FIR_R - 1) / ((long)NT * FIR_R);
-    long grid = ntiles;
-    const long cap = (long)cus * (long)((160 * 1024) / (g.lds_bytes ? g.lds_bytes : 1) > 8 ? 8 : (160 * 1024) / g.lds_bytes);
-    if (grid > cap && cap > 0) grid = cap;
-#define RR_FIR_LAUNCH(NTV)                                                                                    \
-    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, s, \
+    const int NT = cfgs[pick].NT, R = cfgs[pick].R;
+    const long ntiles = (n_out + (long)NT * R - 1) / ((long)NT * R);
+    long per_cu = (long)(160 * 1024) / (long)(g.lds_bytes ? g.lds_bytes : 1);
+    const long by_waves = 32 / (NT / 64);
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    long grid = ntiles < (long)cus * per_cu ? ntiles : (long)cus * per_cu;
+#define RR_FIR_LAUNCH(NTV, RV)                                                                                     \
+    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, s, \
                        src, out, n_out, pl.L, pl.d, pl.qpad, g.np, g.rstride, g.pstride, tp)
-    if (NT == 256) RR_FIR_LAUNCH(256);
-    else if (NT == 128) RR_FIR_LAUNCH(128);
-    else RR_FIR_LAUNCH(64);
+    switch (pick) {
+    case 0: RR_FIR_LAUNCH(256, 8); break;
+    case 1: RR_FIR_LAUNCH(128, 8); break;
+    case 2: RR_FIR_LAUNCH(64, 8); break;
+    case 3: RR_FIR_LAUNCH(128, 4); break;
+    default: RR_FIR_LAUNCH(64, 4); break;
+    }
 #undef RR_FIR_LAUNCH
     RR_HIP(hipGetLastError());
 }
