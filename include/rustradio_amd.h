@@ -148,6 +148,10 @@ int         rr_block_sync(rr_block *b);
 int rr_block_set_profiling(rr_block *b, int on);
 int rr_block_profile(rr_block *b, double *total_ms, size_t *launches, int reset);
 
+/* Measurement builds only (make ABLATE=1, env RR_FFT_STAMPS=1): 16 s_memtime stamps taken at the
+ * phase boundaries of one FftFilter tile; returns 0 in product builds. */
+int rr_debug_fft_stamps(unsigned long long *out16);
+
 /* ---- per-block knobs / introspection ------------------------------------------- */
 /* FftFilter: reference fft_size and nsamples (src/fft_filter.rs:261-262) and the
  * internal overlap-save tile the GPU kernel uses. */

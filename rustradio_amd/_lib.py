@@ -19,7 +19,7 @@ SYMBOLS = [
     "rr_resampler_create", "rr_quaddemod_create", "rr_hilbert_create", "rr_fm_chain_create", "rr_block_destroy",
     "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_in_elem_size",
     "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_set_rotator_mode",
-    "rr_block_set_profiling", "rr_block_profile",
+    "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps",
 ]
 
 _lib = None
@@ -64,6 +64,7 @@ def lib():
     L.rr_block_sync.argtypes = [vp]; L.rr_block_sync.restype = i32
     L.rr_fftfilter_dims.argtypes = [vp, psz, psz, psz]; L.rr_fftfilter_dims.restype = i32
     L.rr_fir_set_rotator_mode.argtypes = [vp, i32]; L.rr_fir_set_rotator_mode.restype = i32
+    L.rr_debug_fft_stamps.argtypes = [vp]; L.rr_debug_fft_stamps.restype = i32
     L.rr_block_set_profiling.argtypes = [vp, i32]; L.rr_block_set_profiling.restype = i32
     L.rr_block_profile.argtypes = [vp, C.POINTER(C.c_double), psz, i32]; L.rr_block_profile.restype = i32
     _lib = L

@@ -149,6 +149,11 @@ int rr_block_profile(rr_block* b, double* total_ms, size_t* launches, int reset)
     catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
 }
 
+/* measurement builds (make ABLATE=1): phase time stamps of one FftFilter tile; 0 in product builds */
+int rr_debug_fft_stamps(unsigned long long* out16) {
+    try { return rr::fft_read_stamps(out16); } catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
+}
+
 int rr_fftfilter_dims(const rr_block* b, size_t* fft_size, size_t* nsamples, size_t* gpu_fft_size) {
     if (!b) return RR_ERR;
     const rr::FftFilter* f = dynamic_cast<const rr::FftFilter*>(b->b.get());

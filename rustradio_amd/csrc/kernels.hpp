@@ -11,6 +11,7 @@ namespace rr {
 //   tw         : device table of w_F^k, k < F
 //   hpos       : device table of H (scaled by 1/F) in digit-reversed position order
 bool fftfilt_supported(int log2f);
+int fft_read_stamps(unsigned long long* host16);   // measurement builds only (else returns 0)
 void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw,
                        const cf* hpos, hipStream_t s);
 

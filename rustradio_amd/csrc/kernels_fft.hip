@@ -15,13 +15,23 @@
 
 #include "kernels.hpp"
 
-// Phase-ablation switches for measurement builds (make ABLATE=1): RR_FFT_ABLATE=bits
-// 1: no input loads, 2: no output stores, 4: no LDS exchanges, 8: no butterflies,
-// 16: inputs re-read from an L2-resident window, 32: outputs written to an L2-resident window.
-#ifdef RR_FFT_ABLATE_BUILD
-#define RR_ABLATE(bit) (ablate & (bit))
+// Measurement builds (never shipped; make ABLATE=<bits> / TIMING=1 OUT=../lib_ablate):
+//   -DRR_FFT_ABLATE_BITS=<bits>  compile-time phase ablation: 1 no input loads, 2 no output stores,
+//        4 no LDS exchanges, 8 no butterflies, 16 inputs from an L2-resident window, 32 outputs to
+//        an L2-resident window.  (Compile-time so that the ablated kernel keeps the production
+//        register allocation; a runtime flag version spilled 208 B/lane and skewed every number.)
+//   -DRR_FFT_TIMING_BUILD  workgroup 0 / thread 0 stamps s_memtime at every phase boundary of its
+//        3rd tile (env RR_FFT_STAMPS=1, read back with rr_debug_fft_stamps).
+#ifndef RR_FFT_ABLATE_BITS
+#define RR_FFT_ABLATE_BITS 0
+#endif
+#define RR_ABLATE(bit) (((RR_FFT_ABLATE_BITS) & (bit)) != 0)
+#ifdef RR_FFT_TIMING_BUILD
+#define RR_STAMP(i) do { if (stamps) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RR_LDSWAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")   // attribute LDS latency to its own interval
 #else
-#define RR_ABLATE(bit) false
+#define RR_STAMP(i) do { } while (0)
+#define RR_LDSWAIT() do { } while (0)
 #endif
 // keep the scheduler from overlapping the live ranges of neighbouring phases
 #define RR_PHASE() __builtin_amdgcn_sched_barrier(0)
@@ -36,7 +46,8 @@ namespace rr {
 // Measured alternatives that lost and were removed (DESIGN.md "FftFilter tuning log"):
 // H/twiddles re-read from L1 at 3 waves/SIMD (2.1x slower: TA-bound), H in LDS shared by
 // several tiles per workgroup at 3-4 waves/SIMD (1.3-1.7x slower: LDS-bound), register
-// prefetch of the next tile (no gain).
+// prefetch of the next tile (no gain), next tile fetched by LDS-DMA (global_load_lds_dwordx4,
+// counted vmcnt; no gain), two tiles per wave interleaved phase by phase (spills; 10 % slower).
 template <int LOG2F, int VAR> struct KCfg {
     static constexpr int T = 1 << (LOG2F - 4);
     static constexpr bool REG = VAR == 0;
@@ -99,8 +110,8 @@ template <int LOG2F, int VAR> struct TileXform {
             }
         }
     }
-    __device__ __forceinline__ void run(creg* v, creg* lds, int ablate) const {
-        (void)ablate;
+    __device__ __forceinline__ void run(creg* v, creg* lds, int ablate, unsigned long long* stamps = nullptr) const {
+        (void)ablate; (void)stamps;
         if constexpr (!REG) asm volatile("" ::: "memory");   // keep per-tile table loads inside the tile loop
         creg twl[15];
         const bool do_lds = !RR_ABLATE(4), do_math = !RR_ABLATE(8);
@@ -111,16 +122,22 @@ template <int LOG2F, int VAR> struct TileXform {
         // ---- forward ----
         get_tw<0>(twl, tw0);
         fwd_pass<LOG2F, 0>(v, twl);
+        RR_PHASE(); RR_STAMP(2);
         lds_store<LOG2F, 0>(v, t, lds);
         tile_sync<T>();
-        RR_PHASE();
+        RR_PHASE(); RR_STAMP(3);
         lds_load<LOG2F, 1>(v, t, lds);
+        RR_LDSWAIT();
+        RR_PHASE(); RR_STAMP(4);
         get_tw<1>(twl, tw1);
         fwd_pass<LOG2F, 1>(v, twl);
+        RR_PHASE(); RR_STAMP(5);
         lds_store<LOG2F, 1>(v, t, lds);
         tile_sync<T>();
         RR_PHASE();
         lds_load<LOG2F, 2>(v, t, lds);
+        RR_LDSWAIT();
+        RR_PHASE(); RR_STAMP(6);
         get_tw<2>(twl, tw1);
         fwd_pass<LOG2F, 2>(v, twl);
         if constexpr (NP == 4) {
@@ -145,18 +162,25 @@ template <int LOG2F, int VAR> struct TileXform {
             get_tw<2>(twl, tw1);
         }
         inv_pass<LOG2F, 2>(v, twl);
+        RR_PHASE(); RR_STAMP(7);
         lds_store<LOG2F, 2>(v, t, lds);
         tile_sync<T>();
         RR_PHASE();
         lds_load<LOG2F, 1>(v, t, lds);
+        RR_LDSWAIT();
+        RR_PHASE(); RR_STAMP(8);
         get_tw<1>(twl, tw1);
         inv_pass<LOG2F, 1>(v, twl);
+        RR_PHASE(); RR_STAMP(9);
         lds_store<LOG2F, 1>(v, t, lds);
         tile_sync<T>();
         RR_PHASE();
         lds_load<LOG2F, 0>(v, t, lds);
+        RR_LDSWAIT();
+        RR_PHASE(); RR_STAMP(10);
         get_tw<0>(twl, tw0);
         inv_pass<LOG2F, 0>(v, twl);
+        RR_PHASE(); RR_STAMP(11);
 #undef lds_store
 #undef lds_load
 #undef fwd_pass
@@ -200,7 +224,8 @@ template <int LOG2F> __device__ __forceinline__ void load_tile16(creg* v, const 
 template <int LOG2F, int VAR>
 __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
 void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles,
-                  const cf* __restrict__ tw, const cf* __restrict__ hpos, int ablate) {
+                  const cf* __restrict__ tw, const cf* __restrict__ hpos, int ablate,
+                  unsigned long long* __restrict__ dbg) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -212,8 +237,16 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
     X.init(t, tw, hpos);
     creg* out_reg = reinterpret_cast<creg*>(out);
 
-    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+    int iter = 0;
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step, iter++) {
         const long tile = it.tile;
+#ifdef RR_FFT_TIMING_BUILD
+        unsigned long long* stamps = (dbg && blockIdx.x == 0 && t == 0 && iter == 2) ? dbg : nullptr;
+#else
+        (void)dbg; (void)iter;
+        unsigned long long* stamps = nullptr;
+#endif
+        RR_STAMP(0);
         creg v[16];
         if (RR_ABLATE(1)) {      // measurement only: no input traffic
 #pragma unroll
@@ -221,8 +254,11 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
         } else {
             load_tile16<LOG2F>(v, src, (RR_ABLATE(16) ? 8 + (tile & 63) : tile) * S, t, lds);
         }
-        RR_PHASE();
-        X.run(v, lds, ablate);
+#ifdef RR_FFT_TIMING_BUILD
+        if (stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // attribute the load latency to interval 0-1
+#endif
+        RR_PHASE(); RR_STAMP(1);
+        X.run(v, lds, ablate, stamps);
 
         if (RR_ABLATE(2)) {          // measurement only: no output traffic (keeps v live)
             bool odd = false;
@@ -246,6 +282,7 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
                 if (idx >= first && o0 + idx < n_out) po[n * T] = v[n];
             }
         }
+        RR_PHASE(); RR_STAMP(12);
         // next tile's first lds_store touches exactly the slots this thread just read
     }
 }
@@ -340,6 +377,27 @@ void k_fm_chain(VSrc<cf> src, float* __restrict__ out, int L, long ntiles, const
     }
 }
 
+// measurement builds: 16 s_memtime stamps of one tile (see RR_STAMP); nullptr otherwise
+static unsigned long long* fft_stamp_buffer() {
+#ifdef RR_FFT_TIMING_BUILD
+    static unsigned long long* p = nullptr;
+    if (!p && getenv("RR_FFT_STAMPS")) {
+        RR_HIP(hipMalloc(reinterpret_cast<void**>(&p), 16 * sizeof(unsigned long long)));
+        RR_HIP(hipMemset(p, 0, 16 * sizeof(unsigned long long)));
+    }
+    return p;
+#else
+    return nullptr;
+#endif
+}
+int fft_read_stamps(unsigned long long* host16) {
+    unsigned long long* p = fft_stamp_buffer();
+    if (!p) return 0;
+    RR_HIP(hipDeviceSynchronize());
+    RR_HIP(hipMemcpy(host16, p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 16;
+}
+
 bool fftfilt_supported(int log2f) { return log2f >= 10 && log2f <= 14; }
 
 int device_cu_count() {
@@ -374,10 +432,9 @@ static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, c
     static bool attr_set = false;
     static int per_cu = 0;
     const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR>, T, smem, ntiles, attr_set, per_cu);
-    static int ablate = -1;
-    if (ablate < 0) { const char* e = getenv("RR_FFT_ABLATE"); ablate = e ? atoi(e) : 0; }   // measurement knob
+    const int ablate = 0;
     hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L,
-                       ntiles, tw, hpos, ablate);
+                       ntiles, tw, hpos, ablate, fft_stamp_buffer());
     RR_HIP(hipGetLastError());
 }
 
