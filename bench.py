@@ -11,6 +11,7 @@ resident in HBM.  Default workload = BASELINE.json configs[1]:
 Other workloads (--workload, also summarised under "others" in the JSON line):
     fir          configs[0]: FirFilter<Complex> 127 real taps, 1,000,000 samples
     fm_chain     configs[2]: FftFilter(463) -> RationalResampler(1:6) -> QuadratureDemod, 2.4 Msps x 10 s
+    fm_multi     configs[3]: 32 such channels per GPU on one shared IQ source (256 channels on 8 GPUs)
     channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in)
 
 Multi-GPU (one process per GPU, weak scaling): the path shards by channel — every rank
@@ -195,6 +196,39 @@ def make_fm_chain_unfused(dev, rank, world, shared_src):
     return make_fm_chain(dev, rank, world, shared_src, fused=False)
 
 
+def make_fm_multi(dev, rank, world, shared_src, per_gpu=32, total=256):
+    """BASELINE configs[3]: 256 FM channels of configs[2] on one shared IQ source, 32 per GPU.
+    Channel c uses the configs[2] low-pass shifted to f_c = (c - 128) * 8 kHz (complex band-pass);
+    rank r owns channels r*32 .. r*32+31 (multi.shard_channels).  `value` counts
+    channel-samples: input samples x channels processed."""
+    w = Workload()
+    fs, n = 2.4e6, 2_400_000
+    taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
+    nch_total = total if world > 1 else per_gpu
+    chans = list(multi.shard_channels(nch_total if world > 1 else per_gpu, world, rank))
+    w.name = (f"{len(chans)} FM channels/GPU (FftFilter 463 taps->RationalResampler 1:6->QuadratureDemod, fused) "
+              f"on one shared 2.4 Msps IQ source, {n:,} samples/step/channel")
+    src = shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0004))
+    taps_all = np.stack([chan_taps(taps, fs, multi.channel_frequency(c, total, 8e3)) for c in chans])
+    blk = rr.FmMulti(taps_all, 1, 6, 1.0, rr.ATAN2_EXACT)     # one kernel: forward FFT shared by all channels
+    w.blocks = [blk]
+    w.src, w.n = src, n
+    cap = n // 6 + 1024
+    w.outs = torch.empty(len(chans) * cap, dtype=torch.float32, device=dev)
+    w.alg_bytes_per_sample = 8.0 / len(chans) + 4.0 / 6.0       # shared read: 8/N B in + 0.67 B out per channel-sample
+    w.dominant, w.dominant_bytes_per_unit = 0, (8.0 / len(chans) + 4.0 / 6.0) * len(chans)
+    w.cpu = ("fm_chain", taps)
+    w.bufs = [src]
+    nch = len(chans)
+
+    def step(stream):
+        st, c, p, need = blk.work_dev(src.data_ptr(), n, w.outs.data_ptr(), cap, stream)
+        w.dom_units += c
+        return c * nch
+    w.step = step
+    return w
+
+
 def make_channelizer(dev, rank, world, shared_src):
     w = Workload()
     w.name = "Hilbert(65)->FirFilter<Complex>(255 real taps, deci 8), 100 Msps f32 x 1 s = 100,000,000 samples/step"
@@ -214,7 +248,7 @@ def make_channelizer(dev, rank, world, shared_src):
 
 
 WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
-             "fm_chain_unfused": make_fm_chain_unfused, "channelizer": make_channelizer}
+             "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "channelizer": make_channelizer}
 
 
 # ---- measurement ------------------------------------------------------------------------------
@@ -368,7 +402,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused") else "k_fm_chain" if args.workload == "fm_chain" else ("k_fir" if args.workload != "channelizer" else "k_fir<hilbert>"),
+                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused") else "k_fm_chain" if args.workload == "fm_chain" else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer" else "k_fir<hilbert>"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),

@@ -107,6 +107,18 @@ rr_block *rr_hilbert_create(size_t ntaps, int window, float window_parm);
 rr_block *rr_fm_chain_create(const rr_c32 *taps, size_t ntaps, size_t interp, size_t deci,
                              float gain, int atan2_mode);
 
+/* `nchan` fused FM chains (rr_fm_chain_create) fed by ONE input stream — the reference's Tee fan-out
+ * (src/tee.rs:10-24) plus nchan x {FftFilter, RationalResampler, QuadratureDemod}.  taps =
+ * [nchan][ntaps] (each channel its own, e.g. the prototype shifted to the channel centre); every
+ * tile's forward FFT is computed once for all channels.  The block has nchan OUTPUT windows:
+ * rr_block_work[_dev] takes `out` as nchan consecutive windows of out_cap elements (channel c at
+ * out + c*out_cap) and reports the per-channel consumed/produced (identical for all channels).
+ * ntaps <= 2048. */
+rr_block *rr_fm_multi_create(const rr_c32 *taps, size_t nchan, size_t ntaps, size_t interp, size_t deci,
+                             float gain, int atan2_mode);
+/* number of output windows of a block (1 except rr_fm_multi_create) */
+size_t rr_block_out_windows(const rr_block *b);
+
 void rr_block_destroy(rr_block *b);
 
 /* ---- Block trait -------------------------------------------------------------- */

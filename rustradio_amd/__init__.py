@@ -113,12 +113,15 @@ class Block:
     def work(self, inp: np.ndarray, out_cap: int):
         """Block::work() over host windows -> (status, consumed, produced, need, out[:produced])."""
         inp = np.ascontiguousarray(inp, self.in_dtype)
-        out = np.zeros(max(out_cap, 1), self.out_dtype)
+        nw = lib().rr_block_out_windows(self._h)
+        out = np.zeros(max(out_cap, 1) * nw, self.out_dtype)
         c, p, n = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
         st = lib().rr_block_work(self._h, _ptr(inp), len(inp), _ptr(out), out_cap,
                                  C.byref(c), C.byref(p), C.byref(n))
         if st == ERR:
             raise RuntimeError(last_error())
+        if nw > 1:      # multi-output block: (windows, produced)
+            return st, c.value, p.value, n.value, out.reshape(nw, max(out_cap, 1))[:, :p.value].copy()
         return st, c.value, p.value, n.value, out[:p.value]
 
     def work_dev(self, d_in: int, in_len: int, d_out: int, out_cap: int, stream: int = 0):
@@ -198,6 +201,16 @@ def FmChain(taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_E
     block / one kernel (examples/rtl_fm.rs:381-419 wiring); Complex in, f32 out."""
     t = np.ascontiguousarray(taps, np.complex64)
     return Block(lib().rr_fm_chain_create(_ptr(t), len(t), interp, deci, gain, mode), np.complex64, np.float32)
+
+
+def FmMulti(taps_per_channel, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
+    """N fused FM chains on one shared input (Tee + N x FmChain); taps_per_channel = [N][ntaps].
+    work() returns out with shape (N, produced); work_dev() takes N windows of out_cap elements."""
+    t = np.ascontiguousarray(taps_per_channel, np.complex64)
+    if t.ndim != 2:
+        raise ValueError("taps_per_channel must be [nchan][ntaps]")
+    h = lib().rr_fm_multi_create(_ptr(t), t.shape[0], t.shape[1], interp, deci, gain, mode)
+    return Block(h, np.complex64, np.float32)
 
 
 def Hilbert(ntaps: int, wtype: int = WIN_HAMMING, parm: float = 0.0) -> Block:

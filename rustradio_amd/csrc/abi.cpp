@@ -100,6 +100,11 @@ rr_block* rr_hilbert_create(size_t ntaps, int window, float window_parm) {
 rr_block* rr_fm_chain_create(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int atan2_mode) {
     return make_block([&] { return new rr::FmChain(taps, ntaps, interp, deci, gain, atan2_mode); });
 }
+rr_block* rr_fm_multi_create(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain,
+                             int atan2_mode) {
+    return make_block([&] { return new rr::FmMulti(taps, nchan, ntaps, interp, deci, gain, atan2_mode); });
+}
+size_t rr_block_out_windows(const rr_block* b) { return b ? b->b->out_windows() : 0; }
 void rr_block_destroy(rr_block* b) { delete b; }
 
 static int guarded(rr_block* b, size_t* consumed, size_t* produced, size_t* need, const char* what,

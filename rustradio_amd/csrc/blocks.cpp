@@ -240,6 +240,22 @@ template <int LOG2F> static void fill_hpos(const std::vector<std::complex<double
     }
 }
 
+// H = FFT(taps || 0) / F (fft_filter.rs:151-162) in f64, rounded once, in digit-reversed position order
+static void compute_hpos(const rr_c32* taps, size_t ntaps, int log2f, std::vector<cf>& hpos) {
+    const size_t F = (size_t)1 << log2f;
+    std::vector<std::complex<double>> H(F, 0.0);
+    for (size_t i = 0; i < ntaps; i++) H[i] = {taps[i].re, taps[i].im};
+    fft64(H);
+    for (auto& h : H) h /= (double)F;
+    switch (log2f) {
+    case 10: fill_hpos<10>(H, hpos); break;
+    case 11: fill_hpos<11>(H, hpos); break;
+    case 12: fill_hpos<12>(H, hpos); break;
+    case 13: fill_hpos<13>(H, hpos); break;
+    default: fill_hpos<14>(H, hpos); break;
+    }
+}
+
 FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8) {
     if (ntaps == 0) throw Error("FftFilter: empty taps");            // fft_filter.rs:146
     L = ntaps;
@@ -260,19 +276,8 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8
     if (!fftfilt_supported(log2f))
         throw Error("FftFilter: more than 8192 taps is not supported by the LDS-resident tile kernel");
     const size_t F = (size_t)1 << log2f;
-    // H = FFT(taps || 0) / F (fft_filter.rs:151-162), computed in f64 and rounded once
-    std::vector<std::complex<double>> H(F, 0.0);
-    for (size_t i = 0; i < ntaps; i++) H[i] = {taps[i].re, taps[i].im};
-    fft64(H);
-    for (auto& h : H) h /= (double)F;
     std::vector<cf> hpos, tw(F);
-    switch (log2f) {
-    case 10: fill_hpos<10>(H, hpos); break;
-    case 11: fill_hpos<11>(H, hpos); break;
-    case 12: fill_hpos<12>(H, hpos); break;
-    case 13: fill_hpos<13>(H, hpos); break;
-    default: fill_hpos<14>(H, hpos); break;
-    }
+    compute_hpos(taps, ntaps, log2f, hpos);
     for (size_t k = 0; k < F; k++) {
         const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)F;
         tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
@@ -383,6 +388,87 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     }
     *produced = N3(n1 + n_y) - o_old;
     n1 += n_y;
+    return st;
+}
+
+// ---- N FM chains on one shared source ---------------------------------------------------------------------
+FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float g, int m)
+    : Block("Tee>N x (FftFilter>RationalResampler>QuadratureDemod)", 8, 4), C(nchan) {
+    if (nchan == 0 || nchan > 4096) throw Error("FmMulti: channel count must be 1..4096");
+    chain.reset(new FmChain(taps, ntaps, interp, deci, g, m));     // bookkeeping, prefix/pending state, twiddles
+    const int lg = chain->f->log2f;
+    if (!fm_multi_supported(lg)) throw Error("FmMulti: at most 2048 taps (3-pass tiles)");
+    const size_t F = (size_t)1 << lg;
+    std::vector<cf> all(C * F), one;
+    for (size_t c = 0; c < C; c++) {
+        compute_hpos(taps + c * ntaps, ntaps, lg, one);
+        std::copy(one.begin(), one.end(), all.begin() + c * F);
+    }
+    d_hpos_all.upload(all.data(), all.size(), stream);
+    for (auto& b : last_r) { b.reserve(C); RR_HIP(hipMemsetAsync(b.p, 0, C * sizeof(cf), stream)); }
+    RR_HIP(hipStreamSynchronize(stream));
+}
+
+// `out` holds C windows of out_cap elements each (channel c at out + c*out_cap); all channels
+// consume and produce the same counts, so the bookkeeping is FmChain's.
+int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                      size_t* produced, size_t* need, hipStream_t s) {
+    FmChain& ch = *chain;
+    FftFilter* f = ch.f.get();
+    *consumed = *produced = *need = 0;
+    const uint64_t S = f->nsamples;
+    const int64_t I = ch.I, D = ch.D;
+    auto N2 = [&](uint64_t y) { return (uint64_t)(((__int128)y * I + D - 1) / D); };
+    auto N3 = [&](uint64_t y) { const uint64_t r = N2(y); return r ? r - 1 : 0; };
+    const uint64_t n1 = ch.n1, o_old = N3(n1);
+    const uint64_t need_next = N3(n1 + S) - o_old;
+    if (need_next > out_cap) { *need = need_next; return RR_WAIT_DST; }
+    const uint64_t total = f->pend_len + in_len, k_in = total / S;
+    const __int128 X = (__int128)(o_old + out_cap + 1) * D / I;
+    uint64_t k_out = X >= (__int128)n1 ? (uint64_t)((X - n1) / S) : 0;
+    while (k_out > 0 && N3(n1 + k_out * S) - o_old > out_cap) k_out--;
+    uint64_t k, new_pend;
+    int st;
+    if (k_in > k_out) {
+        k = k_out; *consumed = k * S - f->pend_len; new_pend = 0;
+        st = RR_WAIT_DST; *need = N3(n1 + (k + 1) * S) - N3(n1 + k * S);
+    } else {
+        k = k_in; *consumed = in_len; new_pend = total - k * S;
+        st = RR_WAIT_SRC; *need = S - new_pend;
+    }
+    const uint64_t n_y = k * S;
+    VSrc<cf> src{f->prefix[f->cur].p, (long)(f->L - 1 + f->pend_len), static_cast<const cf*>(in), (long)in_len};
+    if (k) {
+        FmChainArgs a;
+        a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
+        a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = ch.gain; a.mode = ch.mode;
+        prof_begin(s);
+        launch_fm_multi(f->log2f, src, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_hpos_all.p,
+                        (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        prof_end(s);
+        if (a.r_hi > a.r_lo) cur_lr ^= 1;
+    }
+    if (*consumed) {
+        launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
+        f->cur ^= 1;
+        f->pend_len = new_pend;
+    }
+    *produced = N3(n1 + n_y) - o_old;
+    ch.n1 += n_y;
+    return st;
+}
+
+int FmMulti::work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                       size_t* produced, size_t* need) {
+    RR_HIP(hipSetDevice(device));
+    st_in.reserve(std::max<size_t>(in_len * in_es, 16));
+    st_out.reserve(std::max<size_t>(C * out_cap * out_es, 16));
+    if (in_len) RR_HIP(hipMemcpyAsync(st_in.p, in, in_len * in_es, hipMemcpyHostToDevice, stream));
+    const int st = work_dev(st_in.p, in_len, st_out.p, out_cap, consumed, produced, need, stream);
+    if (*produced)
+        RR_HIP(hipMemcpy2DAsync(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, C,
+                                hipMemcpyDeviceToHost, stream));
+    RR_HIP(hipStreamSynchronize(stream));
     return st;
 }
 

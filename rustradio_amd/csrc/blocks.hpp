@@ -26,8 +26,9 @@ struct Block {
     virtual int work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                          size_t* produced, size_t* need, hipStream_t s) = 0;
     virtual bool eof(bool src_eof);
-    int work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
-                  size_t* produced, size_t* need);
+    virtual int work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                          size_t* produced, size_t* need);
+    virtual size_t out_windows() const { return 1; }   // output streams (windows of out_cap elements each)
     void sync();
 
     // optional HIP-event timing of the block's dominant kernel (bench.py's roofline figure)
@@ -83,6 +84,20 @@ struct FmChain : Block {
     int cur_lr = 0;
     FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
+// N fused FM chains (FmChain) on ONE shared input: the reference's Tee fan-out + N x three blocks.
+// The forward FFT of every tile is computed once for all channels.  Output = N windows.
+struct FmMulti : Block {
+    size_t C;
+    std::unique_ptr<FmChain> chain;   // channel 0's chain object: shared bookkeeping + input carry state
+    DevBuf<cf> d_hpos_all;            // [C][F]
+    DevBuf<cf> last_r[2];             // [C]
+    int cur_lr = 0;
+    FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain, int mode);
+    size_t out_windows() const override { return C; }
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+    int work_host(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*) override;
 };
 
 struct FftFilterFloat : Block {

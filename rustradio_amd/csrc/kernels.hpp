@@ -30,6 +30,12 @@ struct FmChainArgs {
 void launch_fm_chain(int log2f, VSrc<cf> src, float* out, int L, const cf* tw, const cf* hpos,
                      const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 
+// The same for `nchan` channels that share the input: hpos_all = [nchan][F] frequency responses,
+// channel c writes out + c*out_stride and carries last_in[c] / last_out[c].  3-pass tiles (F <= 4096).
+bool fm_multi_supported(int log2f);
+void launch_fm_multi(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
+                     int nchan, const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+
 // ---- kernels_fir.hip ---------------------------------------------------------------
 struct FirPlan {             // host-prepared polyphase tap table
     int L = 0, d = 1;

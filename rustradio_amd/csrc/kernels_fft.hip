@@ -100,6 +100,14 @@ template <int LOG2F, int VAR> struct TileXform {
             load_h<LOG2F, NP - 1>(hreg, t, hpos);
         }
     }
+    // twiddles only: H comes per channel (multi-channel kernel)
+    __device__ __forceinline__ void init_no_h(int t_, const cf* tw_) {
+        t = t_; tw = tw_; hpos = nullptr;
+        if constexpr (REG) {
+            load_twiddles<LOG2F, 0>(tw0, t, tw);
+            load_twiddles<LOG2F, 1>(tw1, t, tw);
+        }
+    }
     template <int I> __device__ __forceinline__ void get_tw(creg* dst, const creg* persist) const {
         if constexpr (pass_has_twiddles<LOG2F, I>()) {
             if constexpr (REG && I < 2) {
@@ -110,16 +118,15 @@ template <int LOG2F, int VAR> struct TileXform {
             }
         }
     }
-    __device__ __forceinline__ void run(creg* v, creg* lds, int ablate, unsigned long long* stamps = nullptr) const {
-        (void)ablate; (void)stamps;
+    // forward half: on exit v holds the spectrum in the (digit-reversed) pass-(NP-1) layout
+    __device__ __forceinline__ void forward(creg* v, creg* lds, unsigned long long* stamps = nullptr) const {
+        (void)stamps;
         if constexpr (!REG) asm volatile("" ::: "memory");   // keep per-tile table loads inside the tile loop
         creg twl[15];
         const bool do_lds = !RR_ABLATE(4), do_math = !RR_ABLATE(8);
 #define lds_store if (do_lds) lds_store
 #define lds_load if (do_lds) lds_load
 #define fwd_pass if (do_math) fwd_pass
-#define inv_pass if (do_math) inv_pass
-        // ---- forward ----
         get_tw<0>(twl, tw0);
         fwd_pass<LOG2F, 0>(v, twl);
         RR_PHASE(); RR_STAMP(2);
@@ -146,21 +153,25 @@ template <int LOG2F, int VAR> struct TileXform {
             lds_load<LOG2F, 3>(v, t, lds);
             fwd_pass<LOG2F, 3>(v, twl);
         }
-        // ---- frequency response, then the mirror ----
-        if constexpr (REG) {
-            apply_h(v, hreg);
-        } else {
-            creg h[16];
-            load_h<LOG2F, NP - 1>(h, t, hpos);
-            apply_h(v, h);
-        }
+#undef lds_store
+#undef lds_load
+#undef fwd_pass
+    }
+    // inverse half (the mirror): spectrum (already multiplied by H) -> v[n] = y[n*T + t]
+    __device__ __forceinline__ void inverse(creg* v, creg* lds, unsigned long long* stamps = nullptr) const {
+        (void)stamps;
+        creg twl[15];
+        const bool do_lds = !RR_ABLATE(4), do_math = !RR_ABLATE(8);
+#define lds_store if (do_lds) lds_store
+#define lds_load if (do_lds) lds_load
+#define inv_pass if (do_math) inv_pass
         if constexpr (NP == 4) {
             inv_pass<LOG2F, 3>(v, twl);
             lds_store<LOG2F, 3>(v, t, lds);
             tile_sync<T>();
             lds_load<LOG2F, 2>(v, t, lds);
-            get_tw<2>(twl, tw1);
         }
+        get_tw<2>(twl, tw1);
         inv_pass<LOG2F, 2>(v, twl);
         RR_PHASE(); RR_STAMP(7);
         lds_store<LOG2F, 2>(v, t, lds);
@@ -183,8 +194,19 @@ template <int LOG2F, int VAR> struct TileXform {
         RR_PHASE(); RR_STAMP(11);
 #undef lds_store
 #undef lds_load
-#undef fwd_pass
 #undef inv_pass
+    }
+    __device__ __forceinline__ void run(creg* v, creg* lds, int ablate, unsigned long long* stamps = nullptr) const {
+        (void)ablate;
+        forward(v, lds, stamps);
+        if constexpr (REG) {
+            apply_h(v, hreg);
+        } else {
+            creg h[16];
+            load_h<LOG2F, NP - 1>(h, t, hpos);
+            apply_h(v, h);
+        }
+        inverse(v, lds, stamps);
     }
 };
 
@@ -377,6 +399,80 @@ void k_fm_chain(VSrc<cf> src, float* __restrict__ out, int L, long ntiles, const
     }
 }
 
+// ---- N FM channels on one shared IQ source (BASELINE configs[3]) --------------------------------------------
+// Every channel of a channelised receiver filters the SAME input with its own band-pass taps.  The
+// reference needs a Tee tree and one FftFilter per channel (src/tee.rs:10-24); here the forward
+// FFT of a tile is computed once, parked in LDS, and each channel only pays H_c * X, the inverse
+// FFT and the resample/demod epilogue.  On-GPU fan-out is free: the input tile is read from HBM
+// once per workgroup, not once per channel.
+template <int LOG2F>
+__global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
+void k_fm_multi(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, long ntiles,
+                const cf* __restrict__ tw, const cf* __restrict__ hpos_all, int nchan, FmArgs a,
+                const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    constexpr int NP = Plan<LOG2F>::NP;
+    static_assert(NP == 3, "multi-channel kernel: 3-pass plans");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    creg* ldsX = lds + lds_elems(F);                     // the tile's spectrum, pass-2 layout (own slots)
+    const int t = threadIdx.x;
+    const int first = L - 1;
+    const long Sp = (F - L + 1) - a.G;
+    TileXform<LOG2F, 0> X;
+    X.init_no_h(t, tw);
+
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long tile = it.tile;
+        const long ys = tile * Sp - a.G;
+        {
+            creg v[16];
+            load_tile16<LOG2F>(v, src, ys, t, lds);
+            RR_PHASE();
+            X.forward(v, lds);
+            lds_store<LOG2F, NP - 1>(v, t, ldsX);
+        }
+        const long y_lo = tile * Sp, y_hi = min((tile + 1) * Sp, a.n_y);
+        long u_lo = ((a.A + y_lo) * a.I + a.D - 1) / a.D;
+        long u_hi = ((a.A + y_hi) * a.I + a.D - 1) / a.D;
+        if (u_lo < a.r_lo) u_lo = a.r_lo;
+        if (u_hi > a.r_hi) u_hi = a.r_hi;
+        for (int c = 0; c < nchan; c++) {
+            RR_PHASE();
+            creg w[16];
+            {
+                creg h[16];
+                lds_load<LOG2F, NP - 1>(w, t, ldsX);
+                load_h<LOG2F, NP - 1>(h, t, hpos_all + (long)c * F);
+                apply_h(w, h);
+            }
+            X.inverse(w, lds);
+            lds_store<LOG2F, 0>(w, t, lds);
+            tile_sync<T>();
+            float* oc = out + (long)c * out_stride;
+            for (long u = u_lo + t; u < u_hi; u += T) {
+                const long gu = (u * a.D) / a.I - a.A;
+                const creg ru = lds[lds_pad((int)(gu - ys) + first)];
+                if (u == a.r_hi - 1) last_r_out[c] = from_reg(ru);
+                if (u == 0) continue;
+                creg rl;
+                if (u == a.r_lo) rl = to_reg(last_r_in[c]);
+                else {
+                    const long gl = ((u - 1) * a.D) / a.I - a.A;
+                    rl = lds[lds_pad((int)(gl - ys) + first)];
+                }
+                const float na = -rl.y;
+                const float re = __fsub_rn(__fmul_rn(rl.x, ru.x), __fmul_rn(na, ru.y));
+                const float im = __fadd_rn(__fmul_rn(rl.x, ru.y), __fmul_rn(na, ru.x));
+                const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                oc[(u - 1) - a.o_base] = __fmul_rn(a.gain, ang);
+            }
+            tile_sync<T>();
+        }
+    }
+}
+
 // measurement builds: 16 s_memtime stamps of one tile (see RR_STAMP); nullptr otherwise
 static unsigned long long* fft_stamp_buffer() {
 #ifdef RR_FFT_TIMING_BUILD
@@ -480,6 +576,39 @@ void launch_fm_chain(int log2f, VSrc<cf> src, float* out, int L, const cf* tw, c
     case 13: launch_fm_one<13, 3>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
     case 14: launch_fm_one<14, 3>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
     default: throw Error("fm_chain: unsupported tile size");
+    }
+}
+
+template <int LOG2F>
+static void launch_fm_multi_one(VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
+                                int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    FmArgs a;
+    a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
+    a.I = h.I; a.D = h.D; a.G = (int)((h.D + h.I - 1) / h.I); a.gain = h.gain; a.mode = h.mode;
+    const long Sp = (F - L + 1) - a.G;
+    if (Sp <= 0) throw Error("fm_multi: decimation too large for the tile");
+    const long ntiles = (h.n_y + Sp - 1) / Sp;
+    if (ntiles <= 0) return;
+    const size_t smem = 2 * sizeof(cf) * lds_elems(F);
+    static bool attr_set = false;
+    static int per_cu = 0;
+    const long grid = grid_for_tiles(k_fm_multi<LOG2F>, T, smem, ntiles, attr_set, per_cu);
+    hipLaunchKernelGGL((k_fm_multi<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles,
+                       tw, hpos_all, nchan, a, last_in, last_out);
+    RR_HIP(hipGetLastError());
+}
+
+bool fm_multi_supported(int log2f) { return log2f >= 10 && log2f <= 12; }
+
+void launch_fm_multi(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
+                     int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    switch (log2f) {
+    case 10: launch_fm_multi_one<10>(src, out, out_stride, L, tw, hpos_all, nchan, h, last_in, last_out, s); break;
+    case 11: launch_fm_multi_one<11>(src, out, out_stride, L, tw, hpos_all, nchan, h, last_in, last_out, s); break;
+    case 12: launch_fm_multi_one<12>(src, out, out_stride, L, tw, hpos_all, nchan, h, last_in, last_out, s); break;
+    default: throw Error("fm_multi: unsupported tile size");
     }
 }
 
