@@ -1,0 +1,153 @@
+"""GPU: (1) edge cases of every block's work() protocol — empty / ragged / zero-capacity windows —
+against the oracle; (2) BASELINE full-size runs checked through size-independent properties:
+random segments against the oracle, linearity, DC gain, resampler index identity."""
+import numpy as np
+import pytest
+
+from harness import AGAIN, WAIT_DST, WAIT_SRC, max_norm_err, run_chain
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def rr():
+    import rustradio_amd
+    return rustradio_amd
+
+
+def rnd_c(n, seed):
+    r = np.random.default_rng(seed)
+    return (r.uniform(-1, 1, n) + 1j * r.uniform(-1, 1, n)).astype(np.complex64)
+
+
+def _makers(m):
+    taps = orc.low_pass_complex(10e6, 1e6, 190e3)
+    return {
+        "fir": lambda: m.FirFilter(taps, deci=3),
+        "fir_f32": lambda: m.FirFilter(taps.real.copy(), deci=2),
+        "fft": lambda: m.FftFilter(taps),
+        "fft_f32": lambda: m.FftFilterFloat(taps.real.copy()),
+        "resamp": lambda: m.RationalResampler(3, 7, np.complex64),
+        "quad": lambda: m.QuadratureDemod(1.0),
+        "hilbert": lambda: m.Hilbert(65),
+    }
+
+
+@pytest.mark.parametrize("name", ["fir", "fir_f32", "fft", "fft_f32", "resamp", "quad", "hilbert"])
+def test_edge_windows_match_oracle(rr, name):
+    """Same (status, consumed, produced, need) and samples as the oracle for degenerate windows."""
+    go, gg = _makers(orc)[name](), _makers(rr)[name]()
+    rng = np.random.default_rng(7)
+    dt = go.in_dtype
+    stream = (rng.uniform(-1, 1, 6000) + 1j * rng.uniform(-1, 1, 6000)).astype(np.complex64)
+    x = stream if dt == np.complex64 else stream.real.copy()
+    # (in_len, out_cap) sequence: empty input, zero output space, 1 sample, ragged, exact thresholds
+    plan = [(0, 10), (5, 0), (1, 1), (2, 1), (126, 5), (127, 5), (129, 1), (130, 40), (777, 3), (2000, 5000),
+            (0, 0), (3000, 2), (3000, 100000), (0, 100000)]
+    po = pg = 0
+    for in_len, cap in plan:
+        wo = x[po:po + in_len]; wg = x[pg:pg + in_len]
+        so, co, pro, no, oo = go.work(wo, cap)
+        sg, cg, prg, ng, og = gg.work(wg, cap)
+        assert (so, co, pro, no) == (sg, cg, prg, ng), (name, in_len, cap)
+        if len(oo):
+            scale = np.pi if name == "quad" else max(1.0, float(np.max(np.abs(oo))))
+            assert max_norm_err(og, oo, scale) <= TOL
+        po += co; pg += cg
+
+
+def test_fir_decimation_larger_than_input(rr):
+    taps = np.ones(1, np.complex64)
+    for deci in (7, 13, 100):
+        b = rr.FirFilter(taps, deci=deci)
+        st, c, p, need, out = b.work(rnd_c(6, 1), 10)
+        assert (st, c, p, need) == (WAIT_SRC, 0, 0, deci)        # fir.rs:498-501
+
+
+def test_constructor_errors(rr):
+    with pytest.raises(ValueError):
+        rr.FirFilter(np.zeros(0, np.complex64))
+    with pytest.raises(ValueError):
+        rr.FirFilter(np.ones(3, np.complex64), deci=0)
+    with pytest.raises(ValueError):
+        rr.FirFilter(np.ones(3, np.float32), translate=(1.0, 1.0))
+    with pytest.raises(ValueError):
+        rr.QuadratureDemod(1.0, 7)
+    with pytest.raises(ValueError):
+        rr.RationalResampler(1, 1, np.dtype("V3"))
+
+
+# ---- full-size properties (BASELINE configs[1]: 1e8 Complex<f32>) ---------------------------------------
+def test_fftfilter_full_size_properties(rr):
+    import torch
+    n = 100_000_000
+    taps = orc.low_pass_complex(10e6, 1e6, 60e3)
+    L, S = len(taps), 623
+    g = torch.Generator(device="cuda"); g.manual_seed(0x5EED0002)
+    x1 = torch.rand(2 * n, generator=g, device="cuda") * 2 - 1
+    x2 = torch.rand(2 * n, generator=g, device="cuda") * 2 - 1
+    n_out = (n // S) * S
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def filt(x):
+        y = torch.empty(2 * (n + 1024), device="cuda")
+        b = rr.FftFilter(taps)
+        st, c, p, need = b.work_dev(x.data_ptr(), n, y.data_ptr(), n + 1024, stream)
+        torch.cuda.synchronize()
+        assert (st, c, p, need) == (WAIT_SRC, n, n_out, S - n % S)
+        return y[:2 * n_out]
+
+    y1 = filt(x1)
+    # (a) random segments against the oracle (needs L-1 samples of history)
+    rng = np.random.default_rng(1)
+    starts = [0, n_out - 5000] + [int(s) for s in rng.integers(L, n_out - 5000, 14)]
+    for s0 in starts:
+        h0 = max(0, s0 - (L - 1))
+        xin = x1[2 * h0:2 * (s0 + 5000)].cpu().numpy().view(np.complex64)
+        ref = np.convolve(xin.astype(np.complex128), taps.astype(np.complex128))[s0 - h0:s0 - h0 + 5000]
+        got = y1[2 * s0:2 * (s0 + 5000)].cpu().numpy().view(np.complex64)
+        assert max_norm_err(got, ref) <= TOL, s0
+    # (b) linearity over the whole 1e8 samples: F(a x1 + b x2) = a F(x1) + b F(x2)
+    a, b = 0.75, -1.5
+    y2 = filt(x2)
+    y12 = filt(a * x1 + b * x2)
+    err = (y12 - (a * y1 + b * y2)).abs().max().item() / y12.abs().max().item()
+    assert err <= TOL, err
+    del y2, y12
+    # (c) DC gain: constant input -> sum(taps) after the start-up transient
+    ydc = filt(torch.ones(2 * n, device="cuda"))
+    want = complex(np.sum(taps.astype(np.complex128)) * (1 + 1j))
+    tail = ydc[2 * L:].view(-1, 2)
+    assert abs(tail[:, 0].min().item() - want.real) < 1e-5 and abs(tail[:, 0].max().item() - want.real) < 1e-5
+    assert abs(tail[:, 1].min().item() - want.imag) < 1e-5 and abs(tail[:, 1].max().item() - want.imag) < 1e-5
+
+
+def test_fm_chain_and_resampler_full_size(rr):
+    """configs[2] at 24e6 samples: fused chain == three separate GPU blocks (bit-level agreement is not
+    required, both are within tolerance of the oracle on small cases); resampler = pure index pick."""
+    import torch
+    n = 24_000_000
+    taps = orc.low_pass_complex(2.4e6, 100e3, 12.5e3)
+    t = torch.arange(n, device="cuda", dtype=torch.float64)
+    ph = -75.0 * torch.cos(2 * np.pi * 1e3 * t / 2.4e6)
+    x = torch.stack([torch.cos(ph), torch.sin(ph)], dim=1).float().reshape(-1).contiguous()
+    s = torch.cuda.current_stream().cuda_stream
+    y = torch.empty(2 * (n + 1024), device="cuda"); r = torch.empty(2 * (n // 6 + 1024), device="cuda")
+    o3 = torch.empty(n // 6 + 1024, device="cuda"); of = torch.empty(n // 6 + 1024, device="cuda")
+    st, c, p1, _ = rr.FftFilter(taps).work_dev(x.data_ptr(), n, y.data_ptr(), n + 1024, s)
+    st, c, p2, _ = rr.RationalResampler(1, 6).work_dev(y.data_ptr(), p1, r.data_ptr(), n // 6 + 1024, s)
+    st, c, p3, _ = rr.QuadratureDemod(1.0).work_dev(r.data_ptr(), p2, o3.data_ptr(), n // 6 + 1024, s)
+    st, c, pf, _ = rr.FmChain(taps, 1, 6, 1.0).work_dev(x.data_ptr(), n, of.data_ptr(), n // 6 + 1024, s)
+    torch.cuda.synchronize()
+    n1 = (n // 561) * 561
+    assert p1 == n1 and p2 == -(-n1 // 6) and p3 == p2 - 1 == pf
+    yy = y[:2 * p1].view(-1, 2); rr_ = r[:2 * p2].view(-1, 2)
+    assert torch.equal(rr_, yy[::6])                                    # resampler: bit-exact pick of every 6th sample
+    skip = len(taps)
+    d = (of[skip:pf] - o3[skip:p3]).abs().max().item()
+    assert d <= TOL * np.pi, d
+    # demodulated FM: 75 kHz deviation, 1 kHz tone at 400 ksps -> phase step amplitude 2 pi 75e3/400e3
+    amp = o3[skip:p3].abs().max().item()
+    assert abs(amp - 2 * np.pi * 75e3 / 400e3) < 2e-3
