@@ -137,9 +137,10 @@ int rr_block_work(rr_block *b, const void *in, size_t in_len, void *out, size_t 
                   size_t *consumed, size_t *produced, size_t *need);
 
 /* Same contract with DEVICE pointers (device-resident streams between GPU
- * blocks: no PCIe hop).  Kernels are enqueued on `hip_stream` (a hipStream_t,
- * NULL = the block's own stream) and the call returns without waiting;
- * counts are final on return (they depend on lengths only). */
+ * blocks: no PCIe hop).  Kernels are enqueued on `hip_stream` exactly as given (a
+ * hipStream_t; NULL = HIP's default stream, which is also what PyTorch's default stream
+ * is), so they are ordered with the caller's other work on that stream.  The call returns
+ * without waiting; counts are final on return (they depend on lengths only). */
 int rr_block_work_dev(rr_block *b, const void *d_in, size_t in_len, void *d_out, size_t out_cap,
                       size_t *consumed, size_t *produced, size_t *need, void *hip_stream);
 
@@ -151,7 +152,7 @@ int         rr_block_eof(rr_block *b, int src_eof);
 const char *rr_block_name(const rr_block *b);
 size_t      rr_block_in_elem_size(const rr_block *b);
 size_t      rr_block_out_elem_size(const rr_block *b);
-/* Wait for everything the block enqueued on its own stream. */
+/* Wait for everything the block enqueued (its private stream and the stream of the last work call). */
 int         rr_block_sync(rr_block *b);
 
 /* Measurement aid: when enabled, every work call brackets the block's dominant kernel

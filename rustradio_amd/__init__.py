@@ -126,7 +126,9 @@ class Block:
 
     def work_dev(self, d_in: int, in_len: int, d_out: int, out_cap: int, stream: int = 0):
         """Block::work() over DEVICE windows (raw device pointers, e.g. tensor.data_ptr());
-        asynchronous on `stream` (0 = the block's own) -> (status, consumed, produced, need)."""
+        asynchronous on `stream` (a hipStream_t handle used as given; 0 = the default stream, which is
+        what torch.cuda.current_stream().cuda_stream returns for torch's default stream)
+        -> (status, consumed, produced, need)."""
         c, p, n = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
         st = lib().rr_block_work_dev(self._h, C.c_void_p(d_in), in_len, C.c_void_p(d_out), out_cap,
                                      C.byref(c), C.byref(p), C.byref(n), C.c_void_p(stream))

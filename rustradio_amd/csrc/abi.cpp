@@ -130,7 +130,10 @@ int rr_block_work_dev(rr_block* b, const void* d_in, size_t in_len, void* d_out,
                       size_t* produced, size_t* need, void* hip_stream) {
     return guarded(b, consumed, produced, need, "rr_block_work_dev", [&] {
         RR_HIP(hipSetDevice(b->b->device));
-        hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : b->b->stream;
+        // the handle is used as given: NULL is HIP's default stream (what torch's default stream is),
+        // NOT the block's private stream — anything else would run unordered against the caller's work
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        b->b->last_stream = s;
         return b->b->work_dev(d_in, in_len, d_out, out_cap, consumed, produced, need, s);
     });
 }

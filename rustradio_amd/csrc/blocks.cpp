@@ -41,6 +41,7 @@ Block::~Block() {
 void Block::sync() {
     RR_HIP(hipSetDevice(device));
     RR_HIP(hipStreamSynchronize(stream));
+    if (last_stream != stream) RR_HIP(hipStreamSynchronize(last_stream));   // nullptr = default stream
 }
 void Block::prof_begin(hipStream_t s) {
     if (!prof_on) return;
@@ -75,6 +76,7 @@ bool Block::eof(bool src_eof) { return src_eof; }   // rustradio_macros_code/src
 int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                      size_t* produced, size_t* need) {
     RR_HIP(hipSetDevice(device));
+    last_stream = stream;
     const size_t in_use = in_len;   // whole window: kernels may touch (zero-weighted) samples past the consumed range
     st_in.reserve(std::max<size_t>(in_use * in_es, 16));
     st_out.reserve(std::max<size_t>(out_cap * out_es, 16));
@@ -461,6 +463,7 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
 int FmMulti::work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                        size_t* produced, size_t* need) {
     RR_HIP(hipSetDevice(device));
+    last_stream = stream;
     st_in.reserve(std::max<size_t>(in_len * in_es, 16));
     st_out.reserve(std::max<size_t>(C * out_cap * out_es, 16));
     if (in_len) RR_HIP(hipMemcpyAsync(st_in.p, in, in_len * in_es, hipMemcpyHostToDevice, stream));

@@ -15,7 +15,8 @@ struct Block {
     const char* name;
     size_t in_es, out_es;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // private stream: host-window work() and setup copies
+    hipStream_t last_stream = nullptr;    // stream of the most recent work call (what sync() waits for)
     DevBuf<unsigned char> st_in, st_out;   // staging for host-window work()
 
     Block(const char* nm, size_t ies, size_t oes);

@@ -52,6 +52,11 @@ static FirGeom fir_geom(int NT, int R, int d, int qpad, size_t es_in, size_t es_
     return g;
 }
 
+// Staging is software-pipelined: the next tile's input is fetched into registers (PRE values
+// per thread, all loads in flight) while the current tile is multiplied out, and only written to
+// LDS after the barrier that ends the current tile.
+constexpr int FIR_MAXPRE = 20;
+
 template <class T, class TapT, class OutT, int NT, int R, bool HILBERT>
 __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
                                             int qpad, int np, int rstride, int pstride,
@@ -63,31 +68,51 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
     OutT* lds_o = reinterpret_cast<OutT*>(smem_raw);
     const int t = threadIdx.x;
     const long ntiles = (n_out + NOUT - 1) / NOUT;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long m0 = tile * NOUT;
-        const long gi0 = m0 * d;
-        const int total = np * d;
-        __syncthreads();                       // previous tile's output reads are done
-        // ---- stage the input tile (lane-consecutive global reads, transposed LDS writes) ----
+    const int total = np * d;
+    const int cnt = (total + NT - 1) / NT;             // staged values per thread
+    const bool piped = cnt <= FIR_MAXPRE;
+
+    T pre[FIR_MAXPRE];
+    auto fetch = [&](long tile) {                       // tile input -> registers (no waits)
+        const long gi0 = tile * NOUT * d;
         const bool interior = gi0 >= src.plen && gi0 - src.plen + total <= src.in_len;
         const T* gp = src.in + (gi0 - src.plen);
-        if (d == 1) {
-            if (interior) {
-                for (int i = t; i < total; i += NT) lds[(i % R) * rstride + i / R] = gp[i];
-            } else {
-                for (int i = t; i < total; i += NT) lds[(i % R) * rstride + i / R] = src.load(gi0 + i);
-            }
-        } else {
-            // i = n*d + p: walk n and p incrementally (NT = a*d + b per step) instead of dividing
-            int p = t % d, n = t / d;
-            const int sp = NT % d, sn = NT / d;
-            for (int i = t; i < total; i += NT) {
-                lds[p * pstride + (n % R) * rstride + n / R] = interior ? gp[i] : src.load(gi0 + i);
-                p += sp; n += sn;
-                if (p >= d) { p -= d; n++; }
-            }
+#pragma unroll
+        for (int c = 0; c < FIR_MAXPRE; c++) {
+            const int i = t + c * NT;
+            if (c < cnt && i < total) pre[c] = interior ? gp[i] : src.load(gi0 + i);
         }
+    };
+    auto commit = [&]() {                               // registers -> transposed LDS tile
+        int p = t % d, n = t / d;
+        const int sp = NT % d, sn = NT / d;
+#pragma unroll
+        for (int c = 0; c < FIR_MAXPRE; c++) {
+            const int i = t + c * NT;
+            if (c < cnt && i < total) lds[p * pstride + (n % R) * rstride + n / R] = pre[c];
+            p += sp; n += sn;
+            if (p >= d) { p -= d; n++; }
+        }
+    };
+    auto stage_direct = [&](long tile) {                // fallback for very large tiles
+        const long gi0 = tile * NOUT * d;
+        int p = t % d, n = t / d;
+        const int sp = NT % d, sn = NT / d;
+        for (int i = t; i < total; i += NT) {
+            lds[p * pstride + (n % R) * rstride + n / R] = src.load(gi0 + i);
+            p += sp; n += sn;
+            if (p >= d) { p -= d; n++; }
+        }
+    };
+
+    long tile = blockIdx.x;
+    if (piped && tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long m0 = tile * NOUT;
+        __syncthreads();                       // previous tile's output reads are done
+        if (piped) commit(); else stage_direct(tile);
         __syncthreads();
+        if (piped && tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
 
         T acc[R];
 #pragma unroll
@@ -148,15 +173,15 @@ __global__ __launch_bounds__(256) void k_fir_direct(VSrc<T> src, OutT* __restric
 }
 
 // Tile choice: the largest tile whose LDS footprint still lets >= 4 workgroups share a CU and
-// that yields >= 2 tiles per CU (small inputs get small tiles); decimating filters use R = 4
-// so that the d-times larger input tile still fits.
+// that yields >= 2 tiles per CU (small inputs get small tiles); decimating filters use R = 2
+// (256 threads x 2 outputs) so that the d-times larger input tile fits with 16 waves per CU.
 template <class T, class TapT, class OutT, bool HILBERT>
 static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, VSrc<T> src, OutT* out,
                            long n_out, hipStream_t s) {
     if (n_out <= 0) return;
     const int cus = device_cu_count();
     struct Cfg { int NT, R; };
-    static const Cfg cfgs[] = {{256, 8}, {128, 8}, {64, 8}, {128, 4}, {64, 4}};
+    static const Cfg cfgs[] = {{256, 8}, {128, 8}, {64, 8}, {256, 2}, {128, 2}};
     int pick = -1;
     FirGeom g{};
     for (int c = 0; c < 5; c++) {
@@ -189,8 +214,8 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
     case 0: RR_FIR_LAUNCH(256, 8); break;
     case 1: RR_FIR_LAUNCH(128, 8); break;
     case 2: RR_FIR_LAUNCH(64, 8); break;
-    case 3: RR_FIR_LAUNCH(128, 4); break;
-    default: RR_FIR_LAUNCH(64, 4); break;
+    case 3: RR_FIR_LAUNCH(256, 2); break;
+    default: RR_FIR_LAUNCH(128, 2); break;
     }
 #undef RR_FIR_LAUNCH
     RR_HIP(hipGetLastError());
