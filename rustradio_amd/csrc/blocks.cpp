@@ -609,6 +609,18 @@ Hilbert::Hilbert(size_t ntaps, int window, float parm) : Block("Hilbert", 4, 8) 
     build_poly(rev, 1, pl.qpad, tp);
     d_rev.upload(rev.data(), rev.size(), stream);
     d_tp.upload(tp.data(), tp.size(), stream);
+    // the transformer is exactly zero on one parity of tap positions (fir.rs:667-676): use the
+    // half-length polyphase form when that holds for these taps
+    par = (int)((((ntaps - 1) / 2) + 1) % 2);
+    skip_ok = true;
+    for (size_t j = 0; j < ntaps; j++) if ((int)(j % 2) != par && rev[j] != 0.0f) skip_ok = false;
+    if (skip_ok) {
+        const size_t q = (ntaps - par + 1) / 2;
+        Q = (int)((q + 7) / 8 * 8);
+        std::vector<float> hq(Q, 0.0f);
+        for (size_t i = 0; i < q && 2 * i + par < ntaps; i++) hq[i] = rev[2 * i + par];
+        d_hq.upload(hq.data(), hq.size(), stream);
+    }
     for (auto& h : hist) {                                                      // :55 — ntaps zeros
         h.reserve(ntaps);
         RR_HIP(hipMemsetAsync(h.p, 0, ntaps * sizeof(float), stream));
@@ -623,7 +635,8 @@ int Hilbert::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     const size_t n = std::min(in_len, out_cap);                                 // :85-87
     VSrc<float> src{hist[cur].p, (long)pl.L, static_cast<const float*>(in), (long)in_len};
     prof_begin(s);
-    launch_hilbert(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)n, s);
+    if (!(skip_ok && launch_hilbert_skip(pl.L, par, Q, d_hq.p, src, static_cast<cf*>(out), (long)n, s)))
+        launch_hilbert(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)n, s);
     prof_end(s);
     launch_vcopy_f32(src, (long)n, hist[cur ^ 1].p, (long)pl.L, s);            // :125
     cur ^= 1;

@@ -132,6 +132,10 @@ struct Hilbert : Block {
     DevBuf<float> d_tp, d_rev;
     DevBuf<float> hist[2];
     int cur = 0;
+    // zero-tap skipping (kernels_fir.hip k_hilbert): taps of one parity only
+    bool skip_ok = false;
+    int par = 0, Q = 0;
+    DevBuf<float> d_hq;
     Hilbert(size_t ntaps, int window, float parm);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };

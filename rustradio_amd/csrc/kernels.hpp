@@ -51,6 +51,9 @@ void launch_fir_f32(const FirPlan& pl, const float* tp, const float* rev, VSrc<f
 // Hilbert: out[k] = (xp[k + L/2], sum_j rev[j] xp[k + j]), xp = virtual stream (history ++ in).
 void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, cf* out,
                     long n_out, hipStream_t s);
+// Hilbert with the zero taps skipped: hq[q] = rev[2q + par] (Q entries, padded to a multiple of 8).
+// Returns false if the shape is not covered (use launch_hilbert).
+bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src, cf* out, long n_out, hipStream_t s);
 // y[m] *= phase0 * step^(m0 + m) evaluated in f64 (RR_ROT_MODEL)
 void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, double sy, long m0,
                          hipStream_t s);

@@ -123,14 +123,20 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
             T w[R];
 #pragma unroll
             for (int j = 0; j < R; j++) w[j] = lp[j * rstride];
-            for (int q0 = 0; q0 < qpad; q0 += R) {
+            // 8 taps per iteration whatever R is (qpad is a multiple of 8): one wide scalar tap load and
+            // 8 LDS reads in flight per 8*R multiply-adds.  Tap q needs x_p[t*R + q + R] next: row
+            // (q % R), column t + q/R + 1 of the transposed tile.  (A variant that also prefetched the
+            // next block's samples and taps measured slower: 106 SGPRs + 60 more VGPRs, 2 waves/SIMD.)
+            for (int q0 = 0; q0 < qpad; q0 += 8) {
                 const T* lq = lp + q0 / R + 1;
+                TapT tap8[8];
 #pragma unroll
-                for (int kk = 0; kk < R; kk++) {
-                    const TapT tap = tpp[q0 + kk];
+                for (int kk = 0; kk < 8; kk++) tap8[kk] = tpp[q0 + kk];
 #pragma unroll
-                    for (int j = 0; j < R; j++) mac(acc[j], tap, w[(kk + j) % R]);
-                    w[kk] = lq[kk * rstride];
+                for (int kk = 0; kk < 8; kk++) {
+#pragma unroll
+                    for (int j = 0; j < R; j++) mac(acc[j], tap8[kk], w[(kk + j) % R]);
+                    w[kk % R] = lq[(kk % R) * rstride + kk / R];
                 }
             }
         }
@@ -235,6 +241,134 @@ void launch_fir_f32(const FirPlan& pl, const float* tp, const float* rev, VSrc<f
 void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, cf* out,
                     long n_out, hipStream_t s) {
     launch_fir_any<float, float, cf, true>(pl, tp, rev, src, out, n_out, s);
+}
+
+// ---- Hilbert with the zero taps skipped -------------------------------------------------------------
+// hilbert() (src/fir.rs:660-680) is non-zero only at odd distances from the centre tap, i.e. the
+// reversed taps rev[j] vanish unless j = par (mod 2).  With h[q] = rev[2q + par]:
+//     Im a[2m]   = sum_q h[q] * A[m + q]        A = input phase of parity  par
+//     Im a[2m+1] = sum_q h[q] * B[m + q + par]  B = input phase of parity !par
+// two d=1 FIRs of half the length over the two polyphase components of the input: 32 instead of
+// 72 multiply-adds per output for the 65-tap transformer.  Each thread produces 16 consecutive
+// outputs (8 even + 8 odd) from two sliding windows; B is staged shifted by `par` so both windows
+// use the same addressing.  Re a[k] = xp[k + L/2] (src/hilbert.rs:115) comes from the same tile.
+constexpr int HIL_PRE = 18;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict__ out, long n_out, int L, int par,
+                                                int Q, int rstride, const float* __restrict__ hq) {
+    constexpr int NOUT = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* ldsA = reinterpret_cast<float*>(smem_raw);
+    float* ldsB = ldsA + 8 * rstride;
+    cf* lds_o = reinterpret_cast<cf*>(smem_raw);
+    const int t = threadIdx.x;
+    const long ntiles = (n_out + NOUT - 1) / NOUT;
+    const int per_phase = NT * 8 + Q + 8;               // samples of each phase a tile may touch
+    const int total = 2 * per_phase + 2;
+    const int cnt = (total + NT - 1) / NT;              // <= HIL_PRE by construction (host checks)
+
+    float pre[HIL_PRE];
+    auto fetch = [&](long tile) {
+        const long gi0 = tile * NOUT;
+        const bool interior = gi0 >= src.plen && gi0 - src.plen + total <= src.in_len;
+        const float* gp = src.in + (gi0 - src.plen);
+#pragma unroll
+        for (int c = 0; c < HIL_PRE; c++) {
+            const int i = t + c * NT;
+            if (c < cnt && i < total) pre[c] = interior ? gp[i] : src.load(gi0 + i);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int c = 0; c < HIL_PRE; c++) {
+            const int i = t + c * NT;
+            if (c < cnt && i < total) {
+                const int e = i & 1;
+                int n = i >> 1;
+                if (e == par) { if (n < per_phase) ldsA[(n % 8) * rstride + n / 8] = pre[c]; }
+                else { n -= par; if (n >= 0 && n < per_phase) ldsB[(n % 8) * rstride + n / 8] = pre[c]; }
+            }
+        }
+    };
+    // sample xp[tile base + idx] from the staged phases
+    auto tile_sample = [&](int idx) -> float {
+        const int e = idx & 1;
+        int n = idx >> 1;
+        if (e == par) return ldsA[(n % 8) * rstride + n / 8];
+        n -= par;
+        return ldsB[(n % 8) * rstride + n / 8];
+    };
+
+    long tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long m0 = tile * NOUT;
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+
+        float accE[8], accO[8], wA[8], wB[8];
+        const float* lA = ldsA + t;
+        const float* lB = ldsB + t;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { accE[j] = 0.0f; accO[j] = 0.0f; wA[j] = lA[j * rstride]; wB[j] = lB[j * rstride]; }
+        for (int q0 = 0; q0 < Q; q0 += 8) {
+            const float* qA = lA + q0 / 8 + 1;
+            const float* qB = lB + q0 / 8 + 1;
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                const float tap = hq[q0 + kk];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    accE[j] = fmaf(tap, wA[(kk + j) % 8], accE[j]);
+                    accO[j] = fmaf(tap, wB[(kk + j) % 8], accO[j]);
+                }
+                wA[kk] = qA[kk * rstride];
+                wB[kk] = qB[kk * rstride];
+            }
+        }
+        cf res[16];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = 16 * t + 2 * j;
+            res[2 * j] = mkcf(tile_sample(k + L / 2), accE[j]);
+            res[2 * j + 1] = mkcf(tile_sample(k + 1 + L / 2), accO[j]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; c++) lds_o[t * 17 + c] = res[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int i = c * NT + t;
+            if (m0 + i < n_out) out[m0 + i] = lds_o[(i / 16) * 17 + i % 16];
+        }
+    }
+}
+
+// hq = device [Q] (Q = taps per phase padded to a multiple of 8); returns false when the shape is
+// not covered (caller falls back to the generic FIR kernel).
+bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src, cf* out, long n_out, hipStream_t s) {
+    if (n_out <= 0) return true;
+    constexpr int NT = 256;
+    const int per_phase = NT * 8 + Q + 8;
+    const int total = 2 * per_phase + 2;
+    if ((total + NT - 1) / NT > HIL_PRE || L / 2 + 2 > 2 * (Q + 8)) return false;
+    int rs = per_phase / 8 + 1;
+    while (rs % 32 != 4) rs++;
+    const size_t in_b = (size_t)2 * 8 * rs * sizeof(float), out_b = (size_t)NT * 17 * sizeof(cf);
+    const size_t smem = in_b > out_b ? in_b : out_b;
+    const long ntiles = (n_out + (long)NT * 16 - 1) / ((long)NT * 16);
+    long per_cu = (long)(160 * 1024) / (long)smem;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const long cap = (long)device_cu_count() * per_cu;
+    const long grid = ntiles < cap ? ntiles : cap;
+    hipLaunchKernelGGL((k_hilbert<NT>), dim3((unsigned)grid), dim3(NT), smem, s, src, out, n_out, L, par, Q, rs, hq);
+    RR_HIP(hipGetLastError());
+    return true;
 }
 
 // ---- frequency-translation rotator (src/fir.rs:464-473) ---------------------------------
