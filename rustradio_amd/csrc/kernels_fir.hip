@@ -25,11 +25,13 @@ __device__ __forceinline__ void mac(cf& acc, cf tap, cf w) {      // complex tap
 }
 __device__ __forceinline__ void mac(float& acc, float tap, float w) { acc = fmaf(tap, w, acc); }
 
+__device__ __forceinline__ float add_of(float a, float b) { return a + b; }
+__device__ __forceinline__ cf add_of(cf a, cf b) { return mkcf(a.x + b.x, a.y + b.y); }
 template <class T> __device__ __forceinline__ T zero_of();
 template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
 template <> __device__ __forceinline__ cf zero_of<cf>() { return mkcf(0.0f, 0.0f); }
 
-// Tile geometry shared by host and device.  NT threads x R outputs each = NOUT outputs per tile.
+// Tile geometry shared by host and device.  NT threads (per phase group) x R outputs each = NOUT outputs per tile.
 //   input  LDS: per phase p, x_p[n] at  p*pstride + (n % R)*rstride + n / R      (transposed)
 //   output LDS: output i of the tile at (i / R)*(R + 1) + i % R                    (re-coalescing)
 struct FirGeom {
@@ -38,7 +40,7 @@ struct FirGeom {
     int pstride;   // phase stride
     size_t lds_bytes;
 };
-static FirGeom fir_geom(int NT, int R, int d, int qpad, size_t es_in, size_t es_out) {
+static FirGeom fir_geom(int NT, int R, int d, int qpad, size_t es_in, size_t es_out, int S = 1) {
     FirGeom g;
     g.np = NT * R + qpad;
     int rs = NT + qpad / R;
@@ -47,7 +49,7 @@ static FirGeom fir_geom(int NT, int R, int d, int qpad, size_t es_in, size_t es_
     g.rstride = rs;
     g.pstride = R * rs + 1;
     const size_t in_b = (size_t)d * g.pstride * es_in;
-    const size_t out_b = (size_t)NT * (R + 1) * es_out;
+    const size_t out_b = (size_t)NT * S * (R + 1) * es_out;
     g.lds_bytes = in_b > out_b ? in_b : out_b;
     return g;
 }
@@ -57,12 +59,21 @@ static FirGeom fir_geom(int NT, int R, int d, int qpad, size_t es_in, size_t es_
 // LDS after the barrier that ends the current tile.
 constexpr int FIR_MAXPRE = 20;
 
-template <class T, class TapT, class OutT, int NT, int R, bool HILBERT>
+//
+// Phase split: a decimating filter's input tile is d times its output tile, so LDS capacity caps the
+// outputs per tile and, with one thread per R outputs, R itself (R = 2 at d = 8), which leaves ONE
+// packed multiply-add pair per LDS read.  With S > 1 the workgroup is S groups of NT/S threads; group
+// s evaluates only the phases p = s (mod S) for its R outputs and the S partial sums meet in the
+// output staging buffer.  Same tile, same thread count, S times fewer LDS reads per multiply-add.
+// A group is a whole number of waves, so taps stay wave-uniform.
+template <class T, class TapT, class OutT, int NT, int R, int S, bool HILBERT>
 __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
                                             int qpad, int np, int rstride, int pstride,
                                             const TapT* __restrict__ tp) {
-    constexpr int NOUT = NT * R;
+    constexpr int NTC = NT / S;                        // threads (output columns) per phase group
+    constexpr int NOUT = NTC * R;
     static_assert(R % 2 == 0 && R <= 8, "qpad is padded to a multiple of 8");
+    static_assert(NTC % 64 == 0 && R % S == 0 && (S == 1 || !HILBERT), "phase groups are whole waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
     OutT* lds_o = reinterpret_cast<OutT*>(smem_raw);
@@ -73,28 +84,41 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
     const bool piped = cnt <= FIR_MAXPRE;
 
     T pre[FIR_MAXPRE];
-    auto fetch = [&](long tile) {                       // tile input -> registers (no waits)
+    // Only INTERIOR tiles (whole window inside the caller's buffer) are pipelined through registers;
+    // the few tiles that touch the carried history or the end of the window are staged in place by
+    // stage_direct().  The test is workgroup-uniform and the loads below are straight-line: a
+    // per-element in-range select compiles to an exec-masked branch per load and the loads then
+    // complete one at a time (measured: 0.43 of 0.61 ms of the 255-tap /8 filter was that).
+    auto interior = [&](long tile) {
         const long gi0 = tile * NOUT * d;
-        const bool interior = gi0 >= src.plen && gi0 - src.plen + total <= src.in_len;
-        const T* gp = src.in + (gi0 - src.plen);
+        return piped && gi0 >= src.plen && gi0 - src.plen + total <= src.in_len;
+    };
+    auto fetch = [&](long tile) {                       // tile input -> registers (no waits)
+        if (!interior(tile)) return;
+        const T* gp = src.in + (tile * NOUT * d - src.plen);
+        int tt = t;
+        asm volatile("" : "+v"(tt));                    // recompute the offsets per tile: hoisted, they cost 20 VGPRs
 #pragma unroll
         for (int c = 0; c < FIR_MAXPRE; c++) {
-            const int i = t + c * NT;
-            if (c < cnt && i < total) pre[c] = interior ? gp[i] : src.load(gi0 + i);
+            int i = tt + c * NT;
+            i = i < total ? i : total - 1;              // clamped: commit() skips the slot
+            if (c < cnt) pre[c] = gp[i];
         }
     };
     auto commit = [&]() {                               // registers -> transposed LDS tile
-        int p = t % d, n = t / d;
+        int tt = t;
+        asm volatile("" : "+v"(tt));                    // (same: keep the 20 LDS addresses out of the live set)
+        int p = tt % d, n = tt / d;
         const int sp = NT % d, sn = NT / d;
 #pragma unroll
         for (int c = 0; c < FIR_MAXPRE; c++) {
-            const int i = t + c * NT;
+            const int i = tt + c * NT;
             if (c < cnt && i < total) lds[p * pstride + (n % R) * rstride + n / R] = pre[c];
             p += sp; n += sn;
             if (p >= d) { p -= d; n++; }
         }
     };
-    auto stage_direct = [&](long tile) {                // fallback for very large tiles
+    auto stage_direct = [&](long tile) {                // boundary tiles and very large tiles
         const long gi0 = tile * NOUT * d;
         int p = t % d, n = t / d;
         const int sp = NT % d, sn = NT / d;
@@ -106,27 +130,30 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
     };
 
     long tile = blockIdx.x;
-    if (piped && tile < ntiles) fetch(tile);
+    if (tile < ntiles) fetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         const long m0 = tile * NOUT;
         __syncthreads();                       // previous tile's output reads are done
-        if (piped) commit(); else stage_direct(tile);
+        if (interior(tile)) commit(); else stage_direct(tile);
         __syncthreads();
-        if (piped && tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
 
+        const int tc = S == 1 ? t : t % NTC;                                   // output column
+        const int sg = S == 1 ? 0 : __builtin_amdgcn_readfirstlane(t / NTC);   // phase group (wave-uniform)
         T acc[R];
 #pragma unroll
         for (int j = 0; j < R; j++) acc[j] = zero_of<T>();
-        for (int p = 0; p < d; p++) {
-            const T* lp = lds + p * pstride + t;
+        for (int p = sg; p < d; p += S) {
+            const T* lp = lds + p * pstride + tc;
             const TapT* tpp = tp + (long)p * qpad;
             T w[R];
 #pragma unroll
             for (int j = 0; j < R; j++) w[j] = lp[j * rstride];
             // 8 taps per iteration whatever R is (qpad is a multiple of 8): one wide scalar tap load and
             // 8 LDS reads in flight per 8*R multiply-adds.  Tap q needs x_p[t*R + q + R] next: row
-            // (q % R), column t + q/R + 1 of the transposed tile.  (A variant that also prefetched the
-            // next block's samples and taps measured slower: 106 SGPRs + 60 more VGPRs, 2 waves/SIMD.)
+            // (q % R), column tc + q/R + 1 of the transposed tile.  (Software-pipelining the loop by one
+            // block — next block's samples and taps issued before this block's multiply-adds — measured
+            // slower twice: +32 VGPRs cost a wave per SIMD and the scalar tap loads force lgkmcnt(0) anyway.)
             for (int q0 = 0; q0 < qpad; q0 += 8) {
                 const T* lq = lp + q0 / R + 1;
                 TapT tap8[8];
@@ -140,7 +167,8 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
                 }
             }
         }
-        // ---- re-coalesce the outputs through LDS: thread t holds outputs t*R .. t*R+R-1 ----
+        // ---- re-coalesce the outputs through LDS: thread (sg, tc) holds group sg's partial sums of
+        //      outputs tc*R .. tc*R+R-1; the reader adds the S partials ----
         OutT res[R];
         if constexpr (HILBERT) {               // re = xp[k + L/2]  (hilbert.rs:115)
 #pragma unroll
@@ -157,9 +185,14 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
         for (int j = 0; j < R; j++) lds_o[t * (R + 1) + j] = res[j];
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < R; c++) {
+        for (int c = 0; c < R / S; c++) {
             const int i = c * NT + t;
-            if (m0 + i < n_out) out[m0 + i] = lds_o[(i / R) * (R + 1) + i % R];
+            OutT v = lds_o[(i / R) * (R + 1) + i % R];
+            if constexpr (S > 1) {
+#pragma unroll
+                for (int g = 1; g < S; g++) v = add_of(v, lds_o[(g * NTC + i / R) * (R + 1) + i % R]);
+            }
+            if (m0 + i < n_out) out[m0 + i] = v;
         }
     }
 }
@@ -178,25 +211,51 @@ __global__ __launch_bounds__(256) void k_fir_direct(VSrc<T> src, OutT* __restric
     }
 }
 
-// Tile choice: the largest tile whose LDS footprint still lets >= 4 workgroups share a CU and
-// that yields >= 2 tiles per CU (small inputs get small tiles); decimating filters use R = 2
-// (256 threads x 2 outputs) so that the d-times larger input tile fits with 16 waves per CU.
+// Tile choice: the cheapest shape by a small cost model of the inner loops (below) among those whose
+// LDS footprint lets >= 4 workgroups share a CU; shapes that would leave CUs idle on a small input
+// are penalised, so small inputs get small tiles.
 template <class T, class TapT, class OutT, bool HILBERT>
 static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, VSrc<T> src, OutT* out,
                            long n_out, hipStream_t s) {
     if (n_out <= 0) return;
     const int cus = device_cu_count();
-    struct Cfg { int NT, R; };
-    static const Cfg cfgs[] = {{256, 8}, {128, 8}, {64, 8}, {256, 2}, {128, 2}};
+    struct Cfg { int NT, R, S; };
+    // {256,8,1}: d = 1..2; the S > 1 shapes are for decimating filters; {128,8,1}/{64,8,1}: small inputs
+    static const Cfg cfgs[] = {{256, 8, 1}, {128, 8, 1}, {64, 8, 1}, {256, 2, 1}, {128, 2, 1},
+                               {256, 4, 2}, {256, 8, 2}, {256, 8, 4}};
+    constexpr int NCFG = 8;
+    const int Q = pl.qpad;
+    auto geom = [&](int c) {
+        return fir_geom(cfgs[c].NT / cfgs[c].S, cfgs[c].R, pl.d, Q, sizeof(T), sizeof(OutT), cfgs[c].S);
+    };
+    auto nout = [&](int c) { return (long)cfgs[c].NT / cfgs[c].S * cfgs[c].R; };
+    // clocks per output: ceil(d/S) phases of Q taps per thread, each R packed multiply-adds (4 clk per
+    // wave) + one LDS read (~2.1 clk, the 4 SIMDs share the LDS port), R reads to fill the window of a
+    // phase; + a fixed per-tile cost (barriers, staging bookkeeping).
+    auto cost = [&](int c) {
+        const int R = cfgs[c].R, S = cfgs[c].S;
+        const double ph = (pl.d + S - 1) / S;
+        return (ph * (Q * R * 4.0 + (Q + R) * 8.4) + 600.0) / (double)nout(c) * (256.0 / cfgs[c].NT);
+    };
     int pick = -1;
     FirGeom g{};
-    for (int c = 0; c < 5; c++) {
-        const FirGeom gc = fir_geom(cfgs[c].NT, cfgs[c].R, pl.d, pl.qpad, sizeof(T), sizeof(OutT));
-        if (gc.lds_bytes > 40 * 1024) continue;
-        const long tiles = (n_out + (long)cfgs[c].NT * cfgs[c].R - 1) / ((long)cfgs[c].NT * cfgs[c].R);
-        if (pick < 0) { pick = c; g = gc; }                       // first (largest) that fits
-        if (tiles >= 2L * cus) { pick = c; g = gc; break; }       // ... preferring one that fills the chip
-        pick = c; g = gc;                                         // otherwise keep shrinking
+    const char* fe = getenv("RR_FIR_CFG");                                  // tuning / test knob
+    const int force = fe ? atoi(fe) : -1;
+    if (force >= 0 && force < NCFG && !(HILBERT && cfgs[force].S > 1)) {
+        const FirGeom gc = geom(force);
+        if (gc.lds_bytes <= 64 * 1024) { pick = force; g = gc; }
+    }
+    if (pick < 0) {
+        double best = 0;
+        for (int c = 0; c < NCFG; c++) {
+            if (HILBERT && cfgs[c].S > 1) continue;
+            const FirGeom gc = geom(c);
+            if (gc.lds_bytes > 40 * 1024) continue;
+            const long tiles = (n_out + nout(c) - 1) / nout(c);
+            double cst = cost(c);
+            if (tiles < 2L * cus) cst *= (2.0 * cus) / (double)tiles;       // does not fill the chip
+            if (pick < 0 || cst < best) { pick = c; g = gc; best = cst; }
+        }
     }
     if (pick < 0) {
         long grid = (n_out + 255) / 256;
@@ -206,22 +265,35 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
         RR_HIP(hipGetLastError());
         return;
     }
-    const int NT = cfgs[pick].NT, R = cfgs[pick].R;
-    const long ntiles = (n_out + (long)NT * R - 1) / ((long)NT * R);
+    const int NT = cfgs[pick].NT;
+    const long ntiles = (n_out + nout(pick) - 1) / nout(pick);
     long per_cu = (long)(160 * 1024) / (long)(g.lds_bytes ? g.lds_bytes : 1);
     const long by_waves = 32 / (NT / 64);
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
+    if (const char* pe = getenv("RR_FIR_PERCU")) per_cu = atoi(pe) > 0 ? atoi(pe) : per_cu;   // measurement knob
     long grid = ntiles < (long)cus * per_cu ? ntiles : (long)cus * per_cu;
-#define RR_FIR_LAUNCH(NTV, RV)                                                                                     \
-    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, s, \
-                       src, out, n_out, pl.L, pl.d, pl.qpad, g.np, g.rstride, g.pstride, tp)
+    const char* qe = getenv("RR_FIR_QCOMPUTE");                             // measurement knob: taps actually multiplied
+    const int qcomp = qe ? atoi(qe) : -1;
+    const int qrun = qcomp >= 0 && qcomp < pl.qpad ? qcomp : pl.qpad;
+#define RR_FIR_LAUNCH(NTV, RV, SV)                                                                                     \
+    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, SV, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, s, \
+                       src, out, n_out, pl.L, pl.d, qrun, g.np, g.rstride, g.pstride, tp)
     switch (pick) {
-    case 0: RR_FIR_LAUNCH(256, 8); break;
-    case 1: RR_FIR_LAUNCH(128, 8); break;
-    case 2: RR_FIR_LAUNCH(64, 8); break;
-    case 3: RR_FIR_LAUNCH(256, 2); break;
-    default: RR_FIR_LAUNCH(128, 2); break;
+    case 0: RR_FIR_LAUNCH(256, 8, 1); break;
+    case 1: RR_FIR_LAUNCH(128, 8, 1); break;
+    case 2: RR_FIR_LAUNCH(64, 8, 1); break;
+    case 3: RR_FIR_LAUNCH(256, 2, 1); break;
+    case 4: RR_FIR_LAUNCH(128, 2, 1); break;
+    default:
+        if constexpr (!HILBERT) {
+            switch (pick) {
+            case 5: RR_FIR_LAUNCH(256, 4, 2); break;
+            case 6: RR_FIR_LAUNCH(256, 8, 2); break;
+            default: RR_FIR_LAUNCH(256, 8, 4); break;
+            }
+        }
+        break;
     }
 #undef RR_FIR_LAUNCH
     RR_HIP(hipGetLastError());

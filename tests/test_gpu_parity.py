@@ -53,6 +53,23 @@ def test_fir_complex(rr, L, deci, cplx):
     both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x)
 
 
+@pytest.mark.parametrize("cfg", range(8))
+@pytest.mark.parametrize("L,deci,cplx", [(255, 8, False), (255, 8, True), (64, 5, False), (33, 3, True), (200, 1, False),
+                                         (77, 2, True), (31, 12, False)])
+def test_fir_every_tile_shape(rr, monkeypatch, cfg, L, deci, cplx):
+    """Every (threads, outputs/thread, phase split) tile shape of the FIR kernel, forced through the
+    RR_FIR_CFG knob (the launcher otherwise picks by input size), incl. streams with boundary tiles."""
+    monkeypatch.setenv("RR_FIR_CFG", str(cfg))
+    x = rnd_c(40000, L * 11 + deci + cfg)
+    taps = rnd_c(L, L + 1) / max(1, L // 8)
+    if not cplx:
+        taps = taps.real.astype(np.complex64)
+    both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x)
+    both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x[:9000], stream_bytes=8 * 2500)
+    xf = rnd_f(30000, cfg + 5)
+    both(rr, lambda m: [m.FirFilter(taps.real.copy(), deci=deci)], xf)
+
+
 def test_fir_complex_chunked(rr):
     x = rnd_c(50000, 3)
     taps = orc.low_pass_complex(10e6, 1e6, 190e3)
