@@ -44,7 +44,9 @@ static FirGeom fir_geom(int NT, int R, int d, int qpad, size_t es_in, size_t es_
     FirGeom g;
     g.np = NT * R + qpad;
     int rs = NT + qpad / R;
-    const int mod = es_in == 8 ? 16 : 32, want = es_in == 8 ? 2 : 4;   // bank-friendly residue
+    // bank-friendly residue: the R rows of a phase must start in different banks, r*rs (in 8-byte
+    // units for Complex, 4-byte for Float) a permutation of the even / multiple-of-4 residues
+    const int mod = es_in == 8 ? 4 : 8, want = es_in == 8 ? 2 : 4;
     while (rs % mod != want) rs++;
     g.rstride = rs;
     g.pstride = R * rs + 1;
@@ -67,7 +69,7 @@ constexpr int FIR_MAXPRE = 20;
 // output staging buffer.  Same tile, same thread count, S times fewer LDS reads per multiply-add.
 // A group is a whole number of waves, so taps stay wave-uniform.
 template <class T, class TapT, class OutT, int NT, int R, int S, bool HILBERT>
-__global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
+__global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
                                             int qpad, int np, int rstride, int pstride,
                                             const TapT* __restrict__ tp) {
     constexpr int NTC = NT / S;                        // threads (output columns) per phase group
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
     const int t = threadIdx.x;
     const long ntiles = (n_out + NOUT - 1) / NOUT;
     const int total = np * d;
-    const int cnt = (total + NT - 1) / NT;             // staged values per thread
-    const bool piped = cnt <= FIR_MAXPRE;
+    const int cnt_k = (total + NT - 1) / NT;           // staged values per thread
+    const bool piped = cnt_k <= FIR_MAXPRE;
 
     T pre[FIR_MAXPRE];
     // Only INTERIOR tiles (whole window inside the caller's buffer) are pipelined through registers;
@@ -96,26 +98,47 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
     auto fetch = [&](long tile) {                       // tile input -> registers (no waits)
         if (!interior(tile)) return;
         const T* gp = src.in + (tile * NOUT * d - src.plen);
-        int tt = t;
+        unsigned tt = t;
         asm volatile("" : "+v"(tt));                    // recompute the offsets per tile: hoisted, they cost 20 VGPRs
+        int cnt = cnt_k;
+        asm volatile("" : "+s"(cnt));                   // ... and the 20 round predicates 40 SGPRs (spilled to lanes)
 #pragma unroll
         for (int c = 0; c < FIR_MAXPRE; c++) {
-            int i = tt + c * NT;
-            i = i < total ? i : total - 1;              // clamped: commit() skips the slot
-            if (c < cnt) pre[c] = gp[i];
+            if (c < cnt - 1) {
+                pre[c] = (gp + c * NT)[tt];             // uniform base + lane offset: no per-load address math
+            } else if (c == cnt - 1) {                  // ragged last round: clamped, commit() skips the slot
+                const unsigned i = tt + c * NT;
+                pre[c] = gp[i < (unsigned)total ? i : (unsigned)total - 1];
+            }
         }
     };
+    // Element i = t + c*NT of the tile is x_p[n] with p = i % d, n = i / d and goes to
+    // lds[p*pstride + (n % R)*rstride + n / R].  When d divides NT and R divides NT/d (all power-of-two
+    // decimations up to NT/R, and d = 1) the slot of round c is slot(0) + c * NT/d/R: one add per value.
+    const bool fast_walk = NT % d == 0 && (NT / d) % R == 0;
     auto commit = [&]() {                               // registers -> transposed LDS tile
-        int tt = t;
+        unsigned tt = t;
         asm volatile("" : "+v"(tt));                    // (same: keep the 20 LDS addresses out of the live set)
-        int p = tt % d, n = tt / d;
-        const int sp = NT % d, sn = NT / d;
+        int cnt = cnt_k;
+        asm volatile("" : "+s"(cnt));
+        const unsigned ud = d, sp = NT % ud, sn = NT / ud;
+        unsigned p = tt % ud, n = tt / ud;
+        if (fast_walk) {
+            T* slot = lds + p * pstride + (n % R) * rstride + n / R;
+            const unsigned K = sn / R;
+#pragma unroll
+            for (int c = 0; c < FIR_MAXPRE; c++) {
+                if (c < cnt - 1) slot[c * K] = pre[c];
+                else if (c == cnt - 1 && tt + c * NT < (unsigned)total) slot[c * K] = pre[c];
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < FIR_MAXPRE; c++) {
-            const int i = tt + c * NT;
-            if (c < cnt && i < total) lds[p * pstride + (n % R) * rstride + n / R] = pre[c];
+            if (c < cnt - 1 || (c == cnt - 1 && tt + c * NT < (unsigned)total))
+                lds[p * pstride + (n % R) * rstride + n / R] = pre[c];
             p += sp; n += sn;
-            if (p >= d) { p -= d; n++; }
+            if (p >= ud) { p -= ud; n++; }
         }
     };
     auto stage_direct = [&](long tile) {                // boundary tiles and very large tiles
@@ -154,6 +177,7 @@ __global__ __launch_bounds__(NT) void k_fir(VSrc<T> src, OutT* __restrict__ out,
             // (q % R), column tc + q/R + 1 of the transposed tile.  (Software-pipelining the loop by one
             // block — next block's samples and taps issued before this block's multiply-adds — measured
             // slower twice: +32 VGPRs cost a wave per SIMD and the scalar tap loads force lgkmcnt(0) anyway.)
+#pragma unroll 2
             for (int q0 = 0; q0 < qpad; q0 += 8) {
                 const T* lq = lp + q0 / R + 1;
                 TapT tap8[8];
