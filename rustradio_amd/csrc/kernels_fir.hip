@@ -341,105 +341,113 @@ void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<f
 
 // ---- Hilbert with the zero taps skipped -------------------------------------------------------------
 // hilbert() (src/fir.rs:660-680) is non-zero only at odd distances from the centre tap, i.e. the
-// reversed taps rev[j] vanish unless j = par (mod 2).  With h[q] = rev[2q + par]:
-//     Im a[2m]   = sum_q h[q] * A[m + q]        A = input phase of parity  par
-//     Im a[2m+1] = sum_q h[q] * B[m + q + par]  B = input phase of parity !par
-// two d=1 FIRs of half the length over the two polyphase components of the input: 32 instead of
-// 72 multiply-adds per output for the 65-tap transformer.  Each thread produces 16 consecutive
-// outputs (8 even + 8 odd) from two sliding windows; B is staged shifted by `par` so both windows
-// use the same addressing.  Re a[k] = xp[k + L/2] (src/hilbert.rs:115) comes from the same tile.
-constexpr int HIL_PRE = 18;
-
+// reversed taps rev[j] vanish unless j = par (mod 2), par = (L/2 + 1) % 2.  With h[q] = rev[2q + par]
+// and the input read as PAIRS  P[n] = (xp[2n + par], xp[2n + par + 1]):
+//     (Im a[2m], Im a[2m+1]) = sum_q h[q] * P[m + q]
+// one d = 1 FIR of half the length whose "samples" are pairs of consecutive floats and whose taps are
+// real: exactly the Complex-sample/real-tap FIR above (one v_pk_fma_f32 per tap and output pair, one
+// ds_read_b64 per tap), 32 instead of 72 multiply-adds per output for the 65-tap transformer.  Each
+// thread produces 8 consecutive output pairs.  Re a[k] = xp[k + L/2] (src/hilbert.rs:115) comes from
+// the same tile: L/2 - par is odd, so Re a[2m] is the .y of pair m + (L/2-par-1)/2 and Re a[2m+1] the
+// .x of the pair after it.
+constexpr int HIL_PRE = 10;
+// A pair = two consecutive input floats, the first of any parity, read with ONE 8-byte load (as a cf)
+// although it is only 4-byte aligned: gfx9+ global memory instructions take dword-aligned addresses
+// (compute queues run in unaligned access mode); with the honest alignment the compiler splits every
+// load in two.  Covered by the Hilbert tests with even and odd L/2 and odd window offsets.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict__ out, long n_out, int L, int par,
-                                                int Q, int rstride, const float* __restrict__ hq) {
-    constexpr int NOUT = NT * 16;
+                                                   int Q, int np, int rstride, const float* __restrict__ hq) {
+    constexpr int R = 8, NP = NT * R;                   // pairs per tile (2*NP outputs)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* ldsA = reinterpret_cast<float*>(smem_raw);
-    float* ldsB = ldsA + 8 * rstride;
+    cf* lds = reinterpret_cast<cf*>(smem_raw);          // pair n at (n % R)*rstride + n / R
     cf* lds_o = reinterpret_cast<cf*>(smem_raw);
     const int t = threadIdx.x;
-    const long ntiles = (n_out + NOUT - 1) / NOUT;
-    const int per_phase = NT * 8 + Q + 8;               // samples of each phase a tile may touch
-    const int total = 2 * per_phase + 2;
-    const int cnt = (total + NT - 1) / NT;              // <= HIL_PRE by construction (host checks)
+    const long ntiles = (n_out + 2 * NP - 1) / (2 * NP);
+    const int cnt_k = (np + NT - 1) / NT;               // <= HIL_PRE (host checks)
 
-    float pre[HIL_PRE];
-    auto fetch = [&](long tile) {
-        const long gi0 = tile * NOUT;
-        const bool interior = gi0 >= src.plen && gi0 - src.plen + total <= src.in_len;
-        const float* gp = src.in + (gi0 - src.plen);
-#pragma unroll
-        for (int c = 0; c < HIL_PRE; c++) {
-            const int i = t + c * NT;
-            if (c < cnt && i < total) pre[c] = interior ? gp[i] : src.load(gi0 + i);
-        }
+    cf pre[HIL_PRE];
+    auto interior = [&](long tile) {
+        const long g0 = tile * 2 * NP + par;
+        return g0 >= src.plen && g0 - src.plen + 2L * np <= src.in_len;
     };
-    auto commit = [&]() {
+    auto fetch = [&](long tile) {                       // (see k_fir for the two asm barriers)
+        if (!interior(tile)) return;
+        const cf* gp = reinterpret_cast<const cf*>(src.in + (tile * 2 * NP + par - src.plen));
+        unsigned tt = t;
+        asm volatile("" : "+v"(tt));
+        int cnt = cnt_k;
+        asm volatile("" : "+s"(cnt));
 #pragma unroll
         for (int c = 0; c < HIL_PRE; c++) {
-            const int i = t + c * NT;
-            if (c < cnt && i < total) {
-                const int e = i & 1;
-                int n = i >> 1;
-                if (e == par) { if (n < per_phase) ldsA[(n % 8) * rstride + n / 8] = pre[c]; }
-                else { n -= par; if (n >= 0 && n < per_phase) ldsB[(n % 8) * rstride + n / 8] = pre[c]; }
+            if (c < cnt - 1) {
+                pre[c] = (gp + c * NT)[tt];
+            } else if (c == cnt - 1) {
+                const unsigned i = tt + c * NT;
+                pre[c] = gp[i < (unsigned)np ? i : (unsigned)np - 1];
             }
         }
     };
-    // sample xp[tile base + idx] from the staged phases
-    auto tile_sample = [&](int idx) -> float {
-        const int e = idx & 1;
-        int n = idx >> 1;
-        if (e == par) return ldsA[(n % 8) * rstride + n / 8];
-        n -= par;
-        return ldsB[(n % 8) * rstride + n / 8];
+    auto commit = [&]() {
+        unsigned tt = t;
+        asm volatile("" : "+v"(tt));
+        int cnt = cnt_k;
+        asm volatile("" : "+s"(cnt));
+        cf* slot = lds + (tt % R) * rstride + tt / R;   // R divides NT: round c lands NT/R columns further
+#pragma unroll
+        for (int c = 0; c < HIL_PRE; c++) {
+            if (c < cnt - 1) slot[c * (NT / R)] = pre[c];
+            else if (c == cnt - 1 && tt + c * NT < (unsigned)np) slot[c * (NT / R)] = pre[c];
+        }
+    };
+    auto stage_direct = [&](long tile) {                // tiles touching the carried history / window end
+        const long g0 = tile * 2 * NP + par;
+        for (int i = t; i < np; i += NT)
+            lds[(i % R) * rstride + i / R] = mkcf(src.load(g0 + 2L * i), src.load(g0 + 2L * i + 1));
     };
 
     long tile = blockIdx.x;
     if (tile < ntiles) fetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
-        const long m0 = tile * NOUT;
+        const long m0 = tile * 2 * NP;
         __syncthreads();
-        commit();
+        if (interior(tile)) commit(); else stage_direct(tile);
         __syncthreads();
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
 
-        float accE[8], accO[8], wA[8], wB[8];
-        const float* lA = ldsA + t;
-        const float* lB = ldsB + t;
+        cf acc[R], w[R];
+        const cf* lp = lds + t;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { accE[j] = 0.0f; accO[j] = 0.0f; wA[j] = lA[j * rstride]; wB[j] = lB[j * rstride]; }
+        for (int j = 0; j < R; j++) { acc[j] = mkcf(0.0f, 0.0f); w[j] = lp[j * rstride]; }
+#pragma unroll 1
         for (int q0 = 0; q0 < Q; q0 += 8) {
-            const float* qA = lA + q0 / 8 + 1;
-            const float* qB = lB + q0 / 8 + 1;
+            const cf* lq = lp + q0 / R + 1;
+            float tap8[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) tap8[kk] = hq[q0 + kk];
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) {
-                const float tap = hq[q0 + kk];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    accE[j] = fmaf(tap, wA[(kk + j) % 8], accE[j]);
-                    accO[j] = fmaf(tap, wB[(kk + j) % 8], accO[j]);
-                }
-                wA[kk] = qA[kk * rstride];
-                wB[kk] = qB[kk * rstride];
+                for (int j = 0; j < R; j++) mac(acc[j], tap8[kk], w[(kk + j) % R]);
+                w[kk] = lq[kk * rstride];
             }
         }
-        cf res[16];
+        cf res[2 * R];
+        const int h0 = (L / 2 - par - 1) / 2;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = 16 * t + 2 * j;
-            res[2 * j] = mkcf(tile_sample(k + L / 2), accE[j]);
-            res[2 * j + 1] = mkcf(tile_sample(k + 1 + L / 2), accO[j]);
+        for (int j = 0; j < R; j++) {
+            const int n0 = t * R + j + h0, n1 = n0 + 1;
+            res[2 * j] = mkcf(lds[(n0 % R) * rstride + n0 / R].y, acc[j].x);
+            res[2 * j + 1] = mkcf(lds[(n1 % R) * rstride + n1 / R].x, acc[j].y);
         }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 16; c++) lds_o[t * 17 + c] = res[c];
+        for (int c = 0; c < 2 * R; c++) lds_o[t * (2 * R + 1) + c] = res[c];
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
+        for (int c = 0; c < 2 * R; c++) {
             const int i = c * NT + t;
-            if (m0 + i < n_out) out[m0 + i] = lds_o[(i / 16) * 17 + i % 16];
+            if (m0 + i < n_out) out[m0 + i] = lds_o[(i / (2 * R)) * (2 * R + 1) + i % (2 * R)];
         }
     }
 }
@@ -448,21 +456,20 @@ __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict_
 // not covered (caller falls back to the generic FIR kernel).
 bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src, cf* out, long n_out, hipStream_t s) {
     if (n_out <= 0) return true;
-    constexpr int NT = 256;
-    const int per_phase = NT * 8 + Q + 8;
-    const int total = 2 * per_phase + 2;
-    if ((total + NT - 1) / NT > HIL_PRE || L / 2 + 2 > 2 * (Q + 8)) return false;
-    int rs = per_phase / 8 + 1;
-    while (rs % 32 != 4) rs++;
-    const size_t in_b = (size_t)2 * 8 * rs * sizeof(float), out_b = (size_t)NT * 17 * sizeof(cf);
+    constexpr int NT = 256, R = 8;
+    const int np = NT * R + Q + 8;                      // pairs a tile may touch (taps, window refill, Re parts)
+    if ((np + NT - 1) / NT > HIL_PRE || (L / 2 - par + 1) / 2 + 1 > Q + 8 || par != (L / 2 + 1) % 2) return false;
+    int rs = np / R + 1;
+    while (rs % 4 != 2) rs++;
+    const size_t in_b = (size_t)R * rs * sizeof(cf), out_b = (size_t)NT * (2 * R + 1) * sizeof(cf);
     const size_t smem = in_b > out_b ? in_b : out_b;
-    const long ntiles = (n_out + (long)NT * 16 - 1) / ((long)NT * 16);
+    const long ntiles = (n_out + (long)NT * 2 * R - 1) / ((long)NT * 2 * R);
     long per_cu = (long)(160 * 1024) / (long)smem;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     const long cap = (long)device_cu_count() * per_cu;
     const long grid = ntiles < cap ? ntiles : cap;
-    hipLaunchKernelGGL((k_hilbert<NT>), dim3((unsigned)grid), dim3(NT), smem, s, src, out, n_out, L, par, Q, rs, hq);
+    hipLaunchKernelGGL((k_hilbert<NT>), dim3((unsigned)grid), dim3(NT), smem, s, src, out, n_out, L, par, Q, np, rs, hq);
     RR_HIP(hipGetLastError());
     return true;
 }

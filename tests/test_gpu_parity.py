@@ -178,6 +178,27 @@ def test_hilbert(rr, L, w):
     both(rr, lambda m: [m.Hilbert(L, w)], x, stream_bytes=4 * 7777)
 
 
+@pytest.mark.parametrize("L", [63, 65, 31, 5])
+@pytest.mark.parametrize("off", [0, 1, 2, 3])
+def test_hilbert_device_windows_any_alignment(rr, L, off):
+    """The Hilbert kernel reads PAIRS of input floats with 8-byte loads at any 4-byte alignment: device
+    windows starting at every float offset, for both tap parities (L/2 even and odd), full-size tiles."""
+    import torch
+    n = 300_000
+    x = rnd_f(n + 8, L + off)
+    yo = run_chain([orc.Hilbert(L, 0)], x[off:off + n], stream_bytes=4 * n)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.zeros(2 * n + 64, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    b = rr.Hilbert(L, 0)
+    st, c, p, need = b.work_dev(dx.data_ptr() + 4 * off, n, dy.data_ptr(), n)
+    b.sync()
+    assert p == len(yo) and p > 0
+    yg = dy.cpu().numpy().view(np.complex64)[:p]
+    assert np.array_equal(yg.real, yo.real)          # the real part is a copy: bit-exact
+    assert max_norm_err(yg, yo) <= TOL
+
+
 def test_hilbert_rejects_even(rr):
     for n in (0, 1, 2, 64):
         with pytest.raises(ValueError):
