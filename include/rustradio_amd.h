@@ -94,6 +94,9 @@ rr_block *rr_fftfilter_float_create(const float *taps, size_t ntaps);
 rr_block *rr_resampler_create(size_t interp, size_t deci, size_t elem_size);
 /* QuadratureDemod::new(src, gain) (src/quadrature_demod.rs:32-43). */
 rr_block *rr_quaddemod_create(float gain, int atan2_mode);
+/* RtlSdrDecode::new(src) (src/rtlsdr_decode.rs:9-47): u8 I/Q byte pairs -> Complex,
+ * (b - 127) * 0.008; input windows are counted in BYTES, an odd trailing byte is left unconsumed. */
+rr_block *rr_rtlsdr_decode_create(void);
 /* Hilbert::new(src, ntaps, &window_type) (src/hilbert.rs:38-61); ntaps odd > 1. */
 rr_block *rr_hilbert_create(size_t ntaps, int window, float window_parm);
 

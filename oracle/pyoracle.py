@@ -56,6 +56,7 @@ def lib():
     L.orc_resampler_new.argtypes = [sz, sz, sz]; L.orc_resampler_new.restype = vp
     L.orc_quaddemod_new.argtypes = [f32, i32]; L.orc_quaddemod_new.restype = vp
     L.orc_hilbert_new.argtypes = [sz, i32, f32]; L.orc_hilbert_new.restype = vp
+    L.orc_rtlsdr_decode_new.argtypes = []; L.orc_rtlsdr_decode_new.restype = vp
     L.orc_block_free.argtypes = [vp]; L.orc_block_free.restype = None
     L.orc_block_work.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.orc_block_work.restype = i32
@@ -212,6 +213,10 @@ def RationalResampler(interp: int, deci: int, dtype=np.complex64) -> OracleBlock
 
 def QuadratureDemod(gain: float = 1.0, mode: int = ATAN2_EXACT) -> OracleBlock:
     return OracleBlock(lib().orc_quaddemod_new(gain, mode), np.complex64, np.float32, "QuadratureDemod")
+
+
+def RtlSdrDecode() -> OracleBlock:
+    return OracleBlock(lib().orc_rtlsdr_decode_new(), np.uint8, np.complex64, "RtlSdrDecode")
 
 
 def Hilbert(ntaps: int, wtype: int = WIN_HAMMING, parm: float = 0.0) -> OracleBlock:

@@ -284,7 +284,7 @@ float orc_fast_atan2(float y, float x) {
 }
 
 /* ---- streaming blocks ----------------------------------------------------------- */
-enum { K_FIR_C32, K_FIR_F32, K_FFTFILT, K_FFTFILT_F, K_RESAMP, K_QUAD, K_HILBERT };
+enum { K_FIR_C32, K_FIR_F32, K_FFTFILT, K_FFTFILT_F, K_RESAMP, K_QUAD, K_HILBERT, K_RTLSDR };
 
 struct orc_block {
     int kind;
@@ -438,6 +438,12 @@ orc_block *orc_quaddemod_new(float gain, int atan2_mode) {
     orc_block *b = (orc_block *)calloc(1, sizeof *b);
     b->kind = K_QUAD; b->in_es = sizeof(orc_c32); b->out_es = sizeof(float);
     b->gain = gain; b->atan2_mode = atan2_mode;
+    return b;
+}
+
+orc_block *orc_rtlsdr_decode_new(void) { /* rtlsdr_decode.rs:9-16 */
+    orc_block *b = (orc_block *)calloc(1, sizeof *b);
+    b->kind = K_RTLSDR; b->in_es = 1; b->out_es = sizeof(orc_c32);
     return b;
 }
 
@@ -626,6 +632,27 @@ static int work_quad(orc_block *b, const orc_c32 *in, size_t in_len, float *out,
     }
 }
 
+/* RtlSdrDecode::work, rtlsdr_decode.rs:18-47: a loop, so one call converts what fits and then
+ * reports the side that ran dry. */
+static int work_rtlsdr(const unsigned char *in, size_t in_len, orc_c32 *out, size_t out_cap,
+                       size_t *consumed, size_t *produced, size_t *need) {
+    size_t ipos = 0, opos = 0;
+    for (;;) {
+        size_t isamples = (in_len - ipos) & ~(size_t)1;                         /* :23 */
+        if (isamples == 0) { *consumed = ipos; *produced = opos; *need = 2; return ORC_WAIT_SRC; } /* :24-26 */
+        size_t olen = out_cap - opos;
+        if (olen == 0) { *consumed = ipos; *produced = opos; *need = 1; return ORC_WAIT_DST; }     /* :28-30 */
+        if (isamples > olen * 2) isamples = olen * 2;                          /* :31 */
+        size_t osamples = isamples / 2;
+        for (size_t i = 0; i < osamples; i++) {                                /* :35-42 */
+            float a = (float)in[ipos + 2 * i], b2 = (float)in[ipos + 2 * i + 1];
+            out[opos + i].re = (a - 127.0f) * 0.008f;
+            out[opos + i].im = (b2 - 127.0f) * 0.008f;
+        }
+        ipos += isamples; opos += osamples;                                    /* :43-44 */
+    }
+}
+
 /* Hilbert::work, hilbert.rs:72-128 */
 static int work_hilbert(orc_block *b, const float *in, size_t in_len, orc_c32 *out, size_t out_cap,
                         size_t *consumed, size_t *produced, size_t *need) {
@@ -659,6 +686,7 @@ int orc_block_work(orc_block *b, const void *in, size_t in_len, void *out, size_
     case K_RESAMP: return work_resampler(b, (const unsigned char *)in, in_len, (unsigned char *)out, out_cap, consumed, produced, need);
     case K_QUAD: return work_quad(b, (const orc_c32 *)in, in_len, (float *)out, out_cap, consumed, produced, need);
     case K_HILBERT: return work_hilbert(b, (const float *)in, in_len, (orc_c32 *)out, out_cap, consumed, produced, need);
+    case K_RTLSDR: return work_rtlsdr((const unsigned char *)in, in_len, (orc_c32 *)out, out_cap, consumed, produced, need);
     }
     set_err("bad block kind");
     return ORC_ERR;

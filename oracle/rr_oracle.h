@@ -85,6 +85,8 @@ orc_block *orc_fftfilter_float_new(const float *taps, size_t ntaps);
 orc_block *orc_resampler_new(size_t interp, size_t deci, size_t elem_size);
 /* QuadratureDemod (quadrature_demod.rs:32-114). */
 orc_block *orc_quaddemod_new(float gain, int atan2_mode);
+/* RtlSdrDecode (rtlsdr_decode.rs:9-47): u8 I/Q pairs -> Complex, (b - 127) * 0.008. */
+orc_block *orc_rtlsdr_decode_new(void);
 /* Hilbert (hilbert.rs:22-129). */
 orc_block *orc_hilbert_new(size_t ntaps, int wtype, float parm);
 

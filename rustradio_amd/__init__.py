@@ -11,6 +11,7 @@ what the reference would pass to `consume()`/`produce()`.
     FftFilterFloat       src/fft_filter.rs:365-491
     RationalResampler    src/rational_resampler.rs:100-213
     QuadratureDemod      src/quadrature_demod.rs:32-114
+    RtlSdrDecode         src/rtlsdr_decode.rs:9-47
     Hilbert              src/hilbert.rs:22-129
     low_pass / low_pass_complex / hilbert_taps / make_window   src/fir.rs:594-680, src/window.rs
 
@@ -192,6 +193,11 @@ def fftfilter_dims(block: Block):
 def RationalResampler(interp: int, deci: int, dtype=np.complex64) -> Block:
     dt = np.dtype(dtype)
     return Block(lib().rr_resampler_create(interp, deci, dt.itemsize), dt, dt)
+
+
+def RtlSdrDecode() -> Block:
+    """RtlSdrDecode::new(src) (src/rtlsdr_decode.rs:9-47): u8 I/Q pairs -> Complex."""
+    return Block(lib().rr_rtlsdr_decode_create(), np.uint8, np.complex64)
 
 
 def QuadratureDemod(gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:

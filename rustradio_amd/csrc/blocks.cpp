@@ -596,6 +596,25 @@ int QuadDemod::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     *need = 1; return RR_WAIT_DST;
 }
 
+// ---- RtlSdrDecode (rtlsdr_decode.rs:9-47) ----------------------------------------------------------------------
+RtlSdrDecode::RtlSdrDecode() : Block("RtlSdrDecode", 1, 8) {}
+int RtlSdrDecode::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                           size_t* produced, size_t* need, hipStream_t s) {
+    *consumed = *produced = *need = 0;
+    size_t isamples = in_len & ~(size_t)1;                                     // :23
+    if (isamples == 0) { *need = 2; return RR_WAIT_SRC; }                      // :24-26
+    if (out_cap == 0) { *need = 1; return RR_WAIT_DST; }                       // :28-30
+    isamples = std::min(isamples, out_cap * 2);                                // :31
+    const size_t osamples = isamples / 2;
+    prof_begin(s);
+    launch_rtlsdr_decode(static_cast<const unsigned char*>(in), static_cast<cf*>(out), (long)osamples, s);
+    prof_end(s);
+    *consumed = isamples; *produced = osamples;                                // :43-44
+    // the reference loops: the next iteration returns the wait
+    if (((in_len - isamples) & ~(size_t)1) == 0) { *need = 2; return RR_WAIT_SRC; }
+    *need = 1; return RR_WAIT_DST;
+}
+
 // ---- Hilbert (hilbert.rs:22-129) -------------------------------------------------------------------------------
 Hilbert::Hilbert(size_t ntaps, int window, float parm) : Block("Hilbert", 4, 8) {
     if (!(ntaps > 1 && (ntaps & 1) == 1)) throw Error("hilbert filter len must be odd and greater than 1");  // :44-47

@@ -127,6 +127,12 @@ struct QuadDemod : Block {
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 
+// RtlSdrDecode (rtlsdr_decode.rs:9-47): stateless u8 pair -> Complex conversion.
+struct RtlSdrDecode : Block {
+    RtlSdrDecode();
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
 struct Hilbert : Block {
     FirPlan pl;
     DevBuf<float> d_tp, d_rev;

@@ -94,6 +94,40 @@ void launch_quaddemod(const cf* in, float* out, long n_out, float gain, int mode
     RR_HIP(hipGetLastError());
 }
 
+// ---- RtlSdrDecode (src/rtlsdr_decode.rs:35-42): u8 I/Q pairs -> Complex ---------------------
+// (Float::from(b) - 127.0) * 0.008, two roundings at most (the subtraction is exact): bit-exact.
+// 10 B of traffic per sample; a thread converts 2 samples (4-byte load, 16-byte store), both
+// lane-consecutive.
+__device__ __forceinline__ float rtl_cvt(unsigned b) { return __fmul_rn(__fsub_rn((float)b, 127.0f), 0.008f); }
+__global__ __launch_bounds__(256) void k_rtlsdr_decode2(const unsigned* __restrict__ in, float4* __restrict__ out,
+                                                        long npairs) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (long)gridDim.x * blockDim.x) {
+        const unsigned w = in[i];
+        out[i] = make_float4(rtl_cvt(w & 0xffu), rtl_cvt((w >> 8) & 0xffu), rtl_cvt((w >> 16) & 0xffu), rtl_cvt(w >> 24));
+    }
+}
+__global__ __launch_bounds__(256) void k_rtlsdr_decode1(const unsigned char* __restrict__ in, cf* __restrict__ out,
+                                                        long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = mkcf(rtl_cvt(in[2 * i]), rtl_cvt(in[2 * i + 1]));
+}
+void launch_rtlsdr_decode(const unsigned char* in, cf* out, long n_out, hipStream_t s) {
+    if (n_out <= 0) return;
+    const bool aligned = ((uintptr_t)in & 3) == 0 && ((uintptr_t)out & 15) == 0;
+    const long npairs = aligned ? n_out / 2 : 0;
+    if (npairs > 0) {
+        hipLaunchKernelGGL(k_rtlsdr_decode2, dim3(grid_for(npairs, 256)), dim3(256), 0, s,
+                           reinterpret_cast<const unsigned*>(in), reinterpret_cast<float4*>(out), npairs);
+        RR_HIP(hipGetLastError());
+    }
+    const long done = 2 * npairs;                        // unaligned windows and the odd last sample
+    if (done < n_out) {
+        hipLaunchKernelGGL(k_rtlsdr_decode1, dim3(grid_for(n_out - done, 256)), dim3(256), 0, s, in + 2 * done,
+                           out + done, n_out - done);
+        RR_HIP(hipGetLastError());
+    }
+}
+
 // ---- carry-state copies -----------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void k_vcopy(VSrc<T> src, long v0, T* __restrict__ dst, long n) {

@@ -458,6 +458,30 @@ public:
     }
 };
 
+// ---- RtlSdrDecode (src/rtlsdr_decode.rs) ----------------------------------------------------------------------------------
+class RtlSdrDecode : public Block {
+    detail::Handle h_;
+    ReadStream<uint8_t> src_;
+    WriteStream<Complex> dst_;
+public:
+    RtlSdrDecode(rr_block* h, ReadStream<uint8_t> src, WriteStream<Complex> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)) {}
+    static std::pair<std::unique_ptr<RtlSdrDecode>, ReadStream<Complex>> new_(ReadStream<uint8_t> src) {   // #[rustradio(new)], :9-16
+        auto [w, r] = new_stream<Complex>();
+        return {std::make_unique<RtlSdrDecode>(rr_rtlsdr_decode_create(), std::move(src), std::move(w)), std::move(r)};
+    }
+    const char* block_name() const override { return rr_block_name(h_.h); }
+    bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
+    BlockRet work() override {                    // :18-47 — tags dropped (":21 TODO: handle tags")
+        auto [input, tags] = src_.read_buf();
+        (void)tags;
+        auto out = dst_.write_buf();
+        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        input.consume(w.consumed);
+        out.produce(w.produced, {});
+        return w.st == RR_WAIT_DST ? BlockRet::wait(dst_.wait_handle(), w.need) : BlockRet::wait(src_.wait_handle(), w.need);
+    }
+};
+
 // ---- Hilbert (src/hilbert.rs) ----------------------------------------------------------------------------------------------
 class Hilbert : public Block {
     detail::Handle h_;

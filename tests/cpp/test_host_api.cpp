@@ -150,6 +150,35 @@ static void quad_known() {              // src/quadrature_demod.rs:210-264
     }
 }
 
+static void rtlsdr_decode_tests() {     // src/rtlsdr_decode.rs:54-100
+    {   // empty
+        auto [b, prev] = VectorSource<uint8_t>::new_(std::vector<uint8_t>{});
+        CHECK(b->work().kind == BlockRet::EOF_);
+        auto [d, out] = RtlSdrDecode::new_(std::move(prev));
+        CHECK(d->work().kind == BlockRet::WaitForStream);
+        auto [o, tags] = out.read_buf();
+        CHECK(o.len() == 0);
+    }
+    {   // some_input: the reference asserts exact equality with these literals
+        auto [b, prev] = VectorSource<uint8_t>::new_({0, 10, 20, 10, 0, 13});
+        b->work();
+        auto [d, out] = RtlSdrDecode::new_(std::move(prev));
+        CHECK(d->work().kind == BlockRet::WaitForStream);
+        auto [o, tags] = out.read_buf();
+        const Complex want[3] = {{-1.016f, -0.93600005f}, {-0.85600007f, -0.93600005f}, {-1.016f, -0.91200006f}};
+        CHECK(o.len() == 3);
+        for (size_t i = 0; i < 3 && i < o.len(); i++) CHECK(o.slice()[i] == want[i]);
+    }
+    {   // uneven
+        auto [b, prev] = VectorSource<uint8_t>::new_({0, 10, 20, 10, 0});
+        b->work();
+        auto [d, out] = RtlSdrDecode::new_(std::move(prev));
+        d->work();
+        auto [o, tags] = out.read_buf();
+        CHECK(o.len() == 2);
+    }
+}
+
 static void hilbert_rejects_even() {    // src/hilbert.rs:44-47
     bool threw = false;
     try { auto [s, so] = VectorSource<Float>::new_({1.f, 2.f}); Hilbert::new_(std::move(so), 64, WindowType::Hamming()); }
@@ -184,7 +213,7 @@ static void graph_fm_chain() {
 
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
-    fft_tag_propagation(); resampler_examples(); quad_known(); hilbert_rejects_even(); graph_fm_chain();
+    fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }

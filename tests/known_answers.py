@@ -271,6 +271,30 @@ def check_quad_fill_out(impl):
         ring = np.concatenate([ring, signal_source_complex_fast(g["samp_rate"], g["freq"], g["amplitude"], cap_in - len(ring))])
 
 
+# ---- RtlSdrDecode (src/rtlsdr_decode.rs tests) -------------------------------------------
+def check_rtlsdr_decode(impl):
+    b = impl.RtlSdrDecode()                                      # empty (:54-64)
+    st, c, p, need, out = b.work(np.zeros(0, np.uint8), 100)
+    assert is_wait(st) and p == 0
+    g = G["rtlsdr_some_input"]                                   # some_input: exact f32 equality
+    st, c, p, need, out = impl.RtlSdrDecode().work(np.asarray(g["input"], np.uint8), 100)
+    assert st == WAIT_SRC and need == 2 and c == 6
+    exp = np.asarray([complex(*e) for e in g["expect"]], np.complex64)
+    assert np.array_equal(out, exp), (out, exp)
+    g = G["rtlsdr_uneven"]                                       # uneven: the odd byte stays
+    st, c, p, need, out = impl.RtlSdrDecode().work(np.asarray(g["input"], np.uint8), 100)
+    assert st == WAIT_SRC and p == g["expect_len"] and c == 2 * g["expect_len"]
+    g = G["rtlsdr_overflow"]                                     # overflow: 4x expansion, 4 rounds
+    b = impl.RtlSdrDecode()
+    ring = np.zeros(g["input_bytes"], np.uint8)
+    for _ in range(g["rounds"]):
+        st, c, p, need, out = b.work(ring, DEFAULT_STREAM_SIZE // 8)
+        assert is_wait(st) and p == g["expect_len_each"] and c == 2 * p
+        ring = ring[c:]
+    st, c, p, need, out = b.work(ring, DEFAULT_STREAM_SIZE // 8)
+    assert len(ring) == 0 and st == WAIT_SRC and p == 0
+
+
 ALL_CHECKS = [
     check_fir_test_complex, check_fir_test_identity, check_fir_test_invert, check_fir_moving_avg,
     check_fir_translate_matches_mixed_input, check_fir_translated_tone,
@@ -279,4 +303,5 @@ ALL_CHECKS = [
     check_resampler_deci, check_resampler_examples, check_resampler_full_output_buffer,
     check_resampler_chained, check_resampler_rates, check_resampler_rejects_zero,
     check_quad_known, check_quad_fill_out,
+    check_rtlsdr_decode,
 ]

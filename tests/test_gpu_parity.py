@@ -199,6 +199,30 @@ def test_hilbert_device_windows_any_alignment(rr, L, off):
     assert max_norm_err(yg, yo) <= TOL
 
 
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 4096, 1_000_001, 3_999_999])
+def test_rtlsdr_decode_bit_exact(rr, n):
+    x = np.random.default_rng(n).integers(0, 256, n, dtype=np.uint8)
+    both(rr, lambda m: [m.RtlSdrDecode()], x, exact=True)
+    both(rr, lambda m: [m.RtlSdrDecode()], x, stream_bytes=8 * 4099, exact=True)
+
+
+@pytest.mark.parametrize("off", [0, 1, 2, 3, 5])
+def test_rtlsdr_decode_device_windows_any_alignment(rr, off):
+    import torch
+    n = 2_000_003
+    x = np.random.default_rng(off).integers(0, 256, n + 8, dtype=np.uint8)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.zeros(n + 16, dtype=torch.float32, device="cuda")        # n/2 Complex
+    b = rr.RtlSdrDecode()
+    for oo in (0, 8):                                                   # 16- and 8-byte aligned outputs
+        st, c, p, need = b.work_dev(dx.data_ptr() + off, n, dy.data_ptr() + oo, n // 2)
+        b.sync()
+        assert (st, c, p, need) == (WAIT_SRC, n - 1, n // 2, 2)
+        yg = dy.cpu().numpy()[oo // 4: oo // 4 + 2 * p]
+        yo = ((x[off:off + n - 1].astype(np.float32) - np.float32(127.0)) * np.float32(0.008))
+        assert np.array_equal(yg, yo)
+
+
 def test_hilbert_rejects_even(rr):
     for n in (0, 1, 2, 64):
         with pytest.raises(ValueError):
