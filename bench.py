@@ -13,6 +13,7 @@ Other workloads (--workload, also summarised under "others" in the JSON line):
     fm_chain     configs[2]: FftFilter(463) -> RationalResampler(1:6) -> QuadratureDemod, 2.4 Msps x 10 s
     fm_multi     configs[3]: 32 such channels per GPU on one shared IQ source (256 channels on 8 GPUs)
     channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in)
+    rtl_fm_chain configs[2] fed by the RTL-SDR byte stream: RtlSdrDecode fused in front (u8 in)
 
 Multi-GPU (one process per GPU, weak scaling): the path shards by channel — every rank
 filters its own channel of a shared IQ source (channel c uses the low-pass taps shifted to
@@ -101,15 +102,17 @@ class Workload:
     alg_bytes_per_sample = 0.0     # SURVEY §8d compulsory traffic per INPUT sample of the chain
     dominant = 0                   # index of the block whose kernel the roofline object describes
     dominant_bytes_per_unit = 0.0  # algorithmic bytes of that kernel per sample it consumes
+    in_mult = 1                    # stream elements of the first block per input sample (2 for u8 I/Q bytes)
 
     def step(self, stream):
         """one pass over the resident batch; returns input samples consumed by the first block"""
-        n_in = self.n
+        n_in = self.n * self.in_mult
         for i, b in enumerate(self.blocks):
             es_out = b.out_dtype.itemsize
             cap = self.caps[i]
             st, c, p, need = b.work_dev(self.bufs[i].data_ptr(), n_in, self.bufs[i + 1].data_ptr(), cap, stream)
             if i == 0:
+                c //= self.in_mult
                 consumed0 = c
             if i == self.dominant:
                 self.dom_units += c
@@ -192,6 +195,27 @@ def make_fm_chain(dev, rank, world, shared_src, fused=True):
     return w
 
 
+def make_rtl_fm_chain(dev, rank, world, shared_src):
+    """configs[2] from the RTL-SDR wire format (examples/rtl_fm.rs:328-419): u8 I/Q pairs in, f32 out."""
+    w = Workload()
+    w.name = ("RtlSdrDecode->FftFilter(463 taps)->RationalResampler(1:6)->QuadratureDemod(exact atan2) fused into one "
+              "kernel (rr.FmChainU8), 2.4 Msps x 10 s = 24,000,000 samples/step, u8 I/Q input")
+    fs, n = 2.4e6, 24_000_000
+    taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
+    f32 = shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0003))
+    src = torch.clamp(torch.round(f32 / 0.008 + 127.0), 0, 255).to(torch.uint8)      # what the dongle delivers
+    w.blocks = [rr.FmChainU8(taps, 1, 6, 1.0, rr.ATAN2_EXACT)]
+    w.bufs = [src, torch.empty(n // 6 + 1024, dtype=torch.float32, device=dev)]
+    w.caps = [n // 6 + 1024]
+    w.in_mult = 2
+    w.dtype = "u8->f32"
+    w.n = n
+    w.alg_bytes_per_sample = w.dominant_bytes_per_unit = 2.0 + 4.0 / 6.0
+    w.dominant = 0
+    w.cpu = ("rtl_fm_chain", taps)
+    return w
+
+
 def make_fm_chain_unfused(dev, rank, world, shared_src):
     return make_fm_chain(dev, rank, world, shared_src, fused=False)
 
@@ -248,7 +272,8 @@ def make_channelizer(dev, rank, world, shared_src):
 
 
 WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
-             "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "channelizer": make_channelizer}
+             "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "channelizer": make_channelizer,
+             "rtl_fm_chain": make_rtl_fm_chain}
 
 
 # ---- measurement ------------------------------------------------------------------------------
@@ -290,6 +315,10 @@ def cpu_baseline(w, seconds=10.0):
         host = w.bufs[0][:win * 2 * nwin].cpu().numpy()
         chain = [orc.Hilbert(65), orc.FirFilter(taps, deci=8)]
         win = 1_024_000
+    elif kind == "rtl_fm_chain":
+        win = 4_096_000                                       # a full u8 ring (src/stream.rs:105)
+        host = w.bufs[0][:win * 4].cpu().numpy()
+        chain = [orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(1, 6), orc.QuadratureDemod(1.0)]
     else:
         host = w.bufs[0][:2 * win * nwin].cpu().numpy().view(np.complex64)
         chain = {"FftFilter": lambda: [orc.FftFilter(taps)],
@@ -304,14 +333,14 @@ def cpu_baseline(w, seconds=10.0):
         chunk = host[(i % nwin) * win:(i % nwin + 1) * win]
         i += 1
         rings[0] = np.concatenate([rings[0], chunk])
-        fed += len(chunk)
+        fed += len(chunk) // w.in_mult
         for j, b in enumerate(chain):
             while True:
                 st, c, p, need, out = b.work(rings[j], 4_096_000 // b.out_dtype.itemsize)
                 rings[j] = rings[j][c:]
                 if j + 1 < len(chain):
                     rings[j + 1] = np.concatenate([rings[j + 1], out])
-                if st != 0 or (c == 0 and p == 0):
+                if st == 1 or (c == 0 and p == 0):      # WAIT_SRC, or no progress (the output is drained every call)
                     break
     dt = time.perf_counter() - t0
     return {"value": round(fed / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
@@ -402,7 +431,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused") else "k_fm_chain" if args.workload == "fm_chain" else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer" else "k_fir<hilbert>"),
+                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer" else "k_fir<hilbert>"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),

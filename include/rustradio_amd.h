@@ -110,6 +110,13 @@ rr_block *rr_hilbert_create(size_t ntaps, int window, float window_parm);
 rr_block *rr_fm_chain_create(const rr_c32 *taps, size_t ntaps, size_t interp, size_t deci,
                              float gain, int atan2_mode);
 
+/* The same with RtlSdrDecode::new(src) (src/rtlsdr_decode.rs:9-47) fused in front, the receive chain of
+ * examples/rtl_fm.rs:328-419 from the RTL-SDR byte stream onwards: u8 in, f32 out, 2 B instead of 8 B
+ * read per sample.  Input windows, `consumed` and the WAIT_SRC `need` count BYTES; an odd trailing
+ * byte stays unconsumed (rtlsdr_decode.rs:23).  Whole-stream output == RtlSdrDecode -> rr_fm_chain. */
+rr_block *rr_fm_chain_u8_create(const rr_c32 *taps, size_t ntaps, size_t interp, size_t deci,
+                                float gain, int atan2_mode);
+
 /* `nchan` fused FM chains (rr_fm_chain_create) fed by ONE input stream — the reference's Tee fan-out
  * (src/tee.rs:10-24) plus nchan x {FftFilter, RationalResampler, QuadratureDemod}.  taps =
  * [nchan][ntaps] (each channel its own, e.g. the prototype shifted to the channel centre); every

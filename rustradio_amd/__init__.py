@@ -211,6 +211,13 @@ def FmChain(taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_E
     return Block(lib().rr_fm_chain_create(_ptr(t), len(t), interp, deci, gain, mode), np.complex64, np.float32)
 
 
+def FmChainU8(taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
+    """RtlSdrDecode -> FmChain fused (examples/rtl_fm.rs:328-419): RTL-SDR bytes in, f32 out; windows,
+    consumed and the WAIT_SRC need count bytes."""
+    t = np.ascontiguousarray(taps, np.complex64)
+    return Block(lib().rr_fm_chain_u8_create(_ptr(t), len(t), interp, deci, gain, mode), np.uint8, np.float32)
+
+
 def FmMulti(taps_per_channel, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
     """N fused FM chains on one shared input (Tee + N x FmChain); taps_per_channel = [N][ntaps].
     work() returns out with shape (N, produced); work_dev() takes N windows of out_cap elements."""

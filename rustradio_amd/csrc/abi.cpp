@@ -91,6 +91,10 @@ rr_block* rr_fftfilter_float_create(const float* taps, size_t ntaps) {
 rr_block* rr_resampler_create(size_t interp, size_t deci, size_t elem_size) {
     return make_block([&] { return new rr::Resampler(interp, deci, elem_size); });
 }
+rr_block* rr_fm_chain_u8_create(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain,
+                                int atan2_mode) {
+    return make_block([&] { return new rr::FmChain(taps, ntaps, interp, deci, gain, atan2_mode, true); });
+}
 rr_block* rr_rtlsdr_decode_create(void) {
     return make_block([&] { return new rr::RtlSdrDecode(); });
 }

@@ -331,8 +331,9 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
 
 // ---- fused FM chain ------------------------------------------------------------------------------------
 static int64_t gcd64(int64_t a, int64_t b);
-FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float g, int m)
-    : Block("FftFilter>RationalResampler>QuadratureDemod", 8, 4), gain(g), mode(m) {
+FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float g, int m, bool u8)
+    : Block(u8 ? "RtlSdrDecode>FftFilter>RationalResampler>QuadratureDemod" : "FftFilter>RationalResampler>QuadratureDemod",
+            u8 ? 1 : 8, 4), gain(g), mode(m), iq8(u8) {
     if (deci == 0) throw Error("RationalResampler created using deci 0");
     if (interp == 0) throw Error("RationalResampler created using interp 0");
     if (m != RR_ATAN2_EXACT && m != RR_ATAN2_FAST) throw Error("QuadratureDemod: bad atan2 mode");
@@ -349,6 +350,14 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
 int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                       size_t* produced, size_t* need, hipStream_t s) {
     *consumed = *produced = *need = 0;
+    if (iq8) in_len /= 2;                          // whole I/Q pairs; an odd trailing byte is never consumed (:23)
+    bool packed = iq8;
+    if (iq8 && ((uintptr_t)in & 1)) {              // odd-addressed byte window: decode out of line
+        decoded.reserve(std::max<size_t>(in_len, 1));
+        launch_rtlsdr_decode(static_cast<const unsigned char*>(in), decoded.p, (long)in_len, s);
+        in = decoded.p;
+        packed = false;
+    }
     const uint64_t S = f->nsamples;
     auto N2 = [&](uint64_t y) { return (uint64_t)(((__int128)y * I + D - 1) / D); };
     auto N3 = [&](uint64_t y) { const uint64_t r = N2(y); return r ? r - 1 : 0; };
@@ -372,24 +381,35 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         st = RR_WAIT_SRC; *need = S - new_pend;
     }
     const uint64_t n_y = k * S;
-    VSrc<cf> src{f->prefix[f->cur].p, (long)(f->L - 1 + f->pend_len), static_cast<const cf*>(in), (long)in_len};
+    const long plen = (long)(f->L - 1 + f->pend_len);
+    VSrc<cf> src{f->prefix[f->cur].p, plen, static_cast<const cf*>(in), (long)in_len};
+    VSrcIQ8 src8{f->prefix[f->cur].p, plen, static_cast<const rr::iq8*>(in), (long)in_len};
     if (k) {
         FmChainArgs a;
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = gain; a.mode = mode;
         prof_begin(s);
-        launch_fm_chain(f->log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a,
-                        last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        if (packed)
+            launch_fm_chain_iq8(f->log2f, src8, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a,
+                                last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else
+            launch_fm_chain(f->log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a,
+                            last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         prof_end(s);
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
     }
     if (*consumed) {
-        launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
+        if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
+        else launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
         f->cur ^= 1;
         f->pend_len = new_pend;
     }
     *produced = N3(n1 + n_y) - o_old;
     n1 += n_y;
+    if (iq8) {                                     // the input stream counts bytes
+        *consumed *= 2;
+        if (st == RR_WAIT_SRC) *need *= 2;
+    }
     return st;
 }
 

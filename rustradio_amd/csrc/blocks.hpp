@@ -83,7 +83,11 @@ struct FmChain : Block {
     uint64_t n1 = 0;                  // filtered samples emitted so far
     DevBuf<cf> last_r[2];
     int cur_lr = 0;
-    FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode);
+    // iq8: the input stream is RTL-SDR bytes (u8 I/Q pairs) and RtlSdrDecode (rtlsdr_decode.rs:35-42)
+    // is fused in front: windows, `consumed` and WAIT_SRC `need` are then counted in BYTES.
+    bool iq8 = false;
+    DevBuf<cf> decoded;               // only for odd-addressed byte windows (decoded out of line)
+    FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 

@@ -63,4 +63,28 @@ template <class T> struct VSrc {
 #endif
 };
 
+// The same with the window still in the RTL-SDR wire format (u8 I/Q pairs, rtlsdr_decode.rs:35-42):
+// the carried prefix is already Complex, window samples are decoded on load —
+// (Float::from(b) - 127.0) * 0.008, bit-identical to the RtlSdrDecode block.
+struct iq8 { unsigned char i, q; };
+struct VSrcIQ8 {
+    const cf* prefix;
+    long plen;
+    const iq8* in;       // 2-byte aligned
+    long in_len;         // samples (byte pairs)
+#if defined(__HIPCC__)
+    static __device__ __forceinline__ float cvt(unsigned b) { return __fmul_rn(__fsub_rn((float)b, 127.0f), 0.008f); }
+    static __device__ __forceinline__ cf decode(unsigned short w) {
+        cf r; r.x = cvt(w & 0xffu); r.y = cvt(w >> 8); return r;
+    }
+    __device__ __forceinline__ cf load(long v) const {
+        if (v < plen) return prefix[v];
+        long i = v - plen;
+        if (i < in_len) return decode(reinterpret_cast<const unsigned short*>(in)[i]);
+        cf z{};
+        return z;
+    }
+#endif
+};
+
 }  // namespace rr

@@ -30,6 +30,10 @@ struct FmChainArgs {
 void launch_fm_chain(int log2f, VSrc<cf> src, float* out, int L, const cf* tw, const cf* hpos,
                      const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 
+// ... with the RtlSdrDecode conversion fused in front (window = u8 I/Q pairs, carried prefix Complex).
+void launch_fm_chain_iq8(int log2f, VSrcIQ8 src, float* out, int L, const cf* tw, const cf* hpos,
+                         const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+
 // The same for `nchan` channels that share the input: hpos_all = [nchan][F] frequency responses,
 // channel c writes out + c*out_stride and carries last_in[c] / last_out[c].  3-pass tiles (F <= 4096).
 bool fm_multi_supported(int log2f);
@@ -70,6 +74,7 @@ void launch_quaddemod(const cf* in, float* out, long n_out, float gain, int mode
 void launch_rtlsdr_decode(const unsigned char* in, cf* out, long n_out, hipStream_t s);
 // dst[i] = src.load(v0 + i), i < n   (carry-state update)
 void launch_vcopy_c32(VSrc<cf> src, long v0, cf* dst, long n, hipStream_t s);
+void launch_vcopy_iq8(VSrcIQ8 src, long v0, cf* dst, long n, hipStream_t s);   // decoding copy
 void launch_vcopy_f32(VSrc<float> src, long v0, float* dst, long n, hipStream_t s);
 void launch_f32_to_c32(const float* in, cf* out, long n, hipStream_t s);
 void launch_c32_re(const cf* in, float* out, long n, hipStream_t s);

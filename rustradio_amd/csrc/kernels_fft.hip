@@ -242,6 +242,33 @@ template <int LOG2F> __device__ __forceinline__ void load_tile16(creg* v, const 
     }
 }
 
+// The same for a window in RTL-SDR wire format (2-byte loads, decoded in registers).
+template <int T>
+__device__ __attribute__((noinline)) void stage_tile_slow_iq8(creg* lds, VSrcIQ8 src, long v0, int t) {
+    for (int n = 0; n < 16; n++) {
+        const int p = n * T + t;
+        const long vi = v0 + p;
+        cf x = mkcf(0.0f, 0.0f);
+        if (vi >= 0) x = src.load(vi);
+        lds[lds_pad(p)] = to_reg(x);
+    }
+}
+template <int LOG2F> __device__ __forceinline__ void load_tile16(creg* v, const VSrcIQ8& src, long v0, int t, creg* lds) {
+    constexpr int T = 1 << (LOG2F - 4);
+    if (v0 >= src.plen && v0 - src.plen + 16 * T <= src.in_len) {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(src.in) + (v0 - src.plen) + t;
+        unsigned short w[16];
+#pragma unroll
+        for (int n = 0; n < 16; n++) w[n] = p[n * T];
+#pragma unroll
+        for (int n = 0; n < 16; n++) v[n] = to_reg(VSrcIQ8::decode(w[n]));
+    } else {
+        stage_tile_slow_iq8<T>(lds, src, v0, t);
+        tile_sync<T>();
+        lds_load<LOG2F, 0>(v, t, lds);
+    }
+}
+
 // ---- FftFilter -----------------------------------------------------------------------------------
 template <int LOG2F, int VAR>
 __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
@@ -343,9 +370,9 @@ struct FmArgs {
 // Tile j transforms y[A + j*Sp - G .. + S') and owns every demod output o[u-1] whose UPPER
 // sample r[u] has its source in [A + j*Sp, A + (j+1)*Sp), Sp = S' - G; the lower sample r[u-1]
 // then lies in the same tile — or is the last r of the previous call (`last_r`).
-template <int LOG2F, int VAR>
+template <int LOG2F, int VAR, class SRC>
 __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
-void k_fm_chain(VSrc<cf> src, float* __restrict__ out, int L, long ntiles, const cf* __restrict__ tw,
+void k_fm_chain(SRC src, float* __restrict__ out, int L, long ntiles, const cf* __restrict__ tw,
                 const cf* __restrict__ hpos, FmArgs a, const cf* __restrict__ last_r_in,
                 cf* __restrict__ last_r_out) {
     constexpr int F = 1 << LOG2F;
@@ -546,8 +573,8 @@ void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, cons
     }
 }
 
-template <int LOG2F, int VAR>
-static void launch_fm_one(VSrc<cf> src, float* out, int L, const cf* tw, const cf* hpos, const FmChainArgs& h,
+template <int LOG2F, int VAR, class SRC>
+static void launch_fm_one(SRC src, float* out, int L, const cf* tw, const cf* hpos, const FmChainArgs& h,
                           const cf* last_in, cf* last_out, hipStream_t s) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
@@ -561,14 +588,25 @@ static void launch_fm_one(VSrc<cf> src, float* out, int L, const cf* tw, const c
     const size_t smem = sizeof(cf) * lds_elems(F);
     static bool attr_set = false;
     static int per_cu = 0;
-    const long grid = grid_for_tiles(k_fm_chain<LOG2F, VAR>, T, smem, ntiles, attr_set, per_cu);
-    hipLaunchKernelGGL((k_fm_chain<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, L, ntiles, tw,
+    const long grid = grid_for_tiles(k_fm_chain<LOG2F, VAR, SRC>, T, smem, ntiles, attr_set, per_cu);
+    hipLaunchKernelGGL((k_fm_chain<LOG2F, VAR, SRC>), dim3((unsigned)grid), dim3(T), smem, s, src, out, L, ntiles, tw,
                        hpos, a, last_in, last_out);
     RR_HIP(hipGetLastError());
 }
 
 void launch_fm_chain(int log2f, VSrc<cf> src, float* out, int L, const cf* tw, const cf* hpos,
                      const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    switch (log2f) {
+    case 10: launch_fm_one<10, 0>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    case 11: launch_fm_one<11, 0>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    case 12: launch_fm_one<12, 0>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    case 13: launch_fm_one<13, 3>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    case 14: launch_fm_one<14, 3>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
+    default: throw Error("fm_chain: unsupported tile size");
+    }
+}
+void launch_fm_chain_iq8(int log2f, VSrcIQ8 src, float* out, int L, const cf* tw, const cf* hpos,
+                         const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
     switch (log2f) {
     case 10: launch_fm_one<10, 0>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
     case 11: launch_fm_one<11, 0>(src, out, L, tw, hpos, h, last_in, last_out, s); break;

@@ -139,6 +139,15 @@ void launch_vcopy_c32(VSrc<cf> src, long v0, cf* dst, long n, hipStream_t s) {
     hipLaunchKernelGGL(k_vcopy<cf>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, v0, dst, n);
     RR_HIP(hipGetLastError());
 }
+__global__ __launch_bounds__(256) void k_vcopy_iq8(VSrcIQ8 src, long v0, cf* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = src.load(v0 + i);
+}
+void launch_vcopy_iq8(VSrcIQ8 src, long v0, cf* dst, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_vcopy_iq8, dim3(grid_for(n, 256)), dim3(256), 0, s, src, v0, dst, n);
+    RR_HIP(hipGetLastError());
+}
 void launch_vcopy_f32(VSrc<float> src, long v0, float* dst, long n, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_vcopy<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, v0, dst, n);

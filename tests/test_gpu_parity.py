@@ -331,6 +331,53 @@ def test_fm_chain_fused_block(rr, L, I, D, stream_bytes):
         assert np.max(d[len(taps) // 6 + 2:]) <= TOL * np.pi
 
 
+@pytest.mark.parametrize("L,I,D", [(463, 1, 6), (127, 25, 128), (33, 3, 2), (2467, 1, 5), (5000, 1, 4)])
+@pytest.mark.parametrize("stream_bytes,odd", [(4_096_000, False), (8 * 20_000, False), (30_001, True)])
+def test_fm_chain_u8_fused_block(rr, L, I, D, stream_bytes, odd):
+    """rr.FmChainU8 (RtlSdrDecode fused into the chain kernel) == RtlSdrDecode -> FftFilter ->
+    RationalResampler -> QuadratureDemod of the oracle on an RTL-SDR byte stream, any chunking, odd
+    total length (the trailing byte is never consumed)."""
+    fs = 2.4e6
+    n = 300_000
+    z = fm_signal(n, fs, 0.0, 5 + L)
+    b = np.empty(2 * n + (1 if odd else 0), np.uint8)                  # what an RTL-SDR would deliver
+    b[0:2 * n:2] = np.clip(np.round(z.real / 0.008 + 127), 0, 255)
+    b[1:2 * n:2] = np.clip(np.round(z.imag / 0.008 + 127), 0, 255)
+    if odd:
+        b[-1] = 200
+    if L == 463:
+        taps = orc.low_pass_complex(fs, 100e3, 12.5e3)
+    else:
+        taps = (rnd_c(L, L) / max(1, L // 4)).astype(np.complex64)
+    gain = 0.9
+    # the oracle's FftFilter ring holds Complex: give it the default stream size, chunk the byte side
+    yo = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(I, D), orc.QuadratureDemod(gain)], b)
+    ro = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(I, D)], b)
+    yg = run_chain([rr.FmChainU8(taps, I, D, gain)], b, stream_bytes=stream_bytes)
+    _demod_close(yg / gain, yo / gain, ro)
+
+
+def test_fm_chain_u8_odd_device_pointer(rr):
+    """an odd-addressed byte window takes the out-of-line decode path: same output"""
+    import torch
+    fs, n = 2.4e6, 200_000
+    taps = orc.low_pass_complex(fs, 100e3, 12.5e3)
+    b = np.random.default_rng(3).integers(0, 256, 2 * n + 1, dtype=np.uint8)
+    db = torch.from_numpy(b).cuda()
+    outs = []
+    for off in (0, 1):
+        blk = rr.FmChainU8(taps, 1, 6)
+        dy = torch.zeros(n, dtype=torch.float32, device="cuda")
+        src = torch.from_numpy(np.ascontiguousarray(b[:2 * n])).cuda() if off == 0 else db
+        if off:
+            db[1:] = torch.from_numpy(b[:2 * n]).cuda()
+        st, c, p, need = blk.work_dev(src.data_ptr() + off, 2 * n, dy.data_ptr(), n)
+        blk.sync()
+        assert st == WAIT_SRC and c == 2 * n and p > 0
+        outs.append(dy.cpu().numpy()[:p].copy())
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_fm_chain_fused_protocol(rr):
     taps = orc.low_pass_complex(2.4e6, 100e3, 12.5e3)       # nsamples 561
     b = rr.FmChain(taps, 1, 6, 1.0)
