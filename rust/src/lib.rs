@@ -33,6 +33,9 @@ unsafe extern "C" {
     fn rr_resampler_create(interp: usize, deci: usize, elem_size: usize) -> *mut RrBlock;
     fn rr_quaddemod_create(gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_hilbert_create(ntaps: usize, window: c_int, window_parm: f32) -> *mut RrBlock;
+    fn rr_rtlsdr_decode_create() -> *mut RrBlock;
+    fn rr_fm_chain_create(taps: *const Complex, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
+    fn rr_fm_chain_u8_create(taps: *const Complex, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_block_destroy(b: *mut RrBlock);
     fn rr_block_work(b: *mut RrBlock, inp: *const c_void, in_len: usize, out: *mut c_void, out_cap: usize,
                      consumed: *mut usize, produced: *mut usize, need: *mut usize) -> c_int;
@@ -177,6 +180,36 @@ impl Block for GpuFirFilter {
     }
 }
 
+/// `RtlSdrDecode -> FftFilter -> RationalResampler -> QuadratureDemod` (examples/rtl_fm.rs:328-419) as ONE
+/// GPU block: RTL-SDR bytes in, demodulated f32 out.  All four reference blocks drop tags.
+pub struct GpuRtlFmChain {
+    h: Handle,
+    src: ReadStream<u8>,
+    dst: WriteStream<Float>,
+}
+impl GpuRtlFmChain {
+    pub fn new(src: ReadStream<u8>, taps: &[Complex], interp: usize, deci: usize, gain: Float, fast_math: bool)
+        -> Result<(Self, ReadStream<Float>)> {
+        // SAFETY: taps is a live slice of repr(C) Complex<f32>.
+        let h = Handle::new(unsafe { rr_fm_chain_u8_create(taps.as_ptr(), taps.len(), interp, deci, gain, fast_math as c_int) })?;
+        let (dst, dr) = new_stream();
+        Ok((Self { h, src, dst }, dr))
+    }
+}
+impl BlockName for GpuRtlFmChain { fn block_name(&self) -> &str { "GpuRtlFmChain" } }
+impl BlockEOF for GpuRtlFmChain { fn eof(&mut self) -> bool { self.src.eof() } }
+impl Block for GpuRtlFmChain {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let (input, _tags) = self.src.read_buf()?;
+        let mut out = self.dst.write_buf()?;
+        let (st, consumed, produced, need) = self.h.work(input.slice(), out.slice())?;   // byte counts on the input side
+        input.consume(consumed);
+        out.produce(produced, &[]);
+        Ok(if st == RR_WAIT_DST { BlockRet::WaitForStream(&self.dst, need) } else { BlockRet::WaitForStream(&self.src, need) })
+    }
+}
+
+// RtlSdrDecode (rr_rtlsdr_decode_create), the Complex-input fused chain (rr_fm_chain_create),
 // RationalResampler<T>, QuadratureDemod, Hilbert and FftFilterFloat follow the same pattern
 // (tags dropped for the first two, `pos < n` kept for Hilbert): see the C++ mirror for the
 // exact work() bodies — rustradio_amd/host/rustradio.hpp — and INTEGRATION.md.
