@@ -12,7 +12,8 @@ Other workloads (--workload, also summarised under "others" in the JSON line):
     fir          configs[0]: FirFilter<Complex> 127 real taps, 1,000,000 samples
     fm_chain     configs[2]: FftFilter(463) -> RationalResampler(1:6) -> QuadratureDemod, 2.4 Msps x 10 s
     fm_multi     configs[3]: 32 such channels per GPU on one shared IQ source (256 channels on 8 GPUs)
-    channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in)
+    channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in), fused into one
+                 composite decimating FIR (rr.HilbertFir); channelizer_unfused = the two blocks
     rtl_fm_chain configs[2] fed by the RTL-SDR byte stream: RtlSdrDecode fused in front (u8 in)
 
 Multi-GPU (one process per GPU, weak scaling): the path shards by channel — every rank
@@ -253,27 +254,40 @@ def make_fm_multi(dev, rank, world, shared_src, per_gpu=32, total=256):
     return w
 
 
-def make_channelizer(dev, rank, world, shared_src):
+def make_channelizer(dev, rank, world, shared_src, fused=True):
     w = Workload()
-    w.name = "Hilbert(65)->FirFilter<Complex>(255 real taps, deci 8), 100 Msps f32 x 1 s = 100,000,000 samples/step"
+    how = ("fused into one composite decimating FIR (rr.HilbertFir)" if fused
+           else "two blocks, device-resident analytic stream")
+    w.name = ("Hilbert(65)->FirFilter<Complex>(255 real taps, deci 8), 100 Msps f32 x 1 s = 100,000,000 samples/step, "
+              + how)
     fs, n = 100e6, 100_000_000
     taps = rr.low_pass_complex(fs, 5e6, 943e3)
     assert len(taps) == 255
-    w.blocks = [rr.Hilbert(65), rr.FirFilter(taps, deci=8)]
+    src = shared_src(lambda: synth_real(n, fs, (3e6, 12e6, 37e6), 0x5EED0005, dev))
     w.n = n
-    w.bufs = [shared_src(lambda: synth_real(n, fs, (3e6, 12e6, 37e6), 0x5EED0005, dev)),
-              torch.empty(2 * n, dtype=torch.float32, device=dev),
-              torch.empty(2 * (n // 8 + 8), dtype=torch.float32, device=dev)]
-    w.caps = [n, n // 8 + 8]
     w.alg_bytes_per_sample = 5.0
-    w.dominant, w.dominant_bytes_per_unit = 0, 12.0
+    if fused:
+        w.blocks = [rr.HilbertFir(65, taps, 8)]
+        w.bufs = [src, torch.empty(2 * (n // 8 + 8), dtype=torch.float32, device=dev)]
+        w.caps = [n // 8 + 8]
+        w.dominant, w.dominant_bytes_per_unit = 0, 5.0
+    else:
+        w.blocks = [rr.Hilbert(65), rr.FirFilter(taps, deci=8)]
+        w.bufs = [src, torch.empty(2 * n, dtype=torch.float32, device=dev),
+                  torch.empty(2 * (n // 8 + 8), dtype=torch.float32, device=dev)]
+        w.caps = [n, n // 8 + 8]
+        w.dominant, w.dominant_bytes_per_unit = 0, 12.0
     w.cpu = ("channelizer", taps)
     return w
 
 
+def make_channelizer_unfused(dev, rank, world, shared_src):
+    return make_channelizer(dev, rank, world, shared_src, fused=False)
+
+
 WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
              "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "channelizer": make_channelizer,
-             "rtl_fm_chain": make_rtl_fm_chain}
+             "rtl_fm_chain": make_rtl_fm_chain, "channelizer_unfused": make_channelizer_unfused}
 
 
 # ---- measurement ------------------------------------------------------------------------------
@@ -431,7 +445,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer" else "k_fir<hilbert>"),
+                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),

@@ -117,6 +117,15 @@ rr_block *rr_fm_chain_create(const rr_c32 *taps, size_t ntaps, size_t interp, si
 rr_block *rr_fm_chain_u8_create(const rr_c32 *taps, size_t ntaps, size_t interp, size_t deci,
                                 float gain, int atan2_mode);
 
+/* Graph-level fusion of Hilbert::new(src, hilbert_ntaps, &window) (src/hilbert.rs:38-61) ->
+ * FirFilter::<Complex>::builder(taps).deci(deci)[.translate(samp_rate, freq)].build(_) (src/fir.rs:303-386,476-486)
+ * as wired in examples/ax25-1200-rx.rs:238-247: f32 in, Complex out, ONE decimating FIR with the composite
+ * Complex taps (Hilbert transformer convolved with `taps`, formed in f64).  Whole-stream output equals the
+ * two blocks in sequence to f32 rounding; work() follows FirFilter's protocol on the real input
+ * (WAIT_SRC(ntaps+deci-1), consumes deci*floor((len-ntaps+1)/deci), RR_AGAIN). */
+rr_block *rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_parm, const rr_c32 *taps, size_t ntaps,
+                                size_t deci, int translate, float samp_rate, float freq);
+
 /* `nchan` fused FM chains (rr_fm_chain_create) fed by ONE input stream — the reference's Tee fan-out
  * (src/tee.rs:10-24) plus nchan x {FftFilter, RationalResampler, QuadratureDemod}.  taps =
  * [nchan][ntaps] (each channel its own, e.g. the prototype shifted to the channel centre); every
@@ -179,7 +188,7 @@ int rr_debug_fft_stamps(unsigned long long *out16);
 /* FftFilter: reference fft_size and nsamples (src/fft_filter.rs:261-262) and the
  * internal overlap-save tile the GPU kernel uses. */
 int rr_fftfilter_dims(const rr_block *b, size_t *fft_size, size_t *nsamples, size_t *gpu_fft_size);
-/* FirFilter translate: rotator mode (default RR_ROT_MODEL). */
+/* FirFilter translate (also inside rr_hilbert_fir_create): rotator mode (default RR_ROT_MODEL). */
 int rr_fir_set_rotator_mode(rr_block *b, int mode);
 
 #ifdef __cplusplus

@@ -218,6 +218,20 @@ def FmChainU8(taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2
     return Block(lib().rr_fm_chain_u8_create(_ptr(t), len(t), interp, deci, gain, mode), np.uint8, np.float32)
 
 
+def HilbertFir(hilbert_ntaps: int, taps, deci: int = 1, translate=None, wtype: int = WIN_HAMMING, parm: float = 0.0,
+               rotator: int = ROT_MODEL) -> Block:
+    """Hilbert(hilbert_ntaps, wtype) -> FirFilter<Complex>(taps, deci[, translate]) fused into one composite
+    decimating FIR on the real input (examples/ax25-1200-rx.rs:238-247 wiring); f32 in, Complex out."""
+    t = np.ascontiguousarray(taps, np.complex64)
+    fs, f = translate if translate is not None else (0.0, 0.0)
+    h = lib().rr_hilbert_fir_create(hilbert_ntaps, wtype, parm, _ptr(t), len(t), deci,
+                                    1 if translate is not None else 0, fs, f)
+    b = Block(h, np.float32, np.complex64)
+    if translate is not None and lib().rr_fir_set_rotator_mode(b._h, rotator) != 0:
+        raise ValueError(last_error())
+    return b
+
+
 def FmMulti(taps_per_channel, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
     """N fused FM chains on one shared input (Tee + N x FmChain); taps_per_channel = [N][ntaps].
     work() returns out with shape (N, produced); work_dev() takes N windows of out_cap elements."""

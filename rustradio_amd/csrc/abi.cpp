@@ -95,6 +95,12 @@ rr_block* rr_fm_chain_u8_create(const rr_c32* taps, size_t ntaps, size_t interp,
                                 int atan2_mode) {
     return make_block([&] { return new rr::FmChain(taps, ntaps, interp, deci, gain, atan2_mode, true); });
 }
+rr_block* rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_parm, const rr_c32* taps, size_t ntaps,
+                                size_t deci, int translate, float samp_rate, float freq) {
+    return make_block([&] {
+        return new rr::HilbertFir(hilbert_ntaps, window, window_parm, taps, ntaps, deci, translate != 0, samp_rate, freq);
+    });
+}
 rr_block* rr_rtlsdr_decode_create(void) {
     return make_block([&] { return new rr::RtlSdrDecode(); });
 }
@@ -183,6 +189,7 @@ int rr_fftfilter_dims(const rr_block* b, size_t* fft_size, size_t* nsamples, siz
 }
 int rr_fir_set_rotator_mode(rr_block* b, int mode) {
     auto* f = b ? dynamic_cast<rr::FirC32*>(b->b.get()) : nullptr;
+    if (!f && b) if (auto* hf = dynamic_cast<rr::HilbertFir*>(b->b.get())) f = hf->fir.get();
     if (!f || (mode != RR_ROT_MODEL && mode != RR_ROT_REPLAY)) { rr::set_last_error("rr_fir_set_rotator_mode: bad argument"); return RR_ERR; }
     f->rot_mode = mode;
     return 0;

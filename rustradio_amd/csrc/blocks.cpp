@@ -124,6 +124,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
         }
     }
     pl.L = (int)ntaps; pl.d = (int)deci;
+    h_taps = t;
     bool real_taps = true;
     for (auto& c : t) if (c.imag() != 0.0f) real_taps = false;
     pl.complex_taps = !real_taps;
@@ -157,7 +158,13 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     prof_begin(s);
     launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
     prof_end(s);
-    if (rot_on) {                                                    // fir.rs:531, 464-473
+    rotate_output(static_cast<cf*>(out), out_n, s);                  // fir.rs:531
+    *consumed = n; *produced = out_n;
+    return RR_AGAIN;                                                 // fir.rs:549
+}
+
+void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
+    if (rot_on) {                                                    // fir.rs:464-473
         if (rot_mode == RR_ROT_REPLAY) {
             h_tab.resize(out_n);
             for (size_t i = 0; i < out_n; i++) {                     // the reference's f32 recurrence
@@ -174,8 +181,58 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
         }
         n_rot += out_n;
     }
+}
+
+// ---- Hilbert -> FirFilter<Complex> as one composite decimating FIR ------------------------------------------
+HilbertFir::HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c32* taps, size_t ntaps, size_t deci,
+                       bool translate, float samp_rate, float freq)
+    : Block("Hilbert>FirFilter<Complex>", 4, 8), hn(hilbert_ntaps) {
+    if (!(hn > 1 && (hn & 1) == 1)) throw Error("hilbert filter len must be odd and greater than 1");  // hilbert.rs:44-47
+    if (hn > 0x3fffff) throw Error("Hilbert: too many taps");
+    std::vector<float> win, ht;
+    if (!make_window(window, parm, hn, win)) throw Error("Hilbert: unknown window type");
+    hilbert_taps(win.data(), hn, ht);                                           // hilbert.rs:48
+    fir.reset(new FirC32(taps, ntaps, deci, translate, samp_rate, freq));       // validates, pre-rotates, rotator
+    // c[j] = delta[j - hn/2] + i * rev_h[j], rev_h = reversed Hilbert taps (Fir::new, fir.rs:160)
+    std::vector<std::complex<double>> c(hn), G(ntaps + hn - 1);
+    for (size_t j = 0; j < hn; j++) c[j] = {j == hn / 2 ? 1.0 : 0.0, (double)ht[hn - 1 - j]};
+    for (size_t k = 0; k < ntaps; k++) {
+        const std::complex<double> r(fir->h_taps[ntaps - 1 - k].real(), fir->h_taps[ntaps - 1 - k].imag());
+        for (size_t j = 0; j < hn; j++) G[k + j] += r * c[j];
+    }
+    plG.L = (int)G.size(); plG.d = (int)deci; plG.complex_taps = true;
+    std::vector<cf> rev(G.size()), tp;
+    for (size_t n = 0; n < G.size(); n++) rev[n] = mkcf((float)G[n].real(), (float)G[n].imag());
+    build_poly(rev, plG.d, plG.qpad, tp);
+    d_revG.upload(rev.data(), rev.size(), stream);
+    d_tpG.upload(tp.data(), tp.size(), stream);
+    for (auto& h : hist) {                                                      // hilbert.rs:55 — hn zeros
+        h.reserve(hn);
+        RR_HIP(hipMemsetAsync(h.p, 0, hn * sizeof(float), stream));
+    }
+    RR_HIP(hipStreamSynchronize(stream));
+}
+
+// One input sample = one analytic sample, so the FirFilter bookkeeping (fir.rs:496-549) applies to the
+// real input window unchanged; the Hilbert window of the first analytic sample reaches hn samples back.
+int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                         size_t* produced, size_t* need, hipStream_t s) {
+    const size_t L = fir->pl.L, d = fir->pl.d;
+    *consumed = *produced = *need = 0;
+    if (in_len < L + d - 1) { *need = L + d - 1; return RR_WAIT_SRC; }
+    size_t n = d * ((in_len - L + 1) / d);
+    if (out_cap < 1) { *need = 1; return RR_WAIT_DST; }
+    n = std::min(n, out_cap * d);
+    const size_t out_n = n / d;
+    VSrc<float> src{hist[cur].p, (long)hn, static_cast<const float*>(in), (long)in_len};
+    prof_begin(s);
+    launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s);
+    prof_end(s);
+    fir->rotate_output(static_cast<cf*>(out), out_n, s);
+    launch_vcopy_f32(src, (long)n, hist[cur ^ 1].p, (long)hn, s);              // the hn samples before the new window
+    cur ^= 1;
     *consumed = n; *produced = out_n;
-    return RR_AGAIN;                                                 // fir.rs:549
+    return RR_AGAIN;
 }
 
 FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<Float>", 4, 4) {

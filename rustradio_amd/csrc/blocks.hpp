@@ -1,5 +1,6 @@
 // blocks.hpp — host-side block objects behind the C ABI (include/rustradio_amd.h).
 #pragma once
+#include <complex>
 #include <memory>
 #include <vector>
 
@@ -50,7 +51,27 @@ struct FirC32 : Block {
     float cur_x = 1, cur_y = 0;                   // REPLAY state
     size_t n_rot = 0;                             // outputs rotated so far
     std::vector<cf> h_tab;
+    std::vector<std::complex<float>> h_taps;      // caller-order taps after the translate pre-rotation
     FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+    void rotate_output(cf* out, size_t out_n, hipStream_t s);   // fir.rs:464-473 (no-op without translate)
+};
+
+// Graph-level fusion of Hilbert::new(src, hn, window) -> FirFilter::builder(taps).deci(d)[.translate()]
+// (examples/ax25-1200-rx.rs:238-247 wiring; BASELINE configs[4]) as ONE decimating FIR: the analytic
+// signal a[k] = sum_j c[j] iv[k+j], c = delta[j - hn/2] + i rev_h[j]  (hilbert.rs:113-116) followed by
+// y[m] = sum_k rev[k] a[m d + k] (fir.rs:166-197) is y[m] = sum_n G[n] iv[m d + n] with the composite
+// Complex taps G = rev (*) c of length ntaps + hn - 1, applied to the REAL input: 4 B in + 8/d B out
+// per sample, neither the analytic stream nor a second kernel.  iv = hn zeros || input (hilbert.rs:55).
+struct HilbertFir : Block {
+    std::unique_ptr<FirC32> fir;      // taps incl. translation, rotator state, decimation bookkeeping
+    size_t hn = 0;                    // Hilbert ntaps
+    FirPlan plG;
+    DevBuf<cf> d_tpG, d_revG;
+    DevBuf<float> hist[2];            // the hn input samples before the window start
+    int cur = 0;
+    HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c32* taps, size_t ntaps, size_t deci,
+               bool translate, float samp_rate, float freq);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 

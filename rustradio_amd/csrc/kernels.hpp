@@ -53,6 +53,9 @@ void launch_fir_c32(const FirPlan& pl, const void* tp, const void* rev, VSrc<cf>
 void launch_fir_f32(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src,
                     float* out, long n_out, hipStream_t s);
 // Hilbert: out[k] = (xp[k + L/2], sum_j rev[j] xp[k + j]), xp = virtual stream (history ++ in).
+// real samples, Complex taps, Complex output (the composite Hilbert -> FirFilter filter)
+void launch_fir_f32c(const FirPlan& pl, const cf* tp, const cf* rev, VSrc<float> src, cf* out, long n_out,
+                     hipStream_t s);
 void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, cf* out,
                     long n_out, hipStream_t s);
 // Hilbert with the zero taps skipped: hq[q] = rev[2q + par] (Q entries, padded to a multiple of 8).

@@ -9,6 +9,9 @@
 // that lane t's window read x_p[t*R + c] is lane-consecutive (conflict-free).  Taps are
 // wave-uniform and come through the scalar cache.  No MFMA: a FIR is a vector
 // contraction, VALU (FP32) bound for long filters — see DESIGN.md for the roofline.
+#include <cstdlib>
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace rr {
@@ -24,6 +27,10 @@ __device__ __forceinline__ void mac(cf& acc, cf tap, cf w) {      // complex tap
     acc.y = fmaf(tap.y, w.x, acc.y);
 }
 __device__ __forceinline__ void mac(float& acc, float tap, float w) { acc = fmaf(tap, w, acc); }
+__device__ __forceinline__ void mac(cf& acc, cf tap, float w) {   // complex tap, real sample (one v_pk_fma_f32)
+    acc.x = fmaf(tap.x, w, acc.x);
+    acc.y = fmaf(tap.y, w, acc.y);
+}
 
 __device__ __forceinline__ float add_of(float a, float b) { return a + b; }
 __device__ __forceinline__ cf add_of(cf a, cf b) { return mkcf(a.x + b.x, a.y + b.y); }
@@ -72,6 +79,7 @@ template <class T, class TapT, class OutT, int NT, int R, int S, bool HILBERT>
 __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
                                             int qpad, int np, int rstride, int pstride,
                                             const TapT* __restrict__ tp) {
+    using AccT = typename std::conditional<HILBERT, T, OutT>::type;   // real samples x complex taps accumulate Complex
     constexpr int NTC = NT / S;                        // threads (output columns) per phase group
     constexpr int NOUT = NTC * R;
     static_assert(R % 2 == 0 && R <= 8, "qpad is padded to a multiple of 8");
@@ -163,9 +171,9 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
 
         const int tc = S == 1 ? t : t % NTC;                                   // output column
         const int sg = S == 1 ? 0 : __builtin_amdgcn_readfirstlane(t / NTC);   // phase group (wave-uniform)
-        T acc[R];
+        AccT acc[R];
 #pragma unroll
-        for (int j = 0; j < R; j++) acc[j] = zero_of<T>();
+        for (int j = 0; j < R; j++) acc[j] = zero_of<AccT>();
         for (int p = sg; p < d; p += S) {
             const T* lp = lds + p * pstride + tc;
             const TapT* tpp = tp + (long)p * qpad;
@@ -227,7 +235,8 @@ template <class T, class TapT, class OutT, bool HILBERT>
 __global__ __launch_bounds__(256) void k_fir_direct(VSrc<T> src, OutT* __restrict__ out, long n_out, int L,
                                                     int d, const TapT* __restrict__ rev) {
     for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < n_out; m += (long)gridDim.x * blockDim.x) {
-        T acc = zero_of<T>();
+        using AccT = typename std::conditional<HILBERT, T, OutT>::type;
+        AccT acc = zero_of<AccT>();
         const long b = m * d;
         for (int k = 0; k < L; k++) mac(acc, rev[k], src.load(b + k));
         if constexpr (HILBERT) out[m] = mkcf(src.load(b + L / 2), acc);
@@ -278,6 +287,7 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
             const long tiles = (n_out + nout(c) - 1) / nout(c);
             double cst = cost(c);
             if (tiles < 2L * cus) cst *= (2.0 * cus) / (double)tiles;       // does not fill the chip
+            if (((long)gc.np * pl.d + cfgs[c].NT - 1) / cfgs[c].NT > FIR_MAXPRE) cst *= 2.0;   // staging not pipelined
             if (pick < 0 || cst < best) { pick = c; g = gc; best = cst; }
         }
     }
@@ -333,6 +343,10 @@ void launch_fir_c32(const FirPlan& pl, const void* tp, const void* rev, VSrc<cf>
 void launch_fir_f32(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, float* out,
                     long n_out, hipStream_t s) {
     launch_fir_any<float, float, float, false>(pl, tp, rev, src, out, n_out, s);
+}
+void launch_fir_f32c(const FirPlan& pl, const cf* tp, const cf* rev, VSrc<float> src, cf* out, long n_out,
+                     hipStream_t s) {
+    launch_fir_any<float, cf, cf, false>(pl, tp, rev, src, out, n_out, s);
 }
 void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, cf* out,
                     long n_out, hipStream_t s) {

@@ -281,6 +281,44 @@ def test_channelizer_cfg5(rr):
     both(rr, lambda m: [m.Hilbert(65), m.FirFilter(taps, deci=8)], x)
 
 
+@pytest.mark.parametrize("hn,L,deci,cplx,tr", [(65, 255, 8, False, None), (65, 255, 8, False, (100e6, 7e6)), (31, 64, 5, True, None),
+                                               (129, 33, 1, False, None), (3, 1, 1, False, None), (63, 100, 12, True, (8.0, 2.0)),
+                                               (65, 401, 16, False, None)])
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 4 * 5_003])
+def test_hilbert_fir_fused_block(rr, hn, L, deci, cplx, tr, stream_bytes):
+    """rr.HilbertFir (one composite decimating FIR on the real input) == Hilbert -> FirFilter<Complex> of the
+    oracle, whole stream, any chunking; with and without .translate()."""
+    x = rnd_f(300_000, hn * 1000 + L + deci)
+    if L == 255:
+        taps = orc.low_pass_complex(100e6, 5e6, 943e3)
+    else:
+        taps = rnd_c(L, L + 3) / max(1, L // 8)
+        if not cplx:
+            taps = taps.real.astype(np.complex64)
+    kw = {"translate": tr} if tr else {}
+    yo = run_chain([orc.Hilbert(hn), orc.FirFilter(taps, deci=deci, **kw)], x)
+    # (the reference's rotator is a drifting f32 recurrence, fir.rs:465 TODO: replay it for long streams)
+    kg = dict(kw, rotator=rr.ROT_REPLAY) if tr else {}
+    yg = run_chain([rr.HilbertFir(hn, taps, deci, **kg)], x, stream_bytes=max(stream_bytes, 4 * (L + deci + 8)))
+    assert len(yg) == len(yo) and len(yo) > 0
+    assert max_norm_err(yg, yo) <= TOL
+
+
+def test_hilbert_fir_protocol(rr):
+    """work() of the fused block follows FirFilter's protocol on the real input (fir.rs:496-549)."""
+    taps = orc.low_pass_complex(100e6, 5e6, 943e3)
+    b = rr.HilbertFir(65, taps, 8)
+    x = rnd_f(5000, 1)
+    assert b.work(x[:261], 100)[:4] == (WAIT_SRC, 0, 0, 262)
+    assert b.work(x[:262], 0)[:4] == (WAIT_DST, 0, 0, 1)
+    st, c, p, need, out = b.work(x[:1000], 100)
+    assert (st, c, p) == (AGAIN, 8 * ((1000 - 254) // 8), (1000 - 254) // 8)
+    st, c, p, need, out = b.work(x[c:], 7)
+    assert (st, c, p) == (AGAIN, 56, 7)
+    with pytest.raises(Exception):
+        rr.HilbertFir(64, taps, 8)
+
+
 def test_device_window_api(rr):
     """rr_block_work_dev: device-resident windows (torch tensors only provide the memory)."""
     import torch
