@@ -174,6 +174,30 @@ size_t      rr_block_out_elem_size(const rr_block *b);
 /* Wait for everything the block enqueued (its private stream and the stream of the last work call). */
 int         rr_block_sync(rr_block *b);
 
+/* ---- device-resident streams ----------------------------------------------------------
+ * A stream ring in HBM with the reference's window contract (src/stream.rs:187-310 over
+ * src/nowasm/circular_buffer.rs:98-128): read window = ALL readable elements, write window = ALL free
+ * space, both contiguous; capacity in bytes (the reference default is 4,096,000, src/stream.rs:105).
+ * GPU blocks chained through these never cross PCIe and never wait for each other: all counts are
+ * host-side, kernels and the occasional ring move are enqueued on the caller's HIP stream. */
+typedef struct rr_dstream rr_dstream;
+rr_dstream *rr_dstream_create(size_t elem_size, size_t capacity_bytes);          /* new_stream(), stream.rs:336-339 */
+void        rr_dstream_destroy(rr_dstream *s);
+size_t      rr_dstream_capacity(const rr_dstream *s);                            /* elements */
+/* ReadStream::read_buf() (stream.rs:208-217): returns the readable element count, *dev_ptr = window */
+size_t      rr_dstream_read_buf(rr_dstream *s, const void **dev_ptr);
+/* WriteStream::write_buf() (stream.rs:301-310): returns the free element count, *dev_ptr = window */
+size_t      rr_dstream_write_buf(rr_dstream *s, void **dev_ptr, void *hip_stream);
+int         rr_dstream_consume(rr_dstream *s, size_t n);                         /* BufferReader::consume */
+int         rr_dstream_produce(rr_dstream *s, size_t n);                         /* BufferWriter::produce */
+/* BufferWriter::fill_from_slice from HOST memory into the write window at `offset` (not yet produced) */
+int         rr_dstream_copy_in(rr_dstream *s, size_t offset, const void *host, size_t n, void *hip_stream);
+/* copy `n` elements at `offset` of the read window to HOST memory; waits for the stream (data valid on return) */
+int         rr_dstream_copy_out(rr_dstream *s, size_t offset, void *host, size_t n, void *hip_stream);
+/* One Block::work() between two device streams: rr_block_work_dev over their windows + consume/produce. */
+int rr_block_work_streams(rr_block *b, rr_dstream *src, rr_dstream *dst, size_t *consumed, size_t *produced,
+                          size_t *need, void *hip_stream);
+
 /* Measurement aid: when enabled, every work call brackets the block's dominant kernel
  * with HIP events on the stream it is launched on; rr_block_profile waits for them and
  * returns the summed kernel time and the number of launches (reset != 0 clears them). */

@@ -137,6 +137,15 @@ class Block:
             raise RuntimeError(last_error())
         return st, c.value, p.value, n.value
 
+    def work_streams(self, src: "DeviceStream", dst: "DeviceStream", stream: int = 0):
+        """Block::work() between two device-resident streams (windows, consume and produce handled by the
+        library) -> (status, consumed, produced, need); asynchronous on `stream`."""
+        c, p, n = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        st = lib().rr_block_work_streams(self._h, src._h, dst._h, C.byref(c), C.byref(p), C.byref(n), C.c_void_p(stream))
+        if st == ERR:
+            raise RuntimeError(last_error())
+        return st, c.value, p.value, n.value
+
     def eof(self, src_eof: bool) -> bool:
         """BlockEOF::eof (src/block.rs:103-110)."""
         return bool(lib().rr_block_eof(self._h, int(src_eof)))
@@ -154,6 +163,52 @@ class Block:
         if lib().rr_block_profile(self._h, C.byref(ms), C.byref(n), int(reset)) != 0:
             raise RuntimeError(last_error())
         return ms.value, n.value
+
+
+class DeviceStream:
+    """new_stream() (src/stream.rs:336-339) in HBM: rr_dstream.  Same window contract as ReadStream /
+    WriteStream: everything readable / all free space, contiguous; `capacity_bytes` as the reference's
+    DEFAULT_STREAM_SIZE."""
+
+    def __init__(self, dtype, capacity_bytes: int = 4_096_000):
+        self.dtype = np.dtype(dtype)
+        self._h = lib().rr_dstream_create(self.dtype.itemsize, capacity_bytes)
+        if not self._h:
+            raise RuntimeError(last_error())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().rr_dstream_destroy(h)
+
+    @property
+    def capacity(self) -> int:
+        return lib().rr_dstream_capacity(self._h)
+
+    def readable(self) -> int:
+        return lib().rr_dstream_read_buf(self._h, None)
+
+    def free(self, stream: int = 0) -> int:
+        return lib().rr_dstream_write_buf(self._h, None, C.c_void_p(stream))
+
+    def push(self, x: np.ndarray, stream: int = 0) -> int:
+        """fill_from_slice + produce of as much of the host array `x` as fits -> elements taken"""
+        x = np.ascontiguousarray(x, self.dtype)
+        n = min(len(x), self.free(stream))
+        if n and (lib().rr_dstream_copy_in(self._h, 0, _ptr(x), n, C.c_void_p(stream)) != 0
+                  or lib().rr_dstream_produce(self._h, n) != 0):
+            raise RuntimeError(last_error())
+        return n
+
+    def pop(self, n: int = None, stream: int = 0) -> np.ndarray:
+        """copy the first n readable elements (default all) to the host and consume them"""
+        m = self.readable()
+        n = m if n is None else min(n, m)
+        out = np.empty(n, self.dtype)
+        if n and (lib().rr_dstream_copy_out(self._h, 0, _ptr(out), n, C.c_void_p(stream)) != 0
+                  or lib().rr_dstream_consume(self._h, n) != 0):
+            raise RuntimeError(last_error())
+        return out
 
 
 def FirFilter(taps, deci: int = 1, translate=None, rotator: int = ROT_MODEL) -> Block:

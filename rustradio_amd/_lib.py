@@ -20,6 +20,8 @@ SYMBOLS = [
     "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_in_elem_size",
     "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_set_rotator_mode",
     "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps",
+    "rr_dstream_create", "rr_dstream_destroy", "rr_dstream_capacity", "rr_dstream_read_buf", "rr_dstream_write_buf",
+    "rr_dstream_consume", "rr_dstream_produce", "rr_dstream_copy_in", "rr_dstream_copy_out", "rr_block_work_streams",
 ]
 
 _lib = None
@@ -70,6 +72,17 @@ def lib():
     L.rr_fftfilter_dims.argtypes = [vp, psz, psz, psz]; L.rr_fftfilter_dims.restype = i32
     L.rr_fir_set_rotator_mode.argtypes = [vp, i32]; L.rr_fir_set_rotator_mode.restype = i32
     L.rr_debug_fft_stamps.argtypes = [vp]; L.rr_debug_fft_stamps.restype = i32
+    pvp = C.POINTER(vp)
+    L.rr_dstream_create.argtypes = [sz, sz]; L.rr_dstream_create.restype = vp
+    L.rr_dstream_destroy.argtypes = [vp]; L.rr_dstream_destroy.restype = None
+    L.rr_dstream_capacity.argtypes = [vp]; L.rr_dstream_capacity.restype = sz
+    L.rr_dstream_read_buf.argtypes = [vp, pvp]; L.rr_dstream_read_buf.restype = sz
+    L.rr_dstream_write_buf.argtypes = [vp, pvp, vp]; L.rr_dstream_write_buf.restype = sz
+    L.rr_dstream_consume.argtypes = [vp, sz]; L.rr_dstream_consume.restype = i32
+    L.rr_dstream_produce.argtypes = [vp, sz]; L.rr_dstream_produce.restype = i32
+    L.rr_dstream_copy_in.argtypes = [vp, sz, vp, sz, vp]; L.rr_dstream_copy_in.restype = i32
+    L.rr_dstream_copy_out.argtypes = [vp, sz, vp, sz, vp]; L.rr_dstream_copy_out.restype = i32
+    L.rr_block_work_streams.argtypes = [vp, vp, vp, psz, psz, psz, vp]; L.rr_block_work_streams.restype = i32
     L.rr_block_set_profiling.argtypes = [vp, i32]; L.rr_block_set_profiling.restype = i32
     L.rr_block_profile.argtypes = [vp, C.POINTER(C.c_double), psz, i32]; L.rr_block_profile.restype = i32
     _lib = L

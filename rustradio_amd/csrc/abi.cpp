@@ -4,10 +4,14 @@
 #include <string>
 
 #include "blocks.hpp"
+#include "dstream.hpp"
 #include "taps.hpp"
 
 struct rr_block {
     std::unique_ptr<rr::Block> b;
+};
+struct rr_dstream {
+    std::unique_ptr<rr::DStream> s;
 };
 
 namespace rr {
@@ -24,6 +28,11 @@ template <class F> static rr_block* make_block(F&& f) {
         rr::set_last_error(e.what());
         return nullptr;
     }
+}
+
+template <class F> static int guarded(F&& f) {
+    try { f(); return 0; }
+    catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
 }
 
 extern "C" {
@@ -187,6 +196,90 @@ int rr_fftfilter_dims(const rr_block* b, size_t* fft_size, size_t* nsamples, siz
     if (gpu_fft_size) *gpu_fft_size = (size_t)1 << f->log2f;
     return 0;
 }
+// ---- device-resident streams ------------------------------------------------------------------------
+rr_dstream* rr_dstream_create(size_t elem_size, size_t capacity_bytes) {
+    try {
+        auto* h = new rr_dstream;
+        h->s.reset(new rr::DStream(elem_size, capacity_bytes));
+        return h;
+    } catch (const std::exception& e) {
+        rr::set_last_error(e.what());
+        return nullptr;
+    }
+}
+void rr_dstream_destroy(rr_dstream* s) { delete s; }
+size_t rr_dstream_capacity(const rr_dstream* s) { return s ? s->s->cap : 0; }
+size_t rr_dstream_read_buf(rr_dstream* s, const void** dev_ptr) {
+    if (!s) return 0;
+    if (dev_ptr) *dev_ptr = s->s->read_ptr();
+    return s->s->used();
+}
+size_t rr_dstream_write_buf(rr_dstream* s, void** dev_ptr, void* hip_stream) {
+    if (!s) return 0;
+    try {
+        void* p = s->s->write_ptr(static_cast<hipStream_t>(hip_stream));
+        if (dev_ptr) *dev_ptr = p;
+        return s->s->free();
+    } catch (const std::exception& e) {
+        rr::set_last_error(e.what());
+        return 0;
+    }
+}
+int rr_dstream_consume(rr_dstream* s, size_t n) {
+    if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }
+    return guarded([&] { s->s->consume(n); });
+}
+int rr_dstream_produce(rr_dstream* s, size_t n) {
+    if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }
+    return guarded([&] { s->s->produce(n); });
+}
+int rr_dstream_copy_in(rr_dstream* s, size_t offset, const void* host, size_t n, void* hip_stream) {
+    if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }
+    return guarded([&] {
+        rr::DStream& d = *s->s;
+        auto st = static_cast<hipStream_t>(hip_stream);
+        unsigned char* w = static_cast<unsigned char*>(d.write_ptr(st));
+        if (offset + n > d.free()) throw rr::Error("dstream copy_in: beyond the write window");
+        RR_HIP(hipSetDevice(d.device));
+        if (n) RR_HIP(hipMemcpyAsync(w + offset * d.es, host, n * d.es, hipMemcpyHostToDevice, st));
+    });
+}
+int rr_dstream_copy_out(rr_dstream* s, size_t offset, void* host, size_t n, void* hip_stream) {
+    if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }
+    return guarded([&] {
+        rr::DStream& d = *s->s;
+        auto st = static_cast<hipStream_t>(hip_stream);
+        if (offset + n > d.used()) throw rr::Error("dstream copy_out: beyond the read window");
+        RR_HIP(hipSetDevice(d.device));
+        if (n) RR_HIP(hipMemcpyAsync(host, static_cast<const unsigned char*>(d.read_ptr()) + offset * d.es, n * d.es,
+                                     hipMemcpyDeviceToHost, st));
+        RR_HIP(hipStreamSynchronize(st));           // the host may read `host` on return
+    });
+}
+int rr_block_work_streams(rr_block* b, rr_dstream* src, rr_dstream* dst, size_t* consumed, size_t* produced,
+                          size_t* need, void* hip_stream) {
+    size_t c = 0, p = 0, nd = 0;
+    if (!b || !src || !dst) { rr::set_last_error("rr_block_work_streams: null argument"); return RR_ERR; }
+    if (b->b->out_windows() != 1) { rr::set_last_error("rr_block_work_streams: single-output blocks only"); return RR_ERR; }
+    if (src->s->es != b->b->in_es || dst->s->es != b->b->out_es) {
+        rr::set_last_error("rr_block_work_streams: stream element size does not match the block");
+        return RR_ERR;
+    }
+    int st = RR_ERR;
+    const int rc = guarded([&] {
+        auto hs = static_cast<hipStream_t>(hip_stream);
+        void* out = dst->s->write_ptr(hs);
+        st = rr_block_work_dev(b, src->s->read_ptr(), src->s->used(), out, dst->s->free(), &c, &p, &nd, hip_stream);
+        if (st == RR_ERR) return;
+        src->s->consume(c);
+        dst->s->produce(p);
+    });
+    if (consumed) *consumed = c;
+    if (produced) *produced = p;
+    if (need) *need = nd;
+    return rc == 0 ? st : RR_ERR;
+}
+
 int rr_fir_set_rotator_mode(rr_block* b, int mode) {
     auto* f = b ? dynamic_cast<rr::FirC32*>(b->b.get()) : nullptr;
     if (!f && b) if (auto* hf = dynamic_cast<rr::HilbertFir*>(b->b.get())) f = hf->fir.get();

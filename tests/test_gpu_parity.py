@@ -466,3 +466,64 @@ def test_fm_multi_shared_source(rr, stream_bytes):
         d = _demod_close(yg, yo, ro)
         if ch == 2:     # centred channel: |r| ~ 1 after the start-up transient
             assert np.max(d[len(proto) // 6 + 2:]) <= TOL * np.pi
+
+
+# ---- device-resident streams (rr_dstream) --------------------------------------------
+def run_chain_device(rr, blocks, x, stream_bytes=4_096_000):
+    """the same stream graph as harness.run_chain, but every ring lives in HBM and blocks run through
+    rr_block_work_streams; only the source push and the sink pop touch the host"""
+    rings = [rr.DeviceStream(blocks[0].in_dtype, stream_bytes)] + [rr.DeviceStream(b.out_dtype, stream_bytes) for b in blocks]
+    x = np.asarray(x, blocks[0].in_dtype)
+    pos, outs = 0, []
+    for _ in range(1_000_000):
+        moved = rings[0].push(x[pos:])
+        pos += moved
+        for i, b in enumerate(blocks):
+            while True:
+                st, c, p, need = b.work_streams(rings[i], rings[i + 1])
+                moved += c + p
+                if st != AGAIN or (c == 0 and p == 0):
+                    break
+        y = rings[-1].pop()
+        moved += len(y)
+        if len(y):
+            outs.append(y)
+        if moved == 0:
+            break
+    return np.concatenate(outs) if outs else np.zeros(0, blocks[-1].out_dtype)
+
+
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 3_001])
+def test_device_streams_equal_host_windows(rr, stream_bytes):
+    """chains over HBM-resident rings (small rings force the wrap-around move) produce bit-identical output
+    to the same blocks driven through host windows"""
+    fs = 2.4e6
+    x = fm_signal(200_000, fs, 0.0, 5)
+    taps = orc.low_pass_complex(fs, 100e3, 12.5e3 * 4)
+    mk = lambda: [rr.FftFilter(taps), rr.RationalResampler(3, 7, np.complex64), rr.QuadratureDemod(0.5)]
+    yh = run_chain(mk(), x, stream_bytes=stream_bytes)
+    yd = run_chain_device(rr, mk(), x, stream_bytes=stream_bytes)
+    assert len(yh) == len(yd) > 0 and np.array_equal(yh, yd)
+    xr = rnd_f(150_000, 8)
+    mk2 = lambda: [rr.Hilbert(65), rr.FirFilter(orc.low_pass_complex(100e6, 5e6, 943e3 * 2), deci=8)]
+    yh = run_chain(mk2(), xr, stream_bytes=max(stream_bytes, 8 * 3_001))
+    yd = run_chain_device(rr, mk2(), xr, stream_bytes=max(stream_bytes, 8 * 3_001))
+    assert len(yh) == len(yd) > 0 and np.array_equal(yh, yd)
+    b = np.random.default_rng(1).integers(0, 256, 100_001, dtype=np.uint8)
+    mk3 = lambda: [rr.RtlSdrDecode(), rr.RationalResampler(5, 3, np.complex64)]
+    assert np.array_equal(run_chain(mk3(), b, stream_bytes=stream_bytes), run_chain_device(rr, mk3(), b, stream_bytes=stream_bytes))
+
+
+def test_device_stream_ring_contract(rr):
+    s = rr.DeviceStream(np.uint32, 4 * 10)
+    assert s.capacity == 10 and s.readable() == 0 and s.free() == 10
+    assert s.push(np.arange(25, dtype=np.uint32)) == 10 and s.free() == 0
+    assert np.array_equal(s.pop(4), np.arange(4, dtype=np.uint32)) and s.readable() == 6 and s.free() == 4
+    total, nxt, got = 10, 10, list(range(4))
+    for k in range(40):                                    # many wrap-arounds of a 10-element ring
+        n = s.push(np.arange(nxt, nxt + 7, dtype=np.uint32)); nxt += n
+        got += list(s.pop(1 + k % 5))
+    got += list(s.pop())
+    assert got == list(range(len(got))) and len(got) == nxt
+    with pytest.raises(Exception):
+        rr.DeviceStream(np.uint32, 2)                      # smaller than one element
