@@ -20,12 +20,14 @@
 // happens in this file.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <complex>
 #include <cstdint>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <variant>
 #include <vector>
@@ -73,19 +75,35 @@ struct StreamWait {
     virtual bool closed() const = 0;
 };
 
+// Where new_stream() places rings.  Memory::Device = an HBM-resident ring (rr_dstream): GPU
+// blocks chained through such streams run rr_block_work_dev on the windows — no PCIe hop and no
+// host/device synchronisation per work(); only sources (fill_from_slice) and sinks (copy_to) cross
+// the bus.  Tags stay a host-side side-band in both cases.  Set once before building a graph.
+enum class Memory { Host, Device };
+inline Memory& default_memory() { static thread_local Memory m = Memory::Host; return m; }
+
 template <class T> struct StreamState : StreamWait {
-    std::vector<T> buf;           // [rpos, buf.size()) readable; capacity `cap` samples
+    std::vector<T> buf;           // host ring: [rpos, buf.size()) readable; capacity `cap` samples
     size_t rpos = 0;
+    rr_dstream* ds = nullptr;     // device ring (then buf is unused)
     size_t cap;
-    std::vector<Tag> tags;        // positions relative to rpos
+    std::vector<Tag> tags;        // positions relative to the read window
     bool writer_alive = true, reader_alive = true;
     size_t id_;
-    explicit StreamState(size_t bytes) : cap(bytes / sizeof(T)) {
+    explicit StreamState(size_t bytes, Memory m = default_memory()) : cap(bytes / sizeof(T)) {
         static size_t next_id = 1;
         id_ = next_id++;
-        buf.reserve(cap);
+        if (m == Memory::Device) {
+            ds = rr_dstream_create(sizeof(T), bytes);
+            if (!ds) throw Error(rr_last_error());
+        } else {
+            buf.reserve(cap);
+        }
     }
-    size_t used() const { return buf.size() - rpos; }
+    ~StreamState() override { if (ds) rr_dstream_destroy(ds); }
+    StreamState(const StreamState&) = delete;
+    bool device() const { return ds != nullptr; }
+    size_t used() const { return ds ? rr_dstream_read_buf(ds, nullptr) : buf.size() - rpos; }
     size_t free() const { return cap - used(); }
     size_t id() const override { return id_; }
     bool closed() const override { return !writer_alive || !reader_alive; }   // src/stream.rs:148-150
@@ -95,28 +113,54 @@ template <class T> class BufferReader {   // circular_buffer.rs:233-251
     std::shared_ptr<StreamState<T>> s_;
 public:
     explicit BufferReader(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {}
-    const T* slice() const { return s_->buf.data() + s_->rpos; }
+    bool device() const { return s_->device(); }
+    // the window: a host pointer, or a DEVICE pointer when the stream lives in HBM
+    const T* slice() const {
+        if (!s_->ds) return s_->buf.data() + s_->rpos;
+        const void* p = nullptr;
+        rr_dstream_read_buf(s_->ds, &p);
+        return static_cast<const T*>(p);
+    }
     size_t len() const { return s_->used(); }
     bool is_empty() const { return len() == 0; }
-    const T* begin() const { return slice(); }
-    const T* end() const { return slice() + len(); }
+    const T* begin() const { host_only(); return slice(); }
+    const T* end() const { host_only(); return slice() + len(); }
+    // first n samples of the window into host memory (any placement)
+    void copy_to(T* host, size_t n) const {
+        if (n > len()) throw Error("copy_to: n > readable");
+        if (!s_->ds) { if (n) std::memcpy(host, slice(), n * sizeof(T)); return; }
+        if (rr_dstream_copy_out(s_->ds, 0, host, n, nullptr) != 0) throw Error(rr_last_error());
+    }
     void consume(size_t n) {               // circular_buffer.rs:472-513
         if (n > s_->used()) throw Error("consume: n > used");
         detail::activity() += n;
-        s_->rpos += n;
         std::vector<Tag> keep;
         for (auto& t : s_->tags)
             if (t.pos() >= n) keep.emplace_back(t.pos() - n, t.key(), t.val());
         s_->tags.swap(keep);
+        if (s_->ds) { if (rr_dstream_consume(s_->ds, n) != 0) throw Error(rr_last_error()); return; }
+        s_->rpos += n;
         if (s_->rpos == s_->buf.size()) { s_->buf.clear(); s_->rpos = 0; }
     }
+private:
+    void host_only() const { if (s_->ds) throw Error("host iteration over a device-resident stream: use copy_to()"); }
+public:
 };
 
 template <class T> class BufferWriter {   // circular_buffer.rs:284-310
     std::shared_ptr<StreamState<T>> s_;
-    size_t base_;
+    size_t base_ = 0;             // readable samples in front of the write window
+    T* dptr_ = nullptr;           // device ring: the write window
+    size_t dlen_ = 0;
 public:
     explicit BufferWriter(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {
+        if (s_->ds) {
+            base_ = s_->used();
+            void* p = nullptr;
+            dlen_ = rr_dstream_write_buf(s_->ds, &p, nullptr);
+            dptr_ = static_cast<T*>(p);
+            return;
+        }
         // make the free space contiguous after the readable window
         if (s_->rpos) {
             s_->buf.erase(s_->buf.begin(), s_->buf.begin() + (std::ptrdiff_t)s_->rpos);
@@ -125,19 +169,26 @@ public:
         base_ = s_->buf.size();
         s_->buf.resize(s_->cap);
     }
-    ~BufferWriter() { if (s_ && s_->buf.size() == s_->cap && !produced_) s_->buf.resize(base_); }
-    BufferWriter(BufferWriter&& o) noexcept : s_(std::move(o.s_)), base_(o.base_), produced_(o.produced_) { o.s_.reset(); }
+    ~BufferWriter() { if (s_ && !s_->ds && s_->buf.size() == s_->cap && !produced_) s_->buf.resize(base_); }
+    BufferWriter(BufferWriter&& o) noexcept
+        : s_(std::move(o.s_)), base_(o.base_), dptr_(o.dptr_), dlen_(o.dlen_), produced_(o.produced_) { o.s_.reset(); }
     BufferWriter(const BufferWriter&) = delete;
-    T* slice() { return s_->buf.data() + base_; }
-    size_t len() const { return s_->cap - base_; }
+    bool device() const { return s_->device(); }
+    T* slice() { return s_->ds ? dptr_ : s_->buf.data() + base_; }     // host or DEVICE pointer
+    size_t len() const { return s_->ds ? dlen_ : s_->cap - base_; }
     bool is_empty() const { return len() == 0; }
-    void fill_from_slice(const T* src, size_t n) { std::memcpy(slice(), src, n * sizeof(T)); }
+    void fill_from_slice(const T* src, size_t n) {                      // src = host memory
+        if (n > len()) throw Error("fill_from_slice: n > free");
+        if (!s_->ds) { std::memcpy(slice(), src, n * sizeof(T)); return; }
+        if (rr_dstream_copy_in(s_->ds, 0, src, n, nullptr) != 0) throw Error(rr_last_error());
+    }
     void produce(size_t n, const std::vector<Tag>& tags) {   // circular_buffer.rs:518-557
         if (n > len()) throw Error("produce: n > free");
-        if (n == 0) { s_->buf.resize(base_); produced_ = true; return; }   // tags dropped (:528-533)
+        if (n == 0) { if (!s_->ds) s_->buf.resize(base_); produced_ = true; return; }   // tags dropped (:528-533)
         detail::activity() += n;
         for (auto& t : tags) s_->tags.emplace_back(t.pos() + base_, t.key(), t.val());
-        s_->buf.resize(base_ + n);
+        if (s_->ds) { if (rr_dstream_produce(s_->ds, n) != 0) throw Error(rr_last_error()); }
+        else s_->buf.resize(base_ + n);
         produced_ = true;
     }
 private:
@@ -154,7 +205,7 @@ public:
     ReadStream& operator=(ReadStream&&) = default;
     ReadStream(const ReadStream&) = delete;
     static ReadStream from_slice(const T* d, size_t n) {    // src/stream.rs:187-195 (test helper)
-        auto st = std::make_shared<StreamState<T>>(DEFAULT_STREAM_SIZE);
+        auto st = std::make_shared<StreamState<T>>(DEFAULT_STREAM_SIZE, Memory::Host);
         st->buf.assign(d, d + n);
         st->writer_alive = false;
         return ReadStream(st);
@@ -182,8 +233,9 @@ public:
     size_t id() const { return s_->id(); }
 };
 
-template <class T> std::pair<WriteStream<T>, ReadStream<T>> new_stream(size_t bytes = DEFAULT_STREAM_SIZE) {  // :336-339
-    auto st = std::make_shared<StreamState<T>>(bytes);
+template <class T> std::pair<WriteStream<T>, ReadStream<T>> new_stream(size_t bytes = DEFAULT_STREAM_SIZE,
+                                                                       Memory m = default_memory()) {  // :336-339
+    auto st = std::make_shared<StreamState<T>>(bytes, m);
     return {WriteStream<T>(st), ReadStream<T>(st)};
 }
 
@@ -255,6 +307,17 @@ inline WorkOut work(rr_block* h, const void* in, size_t in_len, void* out, size_
     if (w.st == RR_ERR) throw Error(rr_last_error());
     return w;
 }
+// Block::work() over a read and a write window of the same placement: host windows go through
+// rr_block_work (PCIe round trip inside), device windows through rr_block_work_dev on the default stream.
+template <class I, class O> inline WorkOut work(rr_block* h, const BufferReader<I>& in, BufferWriter<O>& out) {
+    if (in.device() != out.device())
+        throw Error("a GPU block needs both streams in the same memory: put a MemCopy block in between");
+    if (!in.device()) return work(h, in.slice(), in.len(), out.slice(), out.len());
+    WorkOut w{};
+    w.st = rr_block_work_dev(h, in.slice(), in.len(), out.slice(), out.len(), &w.consumed, &w.produced, &w.need, nullptr);
+    if (w.st == RR_ERR) throw Error(rr_last_error());
+    return w;
+}
 static_assert(sizeof(Complex) == sizeof(rr_c32), "Complex<f32> must be interleaved re, im");
 }  // namespace detail
 
@@ -300,7 +363,7 @@ public:
     BlockRet work() override {                    // fir.rs:492-550
         auto [input, tags] = src_.read_buf();
         auto out = dst_.write_buf();
-        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        auto w = detail::work(h_.h, input, out);
         if (w.st == RR_WAIT_SRC) { out.produce(0, {}); return BlockRet::wait(src_.wait_handle(), w.need); }
         if (w.st == RR_WAIT_DST) { out.produce(0, {}); return BlockRet::wait(dst_.wait_handle(), w.need); }
         std::vector<Tag> keep;                    // :536-545
@@ -360,7 +423,7 @@ public:
     BlockRet work() override {                    // fft_filter.rs:290-354 / 429-490
         auto [input, tags] = src_.read_buf();
         auto out = dst_.write_buf();
-        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        auto w = detail::work(h_.h, input, out);
         // a tag travels with its sample: output sample i is input sample i of the stream
         for (auto& t : tags)
             if (t.pos() < w.consumed) pending_.emplace_back(in_abs_ + t.pos(), t);
@@ -425,7 +488,7 @@ public:
         auto [input, tags] = src_.read_buf();
         (void)tags;
         auto out = dst_.write_buf();
-        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        auto w = detail::work(h_.h, input, out);
         input.consume(w.consumed);
         out.produce(w.produced, {});
         return w.st == RR_WAIT_DST ? BlockRet::wait(dst_.wait_handle(), w.need) : BlockRet::wait(src_.wait_handle(), w.need);
@@ -451,7 +514,7 @@ public:
         auto [input, tags] = src_.read_buf();
         (void)tags;
         auto out = dst_.write_buf();
-        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        auto w = detail::work(h_.h, input, out);
         input.consume(w.consumed);
         out.produce(w.produced, {});
         return w.st == RR_WAIT_DST ? BlockRet::wait(dst_.wait_handle(), w.need) : BlockRet::wait(src_.wait_handle(), w.need);
@@ -475,7 +538,7 @@ public:
         auto [input, tags] = src_.read_buf();
         (void)tags;
         auto out = dst_.write_buf();
-        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        auto w = detail::work(h_.h, input, out);
         input.consume(w.consumed);
         out.produce(w.produced, {});
         return w.st == RR_WAIT_DST ? BlockRet::wait(dst_.wait_handle(), w.need) : BlockRet::wait(src_.wait_handle(), w.need);
@@ -500,7 +563,7 @@ public:
     BlockRet work() override {                    // :72-128
         auto [input, tags] = src_.read_buf();
         auto out = dst_.write_buf();
-        auto w = detail::work(h_.h, input.slice(), input.len(), out.slice(), out.len());
+        auto w = detail::work(h_.h, input, out);
         if (w.st == RR_WAIT_SRC) { out.produce(0, {}); return BlockRet::wait(src_.wait_handle(), w.need); }
         if (w.st == RR_WAIT_DST) { out.produce(0, {}); return BlockRet::wait(dst_.wait_handle(), w.need); }
         std::vector<Tag> keep;                    // :119-123
@@ -565,7 +628,9 @@ public:
         auto [input, tags] = src_.read_buf();
         const size_t n = input.len();
         for (auto& t : tags) tags_->emplace_back(t.pos() + data_->size(), t.key(), t.val());
-        data_->insert(data_->end(), input.begin(), input.end());
+        const size_t at = data_->size();
+        data_->resize(at + n);
+        input.copy_to(data_->data() + at, n);
         input.consume(n);
         return BlockRet::wait(src_.wait_handle(), 1);
     }
@@ -582,6 +647,111 @@ public:
         (void)tags;
         input.consume(input.len());
         return BlockRet::wait(src_.wait_handle(), 1);
+    }
+};
+
+// Moves samples (and tags) between streams of any placement: the explicit upload / download step of a
+// graph that mixes CPU blocks and device-resident GPU chains.  No reference counterpart.
+template <class T> class MemCopy : public Block {
+    ReadStream<T> src_;
+    WriteStream<T> dst_;
+    std::vector<T> bounce_;
+public:
+    MemCopy(ReadStream<T> src, WriteStream<T> dst) : src_(std::move(src)), dst_(std::move(dst)) {}
+    static std::pair<std::unique_ptr<MemCopy<T>>, ReadStream<T>> new_(ReadStream<T> src, Memory to) {
+        auto [w, r] = new_stream<T>(DEFAULT_STREAM_SIZE, to);
+        return {std::make_unique<MemCopy<T>>(std::move(src), std::move(w)), std::move(r)};
+    }
+    const char* block_name() const override { return "MemCopy"; }
+    bool eof() override { return src_.eof(); }
+    BlockRet work() override {
+        auto [input, tags] = src_.read_buf();
+        auto out = dst_.write_buf();
+        const size_t n = std::min(input.len(), out.len());
+        if (n == 0) {
+            out.produce(0, {});
+            return input.len() == 0 ? BlockRet::wait(src_.wait_handle(), 1) : BlockRet::wait(dst_.wait_handle(), 1);
+        }
+        std::vector<Tag> keep;
+        for (auto& t : tags) if (t.pos() < n) keep.push_back(t);
+        if (!input.device()) out.fill_from_slice(input.slice(), n);
+        else if (!out.device()) input.copy_to(out.slice(), n);
+        else { bounce_.resize(n); input.copy_to(bounce_.data(), n); out.fill_from_slice(bounce_.data(), n); }
+        input.consume(n);
+        out.produce(n, keep);
+        return BlockRet::again();
+    }
+};
+
+// Tee (src/tee.rs:10-24): every input sample and tag goes to both outputs.
+template <class T> class Tee : public Block {
+    ReadStream<T> src_;
+    WriteStream<T> dst1_, dst2_;
+    std::vector<T> bounce_;
+public:
+    Tee(ReadStream<T> src, WriteStream<T> d1, WriteStream<T> d2) : src_(std::move(src)), dst1_(std::move(d1)), dst2_(std::move(d2)) {}
+    static std::tuple<std::unique_ptr<Tee<T>>, ReadStream<T>, ReadStream<T>> new_(ReadStream<T> src) {
+        auto [w1, r1] = new_stream<T>();
+        auto [w2, r2] = new_stream<T>();
+        return {std::make_unique<Tee<T>>(std::move(src), std::move(w1), std::move(w2)), std::move(r1), std::move(r2)};
+    }
+    const char* block_name() const override { return "Tee"; }
+    bool eof() override { return src_.eof(); }
+    BlockRet work() override {                    // the `sync` macro loop: min over the input and both outputs
+        auto [input, tags] = src_.read_buf();
+        auto o1 = dst1_.write_buf();
+        auto o2 = dst2_.write_buf();
+        const size_t n = std::min(input.len(), std::min(o1.len(), o2.len()));
+        if (n == 0) {
+            o1.produce(0, {}); o2.produce(0, {});
+            if (input.len() == 0) return BlockRet::wait(src_.wait_handle(), 1);
+            return BlockRet::wait(o1.len() == 0 ? dst1_.wait_handle() : dst2_.wait_handle(), 1);
+        }
+        std::vector<Tag> keep;
+        for (auto& t : tags) if (t.pos() < n) keep.push_back(t);
+        const T* hp = nullptr;
+        if (input.device()) { bounce_.resize(n); input.copy_to(bounce_.data(), n); hp = bounce_.data(); }
+        else hp = input.slice();
+        o1.fill_from_slice(hp, n);
+        o2.fill_from_slice(hp, n);
+        input.consume(n);
+        o1.produce(n, keep);
+        o2.produce(n, keep);
+        return BlockRet::again();
+    }
+};
+
+// SignalSourceComplex (src/signal_source.rs:9-63): amplitude * (sin(c), sin(c - pi/2)), the phase kept in
+// f64 and wrapped with fmod each sample; fills the whole write window per work().
+class SignalSourceComplex : public Block {
+    WriteStream<Complex> dst_;
+    Float amplitude_;
+    double rad_per_sample_, current_ = 0.0;
+    std::vector<Complex> tmp_;
+public:
+    SignalSourceComplex(WriteStream<Complex> dst, Float samp_rate, Float freq, Float amplitude)
+        : dst_(std::move(dst)), amplitude_(amplitude),
+          rad_per_sample_(2.0 * M_PI * (double)freq / (double)samp_rate) {
+        if (!(samp_rate > 0.0f)) throw Error("SignalSourceComplex: samp_rate must be > 0");   // :26 assert
+    }
+    static std::pair<std::unique_ptr<SignalSourceComplex>, ReadStream<Complex>> new_(Float samp_rate, Float freq, Float amplitude) {
+        auto [w, r] = new_stream<Complex>();
+        return {std::make_unique<SignalSourceComplex>(std::move(w), samp_rate, freq, amplitude), std::move(r)};
+    }
+    const char* block_name() const override { return "SignalSourceComplex"; }
+    bool eof() override { return false; }
+    BlockRet work() override {                    // :55-63
+        auto o = dst_.write_buf();
+        const size_t n = o.len();
+        tmp_.resize(n);
+        for (size_t i = 0; i < n; i++) {          // Iterator::next, :41-52
+            current_ = std::fmod(current_ + rad_per_sample_, 2.0 * M_PI);
+            const Complex v((Float)std::sin(current_), (Float)std::sin(current_ - M_PI / 2.0));
+            tmp_[i] = amplitude_ * v;
+        }
+        o.fill_from_slice(tmp_.data(), n);
+        o.produce(n, {});
+        return BlockRet::wait(dst_.wait_handle(), 1);
     }
 };
 

@@ -211,9 +211,102 @@ static void graph_fm_chain() {
     CHECK(worst < 1e-4);
 }
 
+// The same Graph, rings in host memory vs rings in HBM: identical samples and tags.
+template <class F> static auto with_memory(Memory m, F&& f) {
+    const Memory old = default_memory();
+    default_memory() = m;
+    auto r = f();
+    default_memory() = old;
+    return r;
+}
+static void device_resident_graph() {
+    const size_t n = 300000;
+    std::vector<uint8_t> bytes(2 * n + 1);
+    uint32_t lcg = 12345;
+    for (auto& b : bytes) { lcg = lcg * 1664525u + 1013904223u; b = (uint8_t)(lcg >> 24); }
+    auto taps = fir::low_pass_complex(2.4e6f, 100e3f, 50e3f, WindowType::Hamming());
+    auto run = [&]() {
+        auto [src, s0] = VectorSource<uint8_t>::new_(bytes);
+        auto [dec, s1] = RtlSdrDecode::new_(std::move(s0));
+        auto [fft, s2] = FftFilter::new_(std::move(s1), taps);
+        auto [rs, s3] = RationalResampler<Complex>::new_(std::move(s2), 3, 7);
+        auto [qd, s4] = QuadratureDemod::new_(std::move(s3), 0.5f);
+        auto sink = std::make_unique<VectorSink<Float>>(std::move(s4));
+        auto hook = sink->hook();
+        Graph g;
+        g.add(std::move(src)); g.add(std::move(dec)); g.add(std::move(fft)); g.add(std::move(rs)); g.add(std::move(qd));
+        g.add(std::move(sink));
+        g.run();
+        return *hook;
+    };
+    const auto yh = with_memory(Memory::Host, run);
+    const auto yd = with_memory(Memory::Device, run);
+    CHECK(yh.size() > 1000);
+    CHECK(yh == yd);
+    // tags travel host-side with a device-resident FIR exactly as with a host one (fir.rs:536-545)
+    auto run_fir = [&]() {
+        std::vector<Complex> x(5000);
+        for (size_t i = 0; i < x.size(); i++) x[i] = Complex((float)i, -(float)i);
+        auto [src, s0] = VectorSource<Complex>::new_(x, Repeat::finite(3));
+        auto [f, s1] = FirFilter<Complex>::builder({{0.5f, 0}, {0.25f, 0}, {0, 0.25f}}).deci(4).build(std::move(s0));
+        auto sink = std::make_unique<VectorSink<Complex>>(std::move(s1));
+        auto hook = sink->hook();
+        auto th = sink->tag_hook();
+        Graph g;
+        g.add(std::move(src)); g.add(std::move(f)); g.add(std::move(sink));
+        g.run();
+        std::vector<std::pair<size_t, std::string>> tags;
+        for (auto& t : *th) tags.emplace_back(t.pos(), t.key());
+        return std::make_pair(*hook, tags);
+    };
+    const auto fh = with_memory(Memory::Host, run_fir);
+    const auto fd = with_memory(Memory::Device, run_fir);
+    CHECK(fh.first.size() > 3000 && fh.first == fd.first);
+    CHECK(!fh.second.empty() && fh.second == fd.second);
+    // MemCopy: a CPU-side source feeding a device-resident chain and back
+    {
+        std::vector<Float> x(70000);
+        for (size_t i = 0; i < x.size(); i++) x[i] = (float)std::sin(0.5 * (double)i);
+        auto [src, s0] = VectorSource<Float>::new_(x);                                  // host ring
+        auto [up, s1] = MemCopy<Float>::new_(std::move(s0), Memory::Device);
+        auto [hb, s2] = with_memory(Memory::Device, [&, s = std::move(s1)]() mutable {
+            return Hilbert::new_(std::move(s), 65, WindowType::Hamming()); });
+        auto [down, s3] = MemCopy<Complex>::new_(std::move(s2), Memory::Host);
+        auto sink = std::make_unique<VectorSink<Complex>>(std::move(s3));
+        auto hook = sink->hook();
+        Graph g;
+        g.add(std::move(src)); g.add(std::move(up)); g.add(std::move(hb)); g.add(std::move(down)); g.add(std::move(sink));
+        g.run();
+        CHECK(hook->size() == x.size());
+        double worst = 0;                       // analytic signal of a sine: |a| -> 1, re = the input delayed by 32
+        for (size_t i = 2000; i < hook->size(); i++) worst = std::max(worst, std::fabs(std::abs((*hook)[i]) - 1.0));
+        CHECK(worst < 2e-2);
+        CHECK((*hook)[5000].real() == x[5000 - 33]);
+    }
+}
+
+static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal_source.rs:9-63
+    auto [ss, s0] = SignalSourceComplex::new_(1200.0f, 100.0f, 1.0f);
+    CHECK(is_wait(ss->work()));
+    {
+        auto [o, tags] = s0.read_buf();
+        CHECK(o.len() == 512000);                // fills the whole ring (quadrature_demod.rs:176-183)
+        const double w = 2.0 * M_PI * 100.0 / 1200.0;
+        CHECK(std::abs(o.slice()[0] - Complex((float)std::sin(w), (float)std::sin(w - M_PI / 2))) < 1e-6f);
+        o.consume(512000 - 10);
+    }
+    auto [tee, a, b] = Tee<Complex>::new_(std::move(s0));
+    CHECK(tee->work().kind == BlockRet::Again);
+    auto [ra, ta] = a.read_buf();
+    auto [rb, tb] = b.read_buf();
+    CHECK(ra.len() == 10 && rb.len() == 10);
+    for (size_t i = 0; i < 10; i++) CHECK(ra.slice()[i] == rb.slice()[i]);
+}
+
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
     fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
+    device_resident_graph(); tee_and_signal_source();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }
