@@ -538,6 +538,7 @@ template <class KFn> static long grid_for_tiles(KFn kfn, int T, size_t smem, lon
         RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, T, smem));
         if (per_cu < 1) per_cu = 1;
+        if (const char* e = getenv("RR_FFT_PERCU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;   // measurement knob (tools/fft_percu.sh)
         attr_set = true;
     }
     long grid = (long)device_cu_count() * per_cu;
