@@ -97,6 +97,12 @@ rr_block *rr_quaddemod_create(float gain, int atan2_mode);
 /* RtlSdrDecode::new(src) (src/rtlsdr_decode.rs:9-47): u8 I/Q byte pairs -> Complex,
  * (b - 127) * 0.008; input windows are counted in BYTES, an odd trailing byte is left unconsumed. */
 rr_block *rr_rtlsdr_decode_create(void);
+/* MultiplyConst::<Float|Complex>::new(src, val) (src/multiply_const.rs:6-23) and FastFM::new(src)
+ * (src/quadrature_demod.rs:144-165): #[rustradio(sync)] blocks — work() maps min(input, output space)
+ * samples and returns WaitForStream(src|dst, 1) (rustradio_macros_code/src/lib.rs:458-515).  Bit-exact. */
+rr_block *rr_multiply_const_f32_create(float val);
+rr_block *rr_multiply_const_c32_create(float re, float im);
+rr_block *rr_fastfm_create(void);
 /* Hilbert::new(src, ntaps, &window_type) (src/hilbert.rs:38-61); ntaps odd > 1. */
 rr_block *rr_hilbert_create(size_t ntaps, int window, float window_parm);
 

@@ -57,6 +57,9 @@ def lib():
     L.orc_quaddemod_new.argtypes = [f32, i32]; L.orc_quaddemod_new.restype = vp
     L.orc_hilbert_new.argtypes = [sz, i32, f32]; L.orc_hilbert_new.restype = vp
     L.orc_rtlsdr_decode_new.argtypes = []; L.orc_rtlsdr_decode_new.restype = vp
+    L.orc_multiply_const_f32_new.argtypes = [f32]; L.orc_multiply_const_f32_new.restype = vp
+    L.orc_multiply_const_c32_new.argtypes = [f32, f32]; L.orc_multiply_const_c32_new.restype = vp
+    L.orc_fastfm_new.argtypes = []; L.orc_fastfm_new.restype = vp
     L.orc_block_free.argtypes = [vp]; L.orc_block_free.restype = None
     L.orc_block_work.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.orc_block_work.restype = i32
@@ -213,6 +216,17 @@ def RationalResampler(interp: int, deci: int, dtype=np.complex64) -> OracleBlock
 
 def QuadratureDemod(gain: float = 1.0, mode: int = ATAN2_EXACT) -> OracleBlock:
     return OracleBlock(lib().orc_quaddemod_new(gain, mode), np.complex64, np.float32, "QuadratureDemod")
+
+
+def MultiplyConst(val, dtype=np.float32) -> OracleBlock:
+    if np.dtype(dtype) == np.complex64:
+        v = complex(val)
+        return OracleBlock(lib().orc_multiply_const_c32_new(v.real, v.imag), np.complex64, np.complex64, "MultiplyConst")
+    return OracleBlock(lib().orc_multiply_const_f32_new(float(val)), np.float32, np.float32, "MultiplyConst")
+
+
+def FastFM() -> OracleBlock:
+    return OracleBlock(lib().orc_fastfm_new(), np.complex64, np.float32, "FastFM")
 
 
 def RtlSdrDecode() -> OracleBlock:

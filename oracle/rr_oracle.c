@@ -284,7 +284,7 @@ float orc_fast_atan2(float y, float x) {
 }
 
 /* ---- streaming blocks ----------------------------------------------------------- */
-enum { K_FIR_C32, K_FIR_F32, K_FFTFILT, K_FFTFILT_F, K_RESAMP, K_QUAD, K_HILBERT, K_RTLSDR };
+enum { K_FIR_C32, K_FIR_F32, K_FFTFILT, K_FFTFILT_F, K_RESAMP, K_QUAD, K_HILBERT, K_RTLSDR, K_MULC_F, K_MULC_C, K_FASTFM };
 
 struct orc_block {
     int kind;
@@ -315,6 +315,9 @@ struct orc_block {
     float gain; int atan2_mode;
     /* Hilbert */
     float *history;
+    /* MultiplyConst / FastFM */
+    orc_c32 mval;
+    orc_c32 q1, q2;
 };
 
 size_t orc_block_in_elem_size(const orc_block *b) { return b->in_es; }
@@ -438,6 +441,22 @@ orc_block *orc_quaddemod_new(float gain, int atan2_mode) {
     orc_block *b = (orc_block *)calloc(1, sizeof *b);
     b->kind = K_QUAD; b->in_es = sizeof(orc_c32); b->out_es = sizeof(float);
     b->gain = gain; b->atan2_mode = atan2_mode;
+    return b;
+}
+
+orc_block *orc_multiply_const_f32_new(float val) { /* multiply_const.rs:6-23 */
+    orc_block *b = (orc_block *)calloc(1, sizeof *b);
+    b->kind = K_MULC_F; b->in_es = b->out_es = sizeof(float); b->mval.re = val;
+    return b;
+}
+orc_block *orc_multiply_const_c32_new(float re, float im) {
+    orc_block *b = (orc_block *)calloc(1, sizeof *b);
+    b->kind = K_MULC_C; b->in_es = b->out_es = sizeof(orc_c32); b->mval.re = re; b->mval.im = im;
+    return b;
+}
+orc_block *orc_fastfm_new(void) { /* quadrature_demod.rs:144-165; q1 = q2 = 0 (#[rustradio(default)]) */
+    orc_block *b = (orc_block *)calloc(1, sizeof *b);
+    b->kind = K_FASTFM; b->in_es = sizeof(orc_c32); b->out_es = sizeof(float);
     return b;
 }
 
@@ -653,6 +672,33 @@ static int work_rtlsdr(const unsigned char *in, size_t in_len, orc_c32 *out, siz
     }
 }
 
+/* work() of a #[rustradio(sync)] block (rustradio_macros_code/src/lib.rs:458-515): a loop that maps
+ * min(input, output space) samples through process_sync and stops on the side that ran dry. */
+static int work_sync(orc_block *b, const void *in, size_t in_len, void *out, size_t out_cap,
+                     size_t *consumed, size_t *produced, size_t *need) {
+    size_t ipos = 0, opos = 0;
+    *need = 1;
+    for (;;) {
+        if (in_len - ipos == 0) { *consumed = ipos; *produced = opos; return ORC_WAIT_SRC; }
+        if (out_cap - opos == 0) { *consumed = ipos; *produced = opos; return ORC_WAIT_DST; }
+        size_t n = in_len - ipos < out_cap - opos ? in_len - ipos : out_cap - opos;
+        for (size_t i = 0; i < n; i++) {
+            if (b->kind == K_MULC_F) {                                  /* multiply_const.rs:20-22: x * self.val */
+                ((float *)out)[opos + i] = ((const float *)in)[ipos + i] * b->mval.re;
+            } else if (b->kind == K_MULC_C) {
+                ((orc_c32 *)out)[opos + i] = c_mul(((const orc_c32 *)in)[ipos + i], b->mval);
+            } else {                                                    /* FastFM::process_sync, quadrature_demod.rs:158-164 */
+                const orc_c32 s = ((const orc_c32 *)in)[ipos + i];
+                const float top = (s.im - b->q2.im) * b->q1.re;
+                const float bottom = (s.re - b->q2.re) * b->q1.im;
+                b->q2 = b->q1; b->q1 = s;
+                ((float *)out)[opos + i] = top - bottom;
+            }
+        }
+        ipos += n; opos += n;
+    }
+}
+
 /* Hilbert::work, hilbert.rs:72-128 */
 static int work_hilbert(orc_block *b, const float *in, size_t in_len, orc_c32 *out, size_t out_cap,
                         size_t *consumed, size_t *produced, size_t *need) {
@@ -686,6 +732,9 @@ int orc_block_work(orc_block *b, const void *in, size_t in_len, void *out, size_
     case K_RESAMP: return work_resampler(b, (const unsigned char *)in, in_len, (unsigned char *)out, out_cap, consumed, produced, need);
     case K_QUAD: return work_quad(b, (const orc_c32 *)in, in_len, (float *)out, out_cap, consumed, produced, need);
     case K_HILBERT: return work_hilbert(b, (const float *)in, in_len, (orc_c32 *)out, out_cap, consumed, produced, need);
+    case K_MULC_F:
+    case K_MULC_C:
+    case K_FASTFM: return work_sync(b, in, in_len, out, out_cap, consumed, produced, need);
     case K_RTLSDR: return work_rtlsdr((const unsigned char *)in, in_len, (orc_c32 *)out, out_cap, consumed, produced, need);
     }
     set_err("bad block kind");

@@ -87,6 +87,11 @@ orc_block *orc_resampler_new(size_t interp, size_t deci, size_t elem_size);
 orc_block *orc_quaddemod_new(float gain, int atan2_mode);
 /* RtlSdrDecode (rtlsdr_decode.rs:9-47): u8 I/Q pairs -> Complex, (b - 127) * 0.008. */
 orc_block *orc_rtlsdr_decode_new(void);
+/* MultiplyConst<Float> / <Complex> (multiply_const.rs:6-23) and FastFM (quadrature_demod.rs:144-165):
+ * #[rustradio(sync)] blocks, work() per rustradio_macros_code/src/lib.rs:458-515. */
+orc_block *orc_multiply_const_f32_new(float val);
+orc_block *orc_multiply_const_c32_new(float re, float im);
+orc_block *orc_fastfm_new(void);
 /* Hilbert (hilbert.rs:22-129). */
 orc_block *orc_hilbert_new(size_t ntaps, int wtype, float parm);
 

@@ -250,6 +250,19 @@ def RationalResampler(interp: int, deci: int, dtype=np.complex64) -> Block:
     return Block(lib().rr_resampler_create(interp, deci, dt.itemsize), dt, dt)
 
 
+def MultiplyConst(val, dtype=np.float32) -> Block:
+    """MultiplyConst::new(src, val) (src/multiply_const.rs:6-23), Float or Complex."""
+    if np.dtype(dtype) == np.complex64:
+        v = complex(val)
+        return Block(lib().rr_multiply_const_c32_create(v.real, v.imag), np.complex64, np.complex64)
+    return Block(lib().rr_multiply_const_f32_create(float(val)), np.float32, np.float32)
+
+
+def FastFM() -> Block:
+    """FastFM::new(src) (src/quadrature_demod.rs:144-165)."""
+    return Block(lib().rr_fastfm_create(), np.complex64, np.float32)
+
+
 def RtlSdrDecode() -> Block:
     """RtlSdrDecode::new(src) (src/rtlsdr_decode.rs:9-47): u8 I/Q pairs -> Complex."""
     return Block(lib().rr_rtlsdr_decode_create(), np.uint8, np.complex64)

@@ -110,6 +110,15 @@ rr_block* rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_p
         return new rr::HilbertFir(hilbert_ntaps, window, window_parm, taps, ntaps, deci, translate != 0, samp_rate, freq);
     });
 }
+rr_block* rr_multiply_const_f32_create(float val) {
+    return make_block([&] { return new rr::MultiplyConst(4, val, 0.0f); });
+}
+rr_block* rr_multiply_const_c32_create(float re, float im) {
+    return make_block([&] { return new rr::MultiplyConst(8, re, im); });
+}
+rr_block* rr_fastfm_create(void) {
+    return make_block([&] { return new rr::FastFM(); });
+}
 rr_block* rr_rtlsdr_decode_create(void) {
     return make_block([&] { return new rr::RtlSdrDecode(); });
 }

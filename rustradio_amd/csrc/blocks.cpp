@@ -673,6 +673,48 @@ int QuadDemod::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     *need = 1; return RR_WAIT_DST;
 }
 
+// ---- MultiplyConst, FastFM (sync blocks) ------------------------------------------------------------------------
+static int sync_counts(size_t in_len, size_t out_cap, size_t* n, size_t* need) {
+    *need = 1;
+    if (in_len == 0) { *n = 0; return RR_WAIT_SRC; }
+    if (out_cap == 0) { *n = 0; return RR_WAIT_DST; }
+    *n = std::min(in_len, out_cap);
+    return in_len - *n == 0 ? RR_WAIT_SRC : RR_WAIT_DST;      // the loop's next iteration
+}
+MultiplyConst::MultiplyConst(size_t es, float re, float im) : Block("MultiplyConst", es, es), vr(re), vi(im) {
+    if (es != 4 && es != 8) throw Error("MultiplyConst: Float or Complex only");
+}
+int MultiplyConst::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                            size_t* produced, size_t* need, hipStream_t s) {
+    size_t n = 0;
+    const int st = sync_counts(in_len, out_cap, &n, need);
+    prof_begin(s);
+    if (in_es == 4) launch_mulconst_f32(static_cast<const float*>(in), static_cast<float*>(out), (long)n, vr, s);
+    else launch_mulconst_c32(static_cast<const cf*>(in), static_cast<cf*>(out), (long)n, vr, vi, s);
+    prof_end(s);
+    *consumed = *produced = n;
+    return st;
+}
+FastFM::FastFM() : Block("FastFM", 8, 4) {
+    for (auto& h : hist) { h.reserve(2); RR_HIP(hipMemsetAsync(h.p, 0, 2 * sizeof(cf), stream)); }
+    RR_HIP(hipStreamSynchronize(stream));
+}
+int FastFM::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                     size_t* produced, size_t* need, hipStream_t s) {
+    size_t n = 0;
+    const int st = sync_counts(in_len, out_cap, &n, need);
+    if (n) {
+        VSrc<cf> src{hist[cur].p, 2, static_cast<const cf*>(in), (long)in_len};
+        prof_begin(s);
+        launch_fastfm(src, static_cast<float*>(out), (long)n, s);
+        prof_end(s);
+        launch_vcopy_c32(src, (long)n, hist[cur ^ 1].p, 2, s);       // q2, q1 for the next call
+        cur ^= 1;
+    }
+    *consumed = *produced = n;
+    return st;
+}
+
 // ---- RtlSdrDecode (rtlsdr_decode.rs:9-47) ----------------------------------------------------------------------
 RtlSdrDecode::RtlSdrDecode() : Block("RtlSdrDecode", 1, 8) {}
 int RtlSdrDecode::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,

@@ -152,6 +152,20 @@ struct QuadDemod : Block {
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 
+// #[rustradio(sync)] blocks (rustradio_macros_code/src/lib.rs:458-515): map min(input, output space) samples,
+// then WaitForStream on the side that ran dry.
+struct MultiplyConst : Block {        // multiply_const.rs:6-23, T = Float (es 4) or Complex (es 8)
+    float vr, vi;
+    MultiplyConst(size_t es, float re, float im);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+struct FastFM : Block {               // quadrature_demod.rs:144-165; q2, q1 = the two previous samples (zeros at start)
+    DevBuf<cf> hist[2];
+    int cur = 0;
+    FastFM();
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
 // RtlSdrDecode (rtlsdr_decode.rs:9-47): stateless u8 pair -> Complex conversion.
 struct RtlSdrDecode : Block {
     RtlSdrDecode();

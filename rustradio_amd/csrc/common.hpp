@@ -63,6 +63,16 @@ template <class T> struct VSrc {
 #endif
 };
 
+#if defined(__HIPCC__)
+// Exactly-rounded single operations that the optimiser cannot fuse.  The kernels are compiled with
+// -ffp-contract=fast and HIP's __fmul_rn/__fadd_rn/__fsub_rn are plain operators — which it DOES
+// contract into FMAs (found by the bit-exact MultiplyConst<Complex> test).  Used wherever the
+// reference's un-fused f32 arithmetic has to be reproduced bit for bit.
+__device__ __forceinline__ float mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float add_rn(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float sub_rn(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#endif
+
 // The same with the window still in the RTL-SDR wire format (u8 I/Q pairs, rtlsdr_decode.rs:35-42):
 // the carried prefix is already Complex, window samples are decoded on load —
 // (Float::from(b) - 127.0) * 0.008, bit-identical to the RtlSdrDecode block.
@@ -73,7 +83,7 @@ struct VSrcIQ8 {
     const iq8* in;       // 2-byte aligned
     long in_len;         // samples (byte pairs)
 #if defined(__HIPCC__)
-    static __device__ __forceinline__ float cvt(unsigned b) { return __fmul_rn(__fsub_rn((float)b, 127.0f), 0.008f); }
+    static __device__ __forceinline__ float cvt(unsigned b) { return mul_rn(sub_rn((float)b, 127.0f), 0.008f); }
     static __device__ __forceinline__ cf decode(unsigned short w) {
         cf r; r.x = cvt(w & 0xffu); r.y = cvt(w >> 8); return r;
     }

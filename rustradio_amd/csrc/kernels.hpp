@@ -73,6 +73,10 @@ void launch_resample(const void* in, void* out, size_t es, long r, const void* p
                      long n_gather, long I, long D, long c0, hipStream_t s);
 // out[n] = gain * atan2(Im z, Re z), z = conj(x[n]) x[n+1], n < n_out
 void launch_quaddemod(const cf* in, float* out, long n_out, float gain, int mode, hipStream_t s);
+void launch_mulconst_f32(const float* in, float* out, long n, float v, hipStream_t s);
+void launch_mulconst_c32(const cf* in, cf* out, long n, float vr, float vi, hipStream_t s);
+// FastFM over src = (q2, q1) || window: n outputs
+void launch_fastfm(VSrc<cf> src, float* out, long n, hipStream_t s);
 // RtlSdrDecode: out[i] = ((in[2i] - 127) * 0.008, (in[2i+1] - 127) * 0.008)
 void launch_rtlsdr_decode(const unsigned char* in, cf* out, long n_out, hipStream_t s);
 // dst[i] = src.load(v0 + i), i < n   (carry-state update)

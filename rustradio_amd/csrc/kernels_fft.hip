@@ -343,17 +343,17 @@ __device__ __forceinline__ float fmc_flip_sign(float v, float s) {
     return __uint_as_float(__float_as_uint(v) ^ (__float_as_uint(s) & 0x80000000u));
 }
 __device__ __forceinline__ float fmc_atan_raw(float x) {
-    return __fmul_rn(__fsub_rn(__fadd_rn(0.78539816339744830962f, 0.273f), __fmul_rn(0.273f, fabsf(x))), x);
+    return mul_rn(sub_rn(add_rn(0.78539816339744830962f, 0.273f), mul_rn(0.273f, fabsf(x))), x);
 }
 __device__ __forceinline__ float fmc_atan2(float y, float x) {
     if (fabsf(y) < fabsf(x)) {
         const float bias = x > 0.0f ? 0.0f : 3.14159265358979323846f;
-        return __fadd_rn(fmc_flip_sign(bias, y), fmc_atan_raw(__fdiv_rn(y, x)));
+        return add_rn(fmc_flip_sign(bias, y), fmc_atan_raw(__fdiv_rn(y, x)));
     } else if (x == 0.0f) {
         if (y == 0.0f) return 0.0f;
         return fmc_flip_sign(1.57079632679489661923f, y);
     }
-    return __fsub_rn(fmc_flip_sign(1.57079632679489661923f, y), fmc_atan_raw(__fdiv_rn(x, y)));
+    return sub_rn(fmc_flip_sign(1.57079632679489661923f, y), fmc_atan_raw(__fdiv_rn(x, y)));
 }
 
 struct FmArgs {
@@ -417,10 +417,10 @@ void k_fm_chain(SRC src, float* __restrict__ out, int L, long ntiles, const cf* 
             }
             // conj(rl) * ru in num-complex order, un-contracted (quadrature_demod.rs:72)
             const float na = -rl.y;
-            const float re = __fsub_rn(__fmul_rn(rl.x, ru.x), __fmul_rn(na, ru.y));
-            const float im = __fadd_rn(__fmul_rn(rl.x, ru.y), __fmul_rn(na, ru.x));
+            const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
+            const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
             const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
-            out[(u - 1) - a.o_base] = __fmul_rn(a.gain, ang);
+            out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
         }
         tile_sync<T>();        // epilogue reads done before the next tile's first exchange
     }
@@ -490,10 +490,10 @@ void k_fm_multi(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, l
                     rl = lds[lds_pad((int)(gl - ys) + first)];
                 }
                 const float na = -rl.y;
-                const float re = __fsub_rn(__fmul_rn(rl.x, ru.x), __fmul_rn(na, ru.y));
-                const float im = __fadd_rn(__fmul_rn(rl.x, ru.y), __fmul_rn(na, ru.x));
+                const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
+                const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
                 const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
-                oc[(u - 1) - a.o_base] = __fmul_rn(a.gain, ang);
+                oc[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
             }
             tile_sync<T>();
         }

@@ -515,8 +515,8 @@ __global__ __launch_bounds__(256) void k_rotate_table(cf* __restrict__ y, long n
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const cf v = y[i], p = tab[i];
         // sample * phase, un-contracted num-complex order (fir.rs:469)
-        y[i] = mkcf(__fsub_rn(__fmul_rn(v.x, p.x), __fmul_rn(v.y, p.y)),
-                  __fadd_rn(__fmul_rn(v.x, p.y), __fmul_rn(v.y, p.x)));
+        y[i] = mkcf(sub_rn(mul_rn(v.x, p.x), mul_rn(v.y, p.y)),
+                  add_rn(mul_rn(v.x, p.y), mul_rn(v.y, p.x)));
     }
 }
 static unsigned rot_grid(long n) {

@@ -59,17 +59,17 @@ __device__ __forceinline__ float flip_sign(float v, float s) {
     return __uint_as_float(__float_as_uint(v) ^ (__float_as_uint(s) & 0x80000000u));
 }
 __device__ __forceinline__ float fm_atan_raw(float x) {
-    return __fmul_rn(__fsub_rn(__fadd_rn(0.78539816339744830962f, 0.273f), __fmul_rn(0.273f, fabsf(x))), x);
+    return mul_rn(sub_rn(add_rn(0.78539816339744830962f, 0.273f), mul_rn(0.273f, fabsf(x))), x);
 }
 __device__ __forceinline__ float fm_atan2(float y, float x) {
     if (fabsf(y) < fabsf(x)) {
         const float bias = x > 0.0f ? 0.0f : 3.14159265358979323846f;
-        return __fadd_rn(flip_sign(bias, y), fm_atan_raw(__fdiv_rn(y, x)));
+        return add_rn(flip_sign(bias, y), fm_atan_raw(__fdiv_rn(y, x)));
     } else if (x == 0.0f) {
         if (y == 0.0f) return 0.0f;
         return flip_sign(1.57079632679489661923f, y);
     }
-    return __fsub_rn(flip_sign(1.57079632679489661923f, y), fm_atan_raw(__fdiv_rn(x, y)));
+    return sub_rn(flip_sign(1.57079632679489661923f, y), fm_atan_raw(__fdiv_rn(x, y)));
 }
 
 template <int MODE>
@@ -79,10 +79,10 @@ __global__ __launch_bounds__(256) void k_quaddemod(const cf* __restrict__ in, fl
         const cf a = in[n], b = in[n + 1];
         // conj(a) * b in num-complex order, un-contracted so that signed zeros behave as on the CPU
         const float na = -a.y;
-        const float re = __fsub_rn(__fmul_rn(a.x, b.x), __fmul_rn(na, b.y));
-        const float im = __fadd_rn(__fmul_rn(a.x, b.y), __fmul_rn(na, b.x));
+        const float re = sub_rn(mul_rn(a.x, b.x), mul_rn(na, b.y));
+        const float im = add_rn(mul_rn(a.x, b.y), mul_rn(na, b.x));
         const float ang = MODE == 0 ? atan2f(im, re) : fm_atan2(im, re);
-        out[n] = __fmul_rn(gain, ang);
+        out[n] = mul_rn(gain, ang);
     }
 }
 
@@ -98,7 +98,7 @@ void launch_quaddemod(const cf* in, float* out, long n_out, float gain, int mode
 // (Float::from(b) - 127.0) * 0.008, two roundings at most (the subtraction is exact): bit-exact.
 // 10 B of traffic per sample; a thread converts 2 samples (4-byte load, 16-byte store), both
 // lane-consecutive.
-__device__ __forceinline__ float rtl_cvt(unsigned b) { return __fmul_rn(__fsub_rn((float)b, 127.0f), 0.008f); }
+__device__ __forceinline__ float rtl_cvt(unsigned b) { return mul_rn(sub_rn((float)b, 127.0f), 0.008f); }
 __global__ __launch_bounds__(256) void k_rtlsdr_decode2(const unsigned* __restrict__ in, float4* __restrict__ out,
                                                         long npairs) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (long)gridDim.x * blockDim.x) {
@@ -126,6 +126,44 @@ void launch_rtlsdr_decode(const unsigned char* in, cf* out, long n_out, hipStrea
                            out + done, n_out - done);
         RR_HIP(hipGetLastError());
     }
+}
+
+// ---- MultiplyConst (src/multiply_const.rs:20-22) and FastFM (src/quadrature_demod.rs:158-164) -----------
+// bit-exact: one rounding per multiply / subtract, no contraction (num-complex Mul order for Complex)
+__global__ __launch_bounds__(256) void k_mulconst_f32(const float* __restrict__ in, float* __restrict__ out, long n, float v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = mul_rn(in[i], v);
+}
+__global__ __launch_bounds__(256) void k_mulconst_c32(const cf* __restrict__ in, cf* __restrict__ out, long n, float vr, float vi) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const cf a = in[i];
+        out[i] = mkcf(sub_rn(mul_rn(a.x, vr), mul_rn(a.y, vi)), add_rn(mul_rn(a.x, vi), mul_rn(a.y, vr)));
+    }
+}
+void launch_mulconst_f32(const float* in, float* out, long n, float v, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_mulconst_f32, dim3(grid_for(n, 256)), dim3(256), 0, s, in, out, n, v);
+    RR_HIP(hipGetLastError());
+}
+void launch_mulconst_c32(const cf* in, cf* out, long n, float vr, float vi, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_mulconst_c32, dim3(grid_for(n, 256)), dim3(256), 0, s, in, out, n, vr, vi);
+    RR_HIP(hipGetLastError());
+}
+// out[n] = (s[n].im - s[n-2].im) * s[n-1].re - (s[n].re - s[n-2].re) * s[n-1].im over the virtual stream
+// src = (q2, q1) || window: the sequential q1/q2 update of the reference is just a 2-sample history.
+__global__ __launch_bounds__(256) void k_fastfm(VSrc<cf> src, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const cf q2 = src.load(i), q1 = src.load(i + 1), s = src.load(i + 2);
+        const float top = mul_rn(sub_rn(s.y, q2.y), q1.x);
+        const float bottom = mul_rn(sub_rn(s.x, q2.x), q1.y);
+        out[i] = sub_rn(top, bottom);
+    }
+}
+void launch_fastfm(VSrc<cf> src, float* out, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fastfm, dim3(grid_for(n, 256)), dim3(256), 0, s, src, out, n);
+    RR_HIP(hipGetLastError());
 }
 
 // ---- carry-state copies -----------------------------------------------------------------

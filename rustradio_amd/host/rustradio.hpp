@@ -545,6 +545,49 @@ public:
     }
 };
 
+// ---- #[rustradio(sync)] blocks: MultiplyConst (src/multiply_const.rs), FastFM (src/quadrature_demod.rs:144-165) ----------
+// work() per rustradio_macros_code/src/lib.rs:458-515; a tag at position pos < n passes through at pos.
+template <class In, class Out> class SyncBlock : public Block {
+protected:
+    detail::Handle h_;
+    ReadStream<In> src_;
+    WriteStream<Out> dst_;
+public:
+    SyncBlock(rr_block* h, ReadStream<In> src, WriteStream<Out> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)) {}
+    const char* block_name() const override { return rr_block_name(h_.h); }
+    bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
+    BlockRet work() override {
+        auto [input, tags] = src_.read_buf();
+        auto out = dst_.write_buf();
+        auto w = detail::work(h_.h, input, out);
+        std::vector<Tag> keep;
+        for (auto& t : tags) if (t.pos() < w.produced) keep.push_back(t);
+        input.consume(w.consumed);
+        out.produce(w.produced, keep);
+        return w.st == RR_WAIT_DST ? BlockRet::wait(dst_.wait_handle(), w.need) : BlockRet::wait(src_.wait_handle(), w.need);
+    }
+};
+template <class T> class MultiplyConst : public SyncBlock<T, T> {
+    static rr_block* make(T val) {
+        if constexpr (std::is_same<T, Complex>::value) return rr_multiply_const_c32_create(val.real(), val.imag());
+        else return rr_multiply_const_f32_create(val);
+    }
+public:
+    using SyncBlock<T, T>::SyncBlock;
+    static std::pair<std::unique_ptr<MultiplyConst<T>>, ReadStream<T>> new_(ReadStream<T> src, T val) {
+        auto [w, r] = new_stream<T>();
+        return {std::make_unique<MultiplyConst<T>>(make(val), std::move(src), std::move(w)), std::move(r)};
+    }
+};
+class FastFM : public SyncBlock<Complex, Float> {
+public:
+    using SyncBlock<Complex, Float>::SyncBlock;
+    static std::pair<std::unique_ptr<FastFM>, ReadStream<Float>> new_(ReadStream<Complex> src) {
+        auto [w, r] = new_stream<Float>();
+        return {std::make_unique<FastFM>(rr_fastfm_create(), std::move(src), std::move(w)), std::move(r)};
+    }
+};
+
 // ---- Hilbert (src/hilbert.rs) ----------------------------------------------------------------------------------------------
 class Hilbert : public Block {
     detail::Handle h_;

@@ -285,6 +285,25 @@ static void device_resident_graph() {
     }
 }
 
+static void sync_blocks() {                      // multiply_const.rs:20-22, quadrature_demod.rs:158-164
+    auto [src, s0] = VectorSource<Float>::new_({1.5f, -2.0f, 0.25f});
+    src->work();
+    auto [m, s1] = MultiplyConst<Float>::new_(std::move(s0), 3.0f);
+    CHECK(is_wait(m->work()));
+    auto [o, tags] = s1.read_buf();
+    CHECK(o.len() == 3 && o.slice()[0] == 4.5f && o.slice()[1] == -6.0f && o.slice()[2] == 0.75f);
+    CHECK(tags.size() >= 1 && tags[0].pos() == 0);          // VectorSource::start passes through
+    auto [src2, c0] = VectorSource<Complex>::new_({{1, 0}, {0, 1}, {-1, 0}, {0, -1}});
+    src2->work();
+    auto [f, c1] = FastFM::new_(std::move(c0));
+    CHECK(is_wait(f->work()));
+    auto [fo, ft] = c1.read_buf();
+    // q1 = q2 = 0 at start: out = [0, (1-0)*1 - (0-0)*0, (0-0)*0 - (-1-1)*1, (-1-1)*(-1) - ...]
+    const float want[4] = {0.0f, 1.0f, 2.0f, 2.0f};
+    CHECK(fo.len() == 4);
+    for (size_t i = 0; i < 4 && i < fo.len(); i++) CHECK(fo.slice()[i] == want[i]);
+}
+
 static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal_source.rs:9-63
     auto [ss, s0] = SignalSourceComplex::new_(1200.0f, 100.0f, 1.0f);
     CHECK(is_wait(ss->work()));
@@ -306,7 +325,7 @@ static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
     fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
-    device_resident_graph(); tee_and_signal_source();
+    device_resident_graph(); tee_and_signal_source(); sync_blocks();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }

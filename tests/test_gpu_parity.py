@@ -223,6 +223,19 @@ def test_rtlsdr_decode_device_windows_any_alignment(rr, off):
         assert np.array_equal(yg, yo)
 
 
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 4 * 1_003])
+def test_sync_blocks_bit_exact(rr, stream_bytes):
+    """MultiplyConst<Float|Complex> and FastFM: same protocol log, bit-identical samples"""
+    xf, xc = rnd_f(100_001, 4), rnd_c(100_001, 5)
+    both(rr, lambda m: [m.MultiplyConst(0.37)], xf, stream_bytes=stream_bytes, exact=True)
+    both(rr, lambda m: [m.MultiplyConst(0.6 - 1.25j, np.complex64)], xc, stream_bytes=max(stream_bytes, 8 * 1003), exact=True)
+    both(rr, lambda m: [m.FastFM()], xc, stream_bytes=max(stream_bytes, 8 * 1003), exact=True)
+    # the rtl_fm audio stage: demod -> FftFilterFloat -> RationalResampler -> MultiplyConst (examples/rtl_fm.rs:398-418)
+    at = orc.low_pass(200e3, 44.1e3, 5e3)
+    both(rr, lambda m: [m.QuadratureDemod(1.0), m.FftFilterFloat(at), m.RationalResampler(441, 2000, np.float32), m.MultiplyConst(0.5)],
+         xc, stream_bytes=4_096_000)
+
+
 def test_hilbert_rejects_even(rr):
     for n in (0, 1, 2, 64):
         with pytest.raises(ValueError):

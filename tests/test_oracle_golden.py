@@ -169,3 +169,27 @@ def test_tap_counts_for_baseline_configs():
     assert orc.compute_ntaps(2.4e6, 12.5e3) == 463
     assert orc.compute_ntaps(100e6, 943e3) == 255
     assert orc.compute_ntaps(1.024e6, 1e3) == 2467
+
+
+def test_sync_blocks_by_definition():
+    """MultiplyConst / FastFM have no unit tests in the reference: pinned to their one-line definitions
+    (multiply_const.rs:20-22, quadrature_demod.rs:158-164) evaluated in numpy f32 and to the sync
+    work() protocol (rustradio_macros_code/src/lib.rs:458-515)."""
+    import numpy as np
+    from oracle import pyoracle as orc
+    x = (np.arange(1, 8, dtype=np.float32) / 3).astype(np.float32)
+    st, c, p, need, out = orc.MultiplyConst(1.7).work(x, 5)
+    assert (st, c, p, need) == (2, 5, 5, 1) and np.array_equal(out, x[:5] * np.float32(1.7))
+    st, c, p, need, out = orc.MultiplyConst(1.7).work(x, 50)
+    assert (st, c, p, need) == (1, 7, 7, 1)
+    assert orc.MultiplyConst(2.0).work(x[:0], 5)[:4] == (1, 0, 0, 1) and orc.MultiplyConst(2.0).work(x, 0)[:4] == (2, 0, 0, 1)
+    z = (np.arange(6) * (0.5 - 0.25j) + 1j).astype(np.complex64)
+    v = np.complex64(0.3 + 2j)
+    want = (z.real * v.real - z.imag * v.imag) + 1j * (z.real * v.imag + z.imag * v.real)      # num-complex Mul
+    assert np.array_equal(orc.MultiplyConst(v, np.complex64).work(z, 10)[4], want.astype(np.complex64))
+    f = orc.FastFM()
+    got = np.concatenate([f.work(z[:4], 10)[4], f.work(z[4:], 10)[4]])                            # state carries over
+    s = np.concatenate([np.zeros(2, np.complex64), z])
+    exp = [(np.float32(s[i + 2].imag - s[i].imag) * s[i + 1].real) - (np.float32(s[i + 2].real - s[i].real) * s[i + 1].imag)
+           for i in range(len(z))]
+    assert np.array_equal(got, np.asarray(exp, np.float32))
