@@ -165,6 +165,17 @@ class Block:
         return ms.value, n.value
 
 
+def host_register(a: np.ndarray) -> None:
+    """page-lock a host array that will be handed to work()/push()/pop() (rr_host_register)"""
+    if lib().rr_host_register(_ptr(a), a.nbytes) != 0:
+        raise RuntimeError(last_error())
+
+
+def host_unregister(a: np.ndarray) -> None:
+    if lib().rr_host_unregister(_ptr(a)) != 0:
+        raise RuntimeError(last_error())
+
+
 class DeviceStream:
     """new_stream() (src/stream.rs:336-339) in HBM: rr_dstream.  Same window contract as ReadStream /
     WriteStream: everything readable / all free space, contiguous; `capacity_bytes` as the reference's

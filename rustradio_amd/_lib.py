@@ -20,6 +20,7 @@ SYMBOLS = [
     "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_in_elem_size",
     "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_set_rotator_mode",
     "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps",
+    "rr_host_register", "rr_host_unregister",
     "rr_dstream_create", "rr_dstream_destroy", "rr_dstream_capacity", "rr_dstream_read_buf", "rr_dstream_write_buf",
     "rr_dstream_consume", "rr_dstream_produce", "rr_dstream_copy_in", "rr_dstream_copy_out", "rr_block_work_streams",
 ]
@@ -76,6 +77,8 @@ def lib():
     L.rr_fir_set_rotator_mode.argtypes = [vp, i32]; L.rr_fir_set_rotator_mode.restype = i32
     L.rr_debug_fft_stamps.argtypes = [vp]; L.rr_debug_fft_stamps.restype = i32
     pvp = C.POINTER(vp)
+    L.rr_host_register.argtypes = [vp, sz]; L.rr_host_register.restype = i32
+    L.rr_host_unregister.argtypes = [vp]; L.rr_host_unregister.restype = i32
     L.rr_dstream_create.argtypes = [sz, sz]; L.rr_dstream_create.restype = vp
     L.rr_dstream_destroy.argtypes = [vp]; L.rr_dstream_destroy.restype = None
     L.rr_dstream_capacity.argtypes = [vp]; L.rr_dstream_capacity.restype = sz

@@ -205,6 +205,16 @@ int rr_fftfilter_dims(const rr_block* b, size_t* fft_size, size_t* nsamples, siz
     if (gpu_fft_size) *gpu_fft_size = (size_t)1 << f->log2f;
     return 0;
 }
+// ---- host memory registration -----------------------------------------------------------------------
+int rr_host_register(void* ptr, size_t bytes) {
+    if (!ptr || !bytes) { rr::set_last_error("rr_host_register: null / empty range"); return RR_ERR; }
+    return guarded([&] { RR_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault)); });
+}
+int rr_host_unregister(void* ptr) {
+    if (!ptr) { rr::set_last_error("rr_host_unregister: null"); return RR_ERR; }
+    return guarded([&] { RR_HIP(hipHostUnregister(ptr)); });
+}
+
 // ---- device-resident streams ------------------------------------------------------------------------
 rr_dstream* rr_dstream_create(size_t elem_size, size_t capacity_bytes) {
     try {

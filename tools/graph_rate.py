@@ -43,3 +43,11 @@ for name, fn in (("host rings, 3 blocks", lambda: run_chain(mk(), x)),
     fn()
     t0 = time.perf_counter(); y = fn(); dt = time.perf_counter() - t0
     print(f"{name:28s} {n / dt / 1e6:8.1f} Msamples/s  ({len(y)} outputs, {dt*1e3:.0f} ms)")
+rr.host_register(x)          # what the shim does once for the source ring (rr_host_register)
+for name, fn in (("pinned src, host rings", lambda: run_chain(mk(), x)),
+                 ("pinned src, HBM rings", lambda: run_chain_device(mk(), x)),
+                 ("pinned src, HBM, fused", lambda: run_chain_device([rr.FmChain(taps, 1, 6)], x))):
+    fn()
+    t0 = time.perf_counter(); y = fn(); dt = time.perf_counter() - t0
+    print(f"{name:28s} {n / dt / 1e6:8.1f} Msamples/s  ({len(y)} outputs, {dt*1e3:.0f} ms)")
+rr.host_unregister(x)
