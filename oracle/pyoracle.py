@@ -60,6 +60,7 @@ def lib():
     L.orc_multiply_const_f32_new.argtypes = [f32]; L.orc_multiply_const_f32_new.restype = vp
     L.orc_multiply_const_c32_new.argtypes = [f32, f32]; L.orc_multiply_const_c32_new.restype = vp
     L.orc_fastfm_new.argtypes = []; L.orc_fastfm_new.restype = vp
+    L.orc_fftstream_new.argtypes = [sz]; L.orc_fftstream_new.restype = vp
     L.orc_block_free.argtypes = [vp]; L.orc_block_free.restype = None
     L.orc_block_work.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.orc_block_work.restype = i32
@@ -227,6 +228,13 @@ def MultiplyConst(val, dtype=np.float32) -> OracleBlock:
 
 def FastFM() -> OracleBlock:
     return OracleBlock(lib().orc_fastfm_new(), np.complex64, np.float32, "FastFM")
+
+
+def FftStream(size: int) -> OracleBlock:
+    h = lib().orc_fftstream_new(size)
+    if not h:
+        raise ValueError(lib().orc_last_error().decode())
+    return OracleBlock(h, np.complex64, np.complex64, "FftStream")
 
 
 def RtlSdrDecode() -> OracleBlock:

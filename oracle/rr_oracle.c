@@ -284,7 +284,7 @@ float orc_fast_atan2(float y, float x) {
 }
 
 /* ---- streaming blocks ----------------------------------------------------------- */
-enum { K_FIR_C32, K_FIR_F32, K_FFTFILT, K_FFTFILT_F, K_RESAMP, K_QUAD, K_HILBERT, K_RTLSDR, K_MULC_F, K_MULC_C, K_FASTFM };
+enum { K_FIR_C32, K_FIR_F32, K_FFTFILT, K_FFTFILT_F, K_RESAMP, K_QUAD, K_HILBERT, K_RTLSDR, K_MULC_F, K_MULC_C, K_FASTFM, K_FFTSTREAM };
 
 struct orc_block {
     int kind;
@@ -457,6 +457,19 @@ orc_block *orc_multiply_const_c32_new(float re, float im) {
 orc_block *orc_fastfm_new(void) { /* quadrature_demod.rs:144-165; q1 = q2 = 0 (#[rustradio(default)]) */
     orc_block *b = (orc_block *)calloc(1, sizeof *b);
     b->kind = K_FASTFM; b->in_es = sizeof(orc_c32); b->out_es = sizeof(float);
+    return b;
+}
+
+/* FftStream::new (fft_stream.rs:40-60).  The reference plans any size with rustfft; this restatement has a
+ * radix-4/2 transform: powers of two (what the GPU block supports as well). */
+orc_block *orc_fftstream_new(size_t size) {
+    if (size == 0) { set_err("FFT size must be nonzero (fft_stream.rs:42)"); return NULL; }
+    if (size & (size - 1)) { set_err("FftStream: the restatement transforms powers of two only"); return NULL; }
+    if (size > 4096000 / sizeof(orc_c32)) { set_err("FFT size must be no bigger than stream size (fft_stream.rs:46-50)"); return NULL; }
+    orc_block *b = (orc_block *)calloc(1, sizeof *b);
+    b->kind = K_FFTSTREAM; b->in_es = b->out_es = sizeof(orc_c32);
+    b->fft_size = size;
+    b->plan = fftplan_new(size);
     return b;
 }
 
@@ -699,6 +712,20 @@ static int work_sync(orc_block *b, const void *in, size_t in_len, void *out, siz
     }
 }
 
+/* FftStream::work, fft_stream.rs:71-117 (frame tags are the wrapper's business) */
+static int work_fftstream(orc_block *b, const orc_c32 *in, size_t in_len, orc_c32 *out, size_t out_cap,
+                          size_t *consumed, size_t *produced, size_t *need) {
+    const size_t size = b->fft_size;
+    if (in_len < size) { *need = size; return ORC_WAIT_SRC; }      /* :74-76 */
+    if (out_cap < size) { *need = size; return ORC_WAIT_DST; }     /* :79-81 */
+    size_t len = in_len < out_cap ? in_len : out_cap;              /* :82-83 */
+    len -= len % size;
+    memcpy(out, in, len * sizeof(orc_c32));                        /* :84 */
+    for (size_t f = 0; f < len; f += size) fftplan_run(b->plan, out + f, 0);   /* :93-96 forward, unnormalised */
+    *consumed = len; *produced = len;
+    return ORC_AGAIN;
+}
+
 /* Hilbert::work, hilbert.rs:72-128 */
 static int work_hilbert(orc_block *b, const float *in, size_t in_len, orc_c32 *out, size_t out_cap,
                         size_t *consumed, size_t *produced, size_t *need) {
@@ -735,6 +762,7 @@ int orc_block_work(orc_block *b, const void *in, size_t in_len, void *out, size_
     case K_MULC_F:
     case K_MULC_C:
     case K_FASTFM: return work_sync(b, in, in_len, out, out_cap, consumed, produced, need);
+    case K_FFTSTREAM: return work_fftstream(b, (const orc_c32 *)in, in_len, (orc_c32 *)out, out_cap, consumed, produced, need);
     case K_RTLSDR: return work_rtlsdr((const unsigned char *)in, in_len, (orc_c32 *)out, out_cap, consumed, produced, need);
     }
     set_err("bad block kind");

@@ -92,6 +92,8 @@ orc_block *orc_rtlsdr_decode_new(void);
 orc_block *orc_multiply_const_f32_new(float val);
 orc_block *orc_multiply_const_c32_new(float re, float im);
 orc_block *orc_fastfm_new(void);
+/* FftStream (fft_stream.rs:26-117): forward FFT of consecutive `size`-sample frames; power-of-two sizes. */
+orc_block *orc_fftstream_new(size_t size);
 /* Hilbert (hilbert.rs:22-129). */
 orc_block *orc_hilbert_new(size_t ntaps, int wtype, float parm);
 

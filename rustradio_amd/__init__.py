@@ -274,6 +274,14 @@ def FastFM() -> Block:
     return Block(lib().rr_fastfm_create(), np.complex64, np.float32)
 
 
+def FftStream(size: int) -> Block:
+    """FftStream::new(src, size) (src/fft_stream.rs:40-117); power-of-two sizes 2..16384."""
+    h = lib().rr_fftstream_create(size)
+    if not h:
+        raise ValueError(last_error())
+    return Block(h, np.complex64, np.complex64)
+
+
 def RtlSdrDecode() -> Block:
     """RtlSdrDecode::new(src) (src/rtlsdr_decode.rs:9-47): u8 I/Q pairs -> Complex."""
     return Block(lib().rr_rtlsdr_decode_create(), np.uint8, np.complex64)

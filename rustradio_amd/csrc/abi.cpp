@@ -110,6 +110,9 @@ rr_block* rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_p
         return new rr::HilbertFir(hilbert_ntaps, window, window_parm, taps, ntaps, deci, translate != 0, samp_rate, freq);
     });
 }
+rr_block* rr_fftstream_create(size_t size) {
+    return make_block([&] { return new rr::FftStream(size); });
+}
 rr_block* rr_multiply_const_f32_create(float val) {
     return make_block([&] { return new rr::MultiplyConst(4, val, 0.0f); });
 }

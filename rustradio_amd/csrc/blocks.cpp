@@ -673,6 +673,35 @@ int QuadDemod::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     *need = 1; return RR_WAIT_DST;
 }
 
+// ---- FftStream (fft_stream.rs:26-117) ------------------------------------------------------------------------
+FftStream::FftStream(size_t n) : Block("FftStream", 8, 8), size(n) {
+    if (n == 0) throw Error("FFT size must be nonzero");                                   // :42
+    if (n > 4096000 / sizeof(cf)) throw Error("FFT size must be no bigger than stream size");   // :46-50
+    if ((n & (n - 1)) != 0 || n < 2 || n > 16384)
+        throw Error("FftStream: the GPU block transforms power-of-two sizes 2..16384 (the reference plans any size with rustfft)");
+    while (((size_t)1 << log2n) < n) log2n++;
+    std::vector<cf> tw(n);
+    for (size_t k = 0; k < n; k++) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)n;
+        tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+    }
+    d_tw.upload(tw.data(), n, stream);
+    RR_HIP(hipStreamSynchronize(stream));
+}
+int FftStream::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
+                        size_t* produced, size_t* need, hipStream_t s) {
+    *consumed = *produced = *need = 0;
+    if (in_len < size) { *need = size; return RR_WAIT_SRC; }                   // :74-76
+    if (out_cap < size) { *need = size; return RR_WAIT_DST; }                  // :79-81
+    size_t len = std::min(in_len, out_cap);                                    // :82-83
+    len -= len % size;
+    prof_begin(s);
+    launch_fft_frames(log2n, static_cast<const cf*>(in), static_cast<cf*>(out), (long)(len / size), d_tw.p, s);
+    prof_end(s);
+    *consumed = *produced = len;
+    return RR_AGAIN;                                                           // :116
+}
+
 // ---- MultiplyConst, FastFM (sync blocks) ------------------------------------------------------------------------
 static int sync_counts(size_t in_len, size_t out_cap, size_t* n, size_t* need) {
     *need = 1;

@@ -152,6 +152,15 @@ struct QuadDemod : Block {
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 
+// FftStream (fft_stream.rs:26-117): forward FFT of consecutive `size`-sample frames (power-of-two sizes here).
+struct FftStream : Block {
+    size_t size = 0;
+    int log2n = 0;
+    DevBuf<cf> d_tw;
+    explicit FftStream(size_t size);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
 // #[rustradio(sync)] blocks (rustradio_macros_code/src/lib.rs:458-515): map min(input, output space) samples,
 // then WaitForStream on the side that ran dry.
 struct MultiplyConst : Block {        // multiply_const.rs:6-23, T = Float (es 4) or Complex (es 8)

@@ -15,6 +15,10 @@ int fft_read_stamps(unsigned long long* host16);   // measurement builds only (e
 void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw,
                        const cf* hpos, hipStream_t s);
 
+// FftStream: out = forward unnormalised FFT of each of `nframes` consecutive 2^log2n-point frames
+// (log2n 1..14), natural bin order; tw = device table of w_N^k, k < N.
+void launch_fft_frames(int log2n, const cf* in, cf* out, long nframes, const cf* tw, hipStream_t s);
+
 // Fused FftFilter -> RationalResampler -> QuadratureDemod over the same virtual stream.
 struct FmChainArgs {
     long A;            // filtered samples emitted before this call

@@ -336,6 +336,109 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
     }
 }
 
+// ---- FftStream (src/fft_stream.rs:71-117): forward FFT of consecutive frames --------------------------
+// Frames of 1024..16384 points are one tile each: the forward half of the filter transform, then one
+// more LDS exchange that undoes the digit reversal (position p holds bin bin_of_pos(p)) so that the
+// stores are lane-consecutive in natural bin order.  16 B per sample.
+template <int LOG2F, int VAR>
+__global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
+void k_fft_frames(const cf* __restrict__ in, cf* __restrict__ out, long nframes, const cf* __restrict__ tw) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    constexpr int NP = Plan<LOG2F>::NP;
+    using G = PassGeom<LOG2F, NP - 1>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    const int t = threadIdx.x;
+    TileXform<LOG2F, VAR> X;
+    X.init_no_h(t, tw);
+    for (TileIter it(nframes); it.tile < it.end; it.tile += it.step) {
+        const creg* p = reinterpret_cast<const creg*>(in) + it.tile * F + t;
+        creg v[16];
+#pragma unroll
+        for (int n = 0; n < 16; n++) v[n] = p[n * T];
+        X.forward(v, lds);
+        tile_sync<T>();                      // the last exchange's reads are done everywhere
+#pragma unroll
+        for (int u = 0; u < G::U; u++)
+#pragma unroll
+            for (int n = 0; n < G::R; n++)
+                lds[lds_pad(bin_of_pos<LOG2F>(G::pos(t + G::T * u, n)))] = v[u * G::R + n];
+        tile_sync<T>();
+        creg* po = reinterpret_cast<creg*>(out) + it.tile * F + t;
+#pragma unroll
+        for (int n = 0; n < 16; n++) po[n * T] = lds[lds_pad(n * T + t)];
+        tile_sync<T>();                      // before the next frame's first exchange overwrites the slots
+    }
+}
+
+// Frames of 2..512 points: radix-2 Stockham autosort in LDS, one butterfly per thread and stage, 512
+// points (512/N frames) per 256-thread workgroup.  Small transforms are not the hot path.
+__global__ __launch_bounds__(256) void k_fft_small(const cf* __restrict__ in, cf* __restrict__ out, long nframes,
+                                                   int log2n, const cf* __restrict__ tw) {
+    __shared__ cf bufA[512], bufB[512];
+    const int N = 1 << log2n, half = N >> 1;
+    const int fpw = 512 / N;                               // frames per workgroup pass
+    const int t = threadIdx.x;
+    const int fl = t / half, i = t % half;                 // local frame, butterfly index
+    for (long f0 = (long)blockIdx.x * fpw; f0 < nframes; f0 += (long)gridDim.x * fpw) {
+        const long rem = nframes - f0;
+        const int nf = rem < fpw ? (int)rem : fpw;
+        for (int e = t; e < nf * N; e += 256) bufA[e] = in[f0 * N + e];
+        __syncthreads();
+        cf* x = bufA + fl * N;
+        cf* y = bufB + fl * N;
+        int n = N, s = 1;
+        for (int st = 0; st < log2n; st++) {
+            const int m = n >> 1;
+            if (fl < nf) {
+                const int pp = i / s, q = i % s;
+                const cf a = x[q + s * pp], b = x[q + s * (pp + m)];
+                const cf w = tw[pp * s];                       // w_n^p = w_N^(p N/n), N/n = s
+                const cf d = mkcf(a.x - b.x, a.y - b.y);
+                y[q + s * (2 * pp)] = mkcf(a.x + b.x, a.y + b.y);
+                y[q + s * (2 * pp + 1)] = mkcf(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+            }
+            __syncthreads();
+            cf* tmp = x; x = y; y = tmp;
+            n = m; s <<= 1;
+        }
+        const cf* res = (log2n & 1) ? bufB : bufA;
+        for (int e = t; e < nf * N; e += 256) out[f0 * N + e] = res[e];
+        __syncthreads();
+    }
+}
+
+template <int LOG2F, int VAR>
+static void launch_frames_one(const cf* in, cf* out, long nframes, const cf* tw, hipStream_t s) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    const size_t smem = sizeof(cf) * lds_elems(F);
+    static bool attr_set = false;
+    static int per_cu = 0;
+    const long grid = grid_for_tiles(k_fft_frames<LOG2F, VAR>, T, smem, nframes, attr_set, per_cu);
+    hipLaunchKernelGGL((k_fft_frames<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, in, out, nframes, tw);
+    RR_HIP(hipGetLastError());
+}
+void launch_fft_frames(int log2n, const cf* in, cf* out, long nframes, const cf* tw, hipStream_t s) {
+    if (nframes <= 0) return;
+    switch (log2n) {
+    case 10: launch_frames_one<10, 0>(in, out, nframes, tw, s); return;
+    case 11: launch_frames_one<11, 0>(in, out, nframes, tw, s); return;
+    case 12: launch_frames_one<12, 0>(in, out, nframes, tw, s); return;
+    case 13: launch_frames_one<13, 3>(in, out, nframes, tw, s); return;
+    case 14: launch_frames_one<14, 3>(in, out, nframes, tw, s); return;
+    default: break;
+    }
+    if (log2n < 1 || log2n > 9) throw Error("fft_frames: size must be a power of two in 2..16384");
+    const long per_wg = 512 >> log2n;
+    long grid = (nframes + per_wg - 1) / per_wg;
+    const long cap = (long)device_cu_count() * 8;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_fft_small, dim3((unsigned)grid), dim3(256), 0, s, in, out, nframes, log2n, tw);
+    RR_HIP(hipGetLastError());
+}
+
 // ---- fused FftFilter -> RationalResampler -> QuadratureDemod ------------------------------------------
 // fast-math 0.1.1 atan2 restated from its published algorithm (crate not vendored: parity-unpinned
 // flavour); same code as k_quaddemod in kernels_misc.hip.

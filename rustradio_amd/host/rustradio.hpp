@@ -545,6 +545,44 @@ public:
     }
 };
 
+// ---- FftStream (src/fft_stream.rs) -------------------------------------------------------------------------------------------
+inline constexpr const char* TAG_FRAME = "FftStream::frame";            // :18
+inline constexpr const char* TAG_FRAME_SIZE = "FftStream::size";        // :21
+class FftStream : public Block {
+    detail::Handle h_;
+    size_t size_;
+    ReadStream<Complex> src_;
+    WriteStream<Complex> dst_;
+public:
+    FftStream(rr_block* h, size_t size, ReadStream<Complex> src, WriteStream<Complex> dst)
+        : h_(h), size_(size), src_(std::move(src)), dst_(std::move(dst)) {}
+    static std::pair<std::unique_ptr<FftStream>, ReadStream<Complex>> new_(ReadStream<Complex> src, size_t size) {   // :40-60
+        auto [w, r] = new_stream<Complex>();
+        if (size > w.free()) throw Error("FFT size must be no bigger than stream size");
+        return {std::make_unique<FftStream>(rr_fftstream_create(size), size, std::move(src), std::move(w)), std::move(r)};
+    }
+    const char* block_name() const override { return rr_block_name(h_.h); }
+    bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
+    BlockRet work() override {                    // :71-117 — input tags dropped, frame tags added
+        auto [input, tags] = src_.read_buf();
+        (void)tags;
+        auto out = dst_.write_buf();
+        auto w = detail::work(h_.h, input, out);
+        if (w.st == RR_WAIT_SRC) { out.produce(0, {}); return BlockRet::wait(src_.wait_handle(), w.need); }
+        if (w.st == RR_WAIT_DST) { out.produce(0, {}); return BlockRet::wait(dst_.wait_handle(), w.need); }
+        std::vector<Tag> ft;                      // :98-111
+        ft.reserve(w.produced / size_ * 3);
+        for (size_t pos = 0; pos < w.produced; pos += size_) {
+            ft.emplace_back(pos, TAG_FRAME_SIZE, (uint64_t)size_);
+            ft.emplace_back(pos, TAG_FRAME, true);
+            ft.emplace_back(pos + size_ - 1, TAG_FRAME, false);
+        }
+        input.consume(w.consumed);
+        out.produce(w.produced, ft);
+        return BlockRet::again();
+    }
+};
+
 // ---- #[rustradio(sync)] blocks: MultiplyConst (src/multiply_const.rs), FastFM (src/quadrature_demod.rs:144-165) ----------
 // work() per rustradio_macros_code/src/lib.rs:458-515; a tag at position pos < n passes through at pos.
 template <class In, class Out> class SyncBlock : public Block {

@@ -304,6 +304,30 @@ static void sync_blocks() {                      // multiply_const.rs:20-22, qua
     for (size_t i = 0; i < 4 && i < fo.len(); i++) CHECK(fo.slice()[i] == want[i]);
 }
 
+static void fftstream_adds_frame_tags() {        // src/fft_stream.rs:125-150
+    auto src = ReadStream<Complex>::from_slice(std::vector<Complex>(8).data(), 8);
+    auto [fft, out] = FftStream::new_(std::move(src), 4);
+    CHECK(fft->work().kind == BlockRet::Again);
+    auto [buf, tags] = out.read_buf();
+    CHECK(buf.len() == 8);
+    const std::vector<std::pair<size_t, std::string>> want = {{0, TAG_FRAME_SIZE}, {0, TAG_FRAME}, {3, TAG_FRAME},
+                                                              {4, TAG_FRAME_SIZE}, {4, TAG_FRAME}, {7, TAG_FRAME}};
+    CHECK(tags.size() == want.size());
+    for (size_t i = 0; i < want.size() && i < tags.size(); i++) CHECK(tags[i].pos() == want[i].first && tags[i].key() == want[i].second);
+    for (size_t i = 0; i < 8; i++) CHECK(buf.slice()[i] == Complex(0, 0));
+    // a tone lands in its bin
+    std::vector<Complex> x(2048);
+    for (size_t i = 0; i < x.size(); i++) x[i] = Complex((float)std::cos(2 * M_PI * 5 * i / 1024.0), (float)std::sin(2 * M_PI * 5 * i / 1024.0));
+    auto [f2, o2] = FftStream::new_(ReadStream<Complex>::from_slice(x.data(), x.size()), 1024);
+    CHECK(f2->work().kind == BlockRet::Again);
+    auto [b2, t2] = o2.read_buf();
+    CHECK(b2.len() == 2048 && std::abs(b2.slice()[5] - Complex(1024, 0)) < 0.05f && std::abs(b2.slice()[6]) < 0.05f
+          && std::abs(b2.slice()[1024 + 5] - Complex(1024, 0)) < 0.05f);
+    bool threw = false;
+    try { FftStream::new_(ReadStream<Complex>::from_slice(x.data(), 8), 0); } catch (const Error&) { threw = true; }
+    CHECK(threw);
+}
+
 static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal_source.rs:9-63
     auto [ss, s0] = SignalSourceComplex::new_(1200.0f, 100.0f, 1.0f);
     CHECK(is_wait(ss->work()));
@@ -325,7 +349,7 @@ static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
     fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
-    device_resident_graph(); tee_and_signal_source(); sync_blocks();
+    device_resident_graph(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }

@@ -236,6 +236,30 @@ def test_sync_blocks_bit_exact(rr, stream_bytes):
          xc, stream_bytes=4_096_000)
 
 
+@pytest.mark.parametrize("size", [2, 4, 8, 64, 256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_fftstream(rr, size):
+    """FftStream: whole frames only, forward unnormalised transform in natural bin order"""
+    n = max(5 * size + 3, 40_000)
+    x = rnd_c(n, size)
+    e = both(rr, lambda m: [m.FftStream(size)], x)
+    both(rr, lambda m: [m.FftStream(size)], x[:3 * size + 1], stream_bytes=8 * (size + size // 2 + 1))
+    st, c, p, need, out = rr.FftStream(size).work(x[:2 * size], 4 * size)
+    ref = np.fft.fft(x[:2 * size].astype(np.complex128).reshape(2, size), axis=1).reshape(-1)
+    assert (st, c, p) == (AGAIN, 2 * size, 2 * size)
+    assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) <= TOL
+    assert np.array_equal(rr.FftStream(size).work(np.zeros(size, np.complex64), size)[4], np.zeros(size, np.complex64))
+
+
+def test_fftstream_rejects(rr):
+    for bad in (0, 3, 1000, 32768):
+        with pytest.raises(Exception):
+            rr.FftStream(bad)
+    b = rr.FftStream(1024)
+    x = rnd_c(2000, 1)
+    assert b.work(x[:1023], 4096)[:4] == (WAIT_SRC, 0, 0, 1024)
+    assert b.work(x, 1023)[:4] == (WAIT_DST, 0, 0, 1024)
+
+
 def test_hilbert_rejects_even(rr):
     for n in (0, 1, 2, 64):
         with pytest.raises(ValueError):

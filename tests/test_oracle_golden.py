@@ -193,3 +193,21 @@ def test_sync_blocks_by_definition():
     exp = [(np.float32(s[i + 2].imag - s[i].imag) * s[i + 1].real) - (np.float32(s[i + 2].real - s[i].real) * s[i + 1].imag)
            for i in range(len(z))]
     assert np.array_equal(got, np.asarray(exp, np.float32))
+
+
+def test_fftstream_restatement():
+    """FftStream (fft_stream.rs:71-117): frames against numpy's f64 FFT (rustfft's conventions: forward
+    e^{-2 pi i kn/N}, unnormalised — SURVEY §8c), whole frames only, zero in -> zero out (fft.rs:65-85)."""
+    import numpy as np
+    from oracle import pyoracle as orc
+    for size in (2, 4, 16, 128, 1024, 8192):
+        rng = np.random.default_rng(size)
+        x = (rng.standard_normal(3 * size + 1) + 1j * rng.standard_normal(3 * size + 1)).astype(np.complex64)
+        st, c, p, need, out = orc.FftStream(size).work(x, 10 * size)
+        assert (st, c, p) == (0, 3 * size, 3 * size)
+        ref = np.fft.fft(x[:3 * size].astype(np.complex128).reshape(3, size), axis=1).reshape(-1)
+        assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) < 1e-6
+    b = orc.FftStream(4)
+    assert b.work(np.zeros(3, np.complex64), 100)[:4] == (1, 0, 0, 4) and b.work(np.zeros(8, np.complex64), 3)[:4] == (2, 0, 0, 4)
+    st, c, p, need, out = b.work(np.zeros(8, np.complex64), 100)          # adds_frame_tags' data path (:130-150)
+    assert (st, c, p) == (0, 8, 8) and np.array_equal(out, np.zeros(8, np.complex64))
