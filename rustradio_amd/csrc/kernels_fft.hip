@@ -470,6 +470,22 @@ struct FmArgs {
     int mode;        // RR_ATAN2_*
 };
 
+// Sources floor(u*D/I) of the resampled samples r[u], u = u0, u0 + T, u0 + 2T, ...: one 64-bit division
+// per thread and TILE instead of two per output (a software division is ~80 VALU instructions; the
+// epilogue used to cost more than the inverse FFT).
+struct SrcWalk {
+    long q, r;                                           // u*D = q*I + r, 0 <= r < I
+    __device__ __forceinline__ void init(long u, long I, long D) {
+        const long p = u * D;                            // u = -1 occurs (the lower partner of r[0]): floor division
+        if (I == 1) { q = p; r = 0; }
+        else { q = p / I; r = p - q * I; if (r < 0) { r += I; q--; } }
+    }
+    __device__ __forceinline__ void step(long qs, long rs, long I) {
+        q += qs; r += rs;
+        if (r >= I) { q++; r -= I; }
+    }
+};
+
 // Tile j transforms y[A + j*Sp - G .. + S') and owns every demod output o[u-1] whose UPPER
 // sample r[u] has its source in [A + j*Sp, A + (j+1)*Sp), Sp = S' - G; the lower sample r[u-1]
 // then lies in the same tile — or is the last r of the previous call (`last_r`).
@@ -485,6 +501,7 @@ void k_fm_chain(SRC src, float* __restrict__ out, int L, long ntiles, const cf* 
     const int t = threadIdx.x;
     const int first = L - 1;
     const long Sp = (F - L + 1) - a.G;
+    const long qs = ((long)T * a.D) / a.I, rs = ((long)T * a.D) % a.I;      // SrcWalk step of T outputs
     TileXform<LOG2F, VAR> X;
     X.init(t, tw, hpos);
 
@@ -507,23 +524,24 @@ void k_fm_chain(SRC src, float* __restrict__ out, int L, long ntiles, const cf* 
         long u_hi = ((a.A + y_hi) * a.I + a.D - 1) / a.D;
         if (u_lo < a.r_lo) u_lo = a.r_lo;
         if (u_hi > a.r_hi) u_hi = a.r_hi;
-        for (long u = u_lo + t; u < u_hi; u += T) {
-            const long gu = (u * a.D) / a.I - a.A;                 // source of r[u], relative to A
+        SrcWalk wu, wl;
+        wu.init(u_lo + t, a.I, a.D);
+        wl.init(u_lo + t - 1, a.I, a.D);
+        for (long u = u_lo + t; u < u_hi; u += T, wu.step(qs, rs, a.I), wl.step(qs, rs, a.I)) {
+            const long gu = wu.q - a.A;                            // source of r[u], relative to A
             const creg ru = lds[lds_pad((int)(gu - ys) + first)];
             if (u == a.r_hi - 1) last_r_out[0] = from_reg(ru);     // carry for the next call
-            if (u == 0) continue;                                   // r[0] has no lower partner
-            creg rl;
-            if (u == a.r_lo) rl = to_reg(last_r_in[0]);             // lower sample from the previous call
-            else {
-                const long gl = ((u - 1) * a.D) / a.I - a.A;
-                rl = lds[lds_pad((int)(gl - ys) + first)];
+            if (u != 0) {                                           // r[0] has no lower partner
+                creg rl;
+                if (u == a.r_lo) rl = to_reg(last_r_in[0]);         // lower sample from the previous call
+                else rl = lds[lds_pad((int)(wl.q - a.A - ys) + first)];
+                // conj(rl) * ru in num-complex order, un-contracted (quadrature_demod.rs:72)
+                const float na = -rl.y;
+                const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
+                const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
+                const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
             }
-            // conj(rl) * ru in num-complex order, un-contracted (quadrature_demod.rs:72)
-            const float na = -rl.y;
-            const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
-            const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
-            const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
-            out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
         }
         tile_sync<T>();        // epilogue reads done before the next tile's first exchange
     }
@@ -550,6 +568,7 @@ void k_fm_multi(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, l
     const int t = threadIdx.x;
     const int first = L - 1;
     const long Sp = (F - L + 1) - a.G;
+    const long qs = ((long)T * a.D) / a.I, rs = ((long)T * a.D) % a.I;      // SrcWalk step of T outputs
     TileXform<LOG2F, 0> X;
     X.init_no_h(t, tw);
 
@@ -568,6 +587,9 @@ void k_fm_multi(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, l
         long u_hi = ((a.A + y_hi) * a.I + a.D - 1) / a.D;
         if (u_lo < a.r_lo) u_lo = a.r_lo;
         if (u_hi > a.r_hi) u_hi = a.r_hi;
+        SrcWalk wu0, wl0;                                // the same sources for every channel
+        wu0.init(u_lo + t, a.I, a.D);
+        wl0.init(u_lo + t - 1, a.I, a.D);
         for (int c = 0; c < nchan; c++) {
             RR_PHASE();
             creg w[16];
@@ -581,22 +603,21 @@ void k_fm_multi(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, l
             lds_store<LOG2F, 0>(w, t, lds);
             tile_sync<T>();
             float* oc = out + (long)c * out_stride;
-            for (long u = u_lo + t; u < u_hi; u += T) {
-                const long gu = (u * a.D) / a.I - a.A;
+            SrcWalk wu = wu0, wl = wl0;
+            for (long u = u_lo + t; u < u_hi; u += T, wu.step(qs, rs, a.I), wl.step(qs, rs, a.I)) {
+                const long gu = wu.q - a.A;
                 const creg ru = lds[lds_pad((int)(gu - ys) + first)];
                 if (u == a.r_hi - 1) last_r_out[c] = from_reg(ru);
-                if (u == 0) continue;
-                creg rl;
-                if (u == a.r_lo) rl = to_reg(last_r_in[c]);
-                else {
-                    const long gl = ((u - 1) * a.D) / a.I - a.A;
-                    rl = lds[lds_pad((int)(gl - ys) + first)];
+                if (u != 0) {
+                    creg rl;
+                    if (u == a.r_lo) rl = to_reg(last_r_in[c]);
+                    else rl = lds[lds_pad((int)(wl.q - a.A - ys) + first)];
+                    const float na = -rl.y;
+                    const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
+                    const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
+                    const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                    oc[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
                 }
-                const float na = -rl.y;
-                const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
-                const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
-                const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
-                oc[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
             }
             tile_sync<T>();
         }
