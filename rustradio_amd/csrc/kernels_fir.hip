@@ -75,7 +75,7 @@ constexpr int FIR_MAXPRE = 20;
 // s evaluates only the phases p = s (mod S) for its R outputs and the S partial sums meet in the
 // output staging buffer.  Same tile, same thread count, S times fewer LDS reads per multiply-add.
 // A group is a whole number of waves, so taps stay wave-uniform.
-template <class T, class TapT, class OutT, int NT, int R, int S, bool HILBERT>
+template <class T, class TapT, class OutT, int NT, int R, int S, int PRE, bool HILBERT>
 __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
                                             int qpad, int np, int rstride, int pstride,
                                             const TapT* __restrict__ tp) {
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
     const long ntiles = (n_out + NOUT - 1) / NOUT;
     const int total = np * d;
     const int cnt_k = (total + NT - 1) / NT;           // staged values per thread
-    const bool piped = cnt_k <= FIR_MAXPRE;
+    const bool piped = cnt_k <= PRE;                   // PRE = staged values per thread the kernel is built for
 
-    T pre[FIR_MAXPRE];
+    T pre[PRE];
     // Only INTERIOR tiles (whole window inside the caller's buffer) are pipelined through registers;
     // the few tiles that touch the carried history or the end of the window are staged in place by
     // stage_direct().  The test is workgroup-uniform and the loads below are straight-line: a
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
         int cnt = cnt_k;
         asm volatile("" : "+s"(cnt));                   // ... and the 20 round predicates 40 SGPRs (spilled to lanes)
 #pragma unroll
-        for (int c = 0; c < FIR_MAXPRE; c++) {
+        for (int c = 0; c < PRE; c++) {
             if (c < cnt - 1) {
                 pre[c] = (gp + c * NT)[tt];             // uniform base + lane offset: no per-load address math
             } else if (c == cnt - 1) {                  // ragged last round: clamped, commit() skips the slot
@@ -135,14 +135,14 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
             T* slot = lds + p * pstride + (n % R) * rstride + n / R;
             const unsigned K = sn / R;
 #pragma unroll
-            for (int c = 0; c < FIR_MAXPRE; c++) {
+            for (int c = 0; c < PRE; c++) {
                 if (c < cnt - 1) slot[c * K] = pre[c];
                 else if (c == cnt - 1 && tt + c * NT < (unsigned)total) slot[c * K] = pre[c];
             }
             return;
         }
 #pragma unroll
-        for (int c = 0; c < FIR_MAXPRE; c++) {
+        for (int c = 0; c < PRE; c++) {
             if (c < cnt - 1 || (c == cnt - 1 && tt + c * NT < (unsigned)total))
                 lds[p * pstride + (n % R) * rstride + n / R] = pre[c];
             p += sp; n += sn;
@@ -160,12 +160,29 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
         }
     };
 
+    // The outputs of a tile are held in registers across the loop back-edge and stored only AFTER the next
+    // tile's input has been committed: vmcnt counts loads and stores in one in-order queue, so a store
+    // issued between a tile's fetch and its commit makes the commit wait for the store's completion as
+    // well (the compiler emits vmcnt(0)) — measured 0.88 -> see DESIGN.md for the 127-tap d = 1 filter.
+    OutT hold[R / S];
+    long hold_m0 = -1;
+    auto flush = [&]() {
+        if (hold_m0 < 0) return;
+        const bool whole = hold_m0 + NOUT <= n_out;      // workgroup-uniform: unconditional stores for full tiles
+#pragma unroll
+        for (int c = 0; c < R / S; c++) {
+            const int i = c * NT + t;
+            if (whole || hold_m0 + i < n_out) out[hold_m0 + i] = hold[c];
+        }
+    };
+
     long tile = blockIdx.x;
     if (tile < ntiles) fetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         const long m0 = tile * NOUT;
         __syncthreads();                       // previous tile's output reads are done
         if (interior(tile)) commit(); else stage_direct(tile);
+        flush();                               // previous tile's outputs: behind this tile's loads in the queue
         __syncthreads();
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
 
@@ -185,7 +202,10 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
             // (q % R), column tc + q/R + 1 of the transposed tile.  (Software-pipelining the loop by one
             // block — next block's samples and taps issued before this block's multiply-adds — measured
             // slower twice: +32 VGPRs cost a wave per SIMD and the scalar tap loads force lgkmcnt(0) anyway.)
-#pragma unroll 2
+            // two blocks per iteration when the registers allow it (R = 8 without a phase split does not:
+            // the 128-VGPR bound then spills, and every scratch access waits vmcnt(0), i.e. for the
+            // prefetched tile — measured 1.02 vs 0.6 ms for 127 taps at d = 1)
+#pragma unroll(R == 8 && S <= 2 && sizeof(T) == 8 ? 1 : 2)
             for (int q0 = 0; q0 < qpad; q0 += 8) {
                 const T* lq = lp + q0 / R + 1;
                 TapT tap8[8];
@@ -224,9 +244,11 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
 #pragma unroll
                 for (int g = 1; g < S; g++) v = add_of(v, lds_o[(g * NTC + i / R) * (R + 1) + i % R]);
             }
-            if (m0 + i < n_out) out[m0 + i] = v;
+            hold[c] = v;
         }
+        hold_m0 = m0;
     }
+    flush();
 }
 
 // Fallback for shapes whose tile does not fit LDS (very large d or L): one output per thread,
@@ -310,25 +332,35 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
     const char* qe = getenv("RR_FIR_QCOMPUTE");                             // measurement knob: taps actually multiplied
     const int qcomp = qe ? atoi(qe) : -1;
     const int qrun = qcomp >= 0 && qcomp < pl.qpad ? qcomp : pl.qpad;
-#define RR_FIR_LAUNCH(NTV, RV, SV)                                                                                     \
-    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, SV, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, s, \
-                       src, out, n_out, pl.L, pl.d, qrun, g.np, g.rstride, g.pstride, tp)
+    // the R = 8, S = 1 shapes (d = 1) stage <= 10 values per thread: a build with the shorter register
+    // pipeline leaves room for the held outputs without spilling
+    const long staged = ((long)g.np * pl.d + NT - 1) / NT;
+#define RR_FIR_LAUNCH(NTV, RV, SV, PREV)                                                                                \
+    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, SV, PREV, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, \
+                       s, src, out, n_out, pl.L, pl.d, qrun, g.np, g.rstride, g.pstride, tp)
+#define RR_FIR_LAUNCH2(NTV, RV, SV)                                                   \
+    do {                                                                              \
+        if (staged <= 10) RR_FIR_LAUNCH(NTV, RV, SV, 10); else RR_FIR_LAUNCH(NTV, RV, SV, FIR_MAXPRE); \
+    } while (0)
     switch (pick) {
-    case 0: RR_FIR_LAUNCH(256, 8, 1); break;
-    case 1: RR_FIR_LAUNCH(128, 8, 1); break;
-    case 2: RR_FIR_LAUNCH(64, 8, 1); break;
-    case 3: RR_FIR_LAUNCH(256, 2, 1); break;
-    case 4: RR_FIR_LAUNCH(128, 2, 1); break;
+    case 0: RR_FIR_LAUNCH2(256, 8, 1); break;
+    case 1: RR_FIR_LAUNCH2(128, 8, 1); break;
+    case 2: RR_FIR_LAUNCH2(64, 8, 1); break;
+    case 3: RR_FIR_LAUNCH(256, 2, 1, FIR_MAXPRE); break;
+    case 4: RR_FIR_LAUNCH(128, 2, 1, FIR_MAXPRE); break;
     default:
         if constexpr (!HILBERT) {
             switch (pick) {
-            case 5: RR_FIR_LAUNCH(256, 4, 2); break;
-            case 6: RR_FIR_LAUNCH(256, 8, 2); break;
-            default: RR_FIR_LAUNCH(256, 8, 4); break;
+            case 5: RR_FIR_LAUNCH(256, 4, 2, FIR_MAXPRE); break;
+            case 6: RR_FIR_LAUNCH(256, 8, 2, FIR_MAXPRE); break;
+            default:
+                if (staged <= 18) RR_FIR_LAUNCH(256, 8, 4, 18); else RR_FIR_LAUNCH(256, 8, 4, FIR_MAXPRE);
+                break;
             }
         }
         break;
     }
+#undef RR_FIR_LAUNCH2
 #undef RR_FIR_LAUNCH
     RR_HIP(hipGetLastError());
 }
