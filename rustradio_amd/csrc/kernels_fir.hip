@@ -75,11 +75,15 @@ constexpr int FIR_MAXPRE = 20;
 // s evaluates only the phases p = s (mod S) for its R outputs and the S partial sums meet in the
 // output staging buffer.  Same tile, same thread count, S times fewer LDS reads per multiply-add.
 // A group is a whole number of waves, so taps stay wave-uniform.
-template <class T, class TapT, class OutT, int NT, int R, int S, int PRE, bool HILBERT>
+template <class T, class TapT, class OutT, int NT, int R, int S, int PRE, int RSC, bool HILBERT>
 __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
-                                            int qpad, int np, int rstride, int pstride,
+                                            int qpad, int np, int rstride_arg, int pstride_arg,
                                             const TapT* __restrict__ tp) {
     using AccT = typename std::conditional<HILBERT, T, OutT>::type;   // real samples x complex taps accumulate Complex
+    // RSC > 0: the row stride is a compile-time constant, so the R window reads of a tap block are one
+    // address register + immediates (the d = 1 shapes; the host sizes the tile for it)
+    const int rstride = RSC > 0 ? RSC : rstride_arg;
+    const int pstride = RSC > 0 ? R * RSC + 1 : pstride_arg;
     constexpr int NTC = NT / S;                        // threads (output columns) per phase group
     constexpr int NOUT = NTC * R;
     static_assert(R % 2 == 0 && R <= 8, "qpad is padded to a multiple of 8");
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
             // two blocks per iteration when the registers allow it (R = 8 without a phase split does not:
             // the 128-VGPR bound then spills, and every scratch access waits vmcnt(0), i.e. for the
             // prefetched tile — measured 1.02 vs 0.6 ms for 127 taps at d = 1)
-#pragma unroll(R == 8 && S <= 2 && sizeof(T) == 8 ? 1 : 2)
+#pragma unroll(R == 8 && S <= 2 && sizeof(T) == 8 && RSC == 0 ? 1 : 2)
             for (int q0 = 0; q0 < qpad; q0 += 8) {
                 const T* lq = lp + q0 / R + 1;
                 TapT tap8[8];
@@ -335,12 +339,25 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
     // the R = 8, S = 1 shapes (d = 1) stage <= 10 values per thread: a build with the shorter register
     // pipeline leaves room for the held outputs without spilling
     const long staged = ((long)g.np * pl.d + NT - 1) / NT;
+    // d = 1, R = 8, S = 1 and up to 512 taps per phase: fixed row stride NT + 66 (== 2 mod 4: bank-friendly)
+    const bool fixed_rs = pick <= 2 && pl.d == 1 && staged <= 10 && pl.qpad / 8 + 1 <= 66 && !getenv("RR_FIR_NO_RSC");
+    if (fixed_rs) {
+        g.rstride = NT + 66;
+        g.pstride = 8 * g.rstride + 1;
+        const size_t in_b = (size_t)g.pstride * sizeof(T), out_b = (size_t)NT * 9 * sizeof(OutT);
+        g.lds_bytes = in_b > out_b ? in_b : out_b;
+    }
 #define RR_FIR_LAUNCH(NTV, RV, SV, PREV)                                                                                \
-    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, SV, PREV, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, \
+    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, SV, PREV, 0, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, \
                        s, src, out, n_out, pl.L, pl.d, qrun, g.np, g.rstride, g.pstride, tp)
+#define RR_FIR_LAUNCH_RSC(NTV, RV, PREV)                                                                                \
+    hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, 1, PREV, NTV + 66, HILBERT>), dim3((unsigned)grid), dim3(NTV),     \
+                       g.lds_bytes, s, src, out, n_out, pl.L, pl.d, qrun, g.np, g.rstride, g.pstride, tp)
 #define RR_FIR_LAUNCH2(NTV, RV, SV)                                                   \
     do {                                                                              \
-        if (staged <= 10) RR_FIR_LAUNCH(NTV, RV, SV, 10); else RR_FIR_LAUNCH(NTV, RV, SV, FIR_MAXPRE); \
+        if (fixed_rs) RR_FIR_LAUNCH_RSC(NTV, RV, 10);                                 \
+        else if (staged <= 10) RR_FIR_LAUNCH(NTV, RV, SV, 10);                        \
+        else RR_FIR_LAUNCH(NTV, RV, SV, FIR_MAXPRE);                                  \
     } while (0)
     switch (pick) {
     case 0: RR_FIR_LAUNCH2(256, 8, 1); break;
@@ -361,6 +378,7 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
         break;
     }
 #undef RR_FIR_LAUNCH2
+#undef RR_FIR_LAUNCH_RSC
 #undef RR_FIR_LAUNCH
     RR_HIP(hipGetLastError());
 }
