@@ -34,6 +34,8 @@ __device__ __forceinline__ void mac(cf& acc, cf tap, float w) {   // complex tap
 
 __device__ __forceinline__ float add_of(float a, float b) { return a + b; }
 __device__ __forceinline__ cf add_of(cf a, cf b) { return mkcf(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void opaque(cf& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
 template <class T> __device__ __forceinline__ T zero_of();
 template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
 template <> __device__ __forceinline__ cf zero_of<cf>() { return mkcf(0.0f, 0.0f); }
@@ -214,12 +216,20 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
                 const T* lq = lp + q0 / R + 1;
                 TapT tap8[8];
 #pragma unroll
+#ifdef RR_FIR_EXP_NOTAPLOAD      /* measurement build: the same 8 taps every block (hoisted out of the loop) */
+                for (int kk = 0; kk < 8; kk++) tap8[kk] = tpp[kk];
+#else
                 for (int kk = 0; kk < 8; kk++) tap8[kk] = tpp[q0 + kk];
+#endif
 #pragma unroll
                 for (int kk = 0; kk < 8; kk++) {
 #pragma unroll
                     for (int j = 0; j < R; j++) mac(acc[j], tap8[kk], w[(kk + j) % R]);
+#ifdef RR_FIR_EXP_NOLDS          /* measurement build: the window is never refilled */
+                    opaque(w[kk % R]);
+#else
                     w[kk % R] = lq[(kk % R) * rstride + kk / R];
+#endif
                 }
             }
         }
