@@ -590,15 +590,15 @@ void k_fm_multi(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, l
         SrcWalk wu0, wl0;                                // the same sources for every channel
         wu0.init(u_lo + t, a.I, a.D);
         wl0.init(u_lo + t - 1, a.I, a.D);
+        // channel c+1's frequency response is fetched (L2) while channel c is inverse-transformed
+        creg h[16];
+        load_h<LOG2F, NP - 1>(h, t, hpos_all);
         for (int c = 0; c < nchan; c++) {
             RR_PHASE();
             creg w[16];
-            {
-                creg h[16];
-                lds_load<LOG2F, NP - 1>(w, t, ldsX);
-                load_h<LOG2F, NP - 1>(h, t, hpos_all + (long)c * F);
-                apply_h(w, h);
-            }
+            lds_load<LOG2F, NP - 1>(w, t, ldsX);
+            apply_h(w, h);
+            if (c + 1 < nchan) load_h<LOG2F, NP - 1>(h, t, hpos_all + (long)(c + 1) * F);
             X.inverse(w, lds);
             lds_store<LOG2F, 0>(w, t, lds);
             tile_sync<T>();
