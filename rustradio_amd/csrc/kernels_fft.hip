@@ -269,6 +269,15 @@ template <int LOG2F> __device__ __forceinline__ void load_tile16(creg* v, const 
     }
 }
 
+// outputs are written once and never re-read by this kernel: streaming (non-temporal) store
+__device__ __forceinline__ void store_stream(creg* p, creg v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // ---- FftFilter -----------------------------------------------------------------------------------
 template <int LOG2F, int VAR>
 __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
@@ -321,8 +330,8 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
         if (o0 + F <= n_out) {                                  // whole tile inside the output window
 #pragma unroll
             for (int n = 0; n < 16; n++) {
-                if (n * T >= first) po[n * T] = v[n];           // wave-uniform
-                else if ((n + 1) * T > first) { if (n * T + t >= first) po[n * T] = v[n]; }
+                if (n * T >= first) store_stream(&po[n * T], v[n]);           // wave-uniform
+                else if ((n + 1) * T > first) { if (n * T + t >= first) store_stream(&po[n * T], v[n]); }
             }
         } else {
 #pragma unroll
