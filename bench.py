@@ -14,6 +14,7 @@ Other workloads (--workload, also summarised under "others" in the JSON line):
     fm_multi     configs[3]: 32 such channels per GPU on one shared IQ source (256 channels on 8 GPUs)
     channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in), fused into one
                  composite decimating FIR (rr.HilbertFir); channelizer_unfused = the two blocks
+    fir_fft_chain  configs[0] taps -> configs[1] filter as one chain (the north star's ">= 100x CPU" pair)
     rtl_fm_chain configs[2] fed by the RTL-SDR byte stream: RtlSdrDecode fused in front (u8 in)
 
 Multi-GPU (one process per GPU, weak scaling): the path shards by channel — every rank
@@ -167,6 +168,26 @@ def make_fir(dev, rank, world, shared_src):
     return w
 
 
+def make_fir_fft_chain(dev, rank, world, shared_src):
+    """the north star's ">= 100x the CPU reference" pair: 127-tap FirFilter -> FftFilter(401 taps, ref 1024-pt)
+    on the configs[1] input, device-resident intermediate"""
+    w = Workload()
+    w.name = "FirFilter<Complex>(127 real taps) -> FftFilter(401 taps, ref fft_size 1024), 10 Msps Complex<f32>, 100,000,000 samples/step"
+    fs, n = 10e6, 100_000_000
+    t1 = rr.low_pass_complex(fs, 1e6, 190e3)
+    t2 = rr.low_pass_complex(fs, 1e6, 60e3)
+    assert len(t1) == 127 and len(t2) == 401
+    w.blocks = [rr.FirFilter(t1), rr.FftFilter(t2)]
+    w.n = n
+    w.bufs = [shared_src(lambda: synth_complex(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0002, dev)),
+              torch.empty(2 * n, dtype=torch.float32, device=dev), torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev)]
+    w.caps = [n, n + 1024]
+    w.alg_bytes_per_sample = 16.0
+    w.dominant, w.dominant_bytes_per_unit = 1, 16.0
+    w.cpu = ("fir_fft_chain", (t1, t2))
+    return w
+
+
 def make_fm_chain(dev, rank, world, shared_src, fused=True):
     w = Workload()
     how = "fused into one kernel (rr.FmChain)" if fused else "three blocks, device-resident intermediates"
@@ -287,7 +308,8 @@ def make_channelizer_unfused(dev, rank, world, shared_src):
 
 WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
              "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "channelizer": make_channelizer,
-             "rtl_fm_chain": make_rtl_fm_chain, "channelizer_unfused": make_channelizer_unfused}
+             "rtl_fm_chain": make_rtl_fm_chain, "channelizer_unfused": make_channelizer_unfused,
+             "fir_fft_chain": make_fir_fft_chain}
 
 
 # ---- measurement ------------------------------------------------------------------------------
@@ -329,6 +351,9 @@ def cpu_baseline(w, seconds=10.0):
         host = w.bufs[0][:win * 2 * nwin].cpu().numpy()
         chain = [orc.Hilbert(65), orc.FirFilter(taps, deci=8)]
         win = 1_024_000
+    elif kind == "fir_fft_chain":
+        host = w.bufs[0][:2 * win * nwin].cpu().numpy().view(np.complex64)
+        chain = [orc.FirFilter(taps[0]), orc.FftFilter(taps[1])]
     elif kind == "rtl_fm_chain":
         win = 4_096_000                                       # a full u8 ring (src/stream.rs:105)
         host = w.bufs[0][:win * 4].cpu().numpy()
@@ -449,7 +474,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
+                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),
