@@ -34,6 +34,8 @@ unsafe extern "C" {
     fn rr_quaddemod_create(gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_hilbert_create(ntaps: usize, window: c_int, window_parm: f32) -> *mut RrBlock;
     fn rr_rtlsdr_decode_create() -> *mut RrBlock;
+    fn rr_multiply_const_f32_create(val: f32) -> *mut RrBlock;
+    fn rr_fastfm_create() -> *mut RrBlock;
     fn rr_fm_chain_create(taps: *const Complex, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_fm_chain_u8_create(taps: *const Complex, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_block_destroy(b: *mut RrBlock);
@@ -209,7 +211,76 @@ impl Block for GpuRtlFmChain {
     }
 }
 
-// RtlSdrDecode (rr_rtlsdr_decode_create), the Complex-input fused chain (rr_fm_chain_create),
+/// Every hot-path block whose tags are dropped (`RationalResampler`, `QuadratureDemod`, `RtlSdrDecode`) or pass
+/// through position-for-position (`MultiplyConst`, `FastFM`): one input stream, one output stream, the C ABI
+/// does the rest.  `keep_tags` selects the second behaviour (rustradio_macros_code/src/lib.rs:458-515).
+pub struct GpuMap<I: Sample, O: Sample> {
+    h: Handle,
+    name: &'static str,
+    keep_tags: bool,
+    src: ReadStream<I>,
+    dst: WriteStream<O>,
+}
+impl<I: Sample, O: Sample> GpuMap<I, O> {
+    fn wrap(h: *mut RrBlock, name: &'static str, keep_tags: bool, src: ReadStream<I>) -> Result<(Self, ReadStream<O>)> {
+        let h = Handle::new(h)?;
+        let (dst, dr) = new_stream();
+        Ok((Self { h, name, keep_tags, src, dst }, dr))
+    }
+}
+impl<T: Sample> GpuMap<T, T> {
+    /// `RationalResampler::new(src, interp, deci)` (src/rational_resampler.rs:125-151)
+    pub fn rational_resampler(src: ReadStream<T>, interp: usize, deci: usize) -> Result<(Self, ReadStream<T>)> {
+        // SAFETY: plain values.
+        Self::wrap(unsafe { rr_resampler_create(interp, deci, std::mem::size_of::<T>()) }, "GpuRationalResampler", false, src)
+    }
+}
+impl GpuMap<Complex, Float> {
+    /// `QuadratureDemod::new(src, gain)`; `fast_math` = the Cargo feature the application is built with
+    pub fn quadrature_demod(src: ReadStream<Complex>, gain: Float, fast_math: bool) -> Result<(Self, ReadStream<Float>)> {
+        Self::wrap(unsafe { rr_quaddemod_create(gain, fast_math as c_int) }, "GpuQuadratureDemod", false, src)
+    }
+    /// `FastFM::new(src)` (src/quadrature_demod.rs:144-165)
+    pub fn fast_fm(src: ReadStream<Complex>) -> Result<(Self, ReadStream<Float>)> {
+        Self::wrap(unsafe { rr_fastfm_create() }, "GpuFastFM", true, src)
+    }
+}
+impl GpuMap<u8, Complex> {
+    /// `RtlSdrDecode::new(src)` (src/rtlsdr_decode.rs:9-47)
+    pub fn rtlsdr_decode(src: ReadStream<u8>) -> Result<(Self, ReadStream<Complex>)> {
+        Self::wrap(unsafe { rr_rtlsdr_decode_create() }, "GpuRtlSdrDecode", false, src)
+    }
+}
+impl GpuMap<Float, Float> {
+    /// `MultiplyConst::new(src, val)` (src/multiply_const.rs:6-23)
+    pub fn multiply_const(src: ReadStream<Float>, val: Float) -> Result<(Self, ReadStream<Float>)> {
+        Self::wrap(unsafe { rr_multiply_const_f32_create(val) }, "GpuMultiplyConst", true, src)
+    }
+}
+impl<I: Sample, O: Sample> BlockName for GpuMap<I, O> { fn block_name(&self) -> &str { self.name } }
+impl<I: Sample, O: Sample> BlockEOF for GpuMap<I, O> {
+    fn eof(&mut self) -> bool {
+        // SAFETY: valid handle.  (The resampler also needs its pending sample flushed: rational_resampler.rs:209-213.)
+        unsafe { rr_block_eof(self.h.0, self.src.eof() as c_int) != 0 }
+    }
+}
+impl<I: Sample, O: Sample> Block for GpuMap<I, O> {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let (input, mut tags) = self.src.read_buf()?;
+        let mut out = self.dst.write_buf()?;
+        let (st, consumed, produced, need) = self.h.work(input.slice(), out.slice())?;
+        if self.keep_tags { tags.retain(|t| t.pos() < produced); } else { tags.clear(); }
+        input.consume(consumed);
+        out.produce(produced, &tags);
+        Ok(match st {
+            RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
+            RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need),
+            _ => BlockRet::Again,
+        })
+    }
+}
+
+// The Complex-input fused chain (rr_fm_chain_create), the fused Hilbert -> FirFilter (rr_hilbert_fir_create),
 // RationalResampler<T>, QuadratureDemod, Hilbert and FftFilterFloat follow the same pattern
 // (tags dropped for the first two, `pos < n` kept for Hilbert): see the C++ mirror for the
 // exact work() bodies — rustradio_amd/host/rustradio.hpp — and INTEGRATION.md.
