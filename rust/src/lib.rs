@@ -281,9 +281,9 @@ impl<I: Sample, O: Sample> Block for GpuMap<I, O> {
 }
 
 // The Complex-input fused chain (rr_fm_chain_create), the fused Hilbert -> FirFilter (rr_hilbert_fir_create),
-// RationalResampler<T>, QuadratureDemod, Hilbert and FftFilterFloat follow the same pattern
-// (tags dropped for the first two, `pos < n` kept for Hilbert): see the C++ mirror for the
-// exact work() bodies — rustradio_amd/host/rustradio.hpp — and INTEGRATION.md.
+// Hilbert (tags with `pos < n` kept), FftFilterFloat and FftStream (frame tags added from `produced`) follow
+// the same patterns: see the C++ mirror for the exact work() bodies — rustradio_amd/host/rustradio.hpp — and
+// INTEGRATION.md.
 pub fn window_code(w: &WindowType) -> (c_int, f32) {
     match w {
         WindowType::Hamming => (0, 0.0),

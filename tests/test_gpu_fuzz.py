@@ -1,0 +1,122 @@
+"""GPU: seeded random sweep over block parameters, input lengths and ring sizes — every trial drives the oracle
+and the HIP block through identical window sequences (harness.run_chain) and compares the protocol log and
+the samples, like tests/test_gpu_parity.py::both().  Catches boundary-tile / carry-state / tile-shape corner
+cases that fixed parameter lists miss."""
+import numpy as np
+import pytest
+
+from harness import max_norm_err, run_chain
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def rr():
+    import rustradio_amd
+    return rustradio_amd
+
+
+def _c(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+
+
+def _both(rr, make, x, stream_bytes, exact=False, scale=None):
+    lo, lg = [], []
+    yo = run_chain(make(orc), x, stream_bytes=stream_bytes, log=lo)
+    yg = run_chain(make(rr), x, stream_bytes=stream_bytes, log=lg)
+    assert lo == lg, "work() protocol differs"
+    assert len(yo) == len(yg)
+    if exact:
+        assert np.array_equal(yo, yg)
+    elif len(yo):
+        assert max_norm_err(yg, yo, scale) <= TOL
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_fir(rr, seed):
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.choice([1, 2, 3, 7, 8, 9, 31, 64, 65, 127, 200, 255, 256, 257, 511, 1000]))
+    d = int(rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 9, 16, 25, 64]))
+    n = int(rng.integers(L + d, 120_000))
+    cplx_taps = bool(rng.integers(0, 2))
+    real_in = bool(rng.integers(0, 3) == 0)
+    es = 4 if real_in else 8
+    ring = int(rng.choice([4_096_000, es * (L + d + int(rng.integers(8, 5000)))]))
+    if real_in:
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        taps = (rng.uniform(-1, 1, L) / max(1, L // 8)).astype(np.float32)
+    else:
+        x = _c(rng, n)
+        taps = _c(rng, L) / max(1, L // 8)
+        if not cplx_taps:
+            taps = taps.real.astype(np.complex64)
+    _both(rr, lambda m: [m.FirFilter(taps, deci=d)], x, ring)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_fftfilter_and_chain(rr, seed):
+    rng = np.random.default_rng(2000 + seed)
+    L = int(rng.choice([1, 2, 5, 33, 100, 193, 255, 256, 257, 401, 463, 511, 512, 513, 1024, 1500, 2467]))
+    n = int(rng.integers(10, 150_000))
+    x = _c(rng, n)
+    taps = _c(rng, L) / max(1, L // 4)
+    nsamp = 2 * (1 << int(np.ceil(np.log2(L)))) - L if L > 1 else 1
+    ring = int(rng.choice([4_096_000, 8 * (nsamp + int(rng.integers(1, 4000)))]))
+    _both(rr, lambda m: [m.FftFilter(taps)], x, ring)
+    I, D = int(rng.integers(1, 9)), int(rng.integers(1, 40))
+    yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D), orc.QuadratureDemod(1.0)], x, stream_bytes=ring)
+    ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D)], x, stream_bytes=ring)
+    try:
+        blk = rr.FmChain(taps, I, D, 1.0)
+    except Exception:
+        return                                          # decimation too large for the tile: refused, not wrong
+    yg = run_chain([blk], x, stream_bytes=ring)
+    assert len(yg) == len(yo)
+    if len(yo):
+        eps = TOL * float(np.max(np.abs(ro)))
+        mag = np.abs(ro.astype(np.complex128))
+        bound = TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30)
+        dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
+        dd = np.minimum(dd, 2 * np.pi - dd)
+        assert np.all(dd <= bound[:len(dd)])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_streaming_blocks(rr, seed):
+    rng = np.random.default_rng(3000 + seed)
+    n = int(rng.integers(1, 200_000))
+    ring = int(rng.choice([4_096_000, 8 * int(rng.integers(70, 6000))]))
+    x = _c(rng, n)
+    I, D = int(rng.integers(1, 50)), int(rng.integers(1, 50))
+    _both(rr, lambda m: [m.RationalResampler(I, D, np.complex64)], x, ring, exact=True)
+    gain = float(rng.uniform(0.1, 3))
+    _both(rr, lambda m: [m.QuadratureDemod(gain)], x, ring, scale=np.pi * gain)
+    _both(rr, lambda m: [m.FastFM()], x, ring, exact=True)
+    hn = int(rng.choice([3, 5, 31, 33, 63, 65, 127, 129]))
+    xr = rng.uniform(-1, 1, n).astype(np.float32)
+    _both(rr, lambda m: [m.Hilbert(hn)], xr, max(ring, 4 * 300))
+    b = rng.integers(0, 256, n, dtype=np.uint8)
+    _both(rr, lambda m: [m.RtlSdrDecode()], b, ring, exact=True)
+    size = int(rng.choice([2, 8, 64, 512, 1024, 2048, 4096]))
+    _both(rr, lambda m: [m.FftStream(size)], x, max(ring, 8 * (size + 3)))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_hilbert_fir(rr, seed):
+    rng = np.random.default_rng(4000 + seed)
+    hn = int(rng.choice([3, 31, 65, 129]))
+    L = int(rng.choice([1, 8, 33, 100, 255, 400]))
+    d = int(rng.choice([1, 2, 3, 5, 8, 12, 16]))
+    n = int(rng.integers(L + d + hn, 150_000))
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    taps = _c(rng, L) / max(1, L // 8)
+    if rng.integers(0, 2):
+        taps = taps.real.astype(np.complex64)
+    ring = int(rng.choice([4_096_000, 4 * (L + d + int(rng.integers(8, 5000)))]))
+    yo = run_chain([orc.Hilbert(hn), orc.FirFilter(taps, deci=d)], x)
+    yg = run_chain([rr.HilbertFir(hn, taps, d)], x, stream_bytes=ring)
+    assert len(yg) == len(yo)
+    if len(yo):
+        assert max_norm_err(yg, yo) <= TOL
