@@ -120,3 +120,50 @@ def test_fuzz_hilbert_fir(rr, seed):
     assert len(yg) == len(yo)
     if len(yo):
         assert max_norm_err(yg, yo) <= TOL
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_translate_and_u8_chain(rr, seed):
+    rng = np.random.default_rng(5000 + seed)
+    L = int(rng.choice([4, 33, 127, 255]))
+    d = int(rng.choice([1, 3, 8]))
+    n = int(rng.integers(L + d + 8, 60_000))
+    fs = float(rng.choice([8.0, 2.4e6, 100e6]))
+    f = float(rng.uniform(-0.4, 0.4)) * fs
+    x = _c(rng, n)
+    taps = _c(rng, L) / max(1, L // 8)
+    ring = int(rng.choice([4_096_000, 8 * (L + d + int(rng.integers(8, 3000)))]))
+    _both(rr, lambda m: [m.FirFilter(taps, deci=d, translate=(fs, f), **({"rotator": rr.ROT_REPLAY} if m is rr else {}))], x, ring)
+    # RTL-SDR bytes -> fused chain vs the four oracle blocks
+    b = rng.integers(0, 256, 2 * int(rng.integers(2000, 80_000)) + int(rng.integers(0, 2)), dtype=np.uint8)
+    I, D = int(rng.integers(1, 5)), int(rng.integers(1, 12))
+    yo = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(I, D), orc.QuadratureDemod(1.0)], b)
+    ro = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(I, D)], b)
+    yg = run_chain([rr.FmChainU8(taps, I, D, 1.0)], b, stream_bytes=int(rng.choice([4_096_000, 20_001])))
+    assert len(yg) == len(yo)
+    if len(yo):
+        eps = TOL * float(np.max(np.abs(ro)))
+        mag = np.abs(ro.astype(np.complex128))
+        bound = TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30)
+        dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
+        dd = np.minimum(dd, 2 * np.pi - dd)
+        assert np.all(dd <= bound[:len(dd)])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_device_rings(rr, seed):
+    """random chains over HBM-resident rings == the same chains over host windows, bit for bit"""
+    from test_gpu_parity import run_chain_device
+    rng = np.random.default_rng(6000 + seed)
+    n = int(rng.integers(3000, 120_000))
+    x = _c(rng, n)
+    L = int(rng.choice([5, 64, 255]))
+    taps = _c(rng, L) / max(1, L // 8)
+    d = int(rng.choice([1, 2, 8]))
+    I, D = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    ring = int(rng.choice([4_096_000, 8 * (2 * L + d + int(rng.integers(600, 4000)))]))
+    mk = lambda: [rr.FirFilter(taps, deci=d), rr.RationalResampler(I, D, np.complex64), rr.MultiplyConst(0.5 - 2j, np.complex64),
+                  rr.FastFM(), rr.MultiplyConst(1.5)]
+    yh = run_chain(mk(), x, stream_bytes=ring)
+    yd = run_chain_device(rr, mk(), x, stream_bytes=ring)
+    assert len(yh) == len(yd) and np.array_equal(yh, yd)
