@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""GPU box: sample rocm-smi clocks/power while the FftFilter kernel (or packed-FMA FIR) runs back to back."""
+import os, subprocess, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import rustradio_amd as rr
+
+which = sys.argv[1] if len(sys.argv) > 1 else "fft"
+n = 100_000_000
+x = torch.rand(2 * n, device="cuda") * 2 - 1
+y = torch.empty(2 * n + 4096, device="cuda")
+blk = rr.FftFilter(rr.low_pass_complex(10e6, 1e6, 60e3)) if which == "fft" else rr.FirFilter(rr.low_pass_complex(10e6, 1e6, 190e3))
+samples = []
+stop = False
+def poll():
+    while not stop:
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showuse"], capture_output=True, text=True, timeout=10).stdout
+            keep = [l.strip() for l in out.splitlines() if any(k in l for k in ("sclk", "mclk", "fclk", "Power", "GPU use"))]
+            samples.append(" | ".join(keep))
+        except Exception as e:
+            samples.append(f"rocm-smi failed: {e}")
+            return
+th = threading.Thread(target=poll); th.start()
+t0 = time.time()
+while time.time() - t0 < 6:
+    for _ in range(200):
+        blk2 = blk
+        blk2.work_dev(x.data_ptr(), n, y.data_ptr(), n + 2048)
+    torch.cuda.synchronize()
+stop = True; th.join()
+print(f"{which}: idle-first then loaded samples")
+for s in samples[:2] + samples[-4:]:
+    print("  ", s[:300])
