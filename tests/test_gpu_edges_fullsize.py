@@ -151,3 +151,66 @@ def test_fm_chain_and_resampler_full_size(rr):
     # demodulated FM: 75 kHz deviation, 1 kHz tone at 400 ksps -> phase step amplitude 2 pi 75e3/400e3
     amp = o3[skip:p3].abs().max().item()
     assert abs(amp - 2 * np.pi * 75e3 / 400e3) < 2e-3
+
+
+def test_windows_beyond_2_31_elements(rr):
+    """64-bit indexing: single device windows of 2.2e9 elements (> 2^31 elements, > 2^34 bytes).  The last
+    stretch of each output is compared with the same block run on just the tail of the input (time
+    invariance), which the oracle-level parity tests already pin."""
+    import torch
+    n = 2_200_000_000
+    tail = 3_000_000
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    # --- Hilbert: 2.2e9 floats in, 2.2e9 Complex out
+    x = torch.empty(n, dtype=torch.float32, device="cuda")
+    for s in range(0, n, 200_000_000):
+        m = min(200_000_000, n - s)
+        x[s:s + m] = torch.rand(m, generator=g, device="cuda") * 2 - 1
+    y = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+    b = rr.Hilbert(65)
+    st, c, p, need = b.work_dev(x.data_ptr(), n, y.data_ptr(), n)
+    b.sync()
+    assert (st, c, p) == (AGAIN, n, n)
+    b2 = rr.Hilbert(65)
+    y2 = torch.empty(2 * tail, dtype=torch.float32, device="cuda")
+    b2.work_dev(x.data_ptr() + 4 * (n - tail), tail, y2.data_ptr(), tail)
+    b2.sync()
+    a, r = y[2 * (n - tail) + 2 * 65:], y2[2 * 65:]                  # skip the tail run's zero history
+    assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
+    del y, y2
+    # --- decimating FIR (Float in, Float taps) over the same 2.2e9 samples
+    taps = orc.low_pass(100e6, 5e6, 943e3)
+    f = rr.FirFilter(taps, deci=8)
+    yo = torch.empty(n // 8 + 8, dtype=torch.float32, device="cuda")
+    st, c, p, need = f.work_dev(x.data_ptr(), n, yo.data_ptr(), n // 8 + 8)
+    f.sync()
+    assert st == AGAIN and p == (n - len(taps) + 1) // 8 and c == 8 * p
+    f2 = rr.FirFilter(taps, deci=8)
+    start = 8 * ((n - tail) // 8)
+    y2 = torch.empty(tail // 8 + 8, dtype=torch.float32, device="cuda")
+    st2, c2, p2, _ = f2.work_dev(x.data_ptr() + 4 * start, n - start, y2.data_ptr(), tail // 8 + 8)
+    f2.sync()
+    a, r = yo[start // 8: start // 8 + p2], y2[:p2]
+    assert p2 > 1000 and start // 8 + p2 == p
+    assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
+    del yo, y2, x
+    # --- FftFilter: 2.2e9 Complex in (17.6 GB), tail compared from a block boundary on
+    xc = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+    for s in range(0, 2 * n, 400_000_000):
+        m = min(400_000_000, 2 * n - s)
+        xc[s:s + m] = torch.rand(m, generator=g, device="cuda") * 2 - 1
+    ct = orc.low_pass_complex(10e6, 1e6, 60e3)
+    ff = rr.FftFilter(ct)
+    yc = torch.empty(2 * (n + 1024), dtype=torch.float32, device="cuda")
+    st, c, p, need = ff.work_dev(xc.data_ptr(), n, yc.data_ptr(), n + 1024)
+    ff.sync()
+    assert st == WAIT_SRC and c == n and p == (n // 623) * 623
+    start = ((p - tail) // 623) * 623
+    ff2 = rr.FftFilter(ct)
+    y2 = torch.empty(2 * (tail + 1024), dtype=torch.float32, device="cuda")
+    st2, c2, p2, _ = ff2.work_dev(xc.data_ptr() + 8 * start, p - start, y2.data_ptr(), tail + 1024)
+    ff2.sync()
+    assert p2 == p - start
+    skip = 2 * len(ct)                                               # zero history of the tail run
+    a, r = yc[2 * start + skip: 2 * p], y2[skip: 2 * p2]
+    assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
