@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librustradio_amd.so")
@@ -36,6 +37,15 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C rustradio_amd/csrc` (hipcc --offload-arch=gfx950). rustradio_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64, and whichever copy is loaded
+    # first serves both (same SONAME).  If this library pulled in /opt/rocm's copy before torch was imported,
+    # torch would later run on a runtime it was not built against (observed: torch.cuda.is_available() False,
+    # or "no usable HIP device" here).  So when torch is installed, let it load its runtime first.
+    if "torch" not in sys.modules and not os.environ.get("RR_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     sz, f32, vp, i32 = C.c_size_t, C.c_float, C.c_void_p, C.c_int
     psz = C.POINTER(sz)
