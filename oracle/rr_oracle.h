@@ -8,7 +8,7 @@
  *
  * It is a plain-C restatement (not a copy: the reference is Rust) of the
  * algorithms in /root/reference/src/{fir,fft_filter,rational_resampler,
- * quadrature_demod,hilbert,window}.rs, in the reference's operation order,
+ * quadrature_demod,hilbert,window,rtlsdr_decode,multiply_const,fft_stream}.rs, in the reference's operation order,
  * in IEEE f32 without FMA contraction or reassociation (build flags in
  * oracle/Makefile).  Every function cites the reference lines it follows.
  *
@@ -24,6 +24,10 @@
  *     its own f32 Stockham FFT with f64-computed twiddles (what rustfft does
  *     for twiddles).  Bit-level FFT parity is "unpinned"; the reference's own
  *     tests for it (filter_a_signal, tag_propagation) are reproduced.
+ *   - RtlSdrDecode: PINNED (the reference asserts exact f32 equality, src/rtlsdr_decode.rs:66-89).
+ *   - MultiplyConst / FastFM: no reference unit tests; pinned to their one-line definitions evaluated in
+ *     numpy f32 (tests/test_oracle_golden.py::test_sync_blocks_by_definition).
+ *   - FftStream: same FFT as above, checked against numpy's f64 FFT at 1e-6 (conventions of rustfft).
  *   - fast-math atan2 (crate fast-math 0.1.1, not vendored): restated from
  *     its published algorithm; "parity unpinned" beyond the reference's 1e-3
  *     tests.  The exact libm atan2f path is the parity oracle.
