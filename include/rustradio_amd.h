@@ -196,13 +196,16 @@ int rr_host_unregister(void *ptr);
 /* ---- device-resident streams ----------------------------------------------------------
  * A stream ring in HBM with the reference's window contract (src/stream.rs:187-310 over
  * src/nowasm/circular_buffer.rs:98-128): read window = ALL readable elements, write window = ALL free
- * space, both contiguous; capacity in bytes (the reference default is 4,096,000, src/stream.rs:105).
+ * space, both contiguous (double mapping); capacity in bytes (the reference default is 4,096,000, src/stream.rs:105).
  * GPU blocks chained through these never cross PCIe and never wait for each other: all counts are
  * host-side, kernels and the occasional ring move are enqueued on the caller's HIP stream. */
 typedef struct rr_dstream rr_dstream;
 rr_dstream *rr_dstream_create(size_t elem_size, size_t capacity_bytes);          /* new_stream(), stream.rs:336-339 */
 void        rr_dstream_destroy(rr_dstream *s);
 size_t      rr_dstream_capacity(const rr_dstream *s);                            /* elements */
+/* 1: the ring is one physical allocation mapped twice back to back (HIP virtual-memory API), the
+ * reference's own trick (circular_buffer.rs:98-128), no data is ever moved; 0: linear fallback */
+int         rr_dstream_is_double_mapped(const rr_dstream *s);
 /* ReadStream::read_buf() (stream.rs:208-217): returns the readable element count, *dev_ptr = window */
 size_t      rr_dstream_read_buf(rr_dstream *s, const void **dev_ptr);
 /* WriteStream::write_buf() (stream.rs:301-310): returns the free element count, *dev_ptr = window */

@@ -196,6 +196,11 @@ class DeviceStream:
     def capacity(self) -> int:
         return lib().rr_dstream_capacity(self._h)
 
+    @property
+    def double_mapped(self) -> bool:
+        """True when the ring is one physical allocation mapped twice (no data movement, ever)"""
+        return bool(lib().rr_dstream_is_double_mapped(self._h))
+
     def readable(self) -> int:
         return lib().rr_dstream_read_buf(self._h, None)
 

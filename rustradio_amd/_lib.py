@@ -22,7 +22,7 @@ SYMBOLS = [
     "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_set_rotator_mode",
     "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps",
     "rr_host_register", "rr_host_unregister",
-    "rr_dstream_create", "rr_dstream_destroy", "rr_dstream_capacity", "rr_dstream_read_buf", "rr_dstream_write_buf",
+    "rr_dstream_create", "rr_dstream_destroy", "rr_dstream_capacity", "rr_dstream_is_double_mapped", "rr_dstream_read_buf", "rr_dstream_write_buf",
     "rr_dstream_consume", "rr_dstream_produce", "rr_dstream_copy_in", "rr_dstream_copy_out", "rr_block_work_streams",
 ]
 
@@ -93,6 +93,7 @@ def lib():
     L.rr_dstream_create.argtypes = [sz, sz]; L.rr_dstream_create.restype = vp
     L.rr_dstream_destroy.argtypes = [vp]; L.rr_dstream_destroy.restype = None
     L.rr_dstream_capacity.argtypes = [vp]; L.rr_dstream_capacity.restype = sz
+    L.rr_dstream_is_double_mapped.argtypes = [vp]; L.rr_dstream_is_double_mapped.restype = i32
     L.rr_dstream_read_buf.argtypes = [vp, pvp]; L.rr_dstream_read_buf.restype = sz
     L.rr_dstream_write_buf.argtypes = [vp, pvp, vp]; L.rr_dstream_write_buf.restype = sz
     L.rr_dstream_consume.argtypes = [vp, sz]; L.rr_dstream_consume.restype = i32

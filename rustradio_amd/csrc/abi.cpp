@@ -231,6 +231,7 @@ rr_dstream* rr_dstream_create(size_t elem_size, size_t capacity_bytes) {
 }
 void rr_dstream_destroy(rr_dstream* s) { delete s; }
 size_t rr_dstream_capacity(const rr_dstream* s) { return s ? s->s->cap : 0; }
+int rr_dstream_is_double_mapped(const rr_dstream* s) { return s && s->s->vmm ? 1 : 0; }
 size_t rr_dstream_read_buf(rr_dstream* s, const void** dev_ptr) {
     if (!s) return 0;
     if (dev_ptr) *dev_ptr = s->s->read_ptr();

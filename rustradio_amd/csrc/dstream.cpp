@@ -1,9 +1,42 @@
 // dstream.cpp — device-resident stream rings (see dstream.hpp).
 #include "dstream.hpp"
 
+#include <cstdlib>
+
 #include "blocks.hpp"
 
 namespace rr {
+
+bool DStream::try_vmm() {
+    if (getenv("RR_DSTREAM_NO_VMM")) return false;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return false;
+    const size_t bytes = cap * es;
+    phys = (bytes + gran - 1) / gran * gran;
+    if (hipMemCreate(&handle, phys, &prop, 0) != hipSuccess) return false;
+    void* p = nullptr;
+    if (hipMemAddressReserve(&p, 2 * phys, 0, nullptr, 0) != hipSuccess) { (void)hipMemRelease(handle); return false; }
+    va = static_cast<unsigned char*>(p);
+    bool ok = hipMemMap(va, phys, 0, handle, 0) == hipSuccess;
+    bool ok2 = ok && hipMemMap(va + phys, phys, 0, handle, 0) == hipSuccess;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (!ok2 || hipMemSetAccess(va, 2 * phys, &acc, 1) != hipSuccess) {
+        if (ok2) (void)hipMemUnmap(va + phys, phys);
+        if (ok) (void)hipMemUnmap(va, phys);
+        (void)hipMemAddressFree(va, 2 * phys);
+        (void)hipMemRelease(handle);
+        va = nullptr;
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
 
 DStream::DStream(size_t elem_size, size_t capacity_bytes) : es(elem_size), cap(0), device(thread_device()) {
     if (!(es == 1 || es == 2 || es == 4 || es == 8 || es == 16)) throw Error("dstream: element size must be 1,2,4,8 or 16");
@@ -12,10 +45,23 @@ DStream::DStream(size_t elem_size, size_t capacity_bytes) : es(elem_size), cap(0
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw Error("no usable HIP device");
     RR_HIP(hipSetDevice(device));
-    buf.reserve(2 * cap * es);
+    vmm = try_vmm();
+    if (!vmm) buf.reserve(2 * cap * es);
+}
+
+DStream::~DStream() {
+    if (vmm) {
+        (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();            // nothing may still be running on the mapping
+        (void)hipMemUnmap(va, phys);
+        (void)hipMemUnmap(va + phys, phys);
+        (void)hipMemAddressFree(va, 2 * phys);
+        (void)hipMemRelease(handle);
+    }
 }
 
 void* DStream::write_ptr(hipStream_t s) {
+    if (vmm) return va + (rb + used_ * es) % phys;
     if (w + free() > 2 * cap) {                     // the write window would run off the end
         const size_t n = used();                    // here r > cap >= n: source and destination are disjoint
         if (n) RR_HIP(hipMemcpyAsync(buf.p, buf.p + r * es, n * es, hipMemcpyDeviceToDevice, s));
@@ -25,11 +71,19 @@ void* DStream::write_ptr(hipStream_t s) {
 }
 void DStream::consume(size_t n) {
     if (n > used()) throw Error("dstream consume: n > readable");
+    if (vmm) {
+        rb = (rb + n * es) % phys;
+        used_ -= n;
+        if (used_ == 0) rb = 0;
+        return;
+    }
     r += n;
     if (r == w) r = w = 0;
 }
 void DStream::produce(size_t n) {
-    if (n > free() || w + n > 2 * cap) throw Error("dstream produce: n > free");
+    if (n > free()) throw Error("dstream produce: n > free");
+    if (vmm) { used_ += n; return; }
+    if (w + n > 2 * cap) throw Error("dstream produce: n > free");
     w += n;
 }
 

@@ -530,8 +530,11 @@ def run_chain_device(rr, blocks, x, stream_bytes=4_096_000):
     return np.concatenate(outs) if outs else np.zeros(0, blocks[-1].out_dtype)
 
 
+@pytest.mark.parametrize("no_vmm", [False, True])
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 3_001])
-def test_device_streams_equal_host_windows(rr, stream_bytes):
+def test_device_streams_equal_host_windows(rr, monkeypatch, stream_bytes, no_vmm):
+    if no_vmm:
+        monkeypatch.setenv("RR_DSTREAM_NO_VMM", "1")
     """chains over HBM-resident rings (small rings force the wrap-around move) produce bit-identical output
     to the same blocks driven through host windows"""
     fs = 2.4e6
@@ -551,8 +554,12 @@ def test_device_streams_equal_host_windows(rr, stream_bytes):
     assert np.array_equal(run_chain(mk3(), b, stream_bytes=stream_bytes), run_chain_device(rr, mk3(), b, stream_bytes=stream_bytes))
 
 
-def test_device_stream_ring_contract(rr):
+@pytest.mark.parametrize("no_vmm", [False, True])
+def test_device_stream_ring_contract(rr, monkeypatch, no_vmm):
+    if no_vmm:
+        monkeypatch.setenv("RR_DSTREAM_NO_VMM", "1")      # the linear fallback
     s = rr.DeviceStream(np.uint32, 4 * 10)
+    assert s.double_mapped == (not no_vmm)
     assert s.capacity == 10 and s.readable() == 0 and s.free() == 10
     assert s.push(np.arange(25, dtype=np.uint32)) == 10 and s.free() == 0
     assert np.array_equal(s.pop(4), np.arange(4, dtype=np.uint32)) and s.readable() == 6 and s.free() == 4
