@@ -233,7 +233,11 @@ public:
     size_t id() const { return s_->id(); }
 };
 
-template <class T> std::pair<WriteStream<T>, ReadStream<T>> new_stream(size_t bytes = DEFAULT_STREAM_SIZE,
+// Ring size used by new_stream() when none is given.  The reference's 4,096,000 bytes suit CPU caches; rings
+// in HBM want hundreds of MB so that one work() is milliseconds, not microseconds, of kernel.
+inline size_t& default_stream_size() { static thread_local size_t b = DEFAULT_STREAM_SIZE; return b; }
+
+template <class T> std::pair<WriteStream<T>, ReadStream<T>> new_stream(size_t bytes = default_stream_size(),
                                                                        Memory m = default_memory()) {  // :336-339
     auto st = std::make_shared<StreamState<T>>(bytes, m);
     return {WriteStream<T>(st), ReadStream<T>(st)};
@@ -740,7 +744,7 @@ template <class T> class MemCopy : public Block {
 public:
     MemCopy(ReadStream<T> src, WriteStream<T> dst) : src_(std::move(src)), dst_(std::move(dst)) {}
     static std::pair<std::unique_ptr<MemCopy<T>>, ReadStream<T>> new_(ReadStream<T> src, Memory to) {
-        auto [w, r] = new_stream<T>(DEFAULT_STREAM_SIZE, to);
+        auto [w, r] = new_stream<T>(default_stream_size(), to);
         return {std::make_unique<MemCopy<T>>(std::move(src), std::move(w)), std::move(r)};
     }
     const char* block_name() const override { return "MemCopy"; }
