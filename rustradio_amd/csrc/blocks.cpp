@@ -320,20 +320,27 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8
     L = ntaps;
     fft_size = calc_fft_size(ntaps);                                  // fft_filter.rs:261
     nsamples = fft_size - ntaps;                                      // fft_filter.rs:262
-    // GPU tile: overlap-save with F_int >= the reference's fft_size and >= 1024.  When the
-    // taps fill more than a quarter of a <= 2048-point tile the tile is doubled (S' = F - L + 1
-    // new outputs per F-point transform: 61% -> 80% useful for 401 taps; measured 0.43 ->
-    // 0.385 ms per 1e8 samples).  Results do not depend on F beyond f32 rounding.
-    log2f = 10;
-    while (((size_t)1 << log2f) < fft_size) log2f++;
-    if (log2f < 12 && L > ((size_t)1 << log2f) / 4) log2f++;
-    if (const char* e = getenv("RR_FFT_LOG2F")) {          // tuning knob: force a larger tile
+    // GPU tile: overlap-save with any F > L - 1 (S' = F - L + 1 new outputs per F-point transform; results do
+    // not depend on F beyond f32 rounding).  F is the one that minimises measured tile cost / S'
+    // (tools/taps_sweep.py, relative cost of one tile of 1024 .. 16384 points on MI355X; the >= 8192-point
+    // tiles run one workgroup per CU and are disproportionately expensive, so e.g. 2467 taps — the rtl_fm
+    // filter — run 1.7x faster on 4096-point tiles at 40 % useful outputs than on 8192-point ones at 70 %).
+    static const double tile_cost[5] = {285.0, 620.0, 1450.0, 7530.0, 27540.0};
+    double best = 0.0;
+    log2f = -1;
+    for (int lg = 10; lg <= 14; lg++) {
+        const size_t Fc = (size_t)1 << lg;
+        if (Fc < L + 1) continue;                                     // need S' >= 2
+        const double c = tile_cost[lg - 10] / (double)(Fc - L + 1);
+        if (log2f < 0 || c < best) { best = c; log2f = lg; }
+    }
+    if (log2f < 0) log2f = 15;                                        // -> refused below
+    if (const char* e = getenv("RR_FFT_LOG2F")) {          // tuning knob: force a tile size
         const int v = atoi(e);
-        if (v > log2f && v <= 14) log2f = v;
-        else if (v >= 10 && ((size_t)1 << v) >= fft_size) log2f = v;
+        if (v >= 10 && v <= 14 && ((size_t)1 << v) >= L + 1) log2f = v;
     }
     if (!fftfilt_supported(log2f))
-        throw Error("FftFilter: more than 8192 taps is not supported by the LDS-resident tile kernel");
+        throw Error("FftFilter: more than 16383 taps is not supported by the LDS-resident tile kernel");
     const size_t F = (size_t)1 << log2f;
     std::vector<cf> hpos, tw(F);
     compute_hpos(taps, ntaps, log2f, hpos);

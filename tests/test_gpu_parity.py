@@ -111,7 +111,7 @@ def test_fir_translate(rr, mode):
         assert max_norm_err(yg, yo) <= TOL
 
 
-@pytest.mark.parametrize("L", [1, 2, 5, 193, 401, 463, 512, 513, 1025, 2467, 5000])
+@pytest.mark.parametrize("L", [1, 2, 5, 193, 401, 463, 512, 513, 1025, 2467, 3100, 3300, 5000, 8193, 12000, 16383])
 def test_fftfilter(rr, L):
     n = 200_000 if L < 1025 else 400_000
     x = rnd_c(n, L)
@@ -137,7 +137,7 @@ def test_fftfilter_chunked_and_small_outputs(rr):
 
 def test_fftfilter_rejects_too_many_taps(rr):
     with pytest.raises(ValueError):
-        rr.FftFilter(np.ones(8193, np.complex64))
+        rr.FftFilter(np.ones(16384, np.complex64))          # no 16384-point tile leaves room for new samples
     with pytest.raises(ValueError):
         rr.FftFilter(np.ones(0, np.complex64))
 
