@@ -322,10 +322,9 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8
     nsamples = fft_size - ntaps;                                      // fft_filter.rs:262
     // GPU tile: overlap-save with any F > L - 1 (S' = F - L + 1 new outputs per F-point transform; results do
     // not depend on F beyond f32 rounding).  F is the one that minimises measured tile cost / S'
-    // (tools/taps_sweep.py, relative cost of one tile of 1024 .. 16384 points on MI355X; the >= 8192-point
-    // tiles run one workgroup per CU and are disproportionately expensive, so e.g. 2467 taps — the rtl_fm
-    // filter — run 1.7x faster on 4096-point tiles at 40 % useful outputs than on 8192-point ones at 70 %).
-    static const double tile_cost[5] = {285.0, 620.0, 1450.0, 7530.0, 27540.0};
+    // (tools/taps_sweep.py: relative cost of one tile of 1024 .. 16384 points on MI355X; the 8192- and
+    // 16384-point tiles are k_fftfilt_split, 2 / 4 sub-transforms of 4096 points).
+    static const double tile_cost[5] = {285.0, 620.0, 1450.0, 4100.0, 11000.0};
     double best = 0.0;
     log2f = -1;
     for (int lg = 10; lg <= 14; lg++) {
@@ -350,6 +349,33 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8
     }
     d_hpos.upload(hpos.data(), F, stream);
     d_tw.upload(tw.data(), F, stream);
+    if (log2f >= 13 && !getenv("RR_FFT_NO_SPLIT")) {      // split-tile tables (thread-major order, see kernels.hpp)
+        nsub = 1 << (log2f - 12);
+        const size_t M = 4096;
+        std::vector<std::complex<double>> H(F, 0.0);
+        for (size_t i = 0; i < ntaps; i++) H[i] = {taps[i].re, taps[i].im};
+        fft64(H);
+        std::vector<cf> hs((size_t)nsub * M), wk(M), tw4(M);
+        for (size_t pp = 0; pp < M; pp++) {             // hs[r][p] = H[nsub bin(p) + r] / F
+            const size_t k = (size_t)fftfilt_split_bin((int)pp);
+            for (int r = 0; r < nsub; r++) {
+                const auto h = H[(size_t)nsub * k + r] / (double)F;
+                hs[(size_t)r * M + pp] = mkcf((float)h.real(), (float)h.imag());
+            }
+        }
+        for (int t = 0; t < 256; t++)                   // wk[16 t + n] = w_F^(n 256 + t)
+            for (int n = 0; n < 16; n++) {
+                const double a = -2.0 * 3.14159265358979323846 * (double)(n * 256 + t) / (double)F;
+                wk[(size_t)t * 16 + n] = mkcf((float)std::cos(a), (float)std::sin(a));
+            }
+        for (size_t k = 0; k < M; k++) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)M;
+            tw4[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+        }
+        d_hs.upload(hs.data(), hs.size(), stream);
+        d_wk.upload(wk.data(), wk.size(), stream);
+        d_tw4096.upload(tw4.data(), tw4.size(), stream);
+    }
     // prefix = [L-1 history samples][pending < nsamples]; zero history at stream start (A.4)
     const size_t pcap = (L - 1) + nsamples + 1;
     for (auto& p : prefix) {
@@ -380,7 +406,8 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     VSrc<cf> src{prefix[cur].p, plen, static_cast<const cf*>(in), (long)in_len};
     if (k) {
         prof_begin(s);
-        launch_fftfilt_os(log2f, src, static_cast<cf*>(out), (long)n_out, (int)L, d_tw.p, d_hpos.p, s);
+        if (nsub) launch_fftfilt_split(nsub, src, static_cast<cf*>(out), (long)n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s);
+        else launch_fftfilt_os(log2f, src, static_cast<cf*>(out), (long)n_out, (int)L, d_tw.p, d_hpos.p, s);
         prof_end(s);
     }
     if (*consumed) {

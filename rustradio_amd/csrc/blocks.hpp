@@ -86,6 +86,9 @@ struct FftFilter : Block {
     size_t L = 0, fft_size = 0, nsamples = 0;
     int log2f = 10;
     DevBuf<cf> d_tw, d_hpos;
+    // >= 8192-point tiles as nsub interleaved 4096-point sub-transforms (kernels_fft.hip k_fftfilt_split)
+    int nsub = 0;
+    DevBuf<cf> d_tw4096, d_hs, d_wk;
     DevBuf<cf> prefix[2];
     int cur = 0;
     size_t pend_len = 0;

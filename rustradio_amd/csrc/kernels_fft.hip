@@ -345,6 +345,149 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
     }
 }
 
+// ---- FftFilter tiles of 8192 / 16384 points as NSUB = 2 / 4 sub-transforms of 4096 points ---------------------
+// A 512/1024-thread tile fits one workgroup per CU and cannot keep its tables in registers (k_fftfilt_os<13|14, 3>
+// costs 6x / 22x a 4096-point tile).  Split in frequency instead (M = 4096, F = NSUB M, n < M):
+//     u_r[n]  = w_F^(r n) sum_s w_NSUB^(r s) x[n + s M]                     input butterfly + twiddle
+//     X[NSUB k + r] = FFT_M(u_r)[k],   Y = X H,   z_r = IFFT_M(Y[NSUB k + r])   the 4096-point filter body, per r
+//     y[n + s M] = sum_r w_NSUB^(-r s) conj(w_F^(r n)) z_r[n]                output twiddle + butterfly
+// Both butterflies act on the NSUB quarters of the tile at the same n, and a thread's n are the same for all
+// quarters, so they are thread-local: the u_r / z_r wait in the thread's own natural-order LDS slots, nothing is
+// exchanged beyond the sub-transforms' own passes, global loads and stores stay lane-consecutive, and each
+// sub-transform uses its parking area as its exchange area (NSUB x 34.8 KB: 2 workgroups per CU for NSUB = 2).
+// Tables: wk[16 t + n] = w_F^(n T + t);  hs[r][p] = H[NSUB bin(p) + r] / F in the 4096-point position order.
+template <int T>
+__device__ __attribute__((noinline)) void stage_tile_slow_at(creg* lds, VSrc<cf> src, long v0, int t) {
+    for (int n = 0; n < 16; n++) lds[lds_pad(n * T + t)] = to_reg(src.load(v0 + n * T + t));
+}
+
+template <int NSUB>
+__global__ __launch_bounds__(256, 2)
+void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles, const cf* __restrict__ tw,
+                     const cf* __restrict__ hs, const cf* __restrict__ wk) {
+    constexpr int LOG2M = 12, M = 1 << LOG2M, T = M / 16, F = NSUB * M;
+    constexpr int NP = Plan<LOG2M>::NP;
+    constexpr int LE = lds_elems(M);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* area = reinterpret_cast<creg*>(smem_raw);     // NSUB areas of LE slots: u_r, the r-th transform's exchanges, z_r
+    const int t = threadIdx.x;
+    const long S = F - L + 1;
+    const int first = L - 1;
+    TileXform<LOG2M, 0> X;
+    X.init_no_h(t, tw);
+    creg* out_reg = reinterpret_cast<creg*>(out);
+
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long v0 = it.tile * S;                    // virtual index of tile position 0
+        const bool interior = v0 >= src.plen && v0 - src.plen + F <= src.in_len;
+        if (!interior) {                                // boundary tiles: quarters staged out of line, then as below
+#pragma unroll
+            for (int s = 0; s < NSUB; s++) stage_tile_slow_at<T>(area + s * LE, src, v0 + (long)s * M, t);
+        }
+        // ---- input butterfly across the quarters (thread-local), u_r -> own natural slots of area r.
+        //      All loads of a batch are issued before the first use (one memory latency per batch, not per n).
+        {
+            const creg* p = reinterpret_cast<const creg*>(src.in) + (v0 - src.plen) + t;
+            constexpr int NB = 16 / NSUB;                // positions per batch: 16 values + NB twiddles in flight
+#pragma unroll 1
+            for (int n0 = 0; n0 < 16; n0 += NB) {
+                creg xin[NSUB][NB], wkr[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) wkr[k] = to_reg(wk[t * 16 + n0 + k]);
+                if (interior) {
+#pragma unroll
+                    for (int s = 0; s < NSUB; s++)
+#pragma unroll
+                        for (int k = 0; k < NB; k++) xin[s][k] = p[(long)s * M + (n0 + k) * T];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NSUB; s++)
+#pragma unroll
+                        for (int k = 0; k < NB; k++) xin[s][k] = area[s * LE + lds_pad((n0 + k) * T + t)];
+                }
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    const int n = n0 + k;
+                    creg e[NSUB];
+#pragma unroll
+                    for (int s = 0; s < NSUB; s++) e[s] = xin[s][k];
+                    Dft<NSUB, false>::run(e);           // across s -> r
+                    const creg w1 = wkr[k];
+                    e[1] = cmul(e[1], w1);
+                    if constexpr (NSUB == 4) { const creg w2 = cmul(w1, w1); e[2] = cmul(e[2], w2); e[3] = cmul(e[3], cmul(w2, w1)); }
+#pragma unroll
+                    for (int r = 0; r < NSUB; r++) area[r * LE + lds_pad(n * T + t)] = e[r];
+                }
+            }
+        }
+        // ---- the 4096-point filter body per r, exchanges in the r-th area, z_r back to the own natural slots
+#pragma unroll 1
+        for (int r = 0; r < NSUB; r++) {
+            creg* lds = area + r * LE;
+            creg v[16];
+            lds_load<LOG2M, 0>(v, t, lds);
+            X.forward(v, lds);
+            {
+                creg h[16];
+                load_h<LOG2M, NP - 1>(h, t, hs + (long)r * M);
+                apply_h(v, h);
+            }
+            X.inverse(v, lds);
+            lds_store<LOG2M, 0>(v, t, lds);
+        }
+        // ---- output twiddle + butterfly, lane-consecutive stores
+        const long o0 = it.tile * S - first;            // output index of tile position 0
+        creg* po = out_reg + o0 + t;
+        const bool whole = o0 + F <= n_out;
+#pragma unroll 1
+        for (int n0 = 0; n0 < 16; n0 += 8) {
+            creg wko[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) wko[k] = to_reg(wk[t * 16 + n0 + k]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int n = n0 + k;
+                const int slot = lds_pad(n * T + t);
+                creg e[NSUB];
+#pragma unroll
+                for (int r = 0; r < NSUB; r++) e[r] = area[r * LE + slot];
+                const creg w1 = wko[k];
+                e[1] = cmulc(e[1], w1);
+                if constexpr (NSUB == 4) { const creg w2 = cmul(w1, w1); e[2] = cmulc(e[2], w2); e[3] = cmulc(e[3], cmul(w2, w1)); }
+                Dft<NSUB, true>::run(e);                // across r -> s
+#pragma unroll
+                for (int s = 0; s < NSUB; s++) {
+                    const long pos = (long)s * M + n * T + t;
+                    if (pos >= first && (whole || o0 + pos < n_out)) po[(long)s * M + n * T] = e[s];
+                }
+            }
+        }
+        // (the next tile's first writes go to the own natural slots this thread just read)
+    }
+}
+
+int fftfilt_split_bin(int p) { return bin_of_pos<12>(p); }
+
+template <int NSUB>
+static void launch_split_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hs, const cf* wk, hipStream_t s) {
+    constexpr int M = 4096, F = NSUB * M;
+    const long S = F - L + 1;
+    const long ntiles = (n_out + S - 1) / S;
+    if (ntiles <= 0) return;
+    const size_t smem = sizeof(cf) * lds_elems(M) * NSUB;
+    static bool attr_set = false;
+    static int per_cu = 0;
+    const long grid = grid_for_tiles(k_fftfilt_split<NSUB>, 256, smem, ntiles, attr_set, per_cu);
+    hipLaunchKernelGGL((k_fftfilt_split<NSUB>), dim3((unsigned)grid), dim3(256), smem, s, src, out, n_out, L, ntiles, tw, hs, wk);
+    RR_HIP(hipGetLastError());
+}
+void launch_fftfilt_split(int nsub, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw4096, const cf* hs, const cf* wk,
+                          hipStream_t s) {
+    if (nsub == 2) launch_split_one<2>(src, out, n_out, L, tw4096, hs, wk, s);
+    else if (nsub == 4) launch_split_one<4>(src, out, n_out, L, tw4096, hs, wk, s);
+    else throw Error("fftfilt_split: 2 or 4 sub-transforms");
+}
+
 // ---- FftStream (src/fft_stream.rs:71-117): forward FFT of consecutive frames --------------------------
 // Frames of 1024..16384 points are one tile each: the forward half of the filter transform, then one
 // more LDS exchange that undoes the digit reversal (position p holds bin bin_of_pos(p)) so that the
