@@ -15,6 +15,7 @@ Other workloads (--workload, also summarised under "others" in the JSON line):
     channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in), fused into one
                  composite decimating FIR (rr.HilbertFir); channelizer_unfused = the two blocks
     fir_fft_chain  configs[0] taps -> configs[1] filter as one chain (the north star's ">= 100x CPU" pair)
+    rtl_fm_example examples/rtl_fm.rs with its own parameters (1.024 Msps, 2467 taps, 25:128), fused
     rtl_fm_chain configs[2] fed by the RTL-SDR byte stream: RtlSdrDecode fused in front (u8 in)
 
 Multi-GPU (one process per GPU, weak scaling): the path shards by channel — every rank
@@ -238,6 +239,29 @@ def make_rtl_fm_chain(dev, rank, world, shared_src):
     return w
 
 
+def make_rtl_fm_example(dev, rank, world, shared_src):
+    """examples/rtl_fm.rs:328-419 with its own numbers: 1.024 Msps RTL-SDR bytes, low_pass_complex(fs, 100 kHz, 1 kHz)
+    = 2467 taps (reference fft_size 8192), resampled 1,024,000 -> 200,000 (25:128), quadrature demod."""
+    w = Workload()
+    fs, n = 1.024e6, 24_000_000
+    taps = rr.low_pass_complex(fs, 100e3, 1e3)
+    w.name = (f"examples/rtl_fm.rs front end: RtlSdrDecode->FftFilter({len(taps)} taps)->RationalResampler(25:128)->QuadratureDemod "
+              "fused (rr.FmChainU8), 1.024 Msps u8 I/Q, 24,000,000 samples/step")
+    f32 = shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0006))
+    src = torch.clamp(torch.round(f32 / 0.008 + 127.0), 0, 255).to(torch.uint8)
+    w.blocks = [rr.FmChainU8(taps, 200000, 1024000, 1.0, rr.ATAN2_EXACT)]
+    cap = n * 25 // 128 + 4096
+    w.bufs = [src, torch.empty(cap, dtype=torch.float32, device=dev)]
+    w.caps = [cap]
+    w.in_mult = 2
+    w.dtype = "u8->f32"
+    w.n = n
+    w.alg_bytes_per_sample = w.dominant_bytes_per_unit = 2.0 + 4.0 * 25 / 128
+    w.dominant = 0
+    w.cpu = ("rtl_fm_example", taps)
+    return w
+
+
 def make_fm_chain_unfused(dev, rank, world, shared_src):
     return make_fm_chain(dev, rank, world, shared_src, fused=False)
 
@@ -309,7 +333,7 @@ def make_channelizer_unfused(dev, rank, world, shared_src):
 WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
              "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "channelizer": make_channelizer,
              "rtl_fm_chain": make_rtl_fm_chain, "channelizer_unfused": make_channelizer_unfused,
-             "fir_fft_chain": make_fir_fft_chain}
+             "fir_fft_chain": make_fir_fft_chain, "rtl_fm_example": make_rtl_fm_example}
 
 
 # ---- measurement ------------------------------------------------------------------------------
@@ -354,6 +378,10 @@ def cpu_baseline(w, seconds=10.0):
     elif kind == "fir_fft_chain":
         host = w.bufs[0][:2 * win * nwin].cpu().numpy().view(np.complex64)
         chain = [orc.FirFilter(taps[0]), orc.FftFilter(taps[1])]
+    elif kind == "rtl_fm_example":
+        win = 4_096_000
+        host = w.bufs[0][:win * 4].cpu().numpy()
+        chain = [orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(200000, 1024000), orc.QuadratureDemod(1.0)]
     elif kind == "rtl_fm_chain":
         win = 4_096_000                                       # a full u8 ring (src/stream.rs:105)
         host = w.bufs[0][:win * 4].cpu().numpy()
@@ -474,7 +502,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
+                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain", "rtl_fm_example") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),

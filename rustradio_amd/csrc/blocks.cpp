@@ -315,7 +315,7 @@ static void compute_hpos(const rr_c32* taps, size_t ntaps, int log2f, std::vecto
     }
 }
 
-FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8) {
+FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain) : Block("FftFilter", 8, 8) {
     if (ntaps == 0) throw Error("FftFilter: empty taps");            // fft_filter.rs:146
     L = ntaps;
     fft_size = calc_fft_size(ntaps);                                  // fft_filter.rs:261
@@ -324,7 +324,9 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8
     // not depend on F beyond f32 rounding).  F is the one that minimises measured tile cost / S'
     // (tools/taps_sweep.py: relative cost of one tile of 1024 .. 16384 points on MI355X; the 8192- and
     // 16384-point tiles are k_fftfilt_split, 2 / 4 sub-transforms of 4096 points).
-    static const double tile_cost[5] = {285.0, 620.0, 1450.0, 4100.0, 11000.0};
+    static const double cost_filter[5] = {285.0, 620.0, 1450.0, 4100.0, 11000.0};
+    static const double cost_chain[5] = {285.0, 620.0, 1450.0, 7530.0, 27540.0};
+    const double* tile_cost = for_chain ? cost_chain : cost_filter;
     double best = 0.0;
     log2f = -1;
     for (int lg = 10; lg <= 14; lg++) {
@@ -349,7 +351,7 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps) : Block("FftFilter", 8, 8
     }
     d_hpos.upload(hpos.data(), F, stream);
     d_tw.upload(tw.data(), F, stream);
-    if (log2f >= 13 && !getenv("RR_FFT_NO_SPLIT")) {      // split-tile tables (thread-major order, see kernels.hpp)
+    if (log2f >= 13 && !for_chain && !getenv("RR_FFT_NO_SPLIT")) {      // split-tile tables (thread-major order, see kernels.hpp)
         nsub = 1 << (log2f - 12);
         const size_t M = 4096;
         std::vector<std::complex<double>> H(F, 0.0);
@@ -431,7 +433,7 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     if (interp > (size_t)1 << 40 || deci > (size_t)1 << 40) throw Error("FmChain: ratio out of range");
     const int64_t gg = gcd64((int64_t)deci, (int64_t)interp);
     D = (int64_t)deci / gg; I = (int64_t)interp / gg;
-    f.reset(new FftFilter(taps, ntaps));
+    f.reset(new FftFilter(taps, ntaps, true));
     const int64_t G = (D + I - 1) / I;
     if (G >= (int64_t)(((size_t)1 << f->log2f) - f->L + 1)) throw Error("FmChain: decimation too large for the FFT tile");
     for (auto& b : last_r) { b.reserve(1); RR_HIP(hipMemsetAsync(b.p, 0, sizeof(cf), stream)); }

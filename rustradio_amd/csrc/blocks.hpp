@@ -92,7 +92,9 @@ struct FftFilter : Block {
     DevBuf<cf> prefix[2];
     int cur = 0;
     size_t pend_len = 0;
-    FftFilter(const rr_c32* taps, size_t ntaps);
+    // for_chain: the object backs a fused chain kernel (k_fm_chain / k_fm_multi), whose >= 8192-point tiles are
+    // still the one-workgroup-per-CU kind: the tile is then chosen with their cost
+    FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain = false);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 
