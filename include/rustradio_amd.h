@@ -143,7 +143,7 @@ rr_block *rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_p
  * tile's forward FFT is computed once for all channels.  The block has nchan OUTPUT windows:
  * rr_block_work[_dev] takes `out` as nchan consecutive windows of out_cap elements (channel c at
  * out + c*out_cap) and reports the per-channel consumed/produced (identical for all channels).
- * ntaps <= 2048. */
+ * ntaps <= 4094. */
 rr_block *rr_fm_multi_create(const rr_c32 *taps, size_t nchan, size_t ntaps, size_t interp, size_t deci,
                              float gain, int atan2_mode);
 /* number of output windows of a block (1 except rr_fm_multi_create) */

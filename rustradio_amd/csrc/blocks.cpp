@@ -315,7 +315,7 @@ static void compute_hpos(const rr_c32* taps, size_t ntaps, int log2f, std::vecto
     }
 }
 
-FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain) : Block("FftFilter", 8, 8) {
+FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain, int max_log2f) : Block("FftFilter", 8, 8) {
     if (ntaps == 0) throw Error("FftFilter: empty taps");            // fft_filter.rs:146
     L = ntaps;
     fft_size = calc_fft_size(ntaps);                                  // fft_filter.rs:261
@@ -329,7 +329,7 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain) : Block("
     const double* tile_cost = for_chain ? cost_chain : cost_filter;
     double best = 0.0;
     log2f = -1;
-    for (int lg = 10; lg <= 14; lg++) {
+    for (int lg = 10; lg <= max_log2f; lg++) {
         const size_t Fc = (size_t)1 << lg;
         if (Fc < L + 1) continue;                                     // need S' >= 2
         const double c = tile_cost[lg - 10] / (double)(Fc - L + 1);
@@ -341,7 +341,8 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain) : Block("
         if (v >= 10 && v <= 14 && ((size_t)1 << v) >= L + 1) log2f = v;
     }
     if (!fftfilt_supported(log2f))
-        throw Error("FftFilter: more than 16383 taps is not supported by the LDS-resident tile kernel");
+        throw Error("FftFilter: more than " + std::to_string(((size_t)1 << max_log2f) - 1) +
+                    " taps is not supported by the LDS-resident tile kernel");
     const size_t F = (size_t)1 << log2f;
     std::vector<cf> hpos, tw(F);
     compute_hpos(taps, ntaps, log2f, hpos);
@@ -424,7 +425,7 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
 
 // ---- fused FM chain ------------------------------------------------------------------------------------
 static int64_t gcd64(int64_t a, int64_t b);
-FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float g, int m, bool u8)
+FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float g, int m, bool u8, int max_log2f)
     : Block(u8 ? "RtlSdrDecode>FftFilter>RationalResampler>QuadratureDemod" : "FftFilter>RationalResampler>QuadratureDemod",
             u8 ? 1 : 8, 4), gain(g), mode(m), iq8(u8) {
     if (deci == 0) throw Error("RationalResampler created using deci 0");
@@ -433,7 +434,7 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     if (interp > (size_t)1 << 40 || deci > (size_t)1 << 40) throw Error("FmChain: ratio out of range");
     const int64_t gg = gcd64((int64_t)deci, (int64_t)interp);
     D = (int64_t)deci / gg; I = (int64_t)interp / gg;
-    f.reset(new FftFilter(taps, ntaps, true));
+    f.reset(new FftFilter(taps, ntaps, true, max_log2f));
     const int64_t G = (D + I - 1) / I;
     if (G >= (int64_t)(((size_t)1 << f->log2f) - f->L + 1)) throw Error("FmChain: decimation too large for the FFT tile");
     for (auto& b : last_r) { b.reserve(1); RR_HIP(hipMemsetAsync(b.p, 0, sizeof(cf), stream)); }
@@ -510,9 +511,9 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
 FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float g, int m)
     : Block("Tee>N x (FftFilter>RationalResampler>QuadratureDemod)", 8, 4), C(nchan) {
     if (nchan == 0 || nchan > 4096) throw Error("FmMulti: channel count must be 1..4096");
-    chain.reset(new FmChain(taps, ntaps, interp, deci, g, m));     // bookkeeping, prefix/pending state, twiddles
+    chain.reset(new FmChain(taps, ntaps, interp, deci, g, m, false, 12));   // bookkeeping, carry state, twiddles; 3-pass tiles
     const int lg = chain->f->log2f;
-    if (!fm_multi_supported(lg)) throw Error("FmMulti: at most 2048 taps (3-pass tiles)");
+    if (!fm_multi_supported(lg)) throw Error("FmMulti: at most 4094 taps (3-pass tiles)");
     const size_t F = (size_t)1 << lg;
     std::vector<cf> all(C * F), one;
     for (size_t c = 0; c < C; c++) {

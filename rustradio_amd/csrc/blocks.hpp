@@ -94,7 +94,7 @@ struct FftFilter : Block {
     size_t pend_len = 0;
     // for_chain: the object backs a fused chain kernel (k_fm_chain / k_fm_multi), whose >= 8192-point tiles are
     // still the one-workgroup-per-CU kind: the tile is then chosen with their cost
-    FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain = false);
+    FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain = false, int max_log2f = 14);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 
@@ -113,7 +113,8 @@ struct FmChain : Block {
     // is fused in front: windows, `consumed` and WAIT_SRC `need` are then counted in BYTES.
     bool iq8 = false;
     DevBuf<cf> decoded;               // only for odd-addressed byte windows (decoded out of line)
-    FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false);
+    FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false,
+            int max_log2f = 14);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 

@@ -505,6 +505,24 @@ def test_fm_multi_shared_source(rr, stream_bytes):
             assert np.max(d[len(proto) // 6 + 2:]) <= TOL * np.pi
 
 
+def test_fm_multi_long_filters(rr):
+    """FmMulti with the rtl_fm-sized filter (2467 taps -> 4096-point tiles); more than 4094 taps is refused"""
+    fs, n = 1.024e6, 250_000
+    proto = orc.low_pass_complex(fs, 100e3, 1e3)
+    assert len(proto) == 2467
+    k = np.arange(len(proto), dtype=np.float64)
+    taps = np.stack([(proto.astype(np.complex128) * np.exp(2j * np.pi * (c * 50e3) * k / fs)).astype(np.complex64) for c in range(3)])
+    x = fm_signal(n, fs, 0.0, 9)
+    st, c, p, need, out = rr.FmMulti(taps, 25, 128, 1.0).work(x, 200_000)
+    for ch in range(3):
+        yo = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(25, 128), orc.QuadratureDemod(1.0)], x)
+        ro = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(25, 128)], x)       # fresh blocks: they carry state
+        assert p == len(yo)
+        _demod_close(out[ch], yo, ro)
+    with pytest.raises(Exception):
+        rr.FmMulti(np.ones((2, 4095), np.complex64), 1, 6, 1.0)
+
+
 # ---- device-resident streams (rr_dstream, SURVEY §8 f1) --------------------------------------------
 def run_chain_device(rr, blocks, x, stream_bytes=4_096_000):
     """the same stream graph as harness.run_chain, but every ring lives in HBM and blocks run through
