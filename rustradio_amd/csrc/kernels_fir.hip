@@ -555,20 +555,26 @@ __device__ __forceinline__ void zmul(double& ax, double& ay, double bx, double b
     const double x = ax * bx - ay * by, y = ax * by + ay * bx;
     ax = x; ay = y;
 }
+// One binary powering per THREAD (step^(m0 + first index), ~2 log2(m) f64 complex multiplies), then one multiply by
+// step^(grid stride) per element (gx, gy: formed on the host in f64 the same way).  The per-element powering
+// this replaces cost 0.17 ms on the 1.25e7 outputs of the /8 channelizer.
 __global__ __launch_bounds__(256) void k_rotate_model(cf* __restrict__ y, long n, double p0x, double p0y,
-                                                      double sx, double sy, long m0) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        unsigned long e = (unsigned long)(m0 + i);
-        double rx = p0x, ry = p0y, bx = sx, by = sy;
-        while (e) {
-            if (e & 1) zmul(rx, ry, bx, by);
-            zmul(bx, by, bx, by);
-            e >>= 1;
-        }
+                                                      double sx, double sy, long m0, double gx, double gy) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long e = (unsigned long)(m0 + i);
+    double rx = p0x, ry = p0y, bx = sx, by = sy;
+    while (e) {
+        if (e & 1) zmul(rx, ry, bx, by);
+        zmul(bx, by, bx, by);
+        e >>= 1;
+    }
+    for (; i < n; i += (long)gridDim.x * blockDim.x) {
         const cf v = y[i];
         const double ox = (double)v.x * rx - (double)v.y * ry;
         const double oy = (double)v.x * ry + (double)v.y * rx;
         y[i] = mkcf((float)ox, (float)oy);
+        zmul(rx, ry, gx, gy);
     }
 }
 __global__ __launch_bounds__(256) void k_rotate_table(cf* __restrict__ y, long n, const cf* __restrict__ tab) {
@@ -586,7 +592,13 @@ static unsigned rot_grid(long n) {
 }
 void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, double sy, long m0, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_rotate_model, dim3(rot_grid(n)), dim3(256), 0, s, y, n, p0x, p0y, sx, sy, m0);
+    const unsigned grid = rot_grid(n);
+    double gx = 1.0, gy = 0.0, bx = sx, by = sy;                     // step^(grid * 256)
+    for (unsigned long e = (unsigned long)grid * 256; e; e >>= 1) {
+        if (e & 1) { const double x = gx * bx - gy * by, yy = gx * by + gy * bx; gx = x; gy = yy; }
+        const double x = bx * bx - by * by, yy = 2.0 * bx * by; bx = x; by = yy;
+    }
+    hipLaunchKernelGGL(k_rotate_model, dim3(grid), dim3(256), 0, s, y, n, p0x, p0y, sx, sy, m0, gx, gy);
     RR_HIP(hipGetLastError());
 }
 void launch_rotate_table(cf* y, long n, const cf* table, hipStream_t s) {
