@@ -723,6 +723,14 @@ FftStream::FftStream(size_t n) : Block("FftStream", 8, 8), size(n) {
         tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
     }
     d_tw.upload(tw.data(), n, stream);
+    if (n >= 8192 && !getenv("RR_FFT_NO_SPLIT")) {
+        std::vector<cf> t4(4096);
+        for (size_t k = 0; k < 4096; k++) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / 4096.0;
+            t4[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+        }
+        d_tw4096.upload(t4.data(), t4.size(), stream);
+    }
     RR_HIP(hipStreamSynchronize(stream));
 }
 int FftStream::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
@@ -733,7 +741,7 @@ int FftStream::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     size_t len = std::min(in_len, out_cap);                                    // :82-83
     len -= len % size;
     prof_begin(s);
-    launch_fft_frames(log2n, static_cast<const cf*>(in), static_cast<cf*>(out), (long)(len / size), d_tw.p, s);
+    launch_fft_frames(log2n, static_cast<const cf*>(in), static_cast<cf*>(out), (long)(len / size), d_tw.p, d_tw4096.p, s);
     prof_end(s);
     *consumed = *produced = len;
     return RR_AGAIN;                                                           // :116

@@ -162,7 +162,7 @@ struct QuadDemod : Block {
 struct FftStream : Block {
     size_t size = 0;
     int log2n = 0;
-    DevBuf<cf> d_tw;
+    DevBuf<cf> d_tw, d_tw4096;
     explicit FftStream(size_t size);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };

@@ -24,7 +24,8 @@ int fftfilt_split_bin(int p);
 
 // FftStream: out = forward unnormalised FFT of each of `nframes` consecutive 2^log2n-point frames
 // (log2n 1..14), natural bin order; tw = device table of w_N^k, k < N.
-void launch_fft_frames(int log2n, const cf* in, cf* out, long nframes, const cf* tw, hipStream_t s);
+// (tw4096 = w_4096^k: when given, 8192 / 16384-point frames run as 2 / 4 sub-transforms of 4096 points)
+void launch_fft_frames(int log2n, const cf* in, cf* out, long nframes, const cf* tw, const cf* tw4096, hipStream_t s);
 
 // Fused FftFilter -> RationalResampler -> QuadratureDemod over the same virtual stream.
 struct FmChainArgs {

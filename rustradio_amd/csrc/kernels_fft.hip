@@ -561,6 +561,78 @@ __global__ __launch_bounds__(256) void k_fft_small(const cf* __restrict__ in, cf
     }
 }
 
+// Frames of 8192 / 16384 points: the frequency split of k_fftfilt_split, forward half only.  Sub-transform r yields
+// the bins NSUB k + r; each sub-spectrum is scattered into its area at its bin index k and the frame is then
+// written lane-consecutively in natural order (bin j = NSUB k + r sits in area r, slot k).
+// twF = w_F^i (i < F), tw4096 = w_4096^k.
+template <int NSUB>
+__global__ __launch_bounds__(256, 2)
+void k_fft_frames_split(const cf* __restrict__ in, cf* __restrict__ out, long nframes, const cf* __restrict__ tw4096,
+                        const cf* __restrict__ twF) {
+    constexpr int LOG2M = 12, M = 1 << LOG2M, T = M / 16, F = NSUB * M;
+    constexpr int NP = Plan<LOG2M>::NP;
+    constexpr int LE = lds_elems(M);
+    using G = PassGeom<LOG2M, NP - 1>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* area = reinterpret_cast<creg*>(smem_raw);
+    const int t = threadIdx.x;
+    TileXform<LOG2M, 0> X;
+    X.init_no_h(t, tw4096);
+    for (TileIter it(nframes); it.tile < it.end; it.tile += it.step) {
+        const creg* p = reinterpret_cast<const creg*>(in) + it.tile * F + t;
+        constexpr int NB = 16 / NSUB;
+#pragma unroll 1
+        for (int n0 = 0; n0 < 16; n0 += NB) {
+            creg xin[NSUB][NB], wkr[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) wkr[k] = to_reg(twF[(n0 + k) * T + t]);
+#pragma unroll
+            for (int s = 0; s < NSUB; s++)
+#pragma unroll
+                for (int k = 0; k < NB; k++) xin[s][k] = p[(long)s * M + (n0 + k) * T];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                creg e[NSUB];
+#pragma unroll
+                for (int s = 0; s < NSUB; s++) e[s] = xin[s][k];
+                Dft<NSUB, false>::run(e);
+                const creg w1 = wkr[k];
+                e[1] = cmul(e[1], w1);
+                if constexpr (NSUB == 4) { const creg w2 = cmul(w1, w1); e[2] = cmul(e[2], w2); e[3] = cmul(e[3], cmul(w2, w1)); }
+#pragma unroll
+                for (int r = 0; r < NSUB; r++) area[r * LE + lds_pad((n0 + k) * T + t)] = e[r];
+            }
+        }
+#pragma unroll 1
+        for (int r = 0; r < NSUB; r++) {
+            creg* lds = area + r * LE;
+            creg v[16];
+            lds_load<LOG2M, 0>(v, t, lds);
+            X.forward(v, lds);
+            tile_sync<T>();                              // the last exchange is read everywhere: the area can be rewritten
+#pragma unroll
+            for (int n = 0; n < 16; n++) lds[lds_pad(bin_of_pos<LOG2M>(G::pos(t, n)))] = v[n];
+        }
+        tile_sync<T>();
+        creg* po = reinterpret_cast<creg*>(out) + it.tile * F + t;
+#pragma unroll 8
+        for (int c = 0; c < 16 * NSUB; c++) {
+            const int j = c * T + t;                     // natural bin, lane-consecutive
+            po[c * T] = area[(j % NSUB) * LE + lds_pad(j / NSUB)];
+        }
+        tile_sync<T>();                                  // before the next frame overwrites the areas
+    }
+}
+template <int NSUB>
+static void launch_frames_split(const cf* in, cf* out, long nframes, const cf* tw4096, const cf* twF, hipStream_t s) {
+    const size_t smem = sizeof(cf) * lds_elems(4096) * NSUB;
+    static bool attr_set = false;
+    static int per_cu = 0;
+    const long grid = grid_for_tiles(k_fft_frames_split<NSUB>, 256, smem, nframes, attr_set, per_cu);
+    hipLaunchKernelGGL((k_fft_frames_split<NSUB>), dim3((unsigned)grid), dim3(256), smem, s, in, out, nframes, tw4096, twF);
+    RR_HIP(hipGetLastError());
+}
+
 template <int LOG2F, int VAR>
 static void launch_frames_one(const cf* in, cf* out, long nframes, const cf* tw, hipStream_t s) {
     constexpr int F = 1 << LOG2F;
@@ -572,8 +644,10 @@ static void launch_frames_one(const cf* in, cf* out, long nframes, const cf* tw,
     hipLaunchKernelGGL((k_fft_frames<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, in, out, nframes, tw);
     RR_HIP(hipGetLastError());
 }
-void launch_fft_frames(int log2n, const cf* in, cf* out, long nframes, const cf* tw, hipStream_t s) {
+void launch_fft_frames(int log2n, const cf* in, cf* out, long nframes, const cf* tw, const cf* tw4096, hipStream_t s) {
     if (nframes <= 0) return;
+    if (log2n == 13 && tw4096) { launch_frames_split<2>(in, out, nframes, tw4096, tw, s); return; }
+    if (log2n == 14 && tw4096) { launch_frames_split<4>(in, out, nframes, tw4096, tw, s); return; }
     switch (log2n) {
     case 10: launch_frames_one<10, 0>(in, out, nframes, tw, s); return;
     case 11: launch_frames_one<11, 0>(in, out, nframes, tw, s); return;
