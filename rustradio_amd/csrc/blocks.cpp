@@ -326,7 +326,8 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain, int max_l
     // 16384-point tiles are k_fftfilt_split, 2 / 4 sub-transforms of 4096 points).
     static const double cost_filter[5] = {285.0, 620.0, 1450.0, 4100.0, 11000.0};
     static const double cost_chain[5] = {285.0, 620.0, 1450.0, 7530.0, 27540.0};
-    const double* tile_cost = for_chain ? cost_chain : cost_filter;
+    (void)cost_chain;
+    const double* tile_cost = cost_filter;               // the fused chains use the split tiles as well
     double best = 0.0;
     log2f = -1;
     for (int lg = 10; lg <= max_log2f; lg++) {
@@ -352,7 +353,8 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain, int max_l
     }
     d_hpos.upload(hpos.data(), F, stream);
     d_tw.upload(tw.data(), F, stream);
-    if (log2f >= 13 && !for_chain && !getenv("RR_FFT_NO_SPLIT")) {      // split-tile tables (thread-major order, see kernels.hpp)
+    (void)for_chain;
+    if (log2f >= 13 && !getenv("RR_FFT_NO_SPLIT")) {      // split-tile tables (thread-major order, see kernels.hpp)
         nsub = 1 << (log2f - 12);
         const size_t M = 4096;
         std::vector<std::complex<double>> H(F, 0.0);
@@ -483,7 +485,13 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = gain; a.mode = mode;
         prof_begin(s);
-        if (packed)
+        if (f->nsub && packed)
+            launch_fm_chain_split_iq8(f->nsub, src8, static_cast<float*>(out), (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
+                                      last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (f->nsub)
+            launch_fm_chain_split(f->nsub, src, static_cast<float*>(out), (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
+                                  last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (packed)
             launch_fm_chain_iq8(f->log2f, src8, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a,
                                 last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else

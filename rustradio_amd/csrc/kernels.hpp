@@ -46,6 +46,12 @@ void launch_fm_chain(int log2f, VSrc<cf> src, float* out, int L, const cf* tw, c
 void launch_fm_chain_iq8(int log2f, VSrcIQ8 src, float* out, int L, const cf* tw, const cf* hpos,
                          const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 
+// ... on 8192 / 16384-point tiles built from nsub = 2 / 4 sub-transforms (tables as launch_fftfilt_split)
+void launch_fm_chain_split(int nsub, VSrc<cf> src, float* out, int L, const cf* tw4096, const cf* hs, const cf* wk,
+                           const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+void launch_fm_chain_split_iq8(int nsub, VSrcIQ8 src, float* out, int L, const cf* tw4096, const cf* hs, const cf* wk,
+                               const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+
 // The same for `nchan` channels that share the input: hpos_all = [nchan][F] frequency responses,
 // channel c writes out + c*out_stride and carries last_in[c] / last_out[c].  3-pass tiles (F <= 4096).
 bool fm_multi_supported(int log2f);

@@ -356,9 +356,17 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
 // exchanged beyond the sub-transforms' own passes, global loads and stores stay lane-consecutive, and each
 // sub-transform uses its parking area as its exchange area (NSUB x 34.8 KB: 2 workgroups per CU for NSUB = 2).
 // Tables: wk[16 t + n] = w_F^(n T + t);  hs[r][p] = H[NSUB bin(p) + r] / F in the 4096-point position order.
-template <int T>
-__device__ __attribute__((noinline)) void stage_tile_slow_at(creg* lds, VSrc<cf> src, long v0, int t) {
-    for (int n = 0; n < 16; n++) lds[lds_pad(n * T + t)] = to_reg(src.load(v0 + n * T + t));
+template <int T, class SRC>
+__device__ __attribute__((noinline)) void stage_tile_slow_at(creg* lds, SRC src, long v0, int t) {
+    for (int n = 0; n < 16; n++) {
+        const long vi = v0 + n * T + t;                 // negative in front of the first tile of a fused chain
+        lds[lds_pad(n * T + t)] = vi >= 0 ? to_reg(src.load(vi)) : mk(0.0f, 0.0f);
+    }
+}
+// sample i of the caller's window (interior tiles only)
+__device__ __forceinline__ creg window_at(const VSrc<cf>& src, long i) { return reinterpret_cast<const creg*>(src.in)[i]; }
+__device__ __forceinline__ creg window_at(const VSrcIQ8& src, long i) {
+    return to_reg(VSrcIQ8::decode(reinterpret_cast<const unsigned short*>(src.in)[i]));
 }
 
 template <int NSUB>
@@ -966,6 +974,158 @@ void launch_fm_chain_iq8(int log2f, VSrcIQ8 src, float* out, int L, const cf* tw
     case 14: launch_fm_one<14, 3>(src, out, L, tw, hpos, h, last_in, last_out, s); break;
     default: throw Error("fm_chain: unsupported tile size");
     }
+}
+
+// ---- the fused FM chain on 8192 / 16384-point tiles: k_fftfilt_split's filter + k_fm_chain's epilogue ---------------
+// After the output butterfly the filtered tile is written to the thread's own natural slots (quarter s in area s),
+// so tile position p is area[p / M][p % M] for the resample / demod stage.
+template <int NSUB, class SRC>
+__global__ __launch_bounds__(256, 2)
+void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, const cf* __restrict__ tw,
+                      const cf* __restrict__ hs, const cf* __restrict__ wk, FmArgs a,
+                      const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    constexpr int LOG2M = 12, M = 1 << LOG2M, T = M / 16, F = NSUB * M;
+    constexpr int NP = Plan<LOG2M>::NP;
+    constexpr int LE = lds_elems(M);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* area = reinterpret_cast<creg*>(smem_raw);
+    const int t = threadIdx.x;
+    const int first = L - 1;
+    const long Sp = (F - L + 1) - a.G;
+    const long qs = ((long)T * a.D) / a.I, rs = ((long)T * a.D) % a.I;
+    TileXform<LOG2M, 0> X;
+    X.init_no_h(t, tw);
+    auto at = [&](long p) -> creg { return area[(p / M) * LE + lds_pad((int)(p % M))]; };
+
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long tile = it.tile;
+        const long ys = tile * Sp - a.G;                // virtual input index of tile position 0 (see k_fm_chain)
+        const bool interior = ys >= src.plen && ys - src.plen + F <= src.in_len;
+        if (!interior) {
+#pragma unroll
+            for (int s = 0; s < NSUB; s++) stage_tile_slow_at<T>(area + s * LE, src, ys + (long)s * M, t);
+        }
+        {
+            const long i0 = ys - src.plen + t;
+            constexpr int NB = 16 / NSUB;
+#pragma unroll 1
+            for (int n0 = 0; n0 < 16; n0 += NB) {
+                creg xin[NSUB][NB], wkr[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) wkr[k] = to_reg(wk[t * 16 + n0 + k]);
+                if (interior) {
+#pragma unroll
+                    for (int s = 0; s < NSUB; s++)
+#pragma unroll
+                        for (int k = 0; k < NB; k++) xin[s][k] = window_at(src, i0 + (long)s * M + (n0 + k) * T);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NSUB; s++)
+#pragma unroll
+                        for (int k = 0; k < NB; k++) xin[s][k] = area[s * LE + lds_pad((n0 + k) * T + t)];
+                }
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    creg e[NSUB];
+#pragma unroll
+                    for (int s = 0; s < NSUB; s++) e[s] = xin[s][k];
+                    Dft<NSUB, false>::run(e);
+                    const creg w1 = wkr[k];
+                    e[1] = cmul(e[1], w1);
+                    if constexpr (NSUB == 4) { const creg w2 = cmul(w1, w1); e[2] = cmul(e[2], w2); e[3] = cmul(e[3], cmul(w2, w1)); }
+#pragma unroll
+                    for (int r = 0; r < NSUB; r++) area[r * LE + lds_pad((n0 + k) * T + t)] = e[r];
+                }
+            }
+        }
+#pragma unroll 1
+        for (int r = 0; r < NSUB; r++) {
+            creg* lds = area + r * LE;
+            creg v[16];
+            lds_load<LOG2M, 0>(v, t, lds);
+            X.forward(v, lds);
+            {
+                creg h[16];
+                load_h<LOG2M, NP - 1>(h, t, hs + (long)r * M);
+                apply_h(v, h);
+            }
+            X.inverse(v, lds);
+            lds_store<LOG2M, 0>(v, t, lds);
+        }
+        // output butterfly: y[n + s M] into the own natural slots of area s
+#pragma unroll 1
+        for (int n0 = 0; n0 < 16; n0 += 8) {
+            creg wko[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) wko[k] = to_reg(wk[t * 16 + n0 + k]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int slot = lds_pad((n0 + k) * T + t);
+                creg e[NSUB];
+#pragma unroll
+                for (int r = 0; r < NSUB; r++) e[r] = area[r * LE + slot];
+                const creg w1 = wko[k];
+                e[1] = cmulc(e[1], w1);
+                if constexpr (NSUB == 4) { const creg w2 = cmul(w1, w1); e[2] = cmulc(e[2], w2); e[3] = cmulc(e[3], cmul(w2, w1)); }
+                Dft<NSUB, true>::run(e);
+#pragma unroll
+                for (int s = 0; s < NSUB; s++) area[s * LE + slot] = e[s];
+            }
+        }
+        tile_sync<T>();
+        // resample + demodulate (as k_fm_chain)
+        const long y_lo = tile * Sp, y_hi = min((tile + 1) * Sp, a.n_y);
+        long u_lo = ((a.A + y_lo) * a.I + a.D - 1) / a.D;
+        long u_hi = ((a.A + y_hi) * a.I + a.D - 1) / a.D;
+        if (u_lo < a.r_lo) u_lo = a.r_lo;
+        if (u_hi > a.r_hi) u_hi = a.r_hi;
+        SrcWalk wu, wl;
+        wu.init(u_lo + t, a.I, a.D);
+        wl.init(u_lo + t - 1, a.I, a.D);
+        for (long u = u_lo + t; u < u_hi; u += T, wu.step(qs, rs, a.I), wl.step(qs, rs, a.I)) {
+            const creg ru = at(wu.q - a.A - ys + first);
+            if (u == a.r_hi - 1) last_r_out[0] = from_reg(ru);
+            if (u != 0) {
+                const creg rl = u == a.r_lo ? to_reg(last_r_in[0]) : at(wl.q - a.A - ys + first);
+                const float na = -rl.y;
+                const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
+                const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
+                const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
+            }
+        }
+        tile_sync<T>();        // epilogue reads done before the next tile rewrites the areas
+    }
+}
+
+template <int NSUB, class SRC>
+static void launch_fm_split_one(SRC src, float* out, int L, const cf* tw, const cf* hs, const cf* wk, const FmChainArgs& h,
+                                const cf* last_in, cf* last_out, hipStream_t s) {
+    constexpr int F = NSUB * 4096;
+    FmArgs a;
+    a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
+    a.I = h.I; a.D = h.D; a.G = (int)((h.D + h.I - 1) / h.I); a.gain = h.gain; a.mode = h.mode;
+    const long Sp = (F - L + 1) - a.G;
+    if (Sp <= 0) throw Error("fm_chain: decimation too large for the tile");
+    const long ntiles = (h.n_y + Sp - 1) / Sp;
+    if (ntiles <= 0) return;
+    const size_t smem = sizeof(cf) * lds_elems(4096) * NSUB;
+    static bool attr_set = false;
+    static int per_cu = 0;
+    const long grid = grid_for_tiles(k_fm_chain_split<NSUB, SRC>, 256, smem, ntiles, attr_set, per_cu);
+    hipLaunchKernelGGL((k_fm_chain_split<NSUB, SRC>), dim3((unsigned)grid), dim3(256), smem, s, src, out, L, ntiles, tw, hs, wk,
+                       a, last_in, last_out);
+    RR_HIP(hipGetLastError());
+}
+void launch_fm_chain_split(int nsub, VSrc<cf> src, float* out, int L, const cf* tw4096, const cf* hs, const cf* wk,
+                           const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    if (nsub == 2) launch_fm_split_one<2>(src, out, L, tw4096, hs, wk, h, last_in, last_out, s);
+    else launch_fm_split_one<4>(src, out, L, tw4096, hs, wk, h, last_in, last_out, s);
+}
+void launch_fm_chain_split_iq8(int nsub, VSrcIQ8 src, float* out, int L, const cf* tw4096, const cf* hs, const cf* wk,
+                               const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    if (nsub == 2) launch_fm_split_one<2>(src, out, L, tw4096, hs, wk, h, last_in, last_out, s);
+    else launch_fm_split_one<4>(src, out, L, tw4096, hs, wk, h, last_in, last_out, s);
 }
 
 template <int LOG2F>
