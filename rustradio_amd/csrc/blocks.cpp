@@ -324,16 +324,17 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain, int max_l
     // not depend on F beyond f32 rounding).  F is the one that minimises measured tile cost / S'
     // (tools/taps_sweep.py: relative cost of one tile of 1024 .. 16384 points on MI355X; the 8192- and
     // 16384-point tiles are k_fftfilt_split, 2 / 4 sub-transforms of 4096 points).
-    static const double cost_filter[5] = {285.0, 620.0, 1450.0, 4100.0, 11000.0};
-    static const double cost_chain[5] = {285.0, 620.0, 1450.0, 7530.0, 27540.0};
-    (void)cost_chain;
-    const double* tile_cost = cost_filter;               // the fused chains use the split tiles as well
+    // cost of one tile ~ a + b * S' (transform + stores), fitted to tools/taps_sweep.py on MI355X
+    static const double cost_a[5] = {200.0, 300.0, 800.0, 2900.0, 7900.0};
+    static const double cost_b[5] = {0.10, 0.17, 0.16, 0.11, 0.17};
+    (void)for_chain;
     double best = 0.0;
     log2f = -1;
     for (int lg = 10; lg <= max_log2f; lg++) {
         const size_t Fc = (size_t)1 << lg;
         if (Fc < L + 1) continue;                                     // need S' >= 2
-        const double c = tile_cost[lg - 10] / (double)(Fc - L + 1);
+        const double Sc = (double)(Fc - L + 1);
+        const double c = (cost_a[lg - 10] + cost_b[lg - 10] * Sc) / Sc;
         if (log2f < 0 || c < best) { best = c; log2f = lg; }
     }
     if (log2f < 0) log2f = 15;                                        // -> refused below
@@ -353,7 +354,6 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain, int max_l
     }
     d_hpos.upload(hpos.data(), F, stream);
     d_tw.upload(tw.data(), F, stream);
-    (void)for_chain;
     if (log2f >= 13 && !getenv("RR_FFT_NO_SPLIT")) {      // split-tile tables (thread-major order, see kernels.hpp)
         nsub = 1 << (log2f - 12);
         const size_t M = 4096;
@@ -368,11 +368,10 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain, int max_l
                 hs[(size_t)r * M + pp] = mkcf((float)h.real(), (float)h.imag());
             }
         }
-        for (int t = 0; t < 256; t++)                   // wk[16 t + n] = w_F^(n 256 + t)
-            for (int n = 0; n < 16; n++) {
-                const double a = -2.0 * 3.14159265358979323846 * (double)(n * 256 + t) / (double)F;
-                wk[(size_t)t * 16 + n] = mkcf((float)std::cos(a), (float)std::sin(a));
-            }
+        for (int t = 0; t < 256; t++) {                 // wk[t] = w_F^t (the kernels build w_F^(n 256 + t) from it)
+            const double a = -2.0 * 3.14159265358979323846 * (double)t / (double)F;
+            wk[(size_t)t] = mkcf((float)std::cos(a), (float)std::sin(a));
+        }
         for (size_t k = 0; k < M; k++) {
             const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)M;
             tw4[k] = mkcf((float)std::cos(a), (float)std::sin(a));

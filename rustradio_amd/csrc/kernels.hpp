@@ -16,7 +16,7 @@ void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, cons
                        const cf* hpos, hipStream_t s);
 
 // The same filter with an 8192 / 16384-point tile built from nsub = 2 / 4 sub-transforms of 4096 points
-// (k_fftfilt_split).  tw4096: w_4096^k;  wk[16 t + n] = w_F^(n 256 + t);  hs[r][p] = H[nsub bin(p) + r] / F with
+// (k_fftfilt_split).  tw4096: w_4096^k;  wk[t] = w_F^t, t < 256;  hs[r][p] = H[nsub bin(p) + r] / F with
 // bin(p) = fftfilt_split_bin(p), the bin at position p of the 4096-point spectrum layout.
 void launch_fftfilt_split(int nsub, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw4096, const cf* hs, const cf* wk,
                           hipStream_t s);

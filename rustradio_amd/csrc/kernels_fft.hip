@@ -355,7 +355,15 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
 // quarters, so they are thread-local: the u_r / z_r wait in the thread's own natural-order LDS slots, nothing is
 // exchanged beyond the sub-transforms' own passes, global loads and stores stay lane-consecutive, and each
 // sub-transform uses its parking area as its exchange area (NSUB x 34.8 KB: 2 workgroups per CU for NSUB = 2).
-// Tables: wk[16 t + n] = w_F^(n T + t);  hs[r][p] = H[NSUB bin(p) + r] / F in the 4096-point position order.
+// Tables: wk[t] = w_F^t (w_F^(n T + t) = wk[t] * constant);  hs[r][p] = H[NSUB bin(p) + r] / F in the 4096-point position order.
+// w_F^(n T), n < 16, for F / T = 32 (two sub-transforms) and 64 (four): the time-domain twiddle of a thread's n-th
+// element is w_F^(n T + t) = w_F^t * w_F^(n T) — one persistent register and these constants instead of a table read
+__device__ const float kStep32[16][2] = {{1.000000000e+00f, -0.000000000e+00f}, {9.807852804e-01f, -1.950903220e-01f}, {9.238795325e-01f, -3.826834324e-01f}, {8.314696123e-01f, -5.555702330e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {5.555702330e-01f, -8.314696123e-01f}, {3.826834324e-01f, -9.238795325e-01f}, {1.950903220e-01f, -9.807852804e-01f}, {6.123233996e-17f, -1.000000000e+00f}, {-1.950903220e-01f, -9.807852804e-01f}, {-3.826834324e-01f, -9.238795325e-01f}, {-5.555702330e-01f, -8.314696123e-01f}, {-7.071067812e-01f, -7.071067812e-01f}, {-8.314696123e-01f, -5.555702330e-01f}, {-9.238795325e-01f, -3.826834324e-01f}, {-9.807852804e-01f, -1.950903220e-01f}};
+__device__ const float kStep64[16][2] = {{1.000000000e+00f, -0.000000000e+00f}, {9.951847267e-01f, -9.801714033e-02f}, {9.807852804e-01f, -1.950903220e-01f}, {9.569403357e-01f, -2.902846773e-01f}, {9.238795325e-01f, -3.826834324e-01f}, {8.819212643e-01f, -4.713967368e-01f}, {8.314696123e-01f, -5.555702330e-01f}, {7.730104534e-01f, -6.343932842e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {6.343932842e-01f, -7.730104534e-01f}, {5.555702330e-01f, -8.314696123e-01f}, {4.713967368e-01f, -8.819212643e-01f}, {3.826834324e-01f, -9.238795325e-01f}, {2.902846773e-01f, -9.569403357e-01f}, {1.950903220e-01f, -9.807852804e-01f}, {9.801714033e-02f, -9.951847267e-01f}};
+template <int NSUB> __device__ __forceinline__ creg split_step(int n) {
+    return NSUB == 2 ? mk(kStep32[n][0], kStep32[n][1]) : mk(kStep64[n][0], kStep64[n][1]);
+}
+
 template <int T, class SRC>
 __device__ __attribute__((noinline)) void stage_tile_slow_at(creg* lds, SRC src, long v0, int t) {
     for (int n = 0; n < 16; n++) {
@@ -383,6 +391,7 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long
     const int first = L - 1;
     TileXform<LOG2M, 0> X;
     X.init_no_h(t, tw);
+    const creg wbase = to_reg(wk[t]);                   // w_F^t
     creg* out_reg = reinterpret_cast<creg*>(out);
 
     for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
@@ -401,7 +410,7 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long
             for (int n0 = 0; n0 < 16; n0 += NB) {
                 creg xin[NSUB][NB], wkr[NB];
 #pragma unroll
-                for (int k = 0; k < NB; k++) wkr[k] = to_reg(wk[t * 16 + n0 + k]);
+                for (int k = 0; k < NB; k++) wkr[k] = cmul(wbase, split_step<NSUB>(n0 + k));
                 if (interior) {
 #pragma unroll
                     for (int s = 0; s < NSUB; s++)
@@ -433,13 +442,11 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long
         for (int r = 0; r < NSUB; r++) {
             creg* lds = area + r * LE;
             creg v[16];
+            creg h[16];
+            load_h<LOG2M, NP - 1>(h, t, hs + (long)r * M);     // in flight during the forward transform
             lds_load<LOG2M, 0>(v, t, lds);
             X.forward(v, lds);
-            {
-                creg h[16];
-                load_h<LOG2M, NP - 1>(h, t, hs + (long)r * M);
-                apply_h(v, h);
-            }
+            apply_h(v, h);
             X.inverse(v, lds);
             lds_store<LOG2M, 0>(v, t, lds);
         }
@@ -451,7 +458,7 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long
         for (int n0 = 0; n0 < 16; n0 += 8) {
             creg wko[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) wko[k] = to_reg(wk[t * 16 + n0 + k]);
+            for (int k = 0; k < 8; k++) wko[k] = cmul(wbase, split_step<NSUB>(n0 + k));
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int n = n0 + k;
@@ -586,6 +593,7 @@ void k_fft_frames_split(const cf* __restrict__ in, cf* __restrict__ out, long nf
     const int t = threadIdx.x;
     TileXform<LOG2M, 0> X;
     X.init_no_h(t, tw4096);
+    const creg wbase = to_reg(twF[t]);                  // w_F^t
     for (TileIter it(nframes); it.tile < it.end; it.tile += it.step) {
         const creg* p = reinterpret_cast<const creg*>(in) + it.tile * F + t;
         constexpr int NB = 16 / NSUB;
@@ -593,7 +601,7 @@ void k_fft_frames_split(const cf* __restrict__ in, cf* __restrict__ out, long nf
         for (int n0 = 0; n0 < 16; n0 += NB) {
             creg xin[NSUB][NB], wkr[NB];
 #pragma unroll
-            for (int k = 0; k < NB; k++) wkr[k] = to_reg(twF[(n0 + k) * T + t]);
+            for (int k = 0; k < NB; k++) wkr[k] = cmul(wbase, split_step<NSUB>(n0 + k));
 #pragma unroll
             for (int s = 0; s < NSUB; s++)
 #pragma unroll
@@ -995,6 +1003,7 @@ void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, cons
     const long qs = ((long)T * a.D) / a.I, rs = ((long)T * a.D) % a.I;
     TileXform<LOG2M, 0> X;
     X.init_no_h(t, tw);
+    const creg wbase = to_reg(wk[t]);                   // w_F^t
     auto at = [&](long p) -> creg { return area[(p / M) * LE + lds_pad((int)(p % M))]; };
 
     for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
@@ -1012,7 +1021,7 @@ void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, cons
             for (int n0 = 0; n0 < 16; n0 += NB) {
                 creg xin[NSUB][NB], wkr[NB];
 #pragma unroll
-                for (int k = 0; k < NB; k++) wkr[k] = to_reg(wk[t * 16 + n0 + k]);
+                for (int k = 0; k < NB; k++) wkr[k] = cmul(wbase, split_step<NSUB>(n0 + k));
                 if (interior) {
 #pragma unroll
                     for (int s = 0; s < NSUB; s++)
@@ -1042,13 +1051,11 @@ void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, cons
         for (int r = 0; r < NSUB; r++) {
             creg* lds = area + r * LE;
             creg v[16];
+            creg h[16];
+            load_h<LOG2M, NP - 1>(h, t, hs + (long)r * M);     // in flight during the forward transform
             lds_load<LOG2M, 0>(v, t, lds);
             X.forward(v, lds);
-            {
-                creg h[16];
-                load_h<LOG2M, NP - 1>(h, t, hs + (long)r * M);
-                apply_h(v, h);
-            }
+            apply_h(v, h);
             X.inverse(v, lds);
             lds_store<LOG2M, 0>(v, t, lds);
         }
@@ -1057,7 +1064,7 @@ void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, cons
         for (int n0 = 0; n0 < 16; n0 += 8) {
             creg wko[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) wko[k] = to_reg(wk[t * 16 + n0 + k]);
+            for (int k = 0; k < 8; k++) wko[k] = cmul(wbase, split_step<NSUB>(n0 + k));
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int slot = lds_pad((n0 + k) * T + t);

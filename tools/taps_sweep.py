@@ -11,7 +11,7 @@ y = torch.empty(2 * (n + 65536), device="cuda")
 rng = np.random.default_rng(0)
 print("| taps | reference fft_size / nsamples | GPU tile | ms per 1e8 samples | TB/s (16 B/sample) |")
 print("|---|---|---|---|---|")
-for L in (5, 33, 127, 255, 401, 463, 512, 1000, 1025, 2467, 4096, 8191):
+for L in (5, 33, 127, 255, 401, 463, 512, 1000, 1025, 1500, 2000, 2467, 4096, 8191):
     taps = ((rng.standard_normal(L) + 1j * rng.standard_normal(L)) / L).astype(np.complex64)
     b = rr.FftFilter(taps)
     fs, ns, gf = rr.fftfilter_dims(b)
