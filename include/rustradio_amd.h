@@ -84,7 +84,8 @@ rr_block *rr_fir_c32_create(const rr_c32 *taps, size_t ntaps, size_t deci,
                             int translate, float samp_rate, float freq);
 /* FirFilter::<Float> (same generic block, src/fir.rs:343-386). */
 rr_block *rr_fir_f32_create(const float *taps, size_t ntaps, size_t deci);
-/* FftFilter::new(src, taps) (src/fft_filter.rs:242-279). */
+/* FftFilter::new(src, taps) (src/fft_filter.rs:242-279).  1 <= ntaps <= 16383 (the largest LDS-resident
+ * overlap-save tile is 16384 points; the reference has no limit) — NULL beyond. */
 rr_block *rr_fftfilter_create(const rr_c32 *taps, size_t ntaps);
 /* FftFilterFloat::new(src, taps) (src/fft_filter.rs:391-426). */
 rr_block *rr_fftfilter_float_create(const float *taps, size_t ntaps);
