@@ -23,6 +23,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -696,6 +697,67 @@ public:
         pos_ += n;
         if (pos_ == data_.size()) { pos_ = 0; repeat_count_++; }
         return eof() ? BlockRet::eof() : BlockRet::again();
+    }
+};
+
+// FileSource<T> (src/file_source.rs:43-153): raw little-endian samples (`.c32` = interleaved f32 re, im; `.u8`
+// RTL-SDR bytes, ...) from disk into a stream of any placement; a partial trailing sample is dropped at EOF
+// (and on repeat), as the reference does.
+template <class T> class FileSource : public Block {
+    WriteStream<T> dst_;
+    std::string filename_;
+    FILE* f_ = nullptr;
+    Repeat repeat_;
+    uint64_t count_ = 0;                        // Repeat::again() counter (src/lib.rs:477-490)
+    std::vector<uint8_t> buf_;                  // bytes of an incomplete sample + not yet emitted samples
+    std::vector<uint8_t> rd_;
+    bool again() { count_++; return repeat_.infinite || count_ < repeat_.count; }
+public:
+    FileSource(WriteStream<T> dst, std::string filename, Repeat r) : dst_(std::move(dst)), filename_(std::move(filename)), repeat_(r) {
+        f_ = std::fopen(filename_.c_str(), "rb");
+        if (!f_) throw Error("FileSource: cannot open " + filename_);       // Error::file_io (:64-66)
+    }
+    ~FileSource() override { if (f_) std::fclose(f_); }
+    static std::pair<std::unique_ptr<FileSource<T>>, ReadStream<T>> new_(const std::string& filename, Repeat r = Repeat::finite(1)) {
+        auto [w, rd] = new_stream<T>();
+        return {std::make_unique<FileSource<T>>(std::move(w), filename, r), std::move(rd)};
+    }
+    const char* block_name() const override { return "FileSource"; }
+    bool eof() override { return false; }
+    BlockRet work() override {                  // :89-152
+        auto o = dst_.write_buf();
+        constexpr size_t ss = sizeof(T);
+        size_t have = buf_.size() / ss;
+        const size_t want = o.len();
+        if (want == 0) { o.produce(0, {}); return BlockRet::wait(dst_.wait_handle(), 1); }
+        if (have < want) {
+            rd_.resize((want - have) * ss);
+            const size_t n = std::fread(rd_.data(), 1, rd_.size(), f_);
+            if (n == 0) {
+                o.produce(0, {});
+                if (again()) {
+                    buf_.clear();
+                    std::fseek(f_, 0, SEEK_SET);
+                    return BlockRet::again();
+                }
+                return BlockRet::eof();
+            }
+            if (buf_.empty() && n % ss == 0) {  // fast path: whole samples only (:120-128)
+                o.fill_from_slice(reinterpret_cast<const T*>(rd_.data()), n / ss);
+                o.produce(n / ss, {});
+                return BlockRet::again();
+            }
+            buf_.insert(buf_.end(), rd_.begin(), rd_.begin() + (std::ptrdiff_t)n);
+        }
+        have = buf_.size() / ss;
+        if (have == 0) { o.produce(0, {}); return BlockRet{BlockRet::Pending, nullptr, 0}; }
+        const size_t nemit = std::min(have, want);
+        std::vector<T> tmp(nemit);
+        std::memcpy(tmp.data(), buf_.data(), nemit * ss);
+        buf_.erase(buf_.begin(), buf_.begin() + (std::ptrdiff_t)(nemit * ss));
+        o.fill_from_slice(tmp.data(), nemit);
+        o.produce(nemit, {});
+        return BlockRet::again();
     }
 };
 

@@ -328,6 +328,61 @@ static void fftstream_adds_frame_tags() {        // src/fft_stream.rs:125-150
     CHECK(threw);
 }
 
+static void file_source_tests() {                 // src/file_source.rs:171-258
+    const std::string fn = "/tmp/rr_filesource_test.bin";
+    auto write = [&](std::vector<uint8_t> b) { FILE* f = std::fopen(fn.c_str(), "wb"); std::fwrite(b.data(), 1, b.size(), f); std::fclose(f); };
+    const std::vector<uint8_t> four = {0, 0, 128, 63, 0, 0, 64, 64, 195, 245, 72, 64, 195, 245, 72, 192};
+    {   // source_f32
+        write(four);
+        auto [src, out] = FileSource<Float>::new_(fn);
+        CHECK(src->work().kind == BlockRet::Again);
+        CHECK(src->work().kind == BlockRet::EOF_);
+        auto [res, tags] = out.read_buf();
+        CHECK(res.len() == 4 && res.slice()[0] == 1.0f && res.slice()[1] == 3.0f && res.slice()[2] == 3.14f && res.slice()[3] == -3.14f);
+    }
+    {   // source_f32_partial_tail
+        write(std::vector<uint8_t>(four.begin(), four.end() - 1));
+        auto [src, out] = FileSource<Float>::new_(fn);
+        CHECK(src->work().kind == BlockRet::Again);
+        CHECK(src->work().kind == BlockRet::EOF_);
+        auto [res, tags] = out.read_buf();
+        CHECK(res.len() == 3 && res.slice()[2] == 3.14f);
+    }
+    {   // source_f32_twice
+        write(four);
+        auto [src, out] = FileSource<Float>::new_(fn, Repeat::finite(2));
+        CHECK(src->work().kind == BlockRet::Again);
+        CHECK(src->work().kind == BlockRet::Again);
+        CHECK(src->work().kind == BlockRet::Again);
+        CHECK(src->work().kind == BlockRet::EOF_);
+        auto [res, tags] = out.read_buf();
+        CHECK(res.len() == 8 && res.slice()[4] == 1.0f && res.slice()[7] == -3.14f);
+    }
+    {   // a .c32 file straight into an HBM ring and through a GPU filter == the same data from a VectorSource
+        std::vector<Complex> x(100000);
+        for (size_t i = 0; i < x.size(); i++) x[i] = Complex((float)std::sin(0.01 * i), (float)std::cos(0.017 * i));
+        { FILE* f = std::fopen(fn.c_str(), "wb"); std::fwrite(x.data(), sizeof(Complex), x.size(), f); std::fwrite("abc", 1, 3, f); std::fclose(f); }
+        auto taps = fir::low_pass_complex(2.4e6f, 100e3f, 50e3f, WindowType::Hamming());
+        auto run = [&](bool from_file) {
+            default_memory() = Memory::Device;
+            std::unique_ptr<Block> src; ReadStream<Complex> s0;
+            if (from_file) { auto [b, r] = FileSource<Complex>::new_(fn); src = std::move(b); s0 = std::move(r); }
+            else { auto [b, r] = VectorSource<Complex>::new_(x); src = std::move(b); s0 = std::move(r); }
+            auto [fft, s1] = FftFilter::new_(std::move(s0), taps);
+            auto sink = std::make_unique<VectorSink<Complex>>(std::move(s1));
+            auto hook = sink->hook();
+            Graph g;
+            g.add(std::move(src)); g.add(std::move(fft)); g.add(std::move(sink));
+            g.run();
+            default_memory() = Memory::Host;
+            return *hook;
+        };
+        const auto a = run(true), b = run(false);
+        CHECK(a.size() > 90000 && a == b);
+    }
+    std::remove(fn.c_str());
+}
+
 static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal_source.rs:9-63
     auto [ss, s0] = SignalSourceComplex::new_(1200.0f, 100.0f, 1.0f);
     CHECK(is_wait(ss->work()));
@@ -349,7 +404,7 @@ static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
     fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
-    device_resident_graph(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags();
+    device_resident_graph(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }
