@@ -20,6 +20,7 @@
 // happens in this file.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <complex>
 #include <cstdint>
@@ -92,7 +93,7 @@ template <class T> struct StreamState : StreamWait {
     bool writer_alive = true, reader_alive = true;
     size_t id_;
     explicit StreamState(size_t bytes, Memory m = default_memory()) : cap(bytes / sizeof(T)) {
-        static size_t next_id = 1;
+        static std::atomic<size_t> next_id{1};
         id_ = next_id++;
         if (m == Memory::Device) {
             ds = rr_dstream_create(sizeof(T), bytes);

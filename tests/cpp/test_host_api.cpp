@@ -4,6 +4,7 @@
 // Build: g++ -O2 -std=c++17 tests/cpp/test_host_api.cpp -L rustradio_amd/lib -lrustradio_amd
 #include <cmath>
 #include <cstdio>
+#include <thread>
 
 #include "../../rustradio_amd/host/rustradio.hpp"
 
@@ -383,6 +384,44 @@ static void file_source_tests() {                 // src/file_source.rs:171-258
     std::remove(fn.c_str());
 }
 
+// `Block: Send`, one thread per block instance (MTGraph, src/mtgraph.rs:80-82): N handles driven from N host
+// threads at the same time give the single-threaded results.
+static void handles_on_concurrent_threads() {
+    std::vector<Complex> x(400000);
+    uint32_t lcg = 7;
+    for (auto& v : x) { lcg = lcg * 1664525u + 1013904223u; v = Complex((float)(lcg >> 8) / 8388608.0f - 1.0f, (float)((lcg * 13u) >> 8) / 8388608.0f - 1.0f); }
+    auto taps = fir::low_pass_complex(2.4e6f, 100e3f, 12.5e3f, WindowType::Hamming());
+    auto job = [&](int kind) {
+        std::vector<Complex> yc; std::vector<Float> yf;
+        if (kind == 0) {
+            auto [src, s0] = VectorSource<Complex>::new_(x);
+            auto [b, s1] = FftFilter::new_(std::move(s0), taps);
+            auto sink = std::make_unique<VectorSink<Complex>>(std::move(s1)); auto hook = sink->hook();
+            Graph g; g.add(std::move(src)); g.add(std::move(b)); g.add(std::move(sink)); g.run();
+            yc = *hook;
+        } else if (kind == 1) {
+            auto [src, s0] = VectorSource<Complex>::new_(x);
+            auto [b, s1] = FirFilter<Complex>::builder(taps).deci(8).build(std::move(s0));
+            auto sink = std::make_unique<VectorSink<Complex>>(std::move(s1)); auto hook = sink->hook();
+            Graph g; g.add(std::move(src)); g.add(std::move(b)); g.add(std::move(sink)); g.run();
+            yc = *hook;
+        } else {
+            auto [src, s0] = VectorSource<Complex>::new_(x);
+            auto [b, s1] = QuadratureDemod::new_(std::move(s0), 1.0f);
+            auto sink = std::make_unique<VectorSink<Float>>(std::move(s1)); auto hook = sink->hook();
+            Graph g; g.add(std::move(src)); g.add(std::move(b)); g.add(std::move(sink)); g.run();
+            yf = *hook;
+        }
+        return std::make_pair(yc, yf);
+    };
+    std::vector<std::pair<std::vector<Complex>, std::vector<Float>>> ref(3), got(6);
+    for (int k = 0; k < 3; k++) ref[k] = job(k);
+    std::vector<std::thread> th;
+    for (int i = 0; i < 6; i++) th.emplace_back([&, i] { got[i] = job(i % 3); });
+    for (auto& t : th) t.join();
+    for (int i = 0; i < 6; i++) CHECK(got[i] == ref[i % 3] && (got[i].first.size() + got[i].second.size()) > 1000);
+}
+
 static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal_source.rs:9-63
     auto [ss, s0] = SignalSourceComplex::new_(1200.0f, 100.0f, 1.0f);
     CHECK(is_wait(ss->work()));
@@ -404,7 +443,7 @@ static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
     fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
-    device_resident_graph(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests();
+    device_resident_graph(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests(); handles_on_concurrent_threads();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }

@@ -13,7 +13,7 @@ def test_cpp_host_api_reference_tests():
     exe = os.path.join(ROOT, "tests", "cpp", "test_host_api.bin")
     src = os.path.join(ROOT, "tests", "cpp", "test_host_api.cpp")
     lib = os.path.join(ROOT, "rustradio_amd", "lib")
-    subprocess.run(["g++", "-O2", "-std=c++17", src, "-L", lib, "-lrustradio_amd",
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", src, "-L", lib, "-lrustradio_amd",
                     f"-Wl,-rpath,{lib}", "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
