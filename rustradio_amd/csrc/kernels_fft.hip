@@ -12,6 +12,7 @@
 //                  and the conj-multiply + atan2 (src/quadrature_demod.rs:65-109) run as an
 //                  LDS epilogue and only the demodulated f32 stream is written to HBM.
 #include <cstdlib>
+#include <mutex>
 
 #include "kernels.hpp"
 
@@ -900,6 +901,8 @@ int device_cu_count() {
 }
 
 template <class KFn> static long grid_for_tiles(KFn kfn, int T, size_t smem, long ntiles, bool& attr_set, int& per_cu) {
+    static std::mutex mu;                                  // first launches may come from several host threads at once
+    std::lock_guard<std::mutex> lock(mu);
     if (!attr_set) {
         RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, T, smem));
