@@ -86,6 +86,7 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
     // address register + immediates (the d = 1 shapes; the host sizes the tile for it)
     const int rstride = RSC > 0 ? RSC : rstride_arg;
     const int pstride = RSC > 0 ? R * RSC + 1 : pstride_arg;
+    constexpr int UNROLL_TAPS = (R == 8 && S <= 2 && sizeof(T) == 8 && RSC == 0) ? 1 : 2;
     constexpr int NTC = NT / S;                        // threads (output columns) per phase group
     constexpr int NOUT = NTC * R;
     static_assert(R % 2 == 0 && R <= 8, "qpad is padded to a multiple of 8");
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
             // two blocks per iteration when the registers allow it (R = 8 without a phase split does not:
             // the 128-VGPR bound then spills, and every scratch access waits vmcnt(0), i.e. for the
             // prefetched tile — measured 1.02 vs 0.6 ms for 127 taps at d = 1)
-#pragma unroll(R == 8 && S <= 2 && sizeof(T) == 8 && RSC == 0 ? 1 : 2)
+#pragma unroll UNROLL_TAPS
             for (int q0 = 0; q0 < qpad; q0 += 8) {
                 const T* lq = lp + q0 / R + 1;
                 TapT tap8[8];
@@ -323,7 +324,12 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
             const long tiles = (n_out + nout(c) - 1) / nout(c);
             double cst = cost(c);
             if (tiles < 2L * cus) cst *= (2.0 * cus) / (double)tiles;       // does not fill the chip
-            if (((long)gc.np * pl.d + cfgs[c].NT - 1) / cfgs[c].NT > FIR_MAXPRE) cst *= 2.0;   // staging not pipelined
+            const long staged_c = ((long)gc.np * pl.d + cfgs[c].NT - 1) / cfgs[c].NT;
+            if (staged_c > FIR_MAXPRE) cst *= 2.0;                          // staging not pipelined
+            // the R = 8, S = 1 builds with the long register pipeline spill ~50 B for Complex data x Complex taps, and
+            // every scratch access waits for the prefetched tile: prefer a split shape there (measured
+            // at 127 taps /2: 0.78 vs 0.81 ms; with real taps the 12 B spill still wins, 0.46 vs 0.56 ms)
+            if (cfgs[c].R == 8 && cfgs[c].S == 1 && staged_c > 10 && sizeof(T) == 8 && sizeof(TapT) == 8) cst *= 1.5;
             if (pick < 0 || cst < best) { pick = c; g = gc; best = cst; }
         }
     }
