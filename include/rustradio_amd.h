@@ -73,6 +73,9 @@ size_t rr_low_pass(float samp_rate, float cutoff, float twidth, int window, floa
 /* low_pass_complex (src/fir.rs:594-604). */
 size_t rr_low_pass_complex(float samp_rate, float cutoff, float twidth, int window, float parm,
                            rr_c32 *out, size_t cap);
+/* multiband(bands, taps, window) (src/fir.rs:552-590): bands = nbands (low, high) pairs in units of Nyquist,
+ * window = ntaps window values; RR_ERR for the reference's None. */
+int    rr_multiband(const float *bands, size_t nbands, const float *window, size_t ntaps, rr_c32 *out);
 /* hilbert(window) (src/fir.rs:660-680). */
 int    rr_hilbert_taps(const float *window, size_t ntaps, float *out);
 

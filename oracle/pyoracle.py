@@ -45,6 +45,7 @@ def lib():
     L.orc_compute_ntaps.argtypes = [f32, f32, i32]; L.orc_compute_ntaps.restype = sz
     L.orc_low_pass.argtypes = [f32, f32, f32, i32, f32, vp, sz]; L.orc_low_pass.restype = sz
     L.orc_hilbert_taps.argtypes = [vp, sz, vp]; L.orc_hilbert_taps.restype = None
+    L.orc_multiband.argtypes = [vp, sz, vp, sz, vp]; L.orc_multiband.restype = i32
     L.orc_fir_c32_n.argtypes = [vp, sz, sz, vp, vp, sz]; L.orc_fir_c32_n.restype = None
     L.orc_fir_f32_n.argtypes = [vp, sz, sz, vp, vp, sz]; L.orc_fir_f32_n.restype = None
     L.orc_fft.argtypes = [vp, sz, i32]; L.orc_fft.restype = None
@@ -197,6 +198,14 @@ def fir_rotator(block: OracleBlock):
 def FftFilter(taps) -> OracleBlock:
     t = np.ascontiguousarray(taps, np.complex64)
     return OracleBlock(lib().orc_fftfilter_new(_ptr(t), len(t)), np.complex64, np.complex64, "FftFilter")
+
+
+def multiband(bands, window):
+    """fir::multiband(bands, taps, window) (fir.rs:552-590) -> complex64 taps, or None"""
+    b = np.ascontiguousarray(bands, np.float32).reshape(-1, 2)
+    w = np.ascontiguousarray(window, np.float32)
+    out = np.zeros(len(w), np.complex64)
+    return out if lib().orc_multiband(_ptr(b), len(b), _ptr(w), len(w), _ptr(out)) == 0 else None
 
 
 def FftFilterFloat(taps) -> OracleBlock:

@@ -283,6 +283,33 @@ float orc_fast_atan2(float y, float x) {
     }
 }
 
+int orc_multiband(const float *bands, size_t nbands, const float *window, size_t ntaps, orc_c32 *out) {
+    if (ntaps == 0) return -1;                                                   /* :558-560 */
+    double *ideal = (double *)calloc(ntaps, sizeof(double));
+    const float scale = (float)ntaps / 2.0f;                                     /* :563 */
+    for (size_t bi = 0; bi < nbands; bi++) {
+        const size_t a = (size_t)floorf(bands[2 * bi] * scale), b = (size_t)ceilf(bands[2 * bi + 1] * scale);   /* :565-566 */
+        if (a > b || a > ntaps || b > ntaps) { free(ideal); return -1; }         /* :567-569 */
+        for (size_t n = a; n < b; n++) { ideal[n] = 1.0; ideal[ntaps - n - 1] = 1.0; }   /* :570-573 */
+    }
+    const float fscale = sqrtf((float)ntaps);                                    /* :580 */
+    for (size_t n = 0; n < ntaps; n++) {
+        /* ifft (unnormalised, +i) then rotate_right(taps / 2): out[n] = ifft[(n + N - N/2) % N]   (:575-579) */
+        const size_t m = (n + ntaps - ntaps / 2) % ntaps;
+        double re = 0.0, im = 0.0;
+        for (size_t k = 0; k < ntaps; k++) {
+            if (ideal[k] == 0.0) continue;
+            const double ang = 2.0 * 3.14159265358979323846 * (double)((k * m) % ntaps) / (double)ntaps;
+            re += cos(ang); im += sin(ang);
+        }
+        /* v * window[n] / Complex(scale, 0)   (:584-586) */
+        out[n].re = ((float)re * window[n]) / fscale;
+        out[n].im = ((float)im * window[n]) / fscale;
+    }
+    free(ideal);
+    return 0;
+}
+
 /* ---- streaming blocks ----------------------------------------------------------- */
 enum { K_FIR_C32, K_FIR_F32, K_FFTFILT, K_FFTFILT_F, K_RESAMP, K_QUAD, K_HILBERT, K_RTLSDR, K_MULC_F, K_MULC_C, K_FASTFM, K_FFTSTREAM };
 

@@ -61,6 +61,10 @@ size_t orc_compute_ntaps(float samp_rate, float twidth, int wtype);       /* fir
 size_t orc_low_pass(float samp_rate, float cutoff, float twidth, int wtype, float parm,
                     float *out, size_t cap);
 void   orc_hilbert_taps(const float *window, size_t ntaps, float *out);   /* fir.rs:660-680 */
+/* multiband(bands, taps, window) (fir.rs:552-590; "TODO: this is untested" in the reference, rustfft inverse of
+ * any size inside): bands = nbands pairs (low, high) in units of Nyquist.  Returns 0, or -1 for the reference's None.
+ * The inverse DFT is a direct O(N^2) sum in double, rounded once — parity with rustfft's f32 is unpinned. */
+int    orc_multiband(const float *bands, size_t nbands, const float *window, size_t ntaps, orc_c32 *out);
 
 /* ---- single-shot kernels (whole-window, no stream bookkeeping) ---------------- */
 /* Fir::filter_n_inplace, fir.rs:166-197.  taps in caller order (NOT reversed). */

@@ -77,6 +77,14 @@ def low_pass_complex(samp_rate, cutoff, twidth, wtype=WIN_HAMMING, parm=0.0) -> 
     return out
 
 
+def multiband(bands, window):
+    """fir::multiband(bands, taps, window) (src/fir.rs:552-590) -> complex64 taps, or None (the reference's None)"""
+    b = np.ascontiguousarray(bands, np.float32).reshape(-1, 2)
+    w = np.ascontiguousarray(window, np.float32)
+    out = np.zeros(len(w), np.complex64)
+    return out if lib().rr_multiband(_ptr(b), len(b), _ptr(w), len(w), _ptr(out)) == 0 else None
+
+
 def hilbert_taps(window: np.ndarray) -> np.ndarray:
     w = np.ascontiguousarray(window, np.float32)
     out = np.zeros(len(w), np.float32)

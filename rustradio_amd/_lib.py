@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librustradio_amd.so")
 SYMBOLS = [
     "rr_abi_version", "rr_last_error", "rr_device_count", "rr_set_device",
     "rr_max_attenuation", "rr_make_window", "rr_compute_ntaps", "rr_low_pass", "rr_low_pass_complex",
-    "rr_hilbert_taps",
+    "rr_hilbert_taps", "rr_multiband",
     "rr_fir_c32_create", "rr_fir_f32_create", "rr_fftfilter_create", "rr_fftfilter_float_create",
     "rr_resampler_create", "rr_quaddemod_create", "rr_rtlsdr_decode_create", "rr_fftstream_create", "rr_multiply_const_f32_create", "rr_multiply_const_c32_create", "rr_fastfm_create", "rr_hilbert_create", "rr_fm_chain_create", "rr_fm_chain_u8_create", "rr_hilbert_fir_create", "rr_fm_multi_create", "rr_block_out_windows", "rr_block_destroy",
     "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_in_elem_size",
@@ -59,6 +59,7 @@ def lib():
     L.rr_low_pass.argtypes = [f32, f32, f32, i32, f32, vp, sz]; L.rr_low_pass.restype = sz
     L.rr_low_pass_complex.argtypes = [f32, f32, f32, i32, f32, vp, sz]; L.rr_low_pass_complex.restype = sz
     L.rr_hilbert_taps.argtypes = [vp, sz, vp]; L.rr_hilbert_taps.restype = i32
+    L.rr_multiband.argtypes = [vp, sz, vp, sz, vp]; L.rr_multiband.restype = i32
     L.rr_fir_c32_create.argtypes = [vp, sz, sz, i32, f32, f32]; L.rr_fir_c32_create.restype = vp
     L.rr_fir_f32_create.argtypes = [vp, sz, sz]; L.rr_fir_f32_create.restype = vp
     L.rr_fftfilter_create.argtypes = [vp, sz]; L.rr_fftfilter_create.restype = vp

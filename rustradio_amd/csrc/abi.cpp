@@ -78,6 +78,13 @@ size_t rr_low_pass_complex(float samp_rate, float cutoff, float twidth, int wind
     for (size_t i = 0; i < t.size() && i < cap; i++) out[i] = rr_c32{t[i], 0.0f};   // fir.rs:602
     return t.size();
 }
+int rr_multiband(const float* bands, size_t nbands, const float* window, size_t ntaps, rr_c32* out) {
+    std::vector<float> t;
+    if (!bands && nbands) { rr::set_last_error("multiband: null bands"); return RR_ERR; }
+    if (!rr::multiband(bands, nbands, window, ntaps, t)) { rr::set_last_error("multiband: None (fir.rs:558-569)"); return RR_ERR; }
+    std::memcpy(out, t.data(), ntaps * sizeof(rr_c32));
+    return 0;
+}
 int rr_hilbert_taps(const float* window, size_t ntaps, float* out) {
     std::vector<float> t;
     if (!rr::hilbert_taps(window, ntaps, t)) { rr::set_last_error("hilbert: window must have more than 1 tap"); return RR_ERR; }

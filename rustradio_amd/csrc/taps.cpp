@@ -104,4 +104,32 @@ bool hilbert_taps(const float* window, size_t ntaps, std::vector<float>& taps) {
     return true;
 }
 
+// multiband (fir.rs:552-590): ideal brick response sampled at ntaps points (mirrored), inverse DFT of that size,
+// rotated by ntaps/2, windowed, scaled by 1/sqrt(ntaps).  The reference runs rustfft's f32 inverse of any size;
+// this is a direct O(N^2) sum in double, rounded once (setup time; the reference marks the function untested).
+bool multiband(const float* bands, size_t nbands, const float* window, size_t ntaps, std::vector<float>& re_im) {
+    if (ntaps == 0) return false;
+    std::vector<char> ideal(ntaps, 0);
+    const float scale = (float)ntaps / 2.0f;
+    for (size_t bi = 0; bi < nbands; bi++) {
+        const size_t a = (size_t)std::floor(bands[2 * bi] * scale), b = (size_t)std::ceil(bands[2 * bi + 1] * scale);
+        if (a > b || a > ntaps || b > ntaps) return false;
+        for (size_t n = a; n < b; n++) { ideal[n] = 1; ideal[ntaps - n - 1] = 1; }
+    }
+    const float fscale = std::sqrt((float)ntaps);
+    re_im.assign(2 * ntaps, 0.0f);
+    for (size_t n = 0; n < ntaps; n++) {
+        const size_t m = (n + ntaps - ntaps / 2) % ntaps;
+        double re = 0.0, im = 0.0;
+        for (size_t k = 0; k < ntaps; k++) {
+            if (!ideal[k]) continue;
+            const double ang = 2.0 * 3.14159265358979323846 * (double)((k * m) % ntaps) / (double)ntaps;
+            re += std::cos(ang); im += std::sin(ang);
+        }
+        re_im[2 * n] = ((float)re * window[n]) / fscale;
+        re_im[2 * n + 1] = ((float)im * window[n]) / fscale;
+    }
+    return true;
+}
+
 }  // namespace rr

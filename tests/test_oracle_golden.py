@@ -211,3 +211,24 @@ def test_fftstream_restatement():
     assert b.work(np.zeros(3, np.complex64), 100)[:4] == (1, 0, 0, 4) and b.work(np.zeros(8, np.complex64), 3)[:4] == (2, 0, 0, 4)
     st, c, p, need, out = b.work(np.zeros(8, np.complex64), 100)          # adds_frame_tags' data path (:130-150)
     assert (st, c, p) == (0, 8, 8) and np.array_equal(out, np.zeros(8, np.complex64))
+
+
+def test_multiband_restatement():
+    """fir::multiband (fir.rs:552-590, untested in the reference): the restatement against a numpy transcription
+    (ifft of the mirrored brick response, rotate, window, 1/sqrt(N)) and its None cases."""
+    import numpy as np
+    from oracle import pyoracle as orc
+    for ntaps, bands in ((101, [(0.1, 0.3)]), (64, [(0.0, 0.2), (0.5, 0.75)]), (7, [(0.0, 1.0)])):
+        w = np.hamming(ntaps).astype(np.float32)
+        t = orc.multiband(bands, w)
+        ideal = np.zeros(ntaps, np.complex128)
+        for lo, hi in bands:
+            a, b = int(np.floor(np.float32(lo) * np.float32(ntaps / 2))), int(np.ceil(np.float32(hi) * np.float32(ntaps / 2)))
+            for n in range(a, b):
+                ideal[n] = 1.0
+                ideal[ntaps - n - 1] = 1.0
+        ref = np.roll(np.fft.ifft(ideal) * ntaps, ntaps // 2) * w / np.sqrt(np.float32(ntaps))
+        assert t is not None and np.max(np.abs(t - ref)) <= 1e-6 * max(1.0, np.max(np.abs(ref)))
+    assert orc.multiband([(0.5, 0.2)], np.ones(16, np.float32)) is None          # a > b
+    assert orc.multiband([(0.0, 2.5)], np.ones(16, np.float32)) is None          # b > taps (:567)
+    assert orc.multiband([(0.1, 0.2)], np.ones(0, np.float32)) is None           # taps == 0
