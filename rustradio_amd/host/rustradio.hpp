@@ -405,6 +405,16 @@ public:
         if (w.st != RR_AGAIN || w.produced != n_out) throw Error("filter_n: unexpected block state");
         return out;
     }
+    // filter_n_inplace (fir.rs:191-197): out.size() outputs, out[i] = filter(&input[i * deci ..])
+    void filter_n_inplace(const std::vector<T>& input, size_t deci, std::vector<T>& out) const {
+        if (out.empty()) return;
+        if (input.size() < (out.size() - 1) * deci + taps_.size()) throw Error("filter_n_inplace: input too short");
+        std::vector<T> in(input.begin(), input.begin() + (std::ptrdiff_t)((out.size() - 1) * deci + taps_.size()));
+        const auto r = filter_n(in, deci);
+        std::copy(r.begin(), r.begin() + (std::ptrdiff_t)out.size(), out.begin());
+    }
+    // filter (fir.rs:166-177): one output from the first taps.size() samples
+    T filter(const std::vector<T>& input) const { return filter_n(std::vector<T>(input.begin(), input.begin() + (std::ptrdiff_t)taps_.size()), 1)[0]; }
 private:
     static rr_block* FirFilterMaker(const std::vector<T>& taps, size_t deci) {
         if constexpr (std::is_same<T, Complex>::value)

@@ -29,6 +29,10 @@ static void test_complex() {   // src/fir.rs:921-950
     assert_almost_equal_complex(a.data(), a.size(), {{2.3f, 0.22f}, {3.41f, 0.6f}, {4.56f, 0.6f}, {5.6f, 0.84f}});
     auto b = filter.filter_n(SIX, 2);
     assert_almost_equal_complex(b.data(), b.size(), {{2.3f, 0.22f}, {4.56f, 0.6f}});
+    std::vector<Complex> c(2);
+    filter.filter_n_inplace(SIX, 2, c);
+    assert_almost_equal_complex(c.data(), c.size(), {{2.3f, 0.22f}, {4.56f, 0.6f}});
+    CHECK(std::abs(filter.filter(SIX) - Complex(2.3f, 0.22f)) < 1e-3f);
 }
 
 static void test_identity() {  // src/fir.rs:691-741
