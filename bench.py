@@ -9,7 +9,8 @@ resident in HBM.  Default workload = BASELINE.json configs[1]:
     FftFilter, 401 taps (low_pass_complex(10e6, 1e6, 60e3) => reference fft_size 1024,
     nsamples 623), 10 Msps synthetic Complex<f32>, 10 s = 100,000,000 samples per step.
 Other workloads (--workload, also summarised under "others" in the JSON line):
-    fir          configs[0]: FirFilter<Complex> 127 real taps, 1,000,000 samples
+    fir          configs[0]: FirFilter<Complex> 127 real taps, 1,000,000 samples (deci 1 and > 40 taps: the block runs
+                 on overlap-save FFT tiles, the FftFilter kernel with no history)
     fm_chain     configs[2]: FftFilter(463) -> RationalResampler(1:6) -> QuadratureDemod, 2.4 Msps x 10 s
     fm_multi     configs[3]: 32 such channels per GPU on one shared IQ source (256 channels on 8 GPUs)
     channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in), fused into one
@@ -502,7 +503,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain", "rtl_fm_example") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
+                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain", "fir") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain", "rtl_fm_example") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),

@@ -238,6 +238,9 @@ int rr_debug_fft_stamps(unsigned long long *out16);
 /* FftFilter: reference fft_size and nsamples (src/fft_filter.rs:261-262) and the
  * internal overlap-save tile the GPU kernel uses. */
 int rr_fftfilter_dims(const rr_block *b, size_t *fft_size, size_t *nsamples, size_t *gpu_fft_size);
+/* FirFilter<Complex>: size of the overlap-save FFT tile a non-decimating filter runs on, 0 when the block uses the
+ * direct-form kernel (introspection for tests and benches; the result of Fir::filter, src/fir.rs:166-197, either way). */
+size_t rr_fir_fft_tile(const rr_block *b);
 /* FirFilter translate (also inside rr_hilbert_fir_create): rotator mode (default RR_ROT_MODEL). */
 int rr_fir_set_rotator_mode(rr_block *b, int mode);
 

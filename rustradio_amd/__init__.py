@@ -269,6 +269,11 @@ def fftfilter_dims(block: Block):
     return a.value, b.value, c.value
 
 
+def fir_uses_fft_tiles(block: Block) -> bool:
+    """True when a FirFilter<Complex> runs on overlap-save FFT tiles (deci 1, more than a few taps)."""
+    return lib().rr_fir_fft_tile(block._h) != 0
+
+
 def RationalResampler(interp: int, deci: int, dtype=np.complex64) -> Block:
     dt = np.dtype(dtype)
     return Block(lib().rr_resampler_create(interp, deci, dt.itemsize), dt, dt)

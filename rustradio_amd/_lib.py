@@ -19,7 +19,7 @@ SYMBOLS = [
     "rr_fir_c32_create", "rr_fir_f32_create", "rr_fftfilter_create", "rr_fftfilter_float_create",
     "rr_resampler_create", "rr_quaddemod_create", "rr_rtlsdr_decode_create", "rr_fftstream_create", "rr_multiply_const_f32_create", "rr_multiply_const_c32_create", "rr_fastfm_create", "rr_hilbert_create", "rr_fm_chain_create", "rr_fm_chain_u8_create", "rr_hilbert_fir_create", "rr_fm_multi_create", "rr_block_out_windows", "rr_block_destroy",
     "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_in_elem_size",
-    "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_set_rotator_mode",
+    "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_fft_tile", "rr_fir_set_rotator_mode",
     "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps",
     "rr_host_register", "rr_host_unregister",
     "rr_dstream_create", "rr_dstream_destroy", "rr_dstream_capacity", "rr_dstream_is_double_mapped", "rr_dstream_read_buf", "rr_dstream_write_buf",
@@ -86,6 +86,7 @@ def lib():
     L.rr_block_out_elem_size.argtypes = [vp]; L.rr_block_out_elem_size.restype = sz
     L.rr_block_sync.argtypes = [vp]; L.rr_block_sync.restype = i32
     L.rr_fftfilter_dims.argtypes = [vp, psz, psz, psz]; L.rr_fftfilter_dims.restype = i32
+    L.rr_fir_fft_tile.argtypes = [vp]; L.rr_fir_fft_tile.restype = sz
     L.rr_fir_set_rotator_mode.argtypes = [vp, i32]; L.rr_fir_set_rotator_mode.restype = i32
     L.rr_debug_fft_stamps.argtypes = [vp]; L.rr_debug_fft_stamps.restype = i32
     pvp = C.POINTER(vp)

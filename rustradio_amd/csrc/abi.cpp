@@ -215,6 +215,11 @@ int rr_fftfilter_dims(const rr_block* b, size_t* fft_size, size_t* nsamples, siz
     if (gpu_fft_size) *gpu_fft_size = (size_t)1 << f->log2f;
     return 0;
 }
+size_t rr_fir_fft_tile(const rr_block* b) {
+    if (!b) return 0;
+    const rr::FirC32* f = dynamic_cast<const rr::FirC32*>(b->b.get());
+    return f && f->fftk ? (size_t)1 << f->fftk->log2f : 0;
+}
 // ---- host memory registration -----------------------------------------------------------------------
 int rr_host_register(void* ptr, size_t bytes) {
     if (!ptr || !bytes) { rr::set_last_error("rr_host_register: null / empty range"); return RR_ERR; }

@@ -96,7 +96,7 @@ template <class TapT> static void build_poly(const std::vector<TapT>& rev, int d
     for (int k = 0; k < L; k++) tp[(size_t)(k % d) * qpad + k / d] = rev[k];
 }
 
-FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq)
+FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq, bool allow_fft)
     : Block("FirFilter<Complex>", 8, 8) {
     if (ntaps == 0) throw Error("FirFilter: empty taps");            // fir.rs:372
     if (deci == 0) throw Error("FirFilter: decimation 0");           // fir.rs:319
@@ -142,7 +142,24 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
         d_tp.upload(reinterpret_cast<unsigned char*>(tp.data()), tp.size() * 8, stream);
     }
     RR_HIP(hipStreamSynchronize(stream));
+    // d = 1: overlap-save tiles cost a flat ~0.32 ms per 1e8 samples; the direct form stays at its 0.30 ms of
+    // staging up to ~32 real / ~24 Complex taps and then grows by 0.004 / 0.007 ms per tap
+    // (tools/fir_paths_probe.py on MI355X: 127 real taps 0.65 vs 0.32 ms, 127 Complex taps 1.09 vs 0.32 ms)
+    const bool force_direct = getenv("RR_FIR_DIRECT") != nullptr, force_fft = getenv("RR_FIR_FFT") != nullptr;
+    // d > 1: the same tiles with a decimating store (k_fftfilt_deci, tiles up to 4096 points).  The transform cost
+    // per input sample does not shrink with d while the direct form's does, so the bar is on taps per output
+    // phase; beyond ~320 taps the direct form's LDS tile no longer fits for most decimations and it collapses
+    // (tools/fir_deci_probe.py: 401 taps /16 0.69 vs 0.32 ms, 1000 taps /16 95 vs 0.43 ms per 1e8 samples).
+    const size_t min_taps = real_taps ? 40 : 28, min_per_phase = real_taps ? 36 : 16;
+    const bool fits = deci == 1 ? ntaps <= 16383 : (ntaps <= 3584 && deci <= 4096);
+    const bool wins = deci == 1 ? ntaps >= min_taps : (ntaps >= 320 || ntaps / deci >= min_per_phase);
+    if (allow_fft && fits && !force_direct && (force_fft || wins)) {
+        std::vector<rr_c32> ct(ntaps);
+        for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
+        fftk.reset(new FftFilter(ct.data(), ntaps, false, deci == 1 ? 14 : 12));
+    }
 }
+FirC32::~FirC32() = default;
 
 int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                      size_t* produced, size_t* need, hipStream_t s) {
@@ -156,7 +173,9 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     const size_t out_n = n / d;
     VSrc<cf> src{nullptr, 0, static_cast<const cf*>(in), (long)in_len};
     prof_begin(s);
-    launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
+    if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s);
+    else if (fftk) fftk->filter(src, static_cast<cf*>(out), (long)out_n, s);
+    else launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
     prof_end(s);
     rotate_output(static_cast<cf*>(out), out_n, s);                  // fir.rs:531
     *consumed = n; *produced = out_n;
@@ -192,7 +211,7 @@ HilbertFir::HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c3
     std::vector<float> win, ht;
     if (!make_window(window, parm, hn, win)) throw Error("Hilbert: unknown window type");
     hilbert_taps(win.data(), hn, ht);                                           // hilbert.rs:48
-    fir.reset(new FirC32(taps, ntaps, deci, translate, samp_rate, freq));       // validates, pre-rotates, rotator
+    fir.reset(new FirC32(taps, ntaps, deci, translate, samp_rate, freq, false)); // validates, pre-rotates, rotator
     // c[j] = delta[j - hn/2] + i * rev_h[j], rev_h = reversed Hilbert taps (Fir::new, fir.rs:160)
     std::vector<std::complex<double>> c(hn), G(ntaps + hn - 1);
     for (size_t j = 0; j < hn; j++) c[j] = {j == hn / 2 ? 1.0 : 0.0, (double)ht[hn - 1 - j]};
@@ -389,6 +408,11 @@ FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain, int max_l
     RR_HIP(hipStreamSynchronize(stream));
 }
 
+void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s) {
+    if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s);
+    else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s);
+}
+
 int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                         size_t* produced, size_t* need, hipStream_t s) {
     *consumed = *produced = *need = 0;
@@ -410,8 +434,7 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     VSrc<cf> src{prefix[cur].p, plen, static_cast<const cf*>(in), (long)in_len};
     if (k) {
         prof_begin(s);
-        if (nsub) launch_fftfilt_split(nsub, src, static_cast<cf*>(out), (long)n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s);
-        else launch_fftfilt_os(log2f, src, static_cast<cf*>(out), (long)n_out, (int)L, d_tw.p, d_hpos.p, s);
+        filter(src, static_cast<cf*>(out), (long)n_out, s);
         prof_end(s);
     }
     if (*consumed) {

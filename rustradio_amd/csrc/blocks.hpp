@@ -42,8 +42,14 @@ struct Block {
     void prof_read(double* total_ms, size_t* launches, bool reset);
 };
 
+struct FftFilter;
 struct FirC32 : Block {
     FirPlan pl;
+    // Non-decimating filters beyond a few taps run as overlap-save FFT tiles (the FftFilter kernel on a window
+    // with no history: y[m] = sum_k rev[k] x[m + k] is that kernel's output for an empty prefix): the direct form
+    // costs 2-4 multiply-adds per tap and sample, the tiles a constant ~0.3 ms per 1e8 samples.  RR_FIR_DIRECT=1
+    // forces the direct kernel, RR_FIR_FFT=1 the tiles for any length (both read at construction).
+    std::unique_ptr<FftFilter> fftk;
     DevBuf<unsigned char> d_tp, d_rev, d_tab;
     bool rot_on = false;
     int rot_mode = RR_ROT_MODEL;
@@ -52,7 +58,9 @@ struct FirC32 : Block {
     size_t n_rot = 0;                             // outputs rotated so far
     std::vector<cf> h_tab;
     std::vector<std::complex<float>> h_taps;      // caller-order taps after the translate pre-rotation
-    FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq);
+    // allow_fft = false: bookkeeping / direct form only (HilbertFir's inner object)
+    FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq, bool allow_fft = true);
+    ~FirC32() override;
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
     void rotate_output(cf* out, size_t out_n, hipStream_t s);   // fir.rs:464-473 (no-op without translate)
 };
@@ -96,6 +104,8 @@ struct FftFilter : Block {
     // still the one-workgroup-per-CU kind: the tile is then chosen with their cost
     FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain = false, int max_log2f = 14);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+    // out[n] = sum_k t[k] src[n + L - 1 - k], n < n_out (the tile kernel of the chosen size)
+    void filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s);
 };
 
 // Fused FftFilter -> RationalResampler(interp:deci) -> QuadratureDemod (one kernel per call).

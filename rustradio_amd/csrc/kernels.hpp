@@ -15,6 +15,11 @@ int fft_read_stamps(unsigned long long* host16);   // measurement builds only (e
 void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw,
                        const cf* hpos, hipStream_t s);
 
+// The same filter keeping every d-th output: out[m] = y[m d], m < n_out (tiles of 1024..4096 points, d <= 4096) —
+// the decimating FirFilter (fir.rs:181-189) on overlap-save tiles.
+void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
+                         hipStream_t s);
+
 // The same filter with an 8192 / 16384-point tile built from nsub = 2 / 4 sub-transforms of 4096 points
 // (k_fftfilt_split).  tw4096: w_4096^k;  wk[t] = w_F^t, t < 256;  hs[r][p] = H[nsub bin(p) + r] / F with
 // bin(p) = fftfilt_split_bin(p), the bin at position p of the 4096-point spectrum layout.

@@ -346,6 +346,50 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
     }
 }
 
+// ---- decimating FirFilter on the same tiles ----------------------------------------------------------
+// y[m] = z[m d], z = the full-rate filter output of k_fftfilt_os (fir.rs:181-189 evaluates only every d-th window;
+// here every d-th sample of the filtered tile is kept).  The lanes of one store instruction hold 64 consecutive z,
+// so the 64/d samples they keep are contiguous in `out`.  Index arithmetic: g = tile S - first + idx is the z index
+// of tile position idx; with gb = tile S + (K d - first), K = ceil(first / d), the position keeps iff
+// (gb + idx) % d == 0 and lands at (gb + idx) / d - K.  One 64-bit division per tile, then exact float quotients
+// (x < d + F <= 8192 here, so floor((x + 0.5) / d) in f32 is exact).
+template <int LOG2F, int VAR>
+__global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
+void k_fftfilt_deci(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d, long ntiles,
+                    const cf* __restrict__ tw, const cf* __restrict__ hpos) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    const int t = threadIdx.x;
+    const long S = F - L + 1;
+    const int first = L - 1;
+    const long K = (first + d - 1) / d;
+    const float inv_d = 1.0f / (float)d;
+    TileXform<LOG2F, VAR> X;
+    X.init(t, tw, hpos);
+    creg* out_reg = reinterpret_cast<creg*>(out);
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long tile = it.tile;
+        creg v[16];
+        load_tile16<LOG2F>(v, src, tile * S, t, lds);
+        RR_PHASE();
+        X.run(v, lds, 0, nullptr);
+        const long gb = tile * S + (K * d - first);
+        const long qb = gb / d;
+        const int rb = (int)(gb - qb * d) + t;             // (gb + t) - qb d, in [0, d + T)
+        creg* po = out_reg + (qb - K);
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            const int x = rb + n * T;
+            const int q = (int)(((float)x + 0.5f) * inv_d);
+            const long m = (qb - K) + q;
+            if (q * d == x && n * T + t >= first && m < n_out) po[q] = v[n];
+        }
+        RR_PHASE();
+    }
+}
+
 // ---- FftFilter tiles of 8192 / 16384 points as NSUB = 2 / 4 sub-transforms of 4096 points ---------------------
 // A 512/1024-thread tile fits one workgroup per CU and cannot keep its tables in registers (k_fftfilt_os<13|14, 3>
 // costs 6x / 22x a 4096-point tile).  Split in frequency instead (M = 4096, F = NSUB M, n < M):
@@ -940,6 +984,34 @@ void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, cons
     case 13: launch_one<13, 3>(src, out, n_out, L, tw, hpos, s); break;
     case 14: launch_one<14, 3>(src, out, n_out, L, tw, hpos, s); break;
     default: throw Error("fftfilt: unsupported tile size");
+    }
+}
+
+template <int LOG2F, int VAR>
+static void launch_deci_one(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hpos, hipStream_t s) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    const long S = F - L + 1;
+    if (n_out <= 0) return;
+    const long n_full = (n_out - 1) * (long)d + 1;         // full-rate samples up to the last one kept
+    const long ntiles = (n_full + S - 1) / S;
+    const size_t smem = sizeof(cf) * lds_elems(F);
+    static bool attr_set = false;
+    static int per_cu = 0;
+    const long grid = grid_for_tiles(k_fftfilt_deci<LOG2F, VAR>, T, smem, ntiles, attr_set, per_cu);
+    hipLaunchKernelGGL((k_fftfilt_deci<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L, d,
+                       ntiles, tw, hpos);
+    RR_HIP(hipGetLastError());
+}
+
+void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
+                         hipStream_t s) {
+    if (d < 1 || d > 4096) throw Error("fftfilt_deci: decimation out of range");
+    switch (log2f) {
+    case 10: launch_deci_one<10, 0>(src, out, n_out, L, d, tw, hpos, s); break;
+    case 11: launch_deci_one<11, 0>(src, out, n_out, L, d, tw, hpos, s); break;
+    case 12: launch_deci_one<12, 0>(src, out, n_out, L, d, tw, hpos, s); break;
+    default: throw Error("fftfilt_deci: unsupported tile size");
     }
 }
 

@@ -60,6 +60,7 @@ def test_fir_every_tile_shape(rr, monkeypatch, cfg, L, deci, cplx):
     """Every (threads, outputs/thread, phase split) tile shape of the FIR kernel, forced through the
     RR_FIR_CFG knob (the launcher otherwise picks by input size), incl. streams with boundary tiles."""
     monkeypatch.setenv("RR_FIR_CFG", str(cfg))
+    monkeypatch.setenv("RR_FIR_DIRECT", "1")      # d = 1 filters would otherwise take the overlap-save tiles
     x = rnd_c(40000, L * 11 + deci + cfg)
     taps = rnd_c(L, L + 1) / max(1, L // 8)
     if not cplx:
@@ -68,6 +69,48 @@ def test_fir_every_tile_shape(rr, monkeypatch, cfg, L, deci, cplx):
     both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x[:9000], stream_bytes=8 * 2500)
     xf = rnd_f(30000, cfg + 5)
     both(rr, lambda m: [m.FirFilter(taps.real.copy(), deci=deci)], xf)
+
+
+@pytest.mark.parametrize("path", ["direct", "fft", "auto"])
+@pytest.mark.parametrize("L,cplx", [(1, False), (3, True), (16, False), (27, True), (28, True), (39, False), (40, False), (127, False), (127, True), (401, True),
+                                    (1000, False), (2467, False), (9000, True)])
+def test_fir_nondecimating_both_paths(rr, monkeypatch, path, L, cplx):
+    """FirFilter with deci = 1 through the direct-form kernel and through the overlap-save FFT tiles
+    (chosen automatically beyond a few taps): same work() protocol, both within 1e-5 of the oracle,
+    whole windows and small rings (boundary tiles, windows shorter than a tile)."""
+    if path == "direct":
+        monkeypatch.setenv("RR_FIR_DIRECT", "1")
+    elif path == "fft":
+        monkeypatch.setenv("RR_FIR_FFT", "1")
+    x = rnd_c(90000, L * 5 + 1)
+    taps = rnd_c(L, L + 9) / max(1, L // 8)
+    if not cplx:
+        taps = taps.real.astype(np.complex64)
+    both(rr, lambda m: [m.FirFilter(taps)], x)
+    both(rr, lambda m: [m.FirFilter(taps)], x[:30000], stream_bytes=8 * (L + 1500))
+    f = rr.FirFilter(taps)
+    assert rr.fir_uses_fft_tiles(f) == (path == "fft" or (path == "auto" and L >= (28 if cplx else 40)))
+
+
+@pytest.mark.parametrize("path", ["direct", "fft", "auto"])
+@pytest.mark.parametrize("L,deci,cplx", [(5, 2, False), (127, 2, False), (127, 3, True), (255, 8, True), (401, 7, False),
+                                         (1000, 16, True), (64, 100, False), (2000, 5, False), (3584, 4096, False),
+                                         (300, 3000, True)])
+def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
+    """Decimating FirFilter through the direct-form kernel and through the overlap-save tiles with a decimating
+    store: same protocol, same outputs (1e-5), incl. decimations beyond the tile's useful width and small rings."""
+    if path == "direct":
+        monkeypatch.setenv("RR_FIR_DIRECT", "1")
+    elif path == "fft":
+        monkeypatch.setenv("RR_FIR_FFT", "1")
+    x = rnd_c(120000, L * 3 + deci)
+    taps = rnd_c(L, L + deci) / max(1, L // 8)
+    if not cplx:
+        taps = taps.real.astype(np.complex64)
+    both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x)
+    both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x[:40000], stream_bytes=8 * (L + deci + 1700))
+    if path == "fft":
+        assert rr.fir_uses_fft_tiles(rr.FirFilter(taps, deci=deci))
 
 
 def test_fir_complex_chunked(rr):
