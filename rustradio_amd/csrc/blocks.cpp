@@ -146,17 +146,18 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     // staging up to ~32 real / ~24 Complex taps and then grows by 0.004 / 0.007 ms per tap
     // (tools/fir_paths_probe.py on MI355X: 127 real taps 0.65 vs 0.32 ms, 127 Complex taps 1.09 vs 0.32 ms)
     const bool force_direct = getenv("RR_FIR_DIRECT") != nullptr, force_fft = getenv("RR_FIR_FFT") != nullptr;
-    // d > 1: the same tiles with a decimating store (k_fftfilt_deci, tiles up to 4096 points).  The transform cost
+    // d > 1: the same tiles with a decimating store (k_fftfilt_deci, k_fftfilt_split<.., true>).  The transform cost
     // per input sample does not shrink with d while the direct form's does, so the bar is on taps per output
     // phase; beyond ~320 taps the direct form's LDS tile no longer fits for most decimations and it collapses
     // (tools/fir_deci_probe.py: 401 taps /16 0.69 vs 0.32 ms, 1000 taps /16 95 vs 0.43 ms per 1e8 samples).
     const size_t min_taps = real_taps ? 40 : 28, min_per_phase = real_taps ? 36 : 16;
-    const bool fits = deci == 1 ? ntaps <= 16383 : (ntaps <= 3584 && deci <= 4096);
+    const bool fits = ntaps <= 16383 && deci <= 4096;
     const bool wins = deci == 1 ? ntaps >= min_taps : (ntaps >= 320 || ntaps / deci >= min_per_phase);
     if (allow_fft && fits && !force_direct && (force_fft || wins)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
-        fftk.reset(new FftFilter(ct.data(), ntaps, false, deci == 1 ? 14 : 12));
+        fftk.reset(new FftFilter(ct.data(), ntaps));
+        if (deci > 1 && fftk->log2f >= 13 && !fftk->nsub) fftk.reset();   // (RR_FFT_NO_SPLIT measurement runs)
     }
 }
 FirC32::~FirC32() = default;
@@ -173,7 +174,8 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     const size_t out_n = n / d;
     VSrc<cf> src{nullptr, 0, static_cast<const cf*>(in), (long)in_len};
     prof_begin(s);
-    if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s);
+    if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s);
+    else if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s);
     else if (fftk) fftk->filter(src, static_cast<cf*>(out), (long)out_n, s);
     else launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
     prof_end(s);

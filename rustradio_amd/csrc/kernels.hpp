@@ -25,6 +25,8 @@ void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, in
 // bin(p) = fftfilt_split_bin(p), the bin at position p of the 4096-point spectrum layout.
 void launch_fftfilt_split(int nsub, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw4096, const cf* hs, const cf* wk,
                           hipStream_t s);
+void launch_fftfilt_split_deci(int nsub, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw4096, const cf* hs,
+                               const cf* wk, hipStream_t s);   // out[m] = y[m d], m < n_out
 int fftfilt_split_bin(int p);
 
 // FftStream: out = forward unnormalised FFT of each of `nframes` consecutive 2^log2n-point frames

@@ -12,7 +12,9 @@
 //                  and the conj-multiply + atan2 (src/quadrature_demod.rs:65-109) run as an
 //                  LDS epilogue and only the demodulated f32 stream is written to HBM.
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "kernels.hpp"
 
@@ -422,9 +424,11 @@ __device__ __forceinline__ creg window_at(const VSrcIQ8& src, long i) {
     return to_reg(VSrcIQ8::decode(reinterpret_cast<const unsigned short*>(src.in)[i]));
 }
 
-template <int NSUB>
+// DECI: keep every d-th filtered sample (out[m] = y[m d], n_out counts kept samples) — the index arithmetic of
+// k_fftfilt_deci; the decimating FirFilter with more taps than a 4096-point tile takes.
+template <int NSUB, bool DECI>
 __global__ __launch_bounds__(256, 2)
-void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles, const cf* __restrict__ tw,
+void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d, long ntiles, const cf* __restrict__ tw,
                      const cf* __restrict__ hs, const cf* __restrict__ wk) {
     constexpr int LOG2M = 12, M = 1 << LOG2M, T = M / 16, F = NSUB * M;
     constexpr int NP = Plan<LOG2M>::NP;
@@ -499,6 +503,16 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long
         const long o0 = it.tile * S - first;            // output index of tile position 0
         creg* po = out_reg + o0 + t;
         const bool whole = o0 + F <= n_out;
+        long qbK = 0;                                   // DECI: see k_fftfilt_deci
+        int rb = 0;
+        float inv_d = 0.0f;
+        if constexpr (DECI) {
+            const long K = (first + d - 1) / d;
+            const long gb = it.tile * S + (K * d - first), qb = gb / d;
+            rb = (int)(gb - qb * d) + t;
+            qbK = qb - K;
+            inv_d = 1.0f / (float)d;
+        }
 #pragma unroll 1
         for (int n0 = 0; n0 < 16; n0 += 8) {
             creg wko[8];
@@ -518,7 +532,13 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long
 #pragma unroll
                 for (int s = 0; s < NSUB; s++) {
                     const long pos = (long)s * M + n * T + t;
-                    if (pos >= first && (whole || o0 + pos < n_out)) po[(long)s * M + n * T] = e[s];
+                    if constexpr (DECI) {
+                        const int x = rb + s * M + n * T;            // < d + F <= 20480: exact in f32
+                        const int q = (int)(((float)x + 0.5f) * inv_d);
+                        if (q * d == x && pos >= first && qbK + q < n_out) out_reg[qbK + q] = e[s];
+                    } else {
+                        if (pos >= first && (whole || o0 + pos < n_out)) po[(long)s * M + n * T] = e[s];
+                    }
                 }
             }
         }
@@ -528,23 +548,29 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long
 
 int fftfilt_split_bin(int p) { return bin_of_pos<12>(p); }
 
-template <int NSUB>
-static void launch_split_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hs, const cf* wk, hipStream_t s) {
+template <int NSUB, bool DECI>
+static void launch_split_one(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hs, const cf* wk, hipStream_t s) {
     constexpr int M = 4096, F = NSUB * M;
     const long S = F - L + 1;
-    const long ntiles = (n_out + S - 1) / S;
-    if (ntiles <= 0) return;
+    if (n_out <= 0) return;
+    const long n_full = DECI ? (n_out - 1) * (long)d + 1 : n_out;
+    const long ntiles = (n_full + S - 1) / S;
     const size_t smem = sizeof(cf) * lds_elems(M) * NSUB;
-    static bool attr_set = false;
-    static int per_cu = 0;
-    const long grid = grid_for_tiles(k_fftfilt_split<NSUB>, 256, smem, ntiles, attr_set, per_cu);
-    hipLaunchKernelGGL((k_fftfilt_split<NSUB>), dim3((unsigned)grid), dim3(256), smem, s, src, out, n_out, L, ntiles, tw, hs, wk);
+    const long grid = grid_for_tiles(k_fftfilt_split<NSUB, DECI>, 256, smem, ntiles);
+    hipLaunchKernelGGL((k_fftfilt_split<NSUB, DECI>), dim3((unsigned)grid), dim3(256), smem, s, src, out, n_out, L, d, ntiles, tw, hs, wk);
     RR_HIP(hipGetLastError());
 }
 void launch_fftfilt_split(int nsub, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw4096, const cf* hs, const cf* wk,
                           hipStream_t s) {
-    if (nsub == 2) launch_split_one<2>(src, out, n_out, L, tw4096, hs, wk, s);
-    else if (nsub == 4) launch_split_one<4>(src, out, n_out, L, tw4096, hs, wk, s);
+    if (nsub == 2) launch_split_one<2, false>(src, out, n_out, L, 1, tw4096, hs, wk, s);
+    else if (nsub == 4) launch_split_one<4, false>(src, out, n_out, L, 1, tw4096, hs, wk, s);
+    else throw Error("fftfilt_split: 2 or 4 sub-transforms");
+}
+void launch_fftfilt_split_deci(int nsub, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw4096, const cf* hs,
+                               const cf* wk, hipStream_t s) {
+    if (d < 1 || d > 4096) throw Error("fftfilt_split_deci: decimation out of range");
+    if (nsub == 2) launch_split_one<2, true>(src, out, n_out, L, d, tw4096, hs, wk, s);
+    else if (nsub == 4) launch_split_one<4, true>(src, out, n_out, L, d, tw4096, hs, wk, s);
     else throw Error("fftfilt_split: 2 or 4 sub-transforms");
 }
 
@@ -687,9 +713,7 @@ void k_fft_frames_split(const cf* __restrict__ in, cf* __restrict__ out, long nf
 template <int NSUB>
 static void launch_frames_split(const cf* in, cf* out, long nframes, const cf* tw4096, const cf* twF, hipStream_t s) {
     const size_t smem = sizeof(cf) * lds_elems(4096) * NSUB;
-    static bool attr_set = false;
-    static int per_cu = 0;
-    const long grid = grid_for_tiles(k_fft_frames_split<NSUB>, 256, smem, nframes, attr_set, per_cu);
+    const long grid = grid_for_tiles(k_fft_frames_split<NSUB>, 256, smem, nframes);
     hipLaunchKernelGGL((k_fft_frames_split<NSUB>), dim3((unsigned)grid), dim3(256), smem, s, in, out, nframes, tw4096, twF);
     RR_HIP(hipGetLastError());
 }
@@ -699,9 +723,7 @@ static void launch_frames_one(const cf* in, cf* out, long nframes, const cf* tw,
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     const size_t smem = sizeof(cf) * lds_elems(F);
-    static bool attr_set = false;
-    static int per_cu = 0;
-    const long grid = grid_for_tiles(k_fft_frames<LOG2F, VAR>, T, smem, nframes, attr_set, per_cu);
+    const long grid = grid_for_tiles(k_fft_frames<LOG2F, VAR>, T, smem, nframes);
     hipLaunchKernelGGL((k_fft_frames<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, in, out, nframes, tw);
     RR_HIP(hipGetLastError());
 }
@@ -944,15 +966,27 @@ int device_cu_count() {
     return n;
 }
 
-template <class KFn> static long grid_for_tiles(KFn kfn, int T, size_t smem, long ntiles, bool& attr_set, int& per_cu) {
-    static std::mutex mu;                                  // first launches may come from several host threads at once
-    std::lock_guard<std::mutex> lock(mu);
-    if (!attr_set) {
-        RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, T, smem));
-        if (per_cu < 1) per_cu = 1;
-        if (const char* e = getenv("RR_FFT_PERCU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;   // measurement knob (tools/fft_percu.sh)
-        attr_set = true;
+template <class KFn> static long grid_for_tiles(KFn kfn, int T, size_t smem, long ntiles) {
+    // launch setup (shared-memory attribute, occupancy) is per kernel AND per device: a process may drive several
+    // GPUs (rr_set_device); first launches may come from several host threads at once
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> per_cu_of;
+    int dev = 0;
+    RR_HIP(hipGetDevice(&dev));
+    const std::pair<const void*, int> key(reinterpret_cast<const void*>(kfn), dev);
+    int per_cu;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = per_cu_of.find(key);
+        if (it == per_cu_of.end()) {
+            RR_HIP(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            int n = 0;
+            RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, T, smem));
+            if (n < 1) n = 1;
+            if (const char* e = getenv("RR_FFT_PERCU")) n = atoi(e) > 0 ? atoi(e) : n;   // measurement knob (tools/fft_percu.sh)
+            it = per_cu_of.emplace(key, n).first;
+        }
+        per_cu = it->second;
     }
     long grid = (long)device_cu_count() * per_cu;
     return grid > ntiles ? ntiles : grid;
@@ -966,9 +1000,7 @@ static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, c
     const long ntiles = (n_out + S - 1) / S;
     if (ntiles <= 0) return;
     const size_t smem = sizeof(cf) * lds_elems(F);
-    static bool attr_set = false;
-    static int per_cu = 0;
-    const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR>, T, smem, ntiles, attr_set, per_cu);
+    const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR>, T, smem, ntiles);
     const int ablate = 0;
     hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L,
                        ntiles, tw, hpos, ablate, fft_stamp_buffer());
@@ -996,9 +1028,7 @@ static void launch_deci_one(VSrc<cf> src, cf* out, long n_out, int L, int d, con
     const long n_full = (n_out - 1) * (long)d + 1;         // full-rate samples up to the last one kept
     const long ntiles = (n_full + S - 1) / S;
     const size_t smem = sizeof(cf) * lds_elems(F);
-    static bool attr_set = false;
-    static int per_cu = 0;
-    const long grid = grid_for_tiles(k_fftfilt_deci<LOG2F, VAR>, T, smem, ntiles, attr_set, per_cu);
+    const long grid = grid_for_tiles(k_fftfilt_deci<LOG2F, VAR>, T, smem, ntiles);
     hipLaunchKernelGGL((k_fftfilt_deci<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L, d,
                        ntiles, tw, hpos);
     RR_HIP(hipGetLastError());
@@ -1028,9 +1058,7 @@ static void launch_fm_one(SRC src, float* out, int L, const cf* tw, const cf* hp
     const long ntiles = (h.n_y + Sp - 1) / Sp;
     if (ntiles <= 0) return;
     const size_t smem = sizeof(cf) * lds_elems(F);
-    static bool attr_set = false;
-    static int per_cu = 0;
-    const long grid = grid_for_tiles(k_fm_chain<LOG2F, VAR, SRC>, T, smem, ntiles, attr_set, per_cu);
+    const long grid = grid_for_tiles(k_fm_chain<LOG2F, VAR, SRC>, T, smem, ntiles);
     hipLaunchKernelGGL((k_fm_chain<LOG2F, VAR, SRC>), dim3((unsigned)grid), dim3(T), smem, s, src, out, L, ntiles, tw,
                        hpos, a, last_in, last_out);
     RR_HIP(hipGetLastError());
@@ -1192,9 +1220,7 @@ static void launch_fm_split_one(SRC src, float* out, int L, const cf* tw, const 
     const long ntiles = (h.n_y + Sp - 1) / Sp;
     if (ntiles <= 0) return;
     const size_t smem = sizeof(cf) * lds_elems(4096) * NSUB;
-    static bool attr_set = false;
-    static int per_cu = 0;
-    const long grid = grid_for_tiles(k_fm_chain_split<NSUB, SRC>, 256, smem, ntiles, attr_set, per_cu);
+    const long grid = grid_for_tiles(k_fm_chain_split<NSUB, SRC>, 256, smem, ntiles);
     hipLaunchKernelGGL((k_fm_chain_split<NSUB, SRC>), dim3((unsigned)grid), dim3(256), smem, s, src, out, L, ntiles, tw, hs, wk,
                        a, last_in, last_out);
     RR_HIP(hipGetLastError());
@@ -1223,9 +1249,7 @@ static void launch_fm_multi_one(VSrc<cf> src, float* out, long out_stride, int L
     const long ntiles = (h.n_y + Sp - 1) / Sp;
     if (ntiles <= 0) return;
     const size_t smem = 2 * sizeof(cf) * lds_elems(F);
-    static bool attr_set = false;
-    static int per_cu = 0;
-    const long grid = grid_for_tiles(k_fm_multi<LOG2F>, T, smem, ntiles, attr_set, per_cu);
+    const long grid = grid_for_tiles(k_fm_multi<LOG2F>, T, smem, ntiles);
     hipLaunchKernelGGL((k_fm_multi<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles,
                        tw, hpos_all, nchan, a, last_in, last_out);
     RR_HIP(hipGetLastError());

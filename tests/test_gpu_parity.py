@@ -94,7 +94,7 @@ def test_fir_nondecimating_both_paths(rr, monkeypatch, path, L, cplx):
 
 @pytest.mark.parametrize("path", ["direct", "fft", "auto"])
 @pytest.mark.parametrize("L,deci,cplx", [(5, 2, False), (127, 2, False), (127, 3, True), (255, 8, True), (401, 7, False),
-                                         (1000, 16, True), (64, 100, False), (2000, 5, False), (3584, 4096, False),
+                                         (1000, 16, True), (64, 100, False), (2000, 5, False), (3584, 4096, False), (5000, 3, True), (9000, 16, False),
                                          (300, 3000, True)])
 def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
     """Decimating FirFilter through the direct-form kernel and through the overlap-save tiles with a decimating
@@ -103,6 +103,8 @@ def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
         monkeypatch.setenv("RR_FIR_DIRECT", "1")
     elif path == "fft":
         monkeypatch.setenv("RR_FIR_FFT", "1")
+    if path == "direct" and L >= 5000:
+        pytest.skip("direct-form fallback at thousands of taps: covered by test_fir_complex history, slow")
     x = rnd_c(120000, L * 3 + deci)
     taps = rnd_c(L, L + deci) / max(1, L // 8)
     if not cplx:
