@@ -267,7 +267,17 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
     d_rev.upload(rev.data(), rev.size(), stream);
     d_tp.upload(tp.data(), tp.size(), stream);
     RR_HIP(hipStreamSynchronize(stream));
+    // long filters on overlap-save tiles, two real segments per Complex tile (k_fftfilt_real); same rule as FirC32
+    const bool force_direct = getenv("RR_FIR_DIRECT") != nullptr, force_fft = getenv("RR_FIR_FFT") != nullptr;
+    const bool fits = ntaps <= 3584 && deci <= 4096;
+    const bool wins = deci == 1 ? ntaps >= 40 : (ntaps >= 320 || ntaps / deci >= 36);
+    if (fits && !force_direct && (force_fft || wins)) {
+        std::vector<rr_c32> ct(ntaps);
+        for (size_t i = 0; i < ntaps; i++) ct[i] = {taps[i], 0.0f};
+        fftk.reset(new FftFilter(ct.data(), ntaps, false, 12, true));
+    }
 }
+FirF32::~FirF32() = default;
 int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                      size_t* produced, size_t* need, hipStream_t s) {
     const size_t L = pl.L, d = pl.d;
@@ -278,7 +288,8 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     n = std::min(n, out_cap * d);
     VSrc<float> src{nullptr, 0, static_cast<const float*>(in), (long)in_len};
     prof_begin(s);
-    launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
+    if (fftk) fftk->filter_real(src, static_cast<float*>(out), (long)(n / d), (int)d, s);
+    else launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
     prof_end(s);
     *consumed = n; *produced = n / d;
     return RR_AGAIN;
@@ -336,8 +347,17 @@ static void compute_hpos(const rr_c32* taps, size_t ntaps, int log2f, std::vecto
     }
 }
 
-FftFilter::FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain, int max_log2f) : Block("FftFilter", 8, 8) {
+FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int max_log2f, bool real)
+    : Block("FftFilter", real ? 4 : 8, real ? 4 : 8), real_stream(real) {
     if (ntaps == 0) throw Error("FftFilter: empty taps");            // fft_filter.rs:146
+    std::vector<rr_c32> real_taps;
+    const rr_c32* taps = taps_in;
+    if (real) {
+        if (max_log2f > 12) max_log2f = 12;
+        real_taps.assign(taps_in, taps_in + ntaps);
+        for (auto& c : real_taps) c.im = 0.0f;
+        taps = real_taps.data();
+    }
     L = ntaps;
     fft_size = calc_fft_size(ntaps);                                  // fft_filter.rs:261
     nsamples = fft_size - ntaps;                                      // fft_filter.rs:262
@@ -415,6 +435,10 @@ void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s) {
     else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s);
 }
 
+void FftFilter::filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s) {
+    launch_fftfilt_real(log2f, src, out, n_out, (int)L, d, d_tw.p, d_hpos.p, s);
+}
+
 int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                         size_t* produced, size_t* need, hipStream_t s) {
     *consumed = *produced = *need = 0;
@@ -433,6 +457,21 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     }
     const size_t n_out = k * S;
     const long plen = (long)(L - 1 + pend_len);
+    if (real_stream) {
+        VSrc<float> rsrc{reinterpret_cast<const float*>(prefix[cur].p), plen, static_cast<const float*>(in), (long)in_len};
+        if (k) {
+            prof_begin(s);
+            filter_real(rsrc, static_cast<float*>(out), (long)n_out, 1, s);
+            prof_end(s);
+        }
+        if (*consumed) {
+            launch_vcopy_f32(rsrc, (long)n_out, reinterpret_cast<float*>(prefix[cur ^ 1].p), (long)(L - 1 + new_pend), s);
+            cur ^= 1;
+            pend_len = new_pend;
+        }
+        *produced = n_out;
+        return st;
+    }
     VSrc<cf> src{prefix[cur].p, plen, static_cast<const cf*>(in), (long)in_len};
     if (k) {
         prof_begin(s);
@@ -626,10 +665,16 @@ FftFilterFloat::FftFilterFloat(const float* taps, size_t ntaps) : Block("FftFilt
     if (ntaps == 0) throw Error("FftFilterFloat: empty taps");
     std::vector<rr_c32> ct(ntaps);
     for (size_t i = 0; i < ntaps; i++) ct[i] = rr_c32{taps[i], 0.0f};  // fft_filter.rs:398
-    inner.reset(new FftFilter(ct.data(), ntaps));
+    real_inner = ntaps <= 3584 && !getenv("RR_FFTFLOAT_COMPLEX");       // (the knob keeps the three-kernel path testable)
+    inner.reset(real_inner ? new FftFilter(ct.data(), ntaps, false, 12, true) : new FftFilter(ct.data(), ntaps));
     cap = 4096000 / sizeof(cf);                                         // inner streams: stream.rs:105,336-339
-    for (auto& b : iin) b.reserve(cap);
-    for (auto& b : iout) b.reserve(cap);
+    if (real_inner) {
+        for (auto& b : fin) b.reserve(cap);
+        for (auto& b : fout) b.reserve(cap);
+    } else {
+        for (auto& b : iin) b.reserve(cap);
+        for (auto& b : iout) b.reserve(cap);
+    }
 }
 
 int FftFilterFloat::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
@@ -637,25 +682,45 @@ int FftFilterFloat::work_dev(const void* in, size_t in_len, void* out, size_t ou
     *consumed = *produced = *need = 0;
     // outer input -> inner_in as Complex(x, 0)   (fft_filter.rs:431-445)
     const size_t n = std::min(in_len, cap - iin_len);
-    launch_f32_to_c32(static_cast<const float*>(in), iin[ci].p + iin_len, (long)n, s);
+    if (real_inner) {
+        if (n) RR_HIP(hipMemcpyAsync(fin[ci].p + iin_len, in, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+        launch_f32_to_c32(static_cast<const float*>(in), iin[ci].p + iin_len, (long)n, s);
+    }
     iin_len += n;
     *consumed = n;
     // inner complex filter (fft_filter.rs:450)
     size_t ic = 0, ip = 0, ineed = 0;
-    const int st = inner->work_dev(iin[ci].p, iin_len, iout[co].p + iout_len, cap - iout_len, &ic, &ip, &ineed, s);
+    const int st = real_inner
+        ? inner->work_dev(fin[ci].p, iin_len, fout[co].p + iout_len, cap - iout_len, &ic, &ip, &ineed, s)
+        : inner->work_dev(iin[ci].p, iin_len, iout[co].p + iout_len, cap - iout_len, &ic, &ip, &ineed, s);
     if (ic) {
-        VSrc<cf> v{nullptr, 0, iin[ci].p, (long)iin_len};
-        launch_vcopy_c32(v, (long)ic, iin[ci ^ 1].p, (long)(iin_len - ic), s);
+        if (real_inner) {
+            VSrc<float> v{nullptr, 0, fin[ci].p, (long)iin_len};
+            launch_vcopy_f32(v, (long)ic, fin[ci ^ 1].p, (long)(iin_len - ic), s);
+        } else {
+            VSrc<cf> v{nullptr, 0, iin[ci].p, (long)iin_len};
+            launch_vcopy_c32(v, (long)ic, iin[ci ^ 1].p, (long)(iin_len - ic), s);
+        }
         ci ^= 1; iin_len -= ic;
     }
     iout_len += ip;
     // inner_out -> outer output, real part   (fft_filter.rs:453-470)
     const size_t m = std::min(iout_len, out_cap);
     if (m == 0 && iout_len != 0) { *need = 1; return RR_WAIT_DST; }   // :457-459
-    launch_c32_re(iout[co].p, static_cast<float*>(out), (long)m, s);
+    if (real_inner) {
+        if (m) RR_HIP(hipMemcpyAsync(out, fout[co].p, m * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+        launch_c32_re(iout[co].p, static_cast<float*>(out), (long)m, s);
+    }
     if (m) {
-        VSrc<cf> v{nullptr, 0, iout[co].p, (long)iout_len};
-        launch_vcopy_c32(v, (long)m, iout[co ^ 1].p, (long)(iout_len - m), s);
+        if (real_inner) {
+            VSrc<float> v{nullptr, 0, fout[co].p, (long)iout_len};
+            launch_vcopy_f32(v, (long)m, fout[co ^ 1].p, (long)(iout_len - m), s);
+        } else {
+            VSrc<cf> v{nullptr, 0, iout[co].p, (long)iout_len};
+            launch_vcopy_c32(v, (long)m, iout[co ^ 1].p, (long)(iout_len - m), s);
+        }
         co ^= 1; iout_len -= m;
     }
     *produced = m;

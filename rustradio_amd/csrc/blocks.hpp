@@ -86,6 +86,8 @@ struct HilbertFir : Block {
 struct FirF32 : Block {
     FirPlan pl;
     DevBuf<float> d_tp, d_rev;
+    std::unique_ptr<FftFilter> fftk;   // long filters: overlap-save tiles on the real stream (see FirC32::fftk)
+    ~FirF32() override;
     FirF32(const float* taps, size_t ntaps, size_t deci);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
@@ -102,10 +104,14 @@ struct FftFilter : Block {
     size_t pend_len = 0;
     // for_chain: the object backs a fused chain kernel (k_fm_chain / k_fm_multi), whose >= 8192-point tiles are
     // still the one-workgroup-per-CU kind: the tile is then chosen with their cost
-    FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain = false, int max_log2f = 14);
+    // real_stream: f32 windows and real taps (imaginary parts ignored), two overlap-save segments per Complex tile
+    // (k_fftfilt_real; tiles up to 4096 points, so <= 4094 taps); the carry prefix then holds floats
+    bool real_stream = false;
+    FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain = false, int max_log2f = 14, bool real_stream = false);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
     // out[n] = sum_k t[k] src[n + L - 1 - k], n < n_out (the tile kernel of the chosen size)
     void filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s);
+    void filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s);   // out[m] = y[m d]
 };
 
 // Fused FftFilter -> RationalResampler(interp:deci) -> QuadratureDemod (one kernel per call).
@@ -145,6 +151,10 @@ struct FmMulti : Block {
 struct FftFilterFloat : Block {
     std::unique_ptr<FftFilter> inner;
     size_t cap = 0;
+    // inner streams (fft_filter.rs:393-420).  With a real-stream inner filter they hold f32 (the Complex(x, 0)
+    // lift and the .re projection are no-ops on the data); filters too long for it keep the Complex pair.
+    bool real_inner = false;
+    DevBuf<float> fin[2], fout[2];
     DevBuf<cf> iin[2], iout[2];
     int ci = 0, co = 0;
     size_t iin_len = 0, iout_len = 0;

@@ -20,6 +20,11 @@ void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, cons
 void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
                          hipStream_t s);
 
+// Real stream, real taps (hpos from Complex(t, 0)): out[m] = y[m d], y[n] = sum_k t[k] xx[n + L - 1 - k]; two
+// overlap-save segments ride in the real / imaginary lanes of one Complex tile (tiles of 1024..4096 points).
+void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
+                         hipStream_t s);
+
 // The same filter with an 8192 / 16384-point tile built from nsub = 2 / 4 sub-transforms of 4096 points
 // (k_fftfilt_split).  tw4096: w_4096^k;  wk[t] = w_F^t, t < 256;  hs[r][p] = H[nsub bin(p) + r] / F with
 // bin(p) = fftfilt_split_bin(p), the bin at position p of the 4096-point spectrum layout.

@@ -392,6 +392,83 @@ void k_fftfilt_deci(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d
     }
 }
 
+// ---- real streams: two segments per Complex tile -------------------------------------------------------
+// Real taps commute with taking real / imaginary parts: filtering z = a + i b gives (t * a) + i (t * b).  One
+// F-point Complex tile therefore carries TWO consecutive overlap-save segments of a real stream (segment 2j in
+// the real, 2j + 1 in the imaginary lane): half the transform work and 8 B of traffic per real sample, against
+// 40 B for f32 -> Complex(x, 0) -> FftFilter -> .re (what FftFilterFloat does in the reference,
+// fft_filter.rs:365-491) — and the long FirFilter<Float> (fir.rs:113-147) on the same kernel.
+// DECI keeps every d-th filtered sample (see k_fftfilt_deci), n_out counts kept samples.
+template <int T>
+__device__ __attribute__((noinline)) void stage_pair_slow(creg* lds, VSrc<float> src, long va, long vb, int t) {
+    for (int n = 0; n < 16; n++) {
+        const int p = n * T + t;
+        lds[lds_pad(p)] = mk(src.load(va + p), src.load(vb + p));
+    }
+}
+template <int LOG2F, bool DECI>
+__global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
+void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L, int d, long ntiles,
+                    const cf* __restrict__ tw, const cf* __restrict__ hpos) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    const int t = threadIdx.x;
+    const long S = F - L + 1;
+    const int first = L - 1;
+    const long K = DECI ? (first + d - 1) / d : 0;
+    const float inv_d = DECI ? 1.0f / (float)d : 0.0f;
+    TileXform<LOG2F, 0> X;
+    X.init(t, tw, hpos);
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long va = 2 * it.tile * S, vb = va + S;       // virtual index of position 0 of the two segments
+        creg v[16];
+        if (va >= src.plen && vb - src.plen + F <= src.in_len) {
+            const float* pa = src.in + (va - src.plen) + t;
+#pragma unroll
+            for (int n = 0; n < 16; n++) v[n] = mk(pa[n * T], pa[S + n * T]);
+        } else {
+            stage_pair_slow<T>(lds, src, va, vb, t);
+            tile_sync<T>();
+            lds_load<LOG2F, 0>(v, t, lds);
+        }
+        RR_PHASE();
+        X.run(v, lds, 0, nullptr);
+        if constexpr (!DECI) {
+            const long oa = va - first;                      // output index of position 0 of segment A
+            float* po = out + oa + t;
+            if (oa + S + F <= n_out) {
+#pragma unroll
+                for (int n = 0; n < 16; n++)
+                    if (n * T + t >= first) { po[n * T] = v[n].x; po[S + n * T] = v[n].y; }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 16; n++) {
+                    const int idx = n * T + t;
+                    if (idx >= first && oa + idx < n_out) po[n * T] = v[n].x;
+                    if (idx >= first && oa + S + idx < n_out) po[S + n * T] = v[n].y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int seg = 0; seg < 2; seg++) {
+                const long gb = (seg ? vb : va) + (K * d - first);
+                const long qb = gb / d;
+                const int rb = (int)(gb - qb * d) + t;
+                float* po = out + (qb - K);
+#pragma unroll
+                for (int n = 0; n < 16; n++) {
+                    const int x = rb + n * T;
+                    const int q = (int)(((float)x + 0.5f) * inv_d);
+                    if (q * d == x && n * T + t >= first && (qb - K) + q < n_out) po[q] = seg ? v[n].y : v[n].x;
+                }
+            }
+        }
+        RR_PHASE();
+    }
+}
+
 // ---- FftFilter tiles of 8192 / 16384 points as NSUB = 2 / 4 sub-transforms of 4096 points ---------------------
 // A 512/1024-thread tile fits one workgroup per CU and cannot keep its tables in registers (k_fftfilt_os<13|14, 3>
 // costs 6x / 22x a 4096-point tile).  Split in frequency instead (M = 4096, F = NSUB M, n < M):
@@ -1042,6 +1119,36 @@ void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, in
     case 11: launch_deci_one<11, 0>(src, out, n_out, L, d, tw, hpos, s); break;
     case 12: launch_deci_one<12, 0>(src, out, n_out, L, d, tw, hpos, s); break;
     default: throw Error("fftfilt_deci: unsupported tile size");
+    }
+}
+
+template <int LOG2F, bool DECI>
+static void launch_real_one(VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos, hipStream_t s) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    const long S = F - L + 1;
+    if (n_out <= 0) return;
+    const long n_full = DECI ? (n_out - 1) * (long)d + 1 : n_out;
+    const long nseg = (n_full + S - 1) / S;
+    const long ntiles = (nseg + 1) / 2;
+    const size_t smem = sizeof(cf) * lds_elems(F);
+    const long grid = grid_for_tiles(k_fftfilt_real<LOG2F, DECI>, T, smem, ntiles);
+    hipLaunchKernelGGL((k_fftfilt_real<LOG2F, DECI>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L, d,
+                       ntiles, tw, hpos);
+    RR_HIP(hipGetLastError());
+}
+void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
+                         hipStream_t s) {
+    if (d < 1 || d > 4096) throw Error("fftfilt_real: decimation out of range");
+    if (2L * ((1L << log2f) - L + 1) <= 0) throw Error("fftfilt_real: tile too small");
+    switch (log2f * 2 + (d > 1)) {
+    case 20: launch_real_one<10, false>(src, out, n_out, L, d, tw, hpos, s); break;
+    case 21: launch_real_one<10, true>(src, out, n_out, L, d, tw, hpos, s); break;
+    case 22: launch_real_one<11, false>(src, out, n_out, L, d, tw, hpos, s); break;
+    case 23: launch_real_one<11, true>(src, out, n_out, L, d, tw, hpos, s); break;
+    case 24: launch_real_one<12, false>(src, out, n_out, L, d, tw, hpos, s); break;
+    case 25: launch_real_one<12, true>(src, out, n_out, L, d, tw, hpos, s); break;
+    default: throw Error("fftfilt_real: unsupported tile size");
     }
 }
 
