@@ -267,10 +267,12 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
     d_rev.upload(rev.data(), rev.size(), stream);
     d_tp.upload(tp.data(), tp.size(), stream);
     RR_HIP(hipStreamSynchronize(stream));
-    // long filters on overlap-save tiles, two real segments per Complex tile (k_fftfilt_real); same rule as FirC32
+    // long filters on overlap-save tiles, two real segments per Complex tile (k_fftfilt_real): a flat ~0.148 ms per
+    // 1e8 samples (8 B/sample -> 5.4 TB/s) against 0.15 + 0.002 ms per tap for the direct form
+    // (tools/fir_float_probe.py: 65 taps 0.26 -> 0.147 ms, 463 taps 1.25 -> 0.17 ms, 2467 taps 5.96 -> 0.33 ms)
     const bool force_direct = getenv("RR_FIR_DIRECT") != nullptr, force_fft = getenv("RR_FIR_FFT") != nullptr;
     const bool fits = ntaps <= 3584 && deci <= 4096;
-    const bool wins = deci == 1 ? ntaps >= 40 : (ntaps >= 320 || ntaps / deci >= 36);
+    const bool wins = deci == 1 ? ntaps >= 24 : (ntaps >= 320 || ntaps / deci >= 40);
     if (fits && !force_direct && (force_fft || wins)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {taps[i], 0.0f};

@@ -187,11 +187,39 @@ def test_fftfilter_rejects_too_many_taps(rr):
         rr.FftFilter(np.ones(0, np.complex64))
 
 
-def test_fftfilter_float(rr):
+@pytest.mark.parametrize("inner", ["real", "complex"])
+def test_fftfilter_float(rr, monkeypatch, inner):
+    """FftFilterFloat on the real-stream tile kernel (two overlap-save segments per Complex tile) and on the
+    f32 -> Complex -> FftFilter -> .re path it replaces (kept for filters beyond 3584 taps)."""
+    if inner == "complex":
+        monkeypatch.setenv("RR_FFTFLOAT_COMPLEX", "1")
     x = rnd_f(300_000, 5)
     taps = orc.low_pass(200e3, 44.1e3, 500.0)
     both(rr, lambda m: [m.FftFilterFloat(taps)], x)
     both(rr, lambda m: [m.FftFilterFloat(taps)], x, stream_bytes=4 * 30_000)
+
+
+@pytest.mark.parametrize("L", [1, 2, 7, 64, 401, 1024, 1025, 2500, 3584, 3585, 6000])
+def test_fftfilter_float_lengths(rr, L):
+    x = rnd_f(250_000, L)
+    taps = rnd_f(L, L + 77) / max(1, L // 4)
+    both(rr, lambda m: [m.FftFilterFloat(taps)], x)
+    both(rr, lambda m: [m.FftFilterFloat(taps)], x[:120_000], stream_bytes=4 * 50_000)
+
+
+@pytest.mark.parametrize("path", ["direct", "fft", "auto"])
+@pytest.mark.parametrize("L,deci", [(1, 1), (5, 1), (39, 1), (40, 1), (65, 1), (463, 1), (463, 6), (128, 3), (1000, 16),
+                                    (3584, 1), (3584, 4096), (64, 100), (330, 50), (2000, 7)])
+def test_fir_float_both_paths(rr, monkeypatch, path, L, deci):
+    """FirFilter<Float> through the direct-form kernel and through the real-stream overlap-save tiles."""
+    if path == "direct":
+        monkeypatch.setenv("RR_FIR_DIRECT", "1")
+    elif path == "fft":
+        monkeypatch.setenv("RR_FIR_FFT", "1")
+    x = rnd_f(150_000, L * 3 + deci)
+    taps = rnd_f(L, L + deci) / max(1, L // 8)
+    both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x)
+    both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x[:50_000], stream_bytes=4 * (L + deci + 2100))
 
 
 @pytest.mark.parametrize("I,D", [(1, 1), (1, 6), (25, 128), (3, 2), (200000, 1024000), (48, 200), (7, 3), (1, 1000)])

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""GPU box: FirFilter<Float> and FftFilterFloat at 1e8 real samples: direct-form kernel vs real-stream tiles
+(k_fftfilt_real), and FftFilterFloat's real inner filter vs the f32 -> Complex -> FftFilter -> .re path."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import rustradio_amd as rr
+n = 100_000_000
+x = torch.rand(n, device="cuda") * 2 - 1
+y = torch.empty(n, device="cuda")
+rng = np.random.default_rng(1)
+def run(f, k=4):
+    for _ in range(2):
+        f.work_dev(x.data_ptr(), n, y.data_ptr(), n)
+    torch.cuda.synchronize()
+    f.set_profiling(True)
+    for _ in range(k):
+        f.work_dev(x.data_ptr(), n, y.data_ptr(), n)
+    torch.cuda.synchronize()
+    ms, c = f.profile()
+    return ms / c
+for L, d in ((16, 1), (32, 1), (40, 1), (65, 1), (127, 1), (463, 1), (463, 6), (255, 8), (1000, 16), (2467, 1)):
+    t = (rng.uniform(-1, 1, L) / L).astype(np.float32)
+    row = []
+    for env in ("RR_FIR_DIRECT", "RR_FIR_FFT", None):
+        for k in ("RR_FIR_DIRECT", "RR_FIR_FFT"):
+            os.environ.pop(k, None)
+        if env:
+            os.environ[env] = "1"
+        row.append(run(rr.FirFilter(t, deci=d)))
+    print(f"FirFilter<Float> L={L:5d} d={d:3d}: direct {row[0]:.4f} ms  fft {row[1]:.4f} ms  auto {row[2]:.4f} ms", flush=True)
+for k in ("RR_FIR_DIRECT", "RR_FIR_FFT"):
+    os.environ.pop(k, None)
+# FftFilterFloat: inner streams are 512,000 samples, so time whole-stream throughput over ring-sized windows
+m = 512_000
+for L in (127, 401, 2467):
+    t = (rng.uniform(-1, 1, L) / L).astype(np.float32)
+    for env in (None, "RR_FFTFLOAT_COMPLEX"):
+        os.environ.pop("RR_FFTFLOAT_COMPLEX", None)
+        if env:
+            os.environ[env] = "1"
+        f = rr.FftFilterFloat(t)
+        tot = 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(100):
+            st, c, p, need = f.work_dev(x.data_ptr() + 4 * i * m, m, y.data_ptr(), m)
+            tot += c
+        f.sync(); dt = time.perf_counter() - t0
+        print(f"FftFilterFloat L={L:5d} {'complex inner' if env else 'real inner   '}: {tot / dt / 1e6:.0f} Msamples/s over 512k-sample windows", flush=True)
