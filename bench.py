@@ -15,6 +15,8 @@ Other workloads (--workload, also summarised under "others" in the JSON line):
     fm_multi     configs[3]: 32 such channels per GPU on one shared IQ source (256 channels on 8 GPUs)
     channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in), fused into one
                  composite decimating FIR (rr.HilbertFir); channelizer_unfused = the two blocks
+    fir_1e8      the configs[0] filter on 100,000,000 samples (steady state; 1e6 samples is a single ~15 us launch)
+    fir_float    FirFilter<Float>, the same 127 taps on 100,000,000 f32 samples (real-stream tiles, 8 B/sample)
     fir_fft_chain  configs[0] taps -> configs[1] filter as one chain (the north star's ">= 100x CPU" pair)
     rtl_fm_example examples/rtl_fm.rs with its own parameters (1.024 Msps, 2467 taps, 25:128), fused
     rtl_fm_chain configs[2] fed by the RTL-SDR byte stream: RtlSdrDecode fused in front (u8 in)
@@ -167,6 +169,41 @@ def make_fir(dev, rank, world, shared_src):
     w.alg_bytes_per_sample = 16.0
     w.dominant, w.dominant_bytes_per_unit = 0, 16.0
     w.cpu = ("FirFilter", taps)
+    return w
+
+
+def make_fir_1e8(dev, rank, world, shared_src):
+    """configs[0]'s filter at a steady-state size (1e6 samples is one launch of ~15 us: launch-bound)"""
+    w = Workload()
+    w.name = "FirFilter<Complex> 127 real taps, 100,000,000 samples/step (overlap-save tiles)"
+    fs, n = 10e6, 100_000_000
+    taps = rr.low_pass_complex(fs, 1e6, 190e3)
+    w.blocks = [rr.FirFilter(taps)]
+    w.n = n
+    w.bufs = [shared_src(lambda: synth_complex(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0001, dev)),
+              torch.empty(2 * n, dtype=torch.float32, device=dev)]
+    w.caps = [n]
+    w.alg_bytes_per_sample = 16.0
+    w.dominant, w.dominant_bytes_per_unit = 0, 16.0
+    w.cpu = ("FirFilter", taps)
+    return w
+
+
+def make_fir_float(dev, rank, world, shared_src):
+    """Fir<Float> with the configs[0] taps on a real stream: two overlap-save segments per Complex tile"""
+    w = Workload()
+    w.name = "FirFilter<Float> 127 taps, 100,000,000 f32 samples/step (real-stream overlap-save tiles)"
+    fs, n = 10e6, 100_000_000
+    taps = rr.low_pass(fs, 1e6, 190e3)
+    assert len(taps) == 127
+    w.blocks = [rr.FirFilter(taps)]
+    w.n = n
+    w.bufs = [shared_src(lambda: synth_real(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0006, dev)),
+              torch.empty(n, dtype=torch.float32, device=dev)]
+    w.caps = [n]
+    w.alg_bytes_per_sample = 8.0
+    w.dominant, w.dominant_bytes_per_unit = 0, 8.0
+    w.cpu = ("FirFilterFloat", taps)
     return w
 
 
@@ -334,7 +371,8 @@ def make_channelizer_unfused(dev, rank, world, shared_src):
 WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
              "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "channelizer": make_channelizer,
              "rtl_fm_chain": make_rtl_fm_chain, "channelizer_unfused": make_channelizer_unfused,
-             "fir_fft_chain": make_fir_fft_chain, "rtl_fm_example": make_rtl_fm_example}
+             "fir_fft_chain": make_fir_fft_chain, "rtl_fm_example": make_rtl_fm_example,
+             "fir_1e8": make_fir_1e8, "fir_float": make_fir_float}
 
 
 # ---- measurement ------------------------------------------------------------------------------
@@ -375,6 +413,10 @@ def cpu_baseline(w, seconds=10.0):
     if kind == "channelizer":
         host = w.bufs[0][:win * 2 * nwin].cpu().numpy()
         chain = [orc.Hilbert(65), orc.FirFilter(taps, deci=8)]
+        win = 1_024_000
+    elif kind == "FirFilterFloat":
+        host = w.bufs[0][:win * 2 * nwin].cpu().numpy()
+        chain = [orc.FirFilter(taps)]
         win = 1_024_000
     elif kind == "fir_fft_chain":
         host = w.bufs[0][:2 * win * nwin].cpu().numpy().view(np.complex64)
@@ -503,7 +545,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain", "fir") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain", "rtl_fm_example") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
+                         "kernel": "k_fftfilt_real" if args.workload == "fir_float" else "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain", "fir", "fir_1e8") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain", "rtl_fm_example") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),
