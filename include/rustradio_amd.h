@@ -82,10 +82,12 @@ int    rr_hilbert_taps(const float *window, size_t ntaps, float *out);
 /* ---- block constructors ------------------------------------------------------ */
 /* FirFilter::<Complex>::builder(taps).deci(deci)[.translate(samp_rate, freq)].build(src)
  * (src/fir.rs:303-386, 476-486).  translate != 0 requests frequency translation
- * (freq == 0 disables it, fir.rs:438-440).  NULL on invalid args (the reference asserts). */
+ * (freq == 0 disables it, fir.rs:438-440).  NULL on invalid args (the reference asserts).
+ * Arithmetic: Fir::filter_n (fir.rs:166-197) either in direct form or — longer filters — on overlap-save FFT
+ * tiles, whichever is cheaper for (ntaps, deci); both within 1e-5 of the reference (rr_fir_fft_tile tells). */
 rr_block *rr_fir_c32_create(const rr_c32 *taps, size_t ntaps, size_t deci,
                             int translate, float samp_rate, float freq);
-/* FirFilter::<Float> (same generic block, src/fir.rs:343-386). */
+/* FirFilter::<Float> (same generic block, src/fir.rs:343-386; long filters on real-stream overlap-save tiles). */
 rr_block *rr_fir_f32_create(const float *taps, size_t ntaps, size_t deci);
 /* FftFilter::new(src, taps) (src/fft_filter.rs:242-279).  1 <= ntaps <= 16383 (the largest LDS-resident
  * overlap-save tile is 16384 points; the reference has no limit) — NULL beyond. */
