@@ -14,7 +14,8 @@ Other workloads (--workload, also summarised under "others" in the JSON line):
     fm_chain     configs[2]: FftFilter(463) -> RationalResampler(1:6) -> QuadratureDemod, 2.4 Msps x 10 s
     fm_multi     configs[3]: 32 such channels per GPU on one shared IQ source (256 channels on 8 GPUs)
     channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in), fused into one
-                 composite decimating FIR (rr.HilbertFir); channelizer_unfused = the two blocks
+                 composite decimating FIR (rr.HilbertFir: real-stream overlap-save tiles, inverse transform pruned to 1/8);
+                 channelizer_unfused = the two blocks
     fir_1e8      the configs[0] filter on 100,000,000 samples (steady state; 1e6 samples is a single ~15 us launch)
     fir_float    FirFilter<Float>, the same 127 taps on 100,000,000 f32 samples (real-stream tiles, 8 B/sample)
     fir_fft_chain  configs[0] taps -> configs[1] filter as one chain (the north star's ">= 100x CPU" pair)
@@ -545,7 +546,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_real" if args.workload == "fir_float" else "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain", "fir", "fir_1e8") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain", "rtl_fm_example") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
+                         "kernel": "k_fftfilt_real" if args.workload == "fir_float" else "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain", "fir", "fir_1e8") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain", "rtl_fm_example") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fftfilt_prune" if args.workload == "channelizer" else "k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),

@@ -153,7 +153,20 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     const size_t min_taps = real_taps ? 40 : 28, min_per_phase = real_taps ? 36 : 16;
     const bool fits = ntaps <= 16383 && deci <= 4096;
     const bool wins = deci == 1 ? ntaps >= min_taps : (ntaps >= 320 || ntaps / deci >= min_per_phase);
-    if (allow_fft && fits && !force_direct && (force_fft || wins)) {
+    // deci 4 / 8 / 16: the tile whose last radix is the decimation, inverse transform pruned to 1/deci
+    // (tools/prune_probe.py, ms per 1e8 samples, direct / decimating store / pruned: 255 Complex taps /8 0.31 / 0.31 /
+    //  0.21, 401 taps /4 0.60 / 0.34 / 0.27, 1000 taps /16 98 / 0.45 / 0.29; short /8 filters stay direct: 127 taps 0.195 / 0.27 / 0.207)
+    const size_t per_phase = ntaps / deci;
+    const bool prune_default = deci == 4 ? per_phase >= 8 : deci == 8 ? per_phase >= (real_taps ? 28 : 16) : per_phase >= 4;
+    const bool prune_wins = getenv("RR_FIR_PRUNE") ? atoi(getenv("RR_FIR_PRUNE")) != 0 : prune_default;
+    if (allow_fft && !force_direct && prune_wins && prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
+        std::vector<std::complex<double>> td(ntaps);
+        for (size_t i = 0; i < ntaps; i++) td[i] = {t[i].real(), t[i].imag()};
+        prune.reset(new PruneTables());
+        if (!prune->build(td, deci, false, stream)) prune.reset();
+    }
+    if (prune) {
+    } else if (allow_fft && fits && !force_direct && (force_fft || wins)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
         fftk.reset(new FftFilter(ct.data(), ntaps));
@@ -174,7 +187,8 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     const size_t out_n = n / d;
     VSrc<cf> src{nullptr, 0, static_cast<const cf*>(in), (long)in_len};
     prof_begin(s);
-    if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s);
+    if (prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
+    else if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s);
     else if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s);
     else if (fftk) fftk->filter(src, static_cast<cf*>(out), (long)out_n, s);
     else launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
@@ -227,6 +241,17 @@ HilbertFir::HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c3
     build_poly(rev, plG.d, plG.qpad, tp);
     d_revG.upload(rev.data(), rev.size(), stream);
     d_tpG.upload(tp.data(), tp.size(), stream);
+    // deci 4 / 8 / 16: real-stream tiles with the pruned inverse; taps in caller order t[k] = G[Lg - 1 - k]
+    // (tools/prune_probe.py: 65 (*) 255 taps /8 0.219 -> 0.191 ms per 1e8 real samples, /4 0.37 -> 0.23, /16 a tie)
+    const size_t g_per_phase = G.size() / std::max<size_t>(deci, 1);
+    const bool prune_default = deci == 4 ? g_per_phase >= 8 : deci == 8 ? g_per_phase >= 24 : g_per_phase >= 24;
+    if (!getenv("RR_FIR_DIRECT") && (getenv("RR_FIR_PRUNE") ? atoi(getenv("RR_FIR_PRUNE")) != 0 : prune_default) &&
+        prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
+        std::vector<std::complex<double>> td(G.size());
+        for (size_t k = 0; k < G.size(); k++) td[k] = G[G.size() - 1 - k];
+        prune.reset(new PruneTables());
+        if (!prune->build(td, deci, true, stream)) prune.reset();
+    }
     for (auto& h : hist) {                                                      // hilbert.rs:55 — hn zeros
         h.reserve(hn);
         RR_HIP(hipMemsetAsync(h.p, 0, hn * sizeof(float), stream));
@@ -247,7 +272,8 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     const size_t out_n = n / d;
     VSrc<float> src{hist[cur].p, (long)hn, static_cast<const float*>(in), (long)in_len};
     prof_begin(s);
-    launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s);
+    if (prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s);
+    else launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s);
     prof_end(s);
     fir->rotate_output(static_cast<cf*>(out), out_n, s);
     launch_vcopy_f32(src, (long)n, hist[cur ^ 1].p, (long)hn, s);              // the hn samples before the new window
@@ -347,6 +373,49 @@ static void compute_hpos(const rr_c32* taps, size_t ntaps, int log2f, std::vecto
     case 13: fill_hpos<13>(H, hpos); break;
     default: fill_hpos<14>(H, hpos); break;
     }
+}
+
+bool PruneTables::build(const std::vector<std::complex<double>>& t, size_t d, bool split, hipStream_t s) {
+    const size_t L = t.size();
+    log2f = d <= 16 ? prune_log2f_for_deci((int)d) : 0;
+    if (!log2f || L == 0) return false;
+    const size_t F = (size_t)1 << log2f, D = d;
+    if (L > F / 2 + 1) return false;                                  // keep at least half of every tile
+    const size_t c = (L - 1) % D;
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    auto table = [&](bool imag_part, DevBuf<cf>& dst) {
+        std::vector<std::complex<double>> H(F, 0.0);
+        for (size_t i = 0; i < L; i++) H[i] = split ? std::complex<double>(imag_part ? t[i].imag() : t[i].real(), 0.0) : t[i];
+        fft64(H);
+        for (size_t k = 0; k < F; k++) {                              // fold w_D^(-c k3) w_16D^(-c k2), and 1/F
+            const size_t k2 = (k / 16) % 16, k3 = k / 256;
+            const double a = two_pi * (double)c * ((double)k3 / (double)D + (double)k2 / (double)(16 * D));
+            H[k] *= std::polar(1.0 / (double)F, a);
+        }
+        std::vector<cf> hpos;
+        switch (log2f) {
+        case 10: fill_hpos<10>(H, hpos); break;
+        case 11: fill_hpos<11>(H, hpos); break;
+        default: fill_hpos<12>(H, hpos); break;
+        }
+        dst.upload(hpos.data(), F, s);
+    };
+    table(false, d_h2);
+    if (split) table(true, d_h2b);
+    std::vector<cf> tw(F), twb(256);
+    for (size_t k = 0; k < F; k++) {
+        const double a = -two_pi * (double)k / (double)F;
+        tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+    }
+    for (size_t n2 = 0; n2 < 16; n2++)
+        for (size_t k1 = 0; k1 < 16; k1++) {
+            const double a = two_pi * (double)(k1 * (n2 * D + c)) / (double)F;
+            twb[n2 * 16 + k1] = mkcf((float)std::cos(a), (float)std::sin(a));
+        }
+    d_tw.upload(tw.data(), F, s);
+    d_twb.upload(twb.data(), 256, s);
+    RR_HIP(hipStreamSynchronize(s));
+    return true;
 }
 
 FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int max_log2f, bool real)

@@ -43,6 +43,14 @@ struct Block {
 };
 
 struct FftFilter;
+// Tables of k_fftfilt_prune (decimation by the last radix of the tile plan: 4 / 8 / 16 on 1024 / 2048 / 4096 points).
+struct PruneTables {
+    int log2f = 0;
+    DevBuf<cf> d_tw, d_h2, d_h2b, d_twb;
+    // t = taps in caller order (y[n] = sum_k t[k] x[n - k]); split: real-stream kernel, tables for Re t and Im t.
+    // false when (L, d) is not covered.
+    bool build(const std::vector<std::complex<double>>& t, size_t d, bool split, hipStream_t s);
+};
 struct FirC32 : Block {
     FirPlan pl;
     // Non-decimating filters beyond a few taps run as overlap-save FFT tiles (the FftFilter kernel on a window
@@ -50,6 +58,7 @@ struct FirC32 : Block {
     // costs 2-4 multiply-adds per tap and sample, the tiles a constant ~0.3 ms per 1e8 samples.  RR_FIR_DIRECT=1
     // forces the direct kernel, RR_FIR_FFT=1 the tiles for any length (both read at construction).
     std::unique_ptr<FftFilter> fftk;
+    std::unique_ptr<PruneTables> prune;           // deci 4 / 8 / 16: pruned inverse transform (k_fftfilt_prune)
     DevBuf<unsigned char> d_tp, d_rev, d_tab;
     bool rot_on = false;
     int rot_mode = RR_ROT_MODEL;
@@ -78,6 +87,7 @@ struct HilbertFir : Block {
     DevBuf<cf> d_tpG, d_revG;
     DevBuf<float> hist[2];            // the hn input samples before the window start
     int cur = 0;
+    std::unique_ptr<PruneTables> prune;   // deci 4 / 8 / 16: two real segments per tile, pruned inverse (k_fftfilt_prune)
     HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c32* taps, size_t ntaps, size_t deci,
                bool translate, float samp_rate, float freq);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;

@@ -25,6 +25,16 @@ void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, in
 void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
                          hipStream_t s);
 
+// Decimation by D = F / 256 (4 / 8 / 16 on tiles of 1024 / 2048 / 4096 points) with a pruned inverse transform
+// (k_fftfilt_prune): out[m] = y[m D], m < n_out.  Tables (see the kernel): hpos2 = H in position order with the
+// factors w_D^(-c k3) w_16D^(-c k2), c = (L - 1) % D, folded in; twb[n2 * 16 + k1] = exp(+2 pi i k1 (n2 D + c) / F).
+int prune_log2f_for_deci(int d);                 // 0 when d is not 4 / 8 / 16
+void launch_fftfilt_prune_c32(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
+                              const cf* twb, hipStream_t s);
+// real stream, Complex taps t = Gr + i Gi: hpos2r / hpos2i from the real tap sets Gr / Gi; Complex output
+void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
+                               const cf* hpos2i, const cf* twb, hipStream_t s);
+
 // The same filter with an 8192 / 16384-point tile built from nsub = 2 / 4 sub-transforms of 4096 points
 // (k_fftfilt_split).  tw4096: w_4096^k;  wk[t] = w_F^t, t < 256;  hs[r][p] = H[nsub bin(p) + r] / F with
 // bin(p) = fftfilt_split_bin(p), the bin at position p of the 4096-point spectrum layout.

@@ -469,6 +469,147 @@ void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L,
     }
 }
 
+// ---- decimation by the last radix of the tile plan: pruned inverse transform ---------------------------------
+// F = 16 * 16 * D (D = 4 / 8 / 16 for 1024 / 2048 / 4096 points).  Time index n = n1 T + n2 D + n3, bin
+// k = k1 + 16 k2 + 256 k3.  A decimating filter keeps y[n] only for n3 = c (c = (L - 1) % D when tiles advance
+// by a multiple of D), and
+//     y[n1, n2, c] = sum_k1 w16^(-n1 k1) w_F^(-k1 (n2 D + c))  sum_k2 w16^(-n2 k2)  z[k1, k2],
+//     z[k1, k2]    = sum_k3 Y[k1, k2, k3] w_D^(-c k3) w_16D^(-c k2).
+// The two constant factors of z are folded into the frequency response (table hpos2), so after the forward
+// transform and the product the last inverse butterfly collapses to a thread-local SUM of the D registers of a
+// group, and what remains is a 256-point inverse per tile.  D tiles are parked in LDS and finished together as
+// one full-width batch (T = 16 D threads x 16 values): DFT-16 over k2, exchange, twiddle, DFT-16 over k1 — per
+// tile 1 forward + 1/D inverse transforms instead of 1 + 1.  Lanes (tile b, n2) hold 16 consecutive kept samples.
+//   REAL2 = false: Complex stream (decimating FirFilter<Complex>, deci == D).
+//   REAL2 = true : real stream, Complex taps t = Gr + i Gi (the fused Hilbert -> FirFilter): two overlap-save
+//                  segments a, b ride in the re / im lanes (k_fftfilt_real); the real tap sets act on them as
+//                  Gr*a + i Gr*b and Gi*a + i Gi*b (two products, two sums, two tails), and the outputs are
+//                  y_a = (Gr*a) + i (Gi*a),  y_b = (Gr*b) + i (Gi*b).
+template <int T>
+__device__ __forceinline__ void prune_tail(creg* v, creg* park, int t, const creg* __restrict__ twb) {
+    creg* own = park + 17 * t;                          // lds_pad(16 t + k) = 17 t + k
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = own[k];
+    Dft<16, true>::run(v);                              // over k2 -> n2
+#pragma unroll
+    for (int k = 0; k < 16; k++) own[k] = v[k];
+    tile_sync<T>();
+    const creg* col = park + 272 * (t >> 4) + (t & 15); // lds_pad(256 b + 16 k1 + n2) = 272 b + 17 k1 + n2
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = cmul(col[17 * k], twb[k]);   // twb: this thread's row of the L1-resident table
+    Dft<16, true>::run(v);                              // over k1 -> n1
+}
+
+template <int LOG2F, bool REAL2>
+__global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
+void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long n_out, int L, long S, long ntiles,
+                     const cf* __restrict__ tw, const cf* __restrict__ hpos2, const cf* __restrict__ hpos2b,
+                     const cf* __restrict__ twb_tab) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    constexpr int D = F / 256;
+    constexpr int U = 16 / D;
+    constexpr int PARK = 256 * D + 16 * D;              // lds_elems(256 D)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    creg* park = lds + lds_elems(F);
+    creg* parkb = park + PARK;                          // REAL2 only
+    const int t = threadIdx.x;
+    const int first = L - 1;
+    const long fq = first / D;                          // kept samples in front of a tile's first valid one
+    const long Sd = S / D;                              // kept samples per tile (segment)
+    TileXform<LOG2F, 0> X;
+    // Complex stream: the folded response stays in registers like k_fftfilt_os's H.  The real-stream variant has two
+    // of them and re-reads both per tile (L1 / L2): keeping one spills 80-110 B/lane beside the tail's registers.
+    constexpr bool HREG = !REAL2;
+    if constexpr (HREG) X.init(t, tw, hpos2); else X.init_no_h(t, tw);
+    creg* out_reg = reinterpret_cast<creg*>(out);
+    const long nbatch = (ntiles + D - 1) / D;
+    for (TileIter it(nbatch); it.tile < it.end; it.tile += it.step) {
+        const long tile0 = it.tile * D;
+#pragma unroll 1
+        for (int b = 0; b < D; b++) {
+            const long tile = tile0 + b;
+            creg v[16];
+            if constexpr (REAL2) {
+                const long va = 2 * tile * S, vb = va + S;
+                if (va >= rsrc.plen && vb - rsrc.plen + F <= rsrc.in_len) {
+                    const float* pa = rsrc.in + (va - rsrc.plen) + t;
+#pragma unroll
+                    for (int n = 0; n < 16; n++) v[n] = mk(pa[n * T], pa[S + n * T]);
+                } else {
+                    stage_pair_slow<T>(lds, rsrc, va, vb, t);
+                    tile_sync<T>();
+                    lds_load<LOG2F, 0>(v, t, lds);
+                }
+            } else {
+                load_tile16<LOG2F>(v, csrc, tile * S, t, lds);
+            }
+            creg h[16];
+            if constexpr (!HREG) load_h<LOG2F, Plan<LOG2F>::NP - 1>(h, t, hpos2);     // in flight during the forward transform
+            RR_PHASE();
+            X.forward(v, lds);
+            tile_sync<T>();      // the next tile's first exchange overwrites slots other waves read in this one's last
+            // product with the folded response(s), then the collapsed last inverse butterfly: a plain sum
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const creg* h1 = HREG ? X.hreg : h;
+                creg z = cmul(v[u * D], h1[u * D]);
+#pragma unroll
+                for (int k = 1; k < D; k++) z = cadd(z, cmul(v[u * D + k], h1[u * D + k]));
+                park[lds_pad(256 * b + t + T * u)] = z;
+            }
+            if constexpr (REAL2) {
+                RR_PHASE();                                       // (keeps the second table's loads out of the transform)
+                load_h<LOG2F, Plan<LOG2F>::NP - 1>(h, t, hpos2b);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    creg zb = cmul(v[u * D], h[u * D]);
+#pragma unroll
+                    for (int k = 1; k < D; k++) zb = cadd(zb, cmul(v[u * D + k], h[u * D + k]));
+                    parkb[lds_pad(256 * b + t + T * u)] = zb;
+                }
+            }
+            RR_PHASE();
+        }
+        tile_sync<T>();
+        // ---- the batch's 256-point inverses: thread (b, n2) ends with the kept samples 16 n1 + n2 of tile b
+        const creg* twb = reinterpret_cast<const creg*>(twb_tab) + 16 * (t & 15);
+        const int b = t >> 4, n2 = t & 15;
+        const int lo = (int)fq - n2, hi = lo + (int)Sd;              // valid kept samples: lo <= 16 n1 < hi
+        if constexpr (!REAL2) {
+            creg p[16];
+            prune_tail<T>(p, park, t, twb);
+            const long m0 = (tile0 + b) * Sd - fq + n2;
+            const long room = n_out - m0;
+            const int lim = room < hi ? (int)room : hi;
+            creg* po = out_reg + m0;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++)
+                if (16 * n1 >= lo && 16 * n1 < lim) po[16 * n1] = p[n1];
+        } else {
+            // comp 0: (Gr*a) + i (Gr*b) = the real parts of y_a (segment 2 tile) and y_b (segment 2 tile + 1);
+            // comp 1: (Gi*a) + i (Gi*b) = their imaginary parts
+            const long ma = 2 * (tile0 + b) * Sd - fq + n2, mb = ma + Sd;
+            const long ra = n_out - ma, rb = n_out - mb;
+            const int lima = ra < hi ? (int)ra : hi, limb = rb < hi ? (int)rb : hi;
+#pragma unroll 1
+            for (int comp = 0; comp < 2; comp++) {
+                creg p[16];
+                prune_tail<T>(p, park + comp * PARK, t, twb);
+                float* pa = reinterpret_cast<float*>(out) + 2 * ma + comp;
+                float* pb = reinterpret_cast<float*>(out) + 2 * mb + comp;
+#pragma unroll
+                for (int n1 = 0; n1 < 16; n1++) {
+                    if (16 * n1 >= lo && 16 * n1 < lima) pa[32 * n1] = p[n1].x;
+                    if (16 * n1 >= lo && 16 * n1 < limb) pb[32 * n1] = p[n1].y;
+                }
+            }
+        }
+        tile_sync<T>();                                  // the next batch parks into the slots just read
+    }
+}
+
 // ---- FftFilter tiles of 8192 / 16384 points as NSUB = 2 / 4 sub-transforms of 4096 points ---------------------
 // A 512/1024-thread tile fits one workgroup per CU and cannot keep its tables in registers (k_fftfilt_os<13|14, 3>
 // costs 6x / 22x a 4096-point tile).  Split in frequency instead (M = 4096, F = NSUB M, n < M):
@@ -1149,6 +1290,44 @@ void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int
     case 24: launch_real_one<12, false>(src, out, n_out, L, d, tw, hpos, s); break;
     case 25: launch_real_one<12, true>(src, out, n_out, L, d, tw, hpos, s); break;
     default: throw Error("fftfilt_real: unsupported tile size");
+    }
+}
+
+template <int LOG2F, bool REAL2>
+static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
+                             const cf* hpos2b, const cf* twb, hipStream_t s) {
+    constexpr int F = 1 << LOG2F, T = F / 16, D = F / 256;
+    const long S = (F - L + 1) / D * D;                  // tiles advance by a multiple of D: one phase c for all tiles
+    if (S <= 0) throw Error("fftfilt_prune: filter too long for the tile");
+    if (n_out <= 0) return;
+    const long Sd = S / D;
+    const long nseg = (n_out + Sd - 1) / Sd;
+    const long ntiles = REAL2 ? (nseg + 1) / 2 : nseg;
+    const size_t smem = sizeof(cf) * (lds_elems(F) + (REAL2 ? 2 : 1) * lds_elems(256 * D));
+    const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, REAL2>, T, smem, (ntiles + D - 1) / D);
+    hipLaunchKernelGGL((k_fftfilt_prune<LOG2F, REAL2>), dim3((unsigned)grid), dim3(T), smem, s, csrc, rsrc, out, n_out, L, S,
+                       ntiles, tw, hpos2, hpos2b, twb);
+    RR_HIP(hipGetLastError());
+}
+int prune_log2f_for_deci(int d) { return d == 4 ? 10 : d == 8 ? 11 : d == 16 ? 12 : 0; }
+void launch_fftfilt_prune_c32(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
+                              const cf* twb, hipStream_t s) {
+    VSrc<float> none{nullptr, 0, nullptr, 0};
+    switch (log2f) {
+    case 10: launch_prune_one<10, false>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    case 11: launch_prune_one<11, false>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    case 12: launch_prune_one<12, false>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    default: throw Error("fftfilt_prune: unsupported tile size");
+    }
+}
+void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
+                               const cf* hpos2i, const cf* twb, hipStream_t s) {
+    VSrc<cf> none{nullptr, 0, nullptr, 0};
+    switch (log2f) {
+    case 10: launch_prune_one<10, true>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
+    case 11: launch_prune_one<11, true>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
+    case 12: launch_prune_one<12, true>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
+    default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }
 

@@ -92,8 +92,9 @@ def test_fir_nondecimating_both_paths(rr, monkeypatch, path, L, cplx):
     assert rr.fir_uses_fft_tiles(f) == (path == "fft" or (path == "auto" and L >= (28 if cplx else 40)))
 
 
-@pytest.mark.parametrize("path", ["direct", "fft", "auto"])
-@pytest.mark.parametrize("L,deci,cplx", [(5, 2, False), (127, 2, False), (127, 3, True), (255, 8, True), (401, 7, False),
+@pytest.mark.parametrize("path", ["direct", "fft", "auto", "prune"])
+@pytest.mark.parametrize("L,deci,cplx", [(5, 4, True), (40, 4, False), (500, 4, True), (64, 8, False), (1020, 8, True), (3, 16, False), (2049, 16, True),
+                                         (5, 2, False), (127, 2, False), (127, 3, True), (255, 8, True), (401, 7, False),
                                          (1000, 16, True), (64, 100, False), (2000, 5, False), (3584, 4096, False), (5000, 3, True), (9000, 16, False),
                                          (300, 3000, True)])
 def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
@@ -101,8 +102,11 @@ def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
     store: same protocol, same outputs (1e-5), incl. decimations beyond the tile's useful width and small rings."""
     if path == "direct":
         monkeypatch.setenv("RR_FIR_DIRECT", "1")
-    elif path == "fft":
+    elif path == "fft":                               # overlap-save tiles with a decimating store
         monkeypatch.setenv("RR_FIR_FFT", "1")
+        monkeypatch.setenv("RR_FIR_PRUNE", "0")
+    elif path == "prune":                             # deci 4 / 8 / 16: pruned inverse transform (else as "auto")
+        monkeypatch.setenv("RR_FIR_PRUNE", "1")
     if path == "direct" and L >= 5000:
         pytest.skip("direct-form fallback at thousands of taps: covered by test_fir_complex history, slow")
     x = rnd_c(120000, L * 3 + deci)
@@ -393,11 +397,15 @@ def test_channelizer_cfg5(rr):
 
 @pytest.mark.parametrize("hn,L,deci,cplx,tr", [(65, 255, 8, False, None), (65, 255, 8, False, (100e6, 7e6)), (31, 64, 5, True, None),
                                                (129, 33, 1, False, None), (3, 1, 1, False, None), (63, 100, 12, True, (8.0, 2.0)),
-                                               (65, 401, 16, False, None)])
+                                               (65, 401, 16, False, None), (33, 90, 4, True, None), (65, 900, 8, True, None),
+                                               (7, 2, 16, True, (8.0, 1.0)), (65, 1900, 16, False, None)])
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 4 * 5_003])
-def test_hilbert_fir_fused_block(rr, hn, L, deci, cplx, tr, stream_bytes):
+@pytest.mark.parametrize("prune", ["1", "0"])
+def test_hilbert_fir_fused_block(rr, monkeypatch, hn, L, deci, cplx, tr, stream_bytes, prune):
     """rr.HilbertFir (one composite decimating FIR on the real input) == Hilbert -> FirFilter<Complex> of the
-    oracle, whole stream, any chunking; with and without .translate()."""
+    oracle, whole stream, any chunking; with and without .translate().  prune = 1: decimations 4 / 8 / 16 run on
+    real-stream overlap-save tiles with the pruned inverse transform (k_fftfilt_prune), 0: direct form."""
+    monkeypatch.setenv("RR_FIR_PRUNE", prune)
     x = rnd_f(300_000, hn * 1000 + L + deci)
     if L == 255:
         taps = orc.low_pass_complex(100e6, 5e6, 943e3)
