@@ -663,6 +663,15 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
         std::copy(one.begin(), one.end(), all.begin() + c * F);
     }
     d_hpos_all.upload(all.data(), all.size(), stream);
+    half_ok = fm_multi_half_supported(lg, chain->I, chain->D, (int)ntaps) && !getenv("RR_FM_MULTI_FULL");
+    if (half_ok) {
+        std::vector<cf> th(F / 2);
+        for (size_t k = 0; k < F / 2; k++) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)(F / 2);
+            th[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+        }
+        d_tw_half.upload(th.data(), th.size(), stream);
+    }
     for (auto& b : last_r) { b.reserve(C); RR_HIP(hipMemsetAsync(b.p, 0, C * sizeof(cf), stream)); }
     RR_HIP(hipStreamSynchronize(stream));
 }
@@ -701,8 +710,12 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = ch.gain; a.mode = ch.mode;
         prof_begin(s);
-        launch_fm_multi(f->log2f, src, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_hpos_all.p,
-                        (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        if (half_ok)
+            launch_fm_multi_half(f->log2f, src, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_tw_half.p,
+                                 d_hpos_all.p, (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else
+            launch_fm_multi(f->log2f, src, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_hpos_all.p,
+                            (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         prof_end(s);
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
     }

@@ -150,6 +150,8 @@ struct FmMulti : Block {
     size_t C;
     std::unique_ptr<FmChain> chain;   // channel 0's chain object: shared bookkeeping + input carry state
     DevBuf<cf> d_hpos_all;            // [C][F]
+    DevBuf<cf> d_tw_half;             // w_(F/2)^k: half-size inverse transforms (interp 1, even deci; k_fm_multi_half)
+    bool half_ok = false;
     DevBuf<cf> last_r[2];             // [C]
     int cur_lr = 0;
     FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain, int mode);

@@ -80,6 +80,12 @@ bool fm_multi_supported(int log2f);
 void launch_fm_multi(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
                      int nchan, const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 
+// interp 1 and an even decimation on 2048-point tiles: per channel a folded 1024-point inverse on one wave
+// (k_fm_multi_half); tw_half = w_(F/2)^k.
+bool fm_multi_half_supported(int log2f, long I, long D, int L);
+void launch_fm_multi_half(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* tw_half,
+                          const cf* hpos_all, int nchan, const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+
 // ---- kernels_fir.hip ---------------------------------------------------------------
 struct FirPlan {             // host-prepared polyphase tap table
     int L = 0, d = 1;

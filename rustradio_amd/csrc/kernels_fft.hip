@@ -1151,6 +1151,100 @@ void k_fm_multi(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, l
     }
 }
 
+// ---- the same for an even integer decimation (interp 1): half-size inverse transforms ------------------------
+// The resampler then keeps only samples y[u D] (rational_resampler.rs:183-198 with interp 1), all of one parity, so
+// with the tile start shifted by at most one sample they sit at EVEN tile positions p = 2 n', and
+//     y[2 n'] = sum_{k < F/2} (Y[k] + Y[k + F/2]) w_(F/2)^(-n' k)
+// (decimation in time = aliasing in frequency).  k + F/2 is k3 + D/2 in the last digit of the tile plan, i.e. the
+// partner sits in the same thread's group: after H_c X the spectrum is folded by D/2 thread-local additions and the
+// inverse is an F/2-point transform.  For F = 2048 that is a 1024-point tile of ONE wave: each of the two waves of
+// the workgroup takes every other channel and runs product, fold, inverse and the resample / demod epilogue without
+// a single barrier (the full-size version needs four per channel), on half the arithmetic.
+template <int LOG2F>
+__global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
+void k_fm_multi_half(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, long ntiles, long Sp,
+                     const cf* __restrict__ tw, const cf* __restrict__ tw_half, const cf* __restrict__ hpos_all,
+                     int nchan, FmArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    constexpr int F = 1 << LOG2F, T = F / 16, LH = LOG2F - 1, FH = F / 2, TH = T / 2;
+    constexpr int NP = Plan<LOG2F>::NP;
+    constexpr int D3 = F / 256, DH = D3 / 2;             // last radix of the full / the half plan
+    static_assert(NP == 3, "3-pass plans");
+    static_assert(TH == 64, "one wave per half-size tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    creg* ldsX = lds + lds_elems(F);                     // the tile's spectrum, pass-2 layout
+    const int t = threadIdx.x, hg = t / TH, th = t % TH;
+    creg* ldsH = lds + hg * lds_elems(FH);               // this wave's exchange / epilogue area (free once the forward is done)
+    const int first = L - 1;
+    TileXform<LOG2F, 3> XF;                              // forward: once per tile, tables re-read (L1)
+    XF.init_no_h(t, tw);
+    TileXform<LH, 0> XI;                                 // inverse: once per channel and tile, twiddles in registers
+    XI.init_no_h(th, tw_half);
+
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long tile = it.tile;
+        const long base = tile * Sp - a.G;
+        const long ys = base - ((a.A + base - first) & 1);   // needed samples (even global index) at even tile positions
+        {
+            creg v[16];
+            load_tile16<LOG2F>(v, src, ys, t, lds);
+            RR_PHASE();
+            XF.forward(v, lds);
+            lds_store<LOG2F, NP - 1>(v, t, ldsX);
+        }
+        tile_sync<T>();                                  // the spectrum is read by both waves
+        const long y_lo = tile * Sp, y_hi = min((tile + 1) * Sp, a.n_y);
+        long u_lo = (a.A + y_lo + a.D - 1) / a.D;        // interp 1: r[u] = y[u D]
+        long u_hi = (a.A + y_hi + a.D - 1) / a.D;
+        if (u_lo < a.r_lo) u_lo = a.r_lo;
+        if (u_hi > a.r_hi) u_hi = a.r_hi;
+        const int hD = (int)(a.D >> 1);
+#pragma unroll 1
+        for (int c = hg; c < nchan; c += 2) {
+            const creg* hc = reinterpret_cast<const creg*>(hpos_all) + (long)c * F;
+            creg w[16];
+            {
+                creg h[2 * 16];                          // the channel's response at this thread's 32 bins: all in flight at once
+#pragma unroll
+                for (int u = 0; u < 16 / DH; u++)
+#pragma unroll
+                    for (int k = 0; k < D3; k++) h[u * D3 + k] = hc[(th + TH * u) * D3 + k];
+                RR_PHASE();
+#pragma unroll
+                for (int u = 0; u < 16 / DH; u++) {
+                    const int g = th + TH * u;           // group 16 k1 + k2, the same in both plans
+                    const creg* xx = ldsX + lds_pad(g * D3);   // (the D3 <= 16 slots of a group share one padding step)
+#pragma unroll
+                    for (int k = 0; k < DH; k++)
+                        w[u * DH + k] = cadd(cmul(xx[k], h[u * D3 + k]), cmul(xx[k + DH], h[u * D3 + k + DH]));
+                    RR_PHASE();
+                }
+            }
+            XI.inverse(w, ldsH);
+            lds_store<LH, 0>(w, th, ldsH);               // natural order: ldsH[pad(n')] = y[2 n'] of the tile
+            asm volatile("" ::: "memory");
+            float* oc = out + (long)c * out_stride;
+            for (long u = u_lo + th; u < u_hi; u += TH) {
+                const int p2 = (int)((u * a.D - a.A - ys + first) >> 1);      // half the (even) tile position
+                const creg ru = ldsH[lds_pad(p2)];
+                if (u == a.r_hi - 1) last_r_out[c] = from_reg(ru);
+                if (u != 0) {
+                    creg rl;
+                    if (u == a.r_lo) rl = to_reg(last_r_in[c]);
+                    else rl = ldsH[lds_pad(p2 - hD)];
+                    const float na = -rl.y;
+                    const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
+                    const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
+                    const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                    oc[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
+                }
+            }
+            asm volatile("" ::: "memory");               // (one wave: its LDS operations execute in order)
+        }
+        tile_sync<T>();                                  // both waves done before the next forward reuses the areas
+    }
+}
+
 // measurement builds: 16 s_memtime stamps of one tile (see RR_STAMP); nullptr otherwise
 static unsigned long long* fft_stamp_buffer() {
 #ifdef RR_FFT_TIMING_BUILD
@@ -1538,6 +1632,27 @@ static void launch_fm_multi_one(VSrc<cf> src, float* out, long out_stride, int L
     const long grid = grid_for_tiles(k_fm_multi<LOG2F>, T, smem, ntiles);
     hipLaunchKernelGGL((k_fm_multi<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles,
                        tw, hpos_all, nchan, a, last_in, last_out);
+    RR_HIP(hipGetLastError());
+}
+
+bool fm_multi_half_supported(int log2f, long I, long D, int L) {
+    if (log2f != 11 || I != 1 || D < 2 || (D & 1)) return false;
+    return (((1L << log2f) - L + 1) - D - 1) / 2 > 0;
+}
+void launch_fm_multi_half(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* tw_half,
+                          const cf* hpos_all, int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    constexpr int LOG2F = 11, F = 1 << LOG2F, T = F / 16;
+    if (!fm_multi_half_supported(log2f, h.I, h.D, L)) throw Error("fm_multi_half: unsupported shape");
+    FmArgs a;
+    a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
+    a.I = h.I; a.D = h.D; a.G = (int)h.D; a.gain = h.gain; a.mode = h.mode;
+    const long Sp = ((F - L + 1) - a.G - 1) & ~1L;       // even advance: one parity shift per call; room for the shift
+    const long ntiles = (h.n_y + Sp - 1) / Sp;
+    if (ntiles <= 0) return;
+    const size_t smem = 2 * sizeof(cf) * lds_elems(F);
+    const long grid = grid_for_tiles(k_fm_multi_half<LOG2F>, T, smem, ntiles);
+    hipLaunchKernelGGL((k_fm_multi_half<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles, Sp,
+                       tw, tw_half, hpos_all, nchan, a, last_in, last_out);
     RR_HIP(hipGetLastError());
 }
 

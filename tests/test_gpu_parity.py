@@ -553,9 +553,13 @@ def test_fm_chain_fused_protocol(rr):
 
 
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 30_000])
-def test_fm_multi_shared_source(rr, stream_bytes):
+@pytest.mark.parametrize("kernel", ["half", "full"])
+def test_fm_multi_shared_source(rr, monkeypatch, stream_bytes, kernel):
     """rr.FmMulti: N channels on one shared input (forward FFT computed once per tile) — every
-    channel must equal its own oracle chain FftFilter(taps_c) -> RationalResampler -> QuadratureDemod."""
+    channel must equal its own oracle chain FftFilter(taps_c) -> RationalResampler -> QuadratureDemod.
+    kernel = half: interp 1 / even deci on 2048-point tiles runs folded 1024-point inverses (k_fm_multi_half)."""
+    if kernel == "full":
+        monkeypatch.setenv("RR_FM_MULTI_FULL", "1")
     fs, n, nch = 2.4e6, 300_000, 5
     proto = orc.low_pass_complex(fs, 100e3, 12.5e3)
     k = np.arange(len(proto), dtype=np.float64)
@@ -584,6 +588,38 @@ def test_fm_multi_shared_source(rr, stream_bytes):
         d = _demod_close(yg, yo, ro)
         if ch == 2:     # centred channel: |r| ~ 1 after the start-up transient
             assert np.max(d[len(proto) // 6 + 2:]) <= TOL * np.pi
+
+
+@pytest.mark.parametrize("L,D,nch", [(463, 2, 1), (463, 4, 2), (400, 10, 3), (300, 64, 2), (513, 6, 4), (463, 200, 1), (700, 6, 2)])
+def test_fm_multi_even_decimations(rr, L, D, nch):
+    """FmMulti with interp 1 and even decimations (half-size inverse transforms on 2048-point tiles where the tile
+    choice allows), odd and even filter lengths (the reference's nsamples, hence the parity of every call's start,
+    alternates), 1..4 channels, small windows."""
+    fs, n = 2.4e6, 200_000
+    proto = (rnd_c(L, L + D) / max(1, L // 8)).astype(np.complex64)
+    k = np.arange(L, dtype=np.float64)
+    taps = np.stack([(proto.astype(np.complex128) * np.exp(2j * np.pi * (c * 20e3) * k / fs)).astype(np.complex64) for c in range(nch)])
+    x = fm_signal(n, fs, 0.0, L + D)
+    blk = rr.FmMulti(taps, 1, D, 1.0)
+    cap_in = 41_000
+    outs = [[] for _ in range(nch)]
+    pos, ring = 0, np.zeros(0, np.complex64)
+    while True:
+        take = min(cap_in - len(ring), len(x) - pos)
+        ring = np.concatenate([ring, x[pos:pos + take]]); pos += take
+        st, c, p, need, out = blk.work(ring, 30_000)
+        ring = ring[c:]
+        out = out.reshape(nch, -1)                    # (a one-channel block returns a flat window)
+        for ch in range(nch):
+            if p:
+                outs[ch].append(out[ch])
+        if take == 0 and c == 0 and p == 0:
+            break
+    for ch in range(nch):
+        yg = np.concatenate(outs[ch]) if outs[ch] else np.zeros(0, np.float32)
+        yo = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(1, D), orc.QuadratureDemod(1.0)], x, stream_bytes=8 * cap_in)
+        ro = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(1, D)], x, stream_bytes=8 * cap_in)
+        _demod_close(yg, yo, ro)
 
 
 def test_fm_multi_long_filters(rr):
