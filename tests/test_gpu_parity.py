@@ -466,7 +466,8 @@ def _demod_close(yg, yo, ro):
     return d
 
 
-@pytest.mark.parametrize("L,I,D", [(463, 1, 6), (401, 1, 1), (127, 25, 128), (33, 3, 2), (463, 200000, 1024000), (5, 1, 40)])
+@pytest.mark.parametrize("L,I,D", [(463, 1, 6), (401, 1, 1), (127, 25, 128), (33, 3, 2), (463, 200000, 1024000), (5, 1, 40),
+                                   (463, 1, 2), (400, 1, 6), (600, 1, 100), (463, 3, 18)])
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 20_000])
 def test_fm_chain_fused_block(rr, L, I, D, stream_bytes):
     """rr.FmChain (one fused kernel) == FftFilter -> RationalResampler -> QuadratureDemod of the oracle,
