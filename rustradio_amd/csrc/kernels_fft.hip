@@ -1175,11 +1175,18 @@ void k_fm_multi_half(VSrc<cf> src, float* __restrict__ out, long out_stride, int
     creg* ldsX = lds + lds_elems(F);                     // the tile's spectrum, pass-2 layout
     const int t = threadIdx.x, hg = t / TH, th = t % TH;
     creg* ldsH = lds + hg * lds_elems(FH);               // this wave's exchange / epilogue area (free once the forward is done)
+    creg* tw64 = ldsX + lds_elems(F);                    // w_64^j, j < 64: the half plan's pass-1 twiddles (see below)
     const int first = L - 1;
     TileXform<LOG2F, 3> XF;                              // forward: once per tile, tables re-read (L1)
     XF.init_no_h(t, tw);
-    TileXform<LH, 0> XI;                                 // inverse: once per channel and tile, twiddles in registers
-    XI.init_no_h(th, tw_half);
+    // inverse: once per channel and tile.  Its pass-0 twiddles w_(F/2)^(k th) stay in registers; the pass-1 set
+    // w_64^(k (th % 4)) is read from a 64-entry LDS table per use: with both sets resident the kernel spills
+    // ~120 B/lane, and every scratch access waits on the whole in-order vmcnt queue (the channel's H loads).
+    creg tw0h[15];
+    load_twiddles<LH, 0>(tw0h, th, tw_half);
+    static_assert(PassGeom<LH, 1>::R * PassGeom<LH, 1>::P == 64, "pass-1 twiddles of the half plan are powers of w_64");
+    if (t < 64) tw64[t] = to_reg(tw_half[t * (FH / 64)]);
+    const int lo1 = PassGeom<LH, 1>::lo(th);
 
     for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
         const long tile = it.tile;
@@ -1204,23 +1211,46 @@ void k_fm_multi_half(VSrc<cf> src, float* __restrict__ out, long out_stride, int
             const creg* hc = reinterpret_cast<const creg*>(hpos_all) + (long)c * F;
             creg w[16];
             {
-                creg h[2 * 16];                          // the channel's response at this thread's 32 bins: all in flight at once
+                // the channel's response at this thread's 32 bins, half of them in flight at a time
 #pragma unroll
-                for (int u = 0; u < 16 / DH; u++)
+                for (int half = 0; half < 2; half++) {
+                    creg h[16];
 #pragma unroll
-                    for (int k = 0; k < D3; k++) h[u * D3 + k] = hc[(th + TH * u) * D3 + k];
-                RR_PHASE();
+                    for (int uu = 0; uu < 8 / DH; uu++)
 #pragma unroll
-                for (int u = 0; u < 16 / DH; u++) {
-                    const int g = th + TH * u;           // group 16 k1 + k2, the same in both plans
-                    const creg* xx = ldsX + lds_pad(g * D3);   // (the D3 <= 16 slots of a group share one padding step)
+                        for (int k = 0; k < D3; k++) h[uu * D3 + k] = hc[(th + TH * (half * (8 / DH) + uu)) * D3 + k];
+                    RR_PHASE();
 #pragma unroll
-                    for (int k = 0; k < DH; k++)
-                        w[u * DH + k] = cadd(cmul(xx[k], h[u * D3 + k]), cmul(xx[k + DH], h[u * D3 + k + DH]));
+                    for (int uu = 0; uu < 8 / DH; uu++) {
+                        const int u = half * (8 / DH) + uu;
+                        const int g = th + TH * u;           // group 16 k1 + k2, the same in both plans
+                        const creg* xx = ldsX + lds_pad(g * D3);   // (the D3 <= 16 slots of a group share one padding step)
+#pragma unroll
+                        for (int k = 0; k < DH; k++)
+                            w[u * DH + k] = cadd(cmul(xx[k], h[uu * D3 + k]), cmul(xx[k + DH], h[uu * D3 + k + DH]));
+                    }
                     RR_PHASE();
                 }
             }
-            XI.inverse(w, ldsH);
+            {   // TileXform<LH>::inverse for one wave (no barriers), pass-1 twiddles from the LDS table
+                creg twl[15];
+                inv_pass<LH, 2>(w, twl);                 // (P == 1: no twiddles)
+                RR_PHASE();
+                lds_store<LH, 2>(w, th, ldsH);
+                asm volatile("" ::: "memory");
+                lds_load<LH, 1>(w, th, ldsH);
+#pragma unroll
+                for (int k = 1; k < 16; k++) twl[k - 1] = tw64[k * lo1];
+                RR_PHASE();
+                inv_pass<LH, 1>(w, twl);
+                RR_PHASE();
+                lds_store<LH, 1>(w, th, ldsH);
+                asm volatile("" ::: "memory");
+                lds_load<LH, 0>(w, th, ldsH);
+                RR_PHASE();
+                inv_pass<LH, 0>(w, tw0h);
+                RR_PHASE();
+            }
             lds_store<LH, 0>(w, th, ldsH);               // natural order: ldsH[pad(n')] = y[2 n'] of the tile
             asm volatile("" ::: "memory");
             float* oc = out + (long)c * out_stride;
@@ -1649,7 +1679,7 @@ void launch_fm_multi_half(int log2f, VSrc<cf> src, float* out, long out_stride, 
     const long Sp = ((F - L + 1) - a.G - 1) & ~1L;       // even advance: one parity shift per call; room for the shift
     const long ntiles = (h.n_y + Sp - 1) / Sp;
     if (ntiles <= 0) return;
-    const size_t smem = 2 * sizeof(cf) * lds_elems(F);
+    const size_t smem = sizeof(cf) * (2 * lds_elems(F) + 64);
     const long grid = grid_for_tiles(k_fm_multi_half<LOG2F>, T, smem, ntiles);
     hipLaunchKernelGGL((k_fm_multi_half<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles, Sp,
                        tw, tw_half, hpos_all, nchan, a, last_in, last_out);
