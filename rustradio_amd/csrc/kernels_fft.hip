@@ -519,10 +519,23 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
     const long fq = first / D;                          // kept samples in front of a tile's first valid one
     const long Sd = S / D;                              // kept samples per tile (segment)
     TileXform<LOG2F, 0> X;
-    // Complex stream: the folded response stays in registers like k_fftfilt_os's H.  The real-stream variant has two
-    // of them and re-reads both per tile (L1 / L2): keeping one spills 80-110 B/lane beside the tail's registers.
-    constexpr bool HREG = !REAL2;
-    if constexpr (HREG) X.init(t, tw, hpos2); else X.init_no_h(t, tw);
+    // Complex stream: twiddles and the folded response stay in registers like k_fftfilt_os's.  The real-stream
+    // variant has two responses: the first stays in registers, and to make room beside the tail's registers the
+    // pass-1 twiddles w_16D^(k (t % D)) — 16 D distinct values — are read per tile from an LDS table; the second
+    // response is re-read per tile (both sets of twiddles plus one response spill 80-110 B/lane, the LDS table
+    // plus both responses 150 B/lane — and a spill waits on the whole in-order vmcnt queue).
+    creg* tw1tab = park + (REAL2 ? 2 : 1) * PARK;       // REAL2 only: w_16D^j, j < 16 D
+    creg hrA[16], hrB[16], tw0p[15];
+    const int lo1 = PassGeom<LOG2F, 1>::lo(t);
+    if constexpr (REAL2) {
+        static_assert(PassGeom<LOG2F, 1>::R * PassGeom<LOG2F, 1>::P == 16 * D, "pass-1 twiddles are powers of w_16D");
+        load_twiddles<LOG2F, 0>(tw0p, t, tw);
+        load_h<LOG2F, Plan<LOG2F>::NP - 1>(hrA, t, hpos2);
+        for (int j = t; j < 16 * D; j += T) tw1tab[j] = to_reg(tw[j * (F / (16 * D))]);
+        tile_sync<T>();
+    } else {
+        X.init(t, tw, hpos2);
+    }
     creg* out_reg = reinterpret_cast<creg*>(out);
     const long nbatch = (ntiles + D - 1) / D;
     for (TileIter it(nbatch); it.tile < it.end; it.tile += it.step) {
@@ -545,28 +558,45 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             } else {
                 load_tile16<LOG2F>(v, csrc, tile * S, t, lds);
             }
-            creg h[16];
-            if constexpr (!HREG) load_h<LOG2F, Plan<LOG2F>::NP - 1>(h, t, hpos2);     // in flight during the forward transform
             RR_PHASE();
-            X.forward(v, lds);
+            if constexpr (REAL2) {                       // TileXform::forward with the pass-1 twiddles from the LDS table
+                creg twl[15];
+                fwd_pass<LOG2F, 0>(v, tw0p);
+                RR_PHASE();
+                lds_store<LOG2F, 0>(v, t, lds);
+                tile_sync<T>();
+                lds_load<LOG2F, 1>(v, t, lds);
+#pragma unroll
+                for (int k = 1; k < 16; k++) twl[k - 1] = tw1tab[k * lo1];
+                RR_PHASE();
+                fwd_pass<LOG2F, 1>(v, twl);
+                RR_PHASE();
+                lds_store<LOG2F, 1>(v, t, lds);
+                tile_sync<T>();
+                lds_load<LOG2F, 2>(v, t, lds);
+                RR_PHASE();
+                fwd_pass<LOG2F, 2>(v, twl);              // (P == 1: no twiddles)
+            } else {
+                X.forward(v, lds);
+            }
             tile_sync<T>();      // the next tile's first exchange overwrites slots other waves read in this one's last
             // product with the folded response(s), then the collapsed last inverse butterfly: a plain sum
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const creg* h1 = HREG ? X.hreg : h;
+                const creg* h1 = REAL2 ? hrA : X.hreg;
                 creg z = cmul(v[u * D], h1[u * D]);
 #pragma unroll
                 for (int k = 1; k < D; k++) z = cadd(z, cmul(v[u * D + k], h1[u * D + k]));
                 park[lds_pad(256 * b + t + T * u)] = z;
             }
             if constexpr (REAL2) {
-                RR_PHASE();                                       // (keeps the second table's loads out of the transform)
-                load_h<LOG2F, Plan<LOG2F>::NP - 1>(h, t, hpos2b);
+                RR_PHASE();
+                load_h<LOG2F, Plan<LOG2F>::NP - 1>(hrB, t, hpos2b);   // the second response is re-read per tile (L1 / L2)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    creg zb = cmul(v[u * D], h[u * D]);
+                    creg zb = cmul(v[u * D], hrB[u * D]);
 #pragma unroll
-                    for (int k = 1; k < D; k++) zb = cadd(zb, cmul(v[u * D + k], h[u * D + k]));
+                    for (int k = 1; k < D; k++) zb = cadd(zb, cmul(v[u * D + k], hrB[u * D + k]));
                     parkb[lds_pad(256 * b + t + T * u)] = zb;
                 }
             }
@@ -1438,7 +1468,7 @@ static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_ou
     const long Sd = S / D;
     const long nseg = (n_out + Sd - 1) / Sd;
     const long ntiles = REAL2 ? (nseg + 1) / 2 : nseg;
-    const size_t smem = sizeof(cf) * (lds_elems(F) + (REAL2 ? 2 : 1) * lds_elems(256 * D));
+    const size_t smem = sizeof(cf) * (lds_elems(F) + (REAL2 ? 2 : 1) * lds_elems(256 * D) + (REAL2 ? 16 * D : 0));
     const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, REAL2>, T, smem, (ntiles + D - 1) / D);
     hipLaunchKernelGGL((k_fftfilt_prune<LOG2F, REAL2>), dim3((unsigned)grid), dim3(T), smem, s, csrc, rsrc, out, n_out, L, S,
                        ntiles, tw, hpos2, hpos2b, twb);
