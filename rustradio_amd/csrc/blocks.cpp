@@ -573,6 +573,16 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     f.reset(new FftFilter(taps, ntaps, true, max_log2f));
     const int64_t G = (D + I - 1) / I;
     if (G >= (int64_t)(((size_t)1 << f->log2f) - f->L + 1)) throw Error("FmChain: decimation too large for the FFT tile");
+    half_ok = !f->nsub && fm_multi_half_supported(f->log2f, I, D, (int)ntaps) && !getenv("RR_FM_CHAIN_FULL");
+    if (half_ok) {
+        const size_t FH = ((size_t)1 << f->log2f) / 2;
+        std::vector<cf> th(FH);
+        for (size_t k = 0; k < FH; k++) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)FH;
+            th[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+        }
+        d_tw_half.upload(th.data(), th.size(), stream);
+    }
     for (auto& b : last_r) { b.reserve(1); RR_HIP(hipMemsetAsync(b.p, 0, sizeof(cf), stream)); }
     RR_HIP(hipStreamSynchronize(stream));
 }
@@ -625,6 +635,12 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         else if (f->nsub)
             launch_fm_chain_split(f->nsub, src, static_cast<float*>(out), (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
                                   last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (half_ok && packed)
+            launch_fm_chain_half_iq8(src8, static_cast<float*>(out), (int)f->L, f->d_tw.p, d_tw_half.p, f->d_hpos.p, a,
+                                     last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (half_ok)
+            launch_fm_chain_half(src, static_cast<float*>(out), (int)f->L, f->d_tw.p, d_tw_half.p, f->d_hpos.p, a,
+                                 last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (packed)
             launch_fm_chain_iq8(f->log2f, src8, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a,
                                 last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);

@@ -139,6 +139,8 @@ struct FmChain : Block {
     // is fused in front: windows, `consumed` and WAIT_SRC `need` are then counted in BYTES.
     bool iq8 = false;
     DevBuf<cf> decoded;               // only for odd-addressed byte windows (decoded out of line)
+    DevBuf<cf> d_tw_half;             // w_(F/2)^k: half-size inverse (interp 1, even deci, 2048-point tiles; k_fm_chain_half)
+    bool half_ok = false;
     FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false,
             int max_log2f = 14);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;

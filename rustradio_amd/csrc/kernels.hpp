@@ -86,6 +86,12 @@ bool fm_multi_half_supported(int log2f, long I, long D, int L);
 void launch_fm_multi_half(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* tw_half,
                           const cf* hpos_all, int nchan, const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 
+// the single fused chain on the same half-size inverses (2048-point tiles; fm_multi_half_supported(11, I, D, L))
+void launch_fm_chain_half(VSrc<cf> src, float* out, int L, const cf* tw, const cf* tw_half, const cf* hpos,
+                          const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+void launch_fm_chain_half_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, const cf* tw_half, const cf* hpos,
+                              const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+
 // ---- kernels_fir.hip ---------------------------------------------------------------
 struct FirPlan {             // host-prepared polyphase tap table
     int L = 0, d = 1;

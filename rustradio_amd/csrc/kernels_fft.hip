@@ -1316,6 +1316,135 @@ void k_fm_multi_half(VSrc<cf> src, float* __restrict__ out, long out_stride, int
     }
 }
 
+// ---- the single fused chain with the half-size inverse (interp 1, even decimation, 2048-point tiles) ----------
+// Two tiles per workgroup iteration: all T threads run forward transform, H product and the fold of each (the folded
+// spectrum of a tile is F/2 values, parked in LDS), then each of the two waves finishes ONE of the tiles — F/2-point
+// inverse and the resample / demod epilogue — without barriers.  See k_fm_multi_half for the arithmetic.
+// Registers: the pass-0 twiddles of both plans stay resident (60 VGPRs); both pass-1 sets (powers of w_128 and w_64)
+// come from LDS tables, H is re-read per tile (in flight during the transform), and the thread index is made opaque
+// per tile so that the tile body's LDS / table addresses are not hoisted into persistent registers.  A first version
+// without these spilled 130-350 B/lane and ran 1.7x SLOWER than k_fm_chain (a spill waits on the whole vmcnt queue).
+template <int LOG2F, class SRC>
+__global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
+void k_fm_chain_half(SRC src, float* __restrict__ out, int L, long ntiles, long Sp, const cf* __restrict__ tw,
+                     const cf* __restrict__ tw_half, const cf* __restrict__ hpos, FmArgs a,
+                     const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    constexpr int F = 1 << LOG2F, T = F / 16, LH = LOG2F - 1, FH = F / 2, TH = T / 2;
+    constexpr int NP = Plan<LOG2F>::NP;
+    constexpr int D3 = F / 256, DH = D3 / 2, U = 16 / D3;
+    constexpr int N1 = PassGeom<LOG2F, 1>::R * PassGeom<LOG2F, 1>::P;      // 128: pass-1 twiddles of the full plan
+    constexpr int N1H = PassGeom<LH, 1>::R * PassGeom<LH, 1>::P;          // 64: ... of the half plan
+    static_assert(NP == 3 && TH == 64, "one wave per half-size tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);       // forward exchanges; afterwards the two waves' own areas
+    creg* ldsY = lds + lds_elems(F);                     // folded spectra of the two tiles, half-plan pass-2 layout
+    creg* tab1 = ldsY + 2 * lds_elems(FH);               // w_128^j
+    creg* tab1h = tab1 + N1;                             // w_64^j
+    const int t_ = threadIdx.x, hg = t_ / TH, th_ = t_ % TH;
+    const int t = t_, th = th_;
+    const int first = L - 1;
+    creg tw0[15], tw0h[15];
+    load_twiddles<LOG2F, 0>(tw0, t, tw);
+    load_twiddles<LH, 0>(tw0h, th, tw_half);
+    for (int j = t; j < N1; j += T) tab1[j] = to_reg(tw[j * (F / N1)]);
+    for (int j = t; j < N1H; j += T) tab1h[j] = to_reg(tw_half[j * (FH / N1H)]);
+    const int hD = (int)(a.D >> 1);
+    const long npairs = (ntiles + 1) / 2;
+    tile_sync<T>();
+
+    for (TileIter it(npairs); it.tile < it.end; it.tile += it.step) {
+        long ys_mine = 0;
+#pragma unroll 1
+        for (int b = 0; b < 2; b++) {
+            const long tile = 2 * it.tile + b;
+            const long base = tile * Sp - a.G;
+            const long ys = base - ((a.A + base - first) & 1);
+            if (b == hg) ys_mine = ys;
+            if (tile >= ntiles) break;                   // (workgroup-uniform)
+            int t = t_;                                  // opaque per tile: keeps the ~60 LDS / table addresses of the tile body
+            asm volatile("" : "+v"(t));                  // from being hoisted out of the loop into persistent VGPRs
+            creg v[16], twl[15], hreg[16];
+            load_tile16<LOG2F>(v, src, ys, t, lds);
+            load_h<LOG2F, NP - 1>(hreg, t, hpos);            // in flight during the transform
+            RR_PHASE();
+            fwd_pass<LOG2F, 0>(v, tw0);
+            RR_PHASE();
+            lds_store<LOG2F, 0>(v, t, lds);
+            tile_sync<T>();
+            lds_load<LOG2F, 1>(v, t, lds);
+#pragma unroll
+            for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<LOG2F, 1>::lo(t)];
+            RR_PHASE();
+            fwd_pass<LOG2F, 1>(v, twl);
+            RR_PHASE();
+            lds_store<LOG2F, 1>(v, t, lds);
+            tile_sync<T>();
+            lds_load<LOG2F, 2>(v, t, lds);
+            RR_PHASE();
+            fwd_pass<LOG2F, 2>(v, twl);                  // (P == 1: no twiddles)
+            tile_sync<T>();                              // the next forward's first exchange overwrites slots read in this one's last
+            creg* py = ldsY + b * lds_elems(FH);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int g = t + T * u;                 // group 16 k1 + k2; its folded values sit at g * DH + k in the half plan
+#pragma unroll
+                for (int k = 0; k < DH; k++)
+                    py[lds_pad(g * DH + k)] = cadd(cmul(v[u * D3 + k], hreg[u * D3 + k]), cmul(v[u * D3 + k + DH], hreg[u * D3 + k + DH]));
+            }
+            RR_PHASE();
+        }
+        tile_sync<T>();
+        const long tile = 2 * it.tile + hg;
+        if (tile < ntiles) {
+            const long ys = ys_mine;
+            int th = th_;
+            asm volatile("" : "+v"(th));
+            creg* ldsH = lds + hg * lds_elems(FH);
+            creg w[16], twl[15];
+            lds_load<LH, 2>(w, th, ldsY + hg * lds_elems(FH));
+            inv_pass<LH, 2>(w, twl);                     // (P == 1: no twiddles)
+            RR_PHASE();
+            lds_store<LH, 2>(w, th, ldsH);
+            asm volatile("" ::: "memory");
+            lds_load<LH, 1>(w, th, ldsH);
+#pragma unroll
+            for (int k = 1; k < 16; k++) twl[k - 1] = tab1h[k * PassGeom<LH, 1>::lo(th)];
+            RR_PHASE();
+            inv_pass<LH, 1>(w, twl);
+            RR_PHASE();
+            lds_store<LH, 1>(w, th, ldsH);
+            asm volatile("" ::: "memory");
+            lds_load<LH, 0>(w, th, ldsH);
+            RR_PHASE();
+            inv_pass<LH, 0>(w, tw0h);
+            RR_PHASE();
+            lds_store<LH, 0>(w, th, ldsH);               // natural order: ldsH[pad(n')] = y[2 n'] of the tile
+            asm volatile("" ::: "memory");
+            const long y_lo = tile * Sp, y_hi = min((tile + 1) * Sp, a.n_y);
+            long u_lo = (a.A + y_lo + a.D - 1) / a.D;
+            long u_hi = (a.A + y_hi + a.D - 1) / a.D;
+            if (u_lo < a.r_lo) u_lo = a.r_lo;
+            if (u_hi > a.r_hi) u_hi = a.r_hi;
+            for (long u = u_lo + th; u < u_hi; u += TH) {
+                const int p2 = (int)((u * a.D - a.A - ys + first) >> 1);
+                const creg ru = ldsH[lds_pad(p2)];
+                if (u == a.r_hi - 1) last_r_out[0] = from_reg(ru);
+                if (u != 0) {
+                    creg rl;
+                    if (u == a.r_lo) rl = to_reg(last_r_in[0]);
+                    else rl = ldsH[lds_pad(p2 - hD)];
+                    const float na = -rl.y;
+                    const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
+                    const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
+                    const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                    out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
+                }
+            }
+        }
+        tile_sync<T>();
+    }
+}
+
 // measurement builds: 16 s_memtime stamps of one tile (see RR_STAMP); nullptr otherwise
 static unsigned long long* fft_stamp_buffer() {
 #ifdef RR_FFT_TIMING_BUILD
@@ -1726,6 +1855,31 @@ void launch_fm_multi_half(int log2f, VSrc<cf> src, float* out, long out_stride, 
     hipLaunchKernelGGL((k_fm_multi_half<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles, Sp,
                        tw, tw_half, hpos_all, nchan, a, last_in, last_out);
     RR_HIP(hipGetLastError());
+}
+
+template <class SRC>
+static void launch_fm_chain_half_t(SRC src, float* out, int L, const cf* tw, const cf* tw_half, const cf* hpos,
+                                   const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    constexpr int LOG2F = 11, F = 1 << LOG2F, T = F / 16;
+    FmArgs a;
+    a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
+    a.I = h.I; a.D = h.D; a.G = (int)h.D; a.gain = h.gain; a.mode = h.mode;
+    const long Sp = fm_advance(((F - L + 1) - a.G - 1) & ~1L, 1, a.D, 64);
+    const long ntiles = (h.n_y + Sp - 1) / Sp;
+    if (ntiles <= 0) return;
+    const size_t smem = sizeof(cf) * (lds_elems(F) + 2 * lds_elems(F / 2) + 128 + 64);
+    const long grid = grid_for_tiles(k_fm_chain_half<LOG2F, SRC>, T, smem, (ntiles + 1) / 2);
+    hipLaunchKernelGGL((k_fm_chain_half<LOG2F, SRC>), dim3((unsigned)grid), dim3(T), smem, s, src, out, L, ntiles, Sp, tw,
+                       tw_half, hpos, a, last_in, last_out);
+    RR_HIP(hipGetLastError());
+}
+void launch_fm_chain_half(VSrc<cf> src, float* out, int L, const cf* tw, const cf* tw_half, const cf* hpos,
+                          const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s) {
+    launch_fm_chain_half_t(src, out, L, tw, tw_half, hpos, a, last_in, last_out, s);
+}
+void launch_fm_chain_half_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, const cf* tw_half, const cf* hpos,
+                              const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s) {
+    launch_fm_chain_half_t(src, out, L, tw, tw_half, hpos, a, last_in, last_out, s);
 }
 
 bool fm_multi_supported(int log2f) { return log2f >= 10 && log2f <= 12; }

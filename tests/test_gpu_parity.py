@@ -469,9 +469,13 @@ def _demod_close(yg, yo, ro):
 @pytest.mark.parametrize("L,I,D", [(463, 1, 6), (401, 1, 1), (127, 25, 128), (33, 3, 2), (463, 200000, 1024000), (5, 1, 40),
                                    (463, 1, 2), (400, 1, 6), (600, 1, 100), (463, 3, 18)])
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 20_000])
-def test_fm_chain_fused_block(rr, L, I, D, stream_bytes):
+@pytest.mark.parametrize("kernel", ["half", "full"])
+def test_fm_chain_fused_block(rr, monkeypatch, L, I, D, stream_bytes, kernel):
     """rr.FmChain (one fused kernel) == FftFilter -> RationalResampler -> QuadratureDemod of the oracle,
-    for whole-stream output and any chunking."""
+    for whole-stream output and any chunking.  kernel = half: reduced ratios 1:even on 2048-point tiles finish each
+    tile with a folded 1024-point inverse on one wave (k_fm_chain_half); full: the full-size inverse everywhere."""
+    if kernel == "full":
+        monkeypatch.setenv("RR_FM_CHAIN_FULL", "1")
     fs = 2.4e6
     n = 400_000
     x = fm_signal(n, fs, 0.0, 77 + L)
