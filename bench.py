@@ -546,7 +546,7 @@ def main():
                        "parallelism": f"{world} independent channel(s), one per GPU; shared IQ source broadcast before the timed region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload),
-                         "kernel": "k_fftfilt_real" if args.workload == "fir_float" else "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain", "fir", "fir_1e8") else "k_fm_chain" if args.workload in ("fm_chain", "rtl_fm_chain", "rtl_fm_example") else "k_fm_multi" if args.workload == "fm_multi" else ("k_fftfilt_prune" if args.workload == "channelizer" else "k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
+                         "kernel": "k_fftfilt_real" if args.workload == "fir_float" else "k_fftfilt_os" if args.workload in ("fftfilter", "fm_chain_unfused", "fir_fft_chain", "fir", "fir_1e8") else "k_fm_chain_half" if args.workload in ("fm_chain", "rtl_fm_chain") else "k_fm_chain_split" if args.workload == "rtl_fm_example" else "k_fm_multi_half" if args.workload == "fm_multi" else ("k_fftfilt_prune" if args.workload == "channelizer" else "k_fir" if args.workload != "channelizer_unfused" else "k_hilbert"),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "alg_bytes_per_launch": alg_bytes_per_launch},
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),
