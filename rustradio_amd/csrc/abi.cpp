@@ -219,6 +219,7 @@ size_t rr_fir_fft_tile(const rr_block* b) {
     if (!b) return 0;
     const rr::FirC32* f = dynamic_cast<const rr::FirC32*>(b->b.get());
     if (f && f->prune) return (size_t)1 << f->prune->log2f;
+    if (f && f->half_ok) return 2048;
     return f && f->fftk ? (size_t)1 << f->fftk->log2f : 0;
 }
 // ---- host memory registration -----------------------------------------------------------------------

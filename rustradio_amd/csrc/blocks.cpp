@@ -96,6 +96,8 @@ template <class TapT> static void build_poly(const std::vector<TapT>& rev, int d
     for (int k = 0; k < L; k++) tp[(size_t)(k % d) * qpad + k / d] = rev[k];
 }
 
+static void compute_hpos(const rr_c32* taps, size_t ntaps, int log2f, std::vector<cf>& hpos);
+
 FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq, bool allow_fft)
     : Block("FirFilter<Complex>", 8, 8) {
     if (ntaps == 0) throw Error("FirFilter: empty taps");            // fir.rs:372
@@ -165,7 +167,30 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
         prune.reset(new PruneTables());
         if (!prune->build(td, deci, false, stream)) prune.reset();
     }
-    if (prune) {
+    // other even decimations: 2048-point tiles, folded 1024-point inverse (k_fftfilt_half); same bar as the tiles with a
+    // decimating store, which it replaces where it applies
+    const bool half_on = getenv("RR_FIR_HALF") ? atoi(getenv("RR_FIR_HALF")) != 0 : true;
+    if (!prune && allow_fft && !force_direct && (force_fft || wins) && half_on && fftfilt_half_supported((int)std::min<size_t>(ntaps, 1 << 20), (long)std::min<size_t>(deci, 1 << 20))) {
+        const size_t F = 2048;
+        std::vector<rr_c32> ct(ntaps);
+        for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
+        std::vector<cf> hpos, tw(F), twh(F / 2);
+        compute_hpos(ct.data(), ntaps, 11, hpos);
+        for (size_t k = 0; k < F; k++) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)F;
+            tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+        }
+        for (size_t k = 0; k < F / 2; k++) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)(F / 2);
+            twh[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+        }
+        d_hhpos.upload(hpos.data(), F, stream);
+        d_htw.upload(tw.data(), F, stream);
+        d_htw_half.upload(twh.data(), F / 2, stream);
+        RR_HIP(hipStreamSynchronize(stream));
+        half_ok = true;
+    }
+    if (prune || half_ok) {
     } else if (allow_fft && fits && !force_direct && (force_fft || wins)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
@@ -187,7 +212,8 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     const size_t out_n = n / d;
     VSrc<cf> src{nullptr, 0, static_cast<const cf*>(in), (long)in_len};
     prof_begin(s);
-    if (prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
+    if (half_ok) launch_fftfilt_half(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, d_htw.p, d_htw_half.p, d_hhpos.p, s);
+    else if (prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
     else if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s);
     else if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s);
     else if (fftk) fftk->filter(src, static_cast<cf*>(out), (long)out_n, s);

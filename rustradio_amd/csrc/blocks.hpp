@@ -59,6 +59,9 @@ struct FirC32 : Block {
     // forces the direct kernel, RR_FIR_FFT=1 the tiles for any length (both read at construction).
     std::unique_ptr<FftFilter> fftk;
     std::unique_ptr<PruneTables> prune;           // deci 4 / 8 / 16: pruned inverse transform (k_fftfilt_prune)
+    // other even decimations, <= 600 taps: 2048-point tiles with the half-size inverse (k_fftfilt_half)
+    bool half_ok = false;
+    DevBuf<cf> d_htw, d_htw_half, d_hhpos;
     DevBuf<unsigned char> d_tp, d_rev, d_tab;
     bool rot_on = false;
     int rot_mode = RR_ROT_MODEL;

@@ -35,6 +35,12 @@ void launch_fftfilt_prune_c32(int log2f, VSrc<cf> src, cf* out, long n_out, int 
 void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
                                const cf* hpos2i, const cf* twb, hipStream_t s);
 
+// Even decimations on 2048-point tiles with the half-size inverse (k_fftfilt_half): out[m] = y[m d], m < n_out.
+// tw = w_2048^k, tw_half = w_1024^k, hpos = H / F in the 2048-point position order.
+bool fftfilt_half_supported(int L, long d);
+void launch_fftfilt_half(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* tw_half, const cf* hpos,
+                         hipStream_t s);
+
 // The same filter with an 8192 / 16384-point tile built from nsub = 2 / 4 sub-transforms of 4096 points
 // (k_fftfilt_split).  tw4096: w_4096^k;  wk[t] = w_F^t, t < 256;  hs[r][p] = H[nsub bin(p) + r] / F with
 // bin(p) = fftfilt_split_bin(p), the bin at position p of the 4096-point spectrum layout.

@@ -1445,6 +1445,130 @@ void k_fm_chain_half(SRC src, float* __restrict__ out, int L, long ntiles, long 
     }
 }
 
+// ---- decimating FirFilter<Complex> with an even decimation on the half-size inverse -------------------------------
+// out[m] = y[m d], d = 2 d2: the kept samples have even full-rate indices, so (tile start shifted by L - 1's parity,
+// even tile advance) they sit at even tile positions and the inverse is the folded F/2-point transform of
+// k_fm_chain_half — two tiles per iteration, each wave finishes one and stores its kept samples (every d2-th of the
+// half-rate sequence; lane-consecutive for d = 2).  Decimations 4 / 8 / 16 have k_fftfilt_prune.
+template <int LOG2F>
+__global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
+void k_fftfilt_half(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d2, long ntiles, long S,
+                    const cf* __restrict__ tw, const cf* __restrict__ tw_half, const cf* __restrict__ hpos) {
+    constexpr int F = 1 << LOG2F, T = F / 16, LH = LOG2F - 1, FH = F / 2, TH = T / 2;
+    constexpr int NP = Plan<LOG2F>::NP;
+    constexpr int D3 = F / 256, DH = D3 / 2, U = 16 / D3;
+    constexpr int N1 = PassGeom<LOG2F, 1>::R * PassGeom<LOG2F, 1>::P;
+    constexpr int N1H = PassGeom<LH, 1>::R * PassGeom<LH, 1>::P;
+    static_assert(NP == 3 && TH == 64, "one wave per half-size tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    creg* ldsY = lds + lds_elems(F);
+    creg* tab1 = ldsY + 2 * lds_elems(FH);
+    creg* tab1h = tab1 + N1;
+    const int t_ = threadIdx.x, hg = t_ / TH, th_ = t_ % TH;
+    const int first = L - 1;
+    const int delta = first & 1;                         // S even: (tile S - delta - first) is even for every tile
+    creg tw0[15], tw0h[15];
+    load_twiddles<LOG2F, 0>(tw0, t_, tw);
+    load_twiddles<LH, 0>(tw0h, th_, tw_half);
+    for (int j = t_; j < N1; j += T) tab1[j] = to_reg(tw[j * (F / N1)]);
+    for (int j = t_; j < N1H; j += T) tab1h[j] = to_reg(tw_half[j * (FH / N1H)]);
+    const float inv_d2 = 1.0f / (float)d2;
+    const long npairs = (ntiles + 1) / 2;
+    creg* out_reg = reinterpret_cast<creg*>(out);
+    tile_sync<T>();
+
+    for (TileIter it(npairs); it.tile < it.end; it.tile += it.step) {
+#pragma unroll 1
+        for (int b = 0; b < 2; b++) {
+            const long tile = 2 * it.tile + b;
+            if (tile >= ntiles) break;                   // (workgroup-uniform)
+            int t = t_;                                  // opaque per tile (see k_fm_chain_half)
+            asm volatile("" : "+v"(t));
+            creg v[16], twl[15], hreg[16];
+            load_tile16<LOG2F>(v, src, tile * S - delta, t, lds);
+            load_h<LOG2F, NP - 1>(hreg, t, hpos);        // in flight during the transform
+            RR_PHASE();
+            fwd_pass<LOG2F, 0>(v, tw0);
+            RR_PHASE();
+            lds_store<LOG2F, 0>(v, t, lds);
+            tile_sync<T>();
+            lds_load<LOG2F, 1>(v, t, lds);
+#pragma unroll
+            for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<LOG2F, 1>::lo(t)];
+            RR_PHASE();
+            fwd_pass<LOG2F, 1>(v, twl);
+            RR_PHASE();
+            lds_store<LOG2F, 1>(v, t, lds);
+            tile_sync<T>();
+            lds_load<LOG2F, 2>(v, t, lds);
+            RR_PHASE();
+            fwd_pass<LOG2F, 2>(v, twl);
+            tile_sync<T>();
+            creg* py = ldsY + b * lds_elems(FH);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int g = t + T * u;
+#pragma unroll
+                for (int k = 0; k < DH; k++)
+                    py[lds_pad(g * DH + k)] = cadd(cmul(v[u * D3 + k], hreg[u * D3 + k]), cmul(v[u * D3 + k + DH], hreg[u * D3 + k + DH]));
+            }
+            RR_PHASE();
+        }
+        tile_sync<T>();
+        const long tile = 2 * it.tile + hg;
+        if (tile < ntiles) {
+            int th = th_;
+            asm volatile("" : "+v"(th));
+            creg* ldsH = lds + hg * lds_elems(FH);
+            creg w[16], twl[15];
+            lds_load<LH, 2>(w, th, ldsY + hg * lds_elems(FH));
+            inv_pass<LH, 2>(w, twl);
+            RR_PHASE();
+            lds_store<LH, 2>(w, th, ldsH);
+            asm volatile("" ::: "memory");
+            lds_load<LH, 1>(w, th, ldsH);
+#pragma unroll
+            for (int k = 1; k < 16; k++) twl[k - 1] = tab1h[k * PassGeom<LH, 1>::lo(th)];
+            RR_PHASE();
+            inv_pass<LH, 1>(w, twl);
+            RR_PHASE();
+            lds_store<LH, 1>(w, th, ldsH);
+            asm volatile("" ::: "memory");
+            lds_load<LH, 0>(w, th, ldsH);
+            RR_PHASE();
+            inv_pass<LH, 0>(w, tw0h);                    // w[n] = y[2 (n 64 + th)] of the tile
+            RR_PHASE();
+            // half-rate index of tile position 2 n': hb + n', hb = (tile S - delta - first) / 2; this tile owns the
+            // full-rate indices [tile S, (tile + 1) S), i.e. n' in [n_lo, n_hi)
+            const long hb = (tile * S - delta - first) / 2;
+            const int n_lo = (first + delta) / 2, n_hi = n_lo + (int)(S / 2);
+            if (d2 == 1) {
+                creg* po = out_reg + hb + th;
+                const long room = n_out - hb - th;
+#pragma unroll
+                for (int n = 0; n < 16; n++) {
+                    const int np = n * TH + th;
+                    if (np >= n_lo && np < n_hi && n * TH < room) po[n * TH] = w[n];
+                }
+            } else {
+                // keep (hb + n') % d2 == 0 -> out[(hb + n') / d2]   (exact f32 quotients as in k_fftfilt_deci)
+                const long K = (-hb + d2 - 1) / d2 > 0 ? (-hb + d2 - 1) / d2 : 0;   // hb may be negative in tile 0
+                const long gb = hb + K * d2, qb = gb / d2;
+                const int rb = (int)(gb - qb * d2) + th;
+#pragma unroll
+                for (int n = 0; n < 16; n++) {
+                    const int np = n * TH + th, x = rb + n * TH;
+                    const int q = (int)(((float)x + 0.5f) * inv_d2);
+                    const long m = qb - K + q;
+                    if (q * d2 == x && np >= n_lo && np < n_hi && m < n_out) out_reg[m] = w[n];
+                }
+            }
+        }
+        tile_sync<T>();
+    }
+}
+
 // measurement builds: 16 s_memtime stamps of one tile (see RR_STAMP); nullptr otherwise
 static unsigned long long* fft_stamp_buffer() {
 #ifdef RR_FFT_TIMING_BUILD
@@ -1880,6 +2004,23 @@ void launch_fm_chain_half(VSrc<cf> src, float* out, int L, const cf* tw, const c
 void launch_fm_chain_half_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, const cf* tw_half, const cf* hpos,
                               const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s) {
     launch_fm_chain_half_t(src, out, L, tw, tw_half, hpos, a, last_in, last_out, s);
+}
+
+// (beyond ~600 taps the 4096-point tiles with a decimating store win again: 1000 taps /2 0.43 vs 0.50 ms)
+bool fftfilt_half_supported(int L, long d) { return d >= 2 && (d & 1) == 0 && d / 2 <= 2048 && L >= 1 && L <= 600; }
+void launch_fftfilt_half(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* tw_half, const cf* hpos,
+                         hipStream_t s) {
+    constexpr int LOG2F = 11, F = 1 << LOG2F, T = F / 16;
+    if (!fftfilt_half_supported(L, d)) throw Error("fftfilt_half: unsupported shape");
+    if (n_out <= 0) return;
+    const long S = ((F - L + 1) - 1) & ~1L;              // even advance, room for the parity shift
+    const long n_full = (n_out - 1) * (long)d + 1;
+    const long ntiles = (n_full + S - 1) / S;
+    const size_t smem = sizeof(cf) * (lds_elems(F) + 2 * lds_elems(F / 2) + 128 + 64);
+    const long grid = grid_for_tiles(k_fftfilt_half<LOG2F>, T, smem, (ntiles + 1) / 2);
+    hipLaunchKernelGGL((k_fftfilt_half<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L, d / 2, ntiles, S,
+                       tw, tw_half, hpos);
+    RR_HIP(hipGetLastError());
 }
 
 bool fm_multi_supported(int log2f) { return log2f >= 10 && log2f <= 12; }

@@ -92,9 +92,9 @@ def test_fir_nondecimating_both_paths(rr, monkeypatch, path, L, cplx):
     assert rr.fir_uses_fft_tiles(f) == (path == "fft" or (path == "auto" and L >= (28 if cplx else 40)))
 
 
-@pytest.mark.parametrize("path", ["direct", "fft", "auto", "prune"])
+@pytest.mark.parametrize("path", ["direct", "fft", "auto", "prune", "half"])
 @pytest.mark.parametrize("L,deci,cplx", [(5, 4, True), (40, 4, False), (500, 4, True), (64, 8, False), (1020, 8, True), (3, 16, False), (2049, 16, True),
-                                         (5, 2, False), (127, 2, False), (127, 3, True), (255, 8, True), (401, 7, False),
+                                         (5, 2, False), (127, 2, False), (128, 2, True), (600, 2, False), (601, 2, True), (401, 6, True), (90, 10, False), (700, 14, True), (33, 4096, True), (64, 22, False), (127, 3, True), (255, 8, True), (401, 7, False),
                                          (1000, 16, True), (64, 100, False), (2000, 5, False), (3584, 4096, False), (5000, 3, True), (9000, 16, False),
                                          (300, 3000, True)])
 def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
@@ -105,8 +105,12 @@ def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
     elif path == "fft":                               # overlap-save tiles with a decimating store
         monkeypatch.setenv("RR_FIR_FFT", "1")
         monkeypatch.setenv("RR_FIR_PRUNE", "0")
+        monkeypatch.setenv("RR_FIR_HALF", "0")
     elif path == "prune":                             # deci 4 / 8 / 16: pruned inverse transform (else as "auto")
         monkeypatch.setenv("RR_FIR_PRUNE", "1")
+    elif path == "half":                              # even deci, <= 1025 taps: half-size inverse on 2048-point tiles
+        monkeypatch.setenv("RR_FIR_FFT", "1")
+        monkeypatch.setenv("RR_FIR_PRUNE", "0")
     if path == "direct" and L >= 5000:
         pytest.skip("direct-form fallback at thousands of taps: covered by test_fir_complex history, slow")
     x = rnd_c(120000, L * 3 + deci)

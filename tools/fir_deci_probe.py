@@ -9,16 +9,15 @@ n = 100_000_000
 x = torch.rand(2 * n, device="cuda") * 2 - 1
 y = torch.empty(2 * n, device="cuda")
 rng = np.random.default_rng(1)
-for L, d in ((64, 2), (127, 2), (127, 3), (127, 4), (255, 2), (255, 4), (255, 8), (401, 4), (401, 8), (401, 16), (1000, 8), (1000, 16), (1000, 32), (2467, 32), (2467, 64)):
+for L, d in ((32, 2), (64, 2), (127, 2), (255, 2), (401, 2), (1000, 2), (127, 6), (255, 6), (401, 6), (401, 10), (127, 3), (127, 4), (255, 4), (255, 8), (401, 16), (1000, 32), (2467, 32)):
     for cplx in (False, True):
         t = rng.uniform(-1, 1, L) + (1j * rng.uniform(-1, 1, L) if cplx else 0)
         t = (t / L).astype(np.complex64)
         row = []
-        for env in ("RR_FIR_DIRECT", "RR_FIR_FFT", None):
-            for k in ("RR_FIR_DIRECT", "RR_FIR_FFT"):
+        for env in ({"RR_FIR_DIRECT": "1"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0", "RR_FIR_HALF": "0"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0"}, {}):
+            for k in ("RR_FIR_DIRECT", "RR_FIR_FFT", "RR_FIR_PRUNE", "RR_FIR_HALF"):
                 os.environ.pop(k, None)
-            if env:
-                os.environ[env] = "1"
+            os.environ.update(env)
             f = rr.FirFilter(t, deci=d)
             for _ in range(2):
                 f.work_dev(x.data_ptr(), n, y.data_ptr(), n)
@@ -29,4 +28,4 @@ for L, d in ((64, 2), (127, 2), (127, 3), (127, 4), (255, 2), (255, 4), (255, 8)
             torch.cuda.synchronize()
             ms, k = f.profile()
             row.append(ms / k)
-        print(f"L={L:5d} d={d:3d} {'complex' if cplx else 'real   '} taps: direct {row[0]:.4f} ms  fft {row[1]:.4f} ms  auto {row[2]:.4f} ms", flush=True)
+        print(f"L={L:5d} d={d:3d} {'complex' if cplx else 'real   '} taps: direct {row[0]:.4f}  deci-store {row[1]:.4f}  half {row[2]:.4f}  auto {row[3]:.4f} ms", flush=True)
