@@ -618,21 +618,29 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             for (int n1 = 0; n1 < 16; n1++)
                 if (16 * n1 >= lo && 16 * n1 < lim) po[16 * n1] = p[n1];
         } else {
-            // comp 0: (Gr*a) + i (Gr*b) = the real parts of y_a (segment 2 tile) and y_b (segment 2 tile + 1);
-            // comp 1: (Gi*a) + i (Gi*b) = their imaginary parts
+            // tail 0: (Gr*a) + i (Gr*b) = the real parts of y_a (segment 2 tile) and y_b (segment 2 tile + 1), stashed
+            // in the thread's own slots of the (now idle) exchange area; tail 1: (Gi*a) + i (Gi*b) = their imaginary
+            // parts; then whole Complex samples are stored (4-byte stores of the two parts cost 1.34x the write traffic)
             const long ma = 2 * (tile0 + b) * Sd - fq + n2, mb = ma + Sd;
             const long ra = n_out - ma, rb = n_out - mb;
             const int lima = ra < hi ? (int)ra : hi, limb = rb < hi ? (int)rb : hi;
-#pragma unroll 1
-            for (int comp = 0; comp < 2; comp++) {
+            creg* stash = lds + 17 * t;
+            {
                 creg p[16];
-                prune_tail<T>(p, park + comp * PARK, t, twb);
-                float* pa = reinterpret_cast<float*>(out) + 2 * ma + comp;
-                float* pb = reinterpret_cast<float*>(out) + 2 * mb + comp;
+                prune_tail<T>(p, park, t, twb);
+#pragma unroll
+                for (int n1 = 0; n1 < 16; n1++) stash[n1] = p[n1];
+            }
+            {
+                creg p[16];
+                prune_tail<T>(p, parkb, t, twb);
+                creg* pa = out_reg + ma;
+                creg* pb = out_reg + mb;
 #pragma unroll
                 for (int n1 = 0; n1 < 16; n1++) {
-                    if (16 * n1 >= lo && 16 * n1 < lima) pa[32 * n1] = p[n1].x;
-                    if (16 * n1 >= lo && 16 * n1 < limb) pb[32 * n1] = p[n1].y;
+                    const creg q = stash[n1];
+                    if (16 * n1 >= lo && 16 * n1 < lima) pa[16 * n1] = mk(q.x, p[n1].x);
+                    if (16 * n1 >= lo && 16 * n1 < limb) pb[16 * n1] = mk(q.y, p[n1].y);
                 }
             }
         }

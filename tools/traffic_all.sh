@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) of the dominant kernel of several workloads.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for w in fftfilter fm_chain channelizer; do
+for w in ${WORKLOADS:-fftfilter fm_chain channelizer fm_multi fir_1e8 fir_float}; do
   OUT=gpurun_out/traffic_$w; mkdir -p $OUT
   i=0
   for c in FETCH_SIZE WRITE_SIZE; do
