@@ -325,7 +325,16 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
     const bool force_direct = getenv("RR_FIR_DIRECT") != nullptr, force_fft = getenv("RR_FIR_FFT") != nullptr;
     const bool fits = ntaps <= 3584 && deci <= 4096;
     const bool wins = deci == 1 ? ntaps >= 24 : (ntaps >= 320 || ntaps / deci >= 40);
-    if (fits && !force_direct && (force_fft || wins)) {
+    const size_t per_phase = ntaps / deci;
+    const bool prune_default = deci == 4 ? per_phase >= 8 : deci == 8 ? per_phase >= 16 : per_phase >= 4;
+    const bool prune_wins = getenv("RR_FIR_PRUNE") ? atoi(getenv("RR_FIR_PRUNE")) != 0 : prune_default;
+    if (!force_direct && prune_wins && prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
+        std::vector<std::complex<double>> td(ntaps);
+        for (size_t i = 0; i < ntaps; i++) td[i] = {(double)taps[i], 0.0};
+        prune.reset(new PruneTables());
+        if (!prune->build(td, deci, false, stream)) prune.reset();
+    }
+    if (!prune && fits && !force_direct && (force_fft || wins)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {taps[i], 0.0f};
         fftk.reset(new FftFilter(ct.data(), ntaps, false, 12, true));
@@ -342,7 +351,8 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     n = std::min(n, out_cap * d);
     VSrc<float> src{nullptr, 0, static_cast<const float*>(in), (long)in_len};
     prof_begin(s);
-    if (fftk) fftk->filter_real(src, static_cast<float*>(out), (long)(n / d), (int)d, s);
+    if (prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
+    else if (fftk) fftk->filter_real(src, static_cast<float*>(out), (long)(n / d), (int)d, s);
     else launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
     prof_end(s);
     *consumed = n; *produced = n / d;

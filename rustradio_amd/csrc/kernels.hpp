@@ -31,6 +31,9 @@ void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int
 int prune_log2f_for_deci(int d);                 // 0 when d is not 4 / 8 / 16
 void launch_fftfilt_prune_c32(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
                               const cf* twb, hipStream_t s);
+// real stream, real taps, f32 output (decimating FirFilter<Float>)
+void launch_fftfilt_prune_f32(int log2f, VSrc<float> src, float* out, long n_out, int L, const cf* tw, const cf* hpos2,
+                              const cf* twb, hipStream_t s);
 // real stream, Complex taps t = Gr + i Gi: hpos2r / hpos2i from the real tap sets Gr / Gi; Complex output
 void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
                                const cf* hpos2i, const cf* twb, hipStream_t s);

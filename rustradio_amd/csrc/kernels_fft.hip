@@ -500,7 +500,9 @@ __device__ __forceinline__ void prune_tail(creg* v, creg* park, int t, const cre
     Dft<16, true>::run(v);                              // over k1 -> n1
 }
 
-template <int LOG2F, bool REAL2>
+//   MODE 0 = Complex stream, 1 = real stream x Complex taps (REAL2 above), 2 = real stream x real taps (decimating
+//   FirFilter<Float>): one response, one tail, y_a / y_b are its real / imaginary parts, f32 output.
+template <int LOG2F, int MODE>
 __global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
 void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long n_out, int L, long S, long ntiles,
                      const cf* __restrict__ tw, const cf* __restrict__ hpos2, const cf* __restrict__ hpos2b,
@@ -510,10 +512,11 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
     constexpr int D = F / 256;
     constexpr int U = 16 / D;
     constexpr int PARK = 256 * D + 16 * D;              // lds_elems(256 D)
+    constexpr bool REAL2 = MODE != 0, TWO = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     creg* lds = reinterpret_cast<creg*>(smem_raw);
     creg* park = lds + lds_elems(F);
-    creg* parkb = park + PARK;                          // REAL2 only
+    creg* parkb = park + PARK;                          // MODE 1 only
     const int t = threadIdx.x;
     const int first = L - 1;
     const long fq = first / D;                          // kept samples in front of a tile's first valid one
@@ -524,7 +527,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
     // pass-1 twiddles w_16D^(k (t % D)) — 16 D distinct values — are read per tile from an LDS table; the second
     // response is re-read per tile (both sets of twiddles plus one response spill 80-110 B/lane, the LDS table
     // plus both responses 150 B/lane — and a spill waits on the whole in-order vmcnt queue).
-    creg* tw1tab = park + (REAL2 ? 2 : 1) * PARK;       // REAL2 only: w_16D^j, j < 16 D
+    creg* tw1tab = park + (TWO ? 2 : 1) * PARK;         // real streams only: w_16D^j, j < 16 D
     creg hrA[16], hrB[16], tw0p[15];
     const int lo1 = PassGeom<LOG2F, 1>::lo(t);
     if constexpr (REAL2) {
@@ -589,7 +592,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
                 for (int k = 1; k < D; k++) z = cadd(z, cmul(v[u * D + k], h1[u * D + k]));
                 park[lds_pad(256 * b + t + T * u)] = z;
             }
-            if constexpr (REAL2) {
+            if constexpr (TWO) {
                 RR_PHASE();
                 load_h<LOG2F, Plan<LOG2F>::NP - 1>(hrB, t, hpos2b);   // the second response is re-read per tile (L1 / L2)
 #pragma unroll
@@ -607,7 +610,20 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
         const creg* twb = reinterpret_cast<const creg*>(twb_tab) + 16 * (t & 15);
         const int b = t >> 4, n2 = t & 15;
         const int lo = (int)fq - n2, hi = lo + (int)Sd;              // valid kept samples: lo <= 16 n1 < hi
-        if constexpr (!REAL2) {
+        if constexpr (MODE == 2) {                       // real taps: (t*a) + i (t*b), f32 output
+            creg p[16];
+            prune_tail<T>(p, park, t, twb);
+            const long ma = 2 * (tile0 + b) * Sd - fq + n2, mb = ma + Sd;
+            const long ra = n_out - ma, rb = n_out - mb;
+            const int lima = ra < hi ? (int)ra : hi, limb = rb < hi ? (int)rb : hi;
+            float* pa = reinterpret_cast<float*>(out) + ma;
+            float* pb = reinterpret_cast<float*>(out) + mb;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                if (16 * n1 >= lo && 16 * n1 < lima) pa[16 * n1] = p[n1].x;
+                if (16 * n1 >= lo && 16 * n1 < limb) pb[16 * n1] = p[n1].y;
+            }
+        } else if constexpr (!REAL2) {
             creg p[16];
             prune_tail<T>(p, park, t, twb);
             const long m0 = (tile0 + b) * Sd - fq + n2;
@@ -1719,7 +1735,7 @@ void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int
     }
 }
 
-template <int LOG2F, bool REAL2>
+template <int LOG2F, int MODE>
 static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
                              const cf* hpos2b, const cf* twb, hipStream_t s) {
     constexpr int F = 1 << LOG2F, T = F / 16, D = F / 256;
@@ -1728,10 +1744,10 @@ static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_ou
     if (n_out <= 0) return;
     const long Sd = S / D;
     const long nseg = (n_out + Sd - 1) / Sd;
-    const long ntiles = REAL2 ? (nseg + 1) / 2 : nseg;
-    const size_t smem = sizeof(cf) * (lds_elems(F) + (REAL2 ? 2 : 1) * lds_elems(256 * D) + (REAL2 ? 16 * D : 0));
-    const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, REAL2>, T, smem, (ntiles + D - 1) / D);
-    hipLaunchKernelGGL((k_fftfilt_prune<LOG2F, REAL2>), dim3((unsigned)grid), dim3(T), smem, s, csrc, rsrc, out, n_out, L, S,
+    const long ntiles = MODE ? (nseg + 1) / 2 : nseg;
+    const size_t smem = sizeof(cf) * (lds_elems(F) + (MODE == 1 ? 2 : 1) * lds_elems(256 * D) + (MODE ? 16 * D : 0));
+    const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, MODE>, T, smem, (ntiles + D - 1) / D);
+    hipLaunchKernelGGL((k_fftfilt_prune<LOG2F, MODE>), dim3((unsigned)grid), dim3(T), smem, s, csrc, rsrc, out, n_out, L, S,
                        ntiles, tw, hpos2, hpos2b, twb);
     RR_HIP(hipGetLastError());
 }
@@ -1740,9 +1756,20 @@ void launch_fftfilt_prune_c32(int log2f, VSrc<cf> src, cf* out, long n_out, int 
                               const cf* twb, hipStream_t s) {
     VSrc<float> none{nullptr, 0, nullptr, 0};
     switch (log2f) {
-    case 10: launch_prune_one<10, false>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
-    case 11: launch_prune_one<11, false>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
-    case 12: launch_prune_one<12, false>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    case 10: launch_prune_one<10, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    case 11: launch_prune_one<11, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    case 12: launch_prune_one<12, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    default: throw Error("fftfilt_prune: unsupported tile size");
+    }
+}
+void launch_fftfilt_prune_f32(int log2f, VSrc<float> src, float* out, long n_out, int L, const cf* tw, const cf* hpos2,
+                              const cf* twb, hipStream_t s) {
+    VSrc<cf> none{nullptr, 0, nullptr, 0};
+    cf* o = reinterpret_cast<cf*>(out);
+    switch (log2f) {
+    case 10: launch_prune_one<10, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    case 11: launch_prune_one<11, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    case 12: launch_prune_one<12, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s); break;
     default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }
@@ -1750,9 +1777,9 @@ void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, 
                                const cf* hpos2i, const cf* twb, hipStream_t s) {
     VSrc<cf> none{nullptr, 0, nullptr, 0};
     switch (log2f) {
-    case 10: launch_prune_one<10, true>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
-    case 11: launch_prune_one<11, true>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
-    case 12: launch_prune_one<12, true>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
+    case 10: launch_prune_one<10, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
+    case 11: launch_prune_one<11, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
+    case 12: launch_prune_one<12, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
     default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }

@@ -215,15 +215,20 @@ def test_fftfilter_float_lengths(rr, L):
     both(rr, lambda m: [m.FftFilterFloat(taps)], x[:120_000], stream_bytes=4 * 50_000)
 
 
-@pytest.mark.parametrize("path", ["direct", "fft", "auto"])
+@pytest.mark.parametrize("path", ["direct", "fft", "auto", "prune"])
 @pytest.mark.parametrize("L,deci", [(1, 1), (5, 1), (39, 1), (40, 1), (65, 1), (463, 1), (463, 6), (128, 3), (1000, 16),
-                                    (3584, 1), (3584, 4096), (64, 100), (330, 50), (2000, 7)])
+                                    (3584, 1), (3584, 4096), (64, 100), (330, 50), (2000, 7), (3, 4), (64, 4), (513, 4),
+                                    (255, 8), (1025, 8), (2049, 16), (31, 16)])
 def test_fir_float_both_paths(rr, monkeypatch, path, L, deci):
-    """FirFilter<Float> through the direct-form kernel and through the real-stream overlap-save tiles."""
+    """FirFilter<Float> through the direct-form kernel, the real-stream overlap-save tiles (decimating store) and —
+    deci 4 / 8 / 16 — the tiles with the pruned inverse transform."""
     if path == "direct":
         monkeypatch.setenv("RR_FIR_DIRECT", "1")
     elif path == "fft":
         monkeypatch.setenv("RR_FIR_FFT", "1")
+        monkeypatch.setenv("RR_FIR_PRUNE", "0")
+    elif path == "prune":
+        monkeypatch.setenv("RR_FIR_PRUNE", "1")
     x = rnd_f(150_000, L * 3 + deci)
     taps = rnd_f(L, L + deci) / max(1, L // 8)
     both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x)

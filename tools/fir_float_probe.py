@@ -19,17 +19,16 @@ def run(f, k=4):
     torch.cuda.synchronize()
     ms, c = f.profile()
     return ms / c
-for L, d in ((16, 1), (32, 1), (40, 1), (65, 1), (127, 1), (463, 1), (463, 6), (255, 8), (1000, 16), (2467, 1)):
+for L, d in ((65, 1), (127, 1), (463, 1), (463, 6), (64, 4), (255, 4), (127, 8), (255, 8), (1000, 8), (255, 16), (1000, 16)):
     t = (rng.uniform(-1, 1, L) / L).astype(np.float32)
     row = []
-    for env in ("RR_FIR_DIRECT", "RR_FIR_FFT", None):
-        for k in ("RR_FIR_DIRECT", "RR_FIR_FFT"):
+    for env in ({"RR_FIR_DIRECT": "1"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0"}, {"RR_FIR_PRUNE": "1"}, {}):
+        for k in ("RR_FIR_DIRECT", "RR_FIR_FFT", "RR_FIR_PRUNE"):
             os.environ.pop(k, None)
-        if env:
-            os.environ[env] = "1"
+        os.environ.update(env)
         row.append(run(rr.FirFilter(t, deci=d)))
-    print(f"FirFilter<Float> L={L:5d} d={d:3d}: direct {row[0]:.4f} ms  fft {row[1]:.4f} ms  auto {row[2]:.4f} ms", flush=True)
-for k in ("RR_FIR_DIRECT", "RR_FIR_FFT"):
+    print(f"FirFilter<Float> L={L:5d} d={d:3d}: direct {row[0]:.4f}  tiles {row[1]:.4f}  pruned {row[2]:.4f}  auto {row[3]:.4f} ms", flush=True)
+for k in ("RR_FIR_DIRECT", "RR_FIR_FFT", "RR_FIR_PRUNE"):
     os.environ.pop(k, None)
 # FftFilterFloat: inner streams are 512,000 samples, so time whole-stream throughput over ring-sized windows
 m = 512_000
