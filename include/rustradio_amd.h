@@ -106,7 +106,8 @@ rr_block *rr_rtlsdr_decode_create(void);
 /* FftStream::new(src, size) (src/fft_stream.rs:40-117): the forward, unnormalised FFT of every consecutive
  * `size`-sample frame, natural bin order; work(): WAIT_SRC(size) / WAIT_DST(size), else whole frames of
  * min(in, out), RR_AGAIN.  The frame tags (TAG_FRAME, TAG_FRAME_SIZE) are added by the shim from
- * `produced`.  GPU sizes: powers of two 2..16384 (NULL otherwise; rustfft plans any size). */
+ * `produced`.  GPU sizes: every size 2..2048 (sizes that are not a power of two as Bluestein chirp-z convolutions) and
+ * the powers of two up to 16384 (NULL otherwise; rustfft plans any size). */
 rr_block *rr_fftstream_create(size_t size);
 /* MultiplyConst::<Float|Complex>::new(src, val) (src/multiply_const.rs:6-23) and FastFM::new(src)
  * (src/quadrature_demod.rs:144-165): #[rustradio(sync)] blocks — work() maps min(input, output space)

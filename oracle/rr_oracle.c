@@ -487,17 +487,39 @@ orc_block *orc_fastfm_new(void) { /* quadrature_demod.rs:144-165; q1 = q2 = 0 (#
     return b;
 }
 
-/* FftStream::new (fft_stream.rs:40-60).  The reference plans any size with rustfft; this restatement has a
- * radix-4/2 transform: powers of two (what the GPU block supports as well). */
+/* FftStream::new (fft_stream.rs:40-60).  The reference plans any size with rustfft (forward, unnormalised,
+ * e^{-2 pi i k n / N}); this restatement has a radix-4/2 transform for powers of two and evaluates the defining sum in
+ * f64 (rounded once to f32) for every other size. */
 orc_block *orc_fftstream_new(size_t size) {
     if (size == 0) { set_err("FFT size must be nonzero (fft_stream.rs:42)"); return NULL; }
-    if (size & (size - 1)) { set_err("FftStream: the restatement transforms powers of two only"); return NULL; }
     if (size > 4096000 / sizeof(orc_c32)) { set_err("FFT size must be no bigger than stream size (fft_stream.rs:46-50)"); return NULL; }
     orc_block *b = (orc_block *)calloc(1, sizeof *b);
     b->kind = K_FFTSTREAM; b->in_es = b->out_es = sizeof(orc_c32);
     b->fft_size = size;
-    b->plan = fftplan_new(size);
+    b->plan = (size & (size - 1)) ? NULL : fftplan_new(size);
     return b;
+}
+
+/* the defining sum X[k] = sum_n x[n] e^{-2 pi i k n / N} in f64, in place */
+static void dft_f64_inplace(orc_c32 *x, size_t n) {
+    double *wr = (double *)malloc(sizeof(double) * n), *wi = (double *)malloc(sizeof(double) * n);
+    orc_c32 *y = (orc_c32 *)malloc(sizeof(orc_c32) * n);
+    for (size_t j = 0; j < n; j++) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)j / (double)n;
+        wr[j] = cos(a); wi[j] = sin(a);
+    }
+    for (size_t k = 0; k < n; k++) {
+        double sr = 0.0, si = 0.0;
+        size_t idx = 0;                                 /* k * m mod n */
+        for (size_t m = 0; m < n; m++) {
+            sr += (double)x[m].re * wr[idx] - (double)x[m].im * wi[idx];
+            si += (double)x[m].re * wi[idx] + (double)x[m].im * wr[idx];
+            idx += k; if (idx >= n) idx -= n;
+        }
+        y[k].re = (float)sr; y[k].im = (float)si;
+    }
+    memcpy(x, y, sizeof(orc_c32) * n);
+    free(wr); free(wi); free(y);
 }
 
 orc_block *orc_rtlsdr_decode_new(void) { /* rtlsdr_decode.rs:9-16 */
@@ -748,7 +770,10 @@ static int work_fftstream(orc_block *b, const orc_c32 *in, size_t in_len, orc_c3
     size_t len = in_len < out_cap ? in_len : out_cap;              /* :82-83 */
     len -= len % size;
     memcpy(out, in, len * sizeof(orc_c32));                        /* :84 */
-    for (size_t f = 0; f < len; f += size) fftplan_run(b->plan, out + f, 0);   /* :93-96 forward, unnormalised */
+    for (size_t f = 0; f < len; f += size) {                       /* :93-96 forward, unnormalised */
+        if (b->plan) fftplan_run(b->plan, out + f, 0);
+        else dft_f64_inplace(out + f, size);
+    }
     *consumed = len; *produced = len;
     return ORC_AGAIN;
 }

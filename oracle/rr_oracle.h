@@ -100,7 +100,8 @@ orc_block *orc_rtlsdr_decode_new(void);
 orc_block *orc_multiply_const_f32_new(float val);
 orc_block *orc_multiply_const_c32_new(float re, float im);
 orc_block *orc_fastfm_new(void);
-/* FftStream (fft_stream.rs:26-117): forward FFT of consecutive `size`-sample frames; power-of-two sizes. */
+/* FftStream (fft_stream.rs:26-117): forward FFT of consecutive `size`-sample frames (sizes that are not a power of
+ * two: the defining sum in f64). */
 orc_block *orc_fftstream_new(size_t size);
 /* Hilbert (hilbert.rs:22-129). */
 orc_block *orc_hilbert_new(size_t ntaps, int wtype, float parm);

@@ -947,8 +947,38 @@ int QuadDemod::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
 FftStream::FftStream(size_t n) : Block("FftStream", 8, 8), size(n) {
     if (n == 0) throw Error("FFT size must be nonzero");                                   // :42
     if (n > 4096000 / sizeof(cf)) throw Error("FFT size must be no bigger than stream size");   // :46-50
-    if ((n & (n - 1)) != 0 || n < 2 || n > 16384)
-        throw Error("FftStream: the GPU block transforms power-of-two sizes 2..16384 (the reference plans any size with rustfft)");
+    if (n < 2 || n > 16384 || ((n & (n - 1)) != 0 && n > 2048))
+        throw Error("FftStream: the GPU block transforms sizes 2..2048 and the powers of two up to 16384 (the reference plans any size with rustfft)");
+    if ((n & (n - 1)) != 0) {                             // Bluestein on a filter tile of M >= 2 n - 1 points
+        log2m = 10;
+        while (((size_t)1 << log2m) < 2 * n - 1) log2m++;
+        const size_t M = (size_t)1 << log2m;
+        std::vector<std::complex<double>> c(n), B(M, 0.0);
+        for (size_t k = 0; k < n; k++) {                  // c[k] = exp(-i pi k^2 / n), k^2 reduced mod 2 n
+            const size_t q = (k * k) % (2 * n);
+            c[k] = std::polar(1.0, -3.14159265358979323846 * (double)q / (double)n);
+        }
+        B[0] = std::conj(c[0]);
+        for (size_t m = 1; m < n; m++) B[m] = B[M - m] = std::conj(c[m]);
+        fft64(B);
+        for (auto& h : B) h /= (double)M;
+        std::vector<cf> hpos, tw(M), chirp(n);
+        switch (log2m) {
+        case 10: fill_hpos<10>(B, hpos); break;
+        case 11: fill_hpos<11>(B, hpos); break;
+        default: fill_hpos<12>(B, hpos); break;
+        }
+        for (size_t k = 0; k < M; k++) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)M;
+            tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+        }
+        for (size_t k = 0; k < n; k++) chirp[k] = mkcf((float)c[k].real(), (float)c[k].imag());
+        d_tw.upload(tw.data(), M, stream);
+        d_bh.upload(hpos.data(), M, stream);
+        d_chirp.upload(chirp.data(), n, stream);
+        RR_HIP(hipStreamSynchronize(stream));
+        return;
+    }
     while (((size_t)1 << log2n) < n) log2n++;
     std::vector<cf> tw(n);
     for (size_t k = 0; k < n; k++) {
@@ -974,7 +1004,8 @@ int FftStream::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     size_t len = std::min(in_len, out_cap);                                    // :82-83
     len -= len % size;
     prof_begin(s);
-    launch_fft_frames(log2n, static_cast<const cf*>(in), static_cast<cf*>(out), (long)(len / size), d_tw.p, d_tw4096.p, s);
+    if (log2m) launch_fft_bluestein(log2m, static_cast<const cf*>(in), static_cast<cf*>(out), (long)(len / size), (int)size, d_tw.p, d_bh.p, d_chirp.p, s);
+    else launch_fft_frames(log2n, static_cast<const cf*>(in), static_cast<cf*>(out), (long)(len / size), d_tw.p, d_tw4096.p, s);
     prof_end(s);
     *consumed = *produced = len;
     return RR_AGAIN;                                                           // :116

@@ -201,6 +201,9 @@ struct FftStream : Block {
     size_t size = 0;
     int log2n = 0;
     DevBuf<cf> d_tw, d_tw4096;
+    // sizes that are not a power of two (3..2048): Bluestein on a 2^log2m-point filter tile
+    int log2m = 0;
+    DevBuf<cf> d_bh, d_chirp;
     explicit FftStream(size_t size);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };

@@ -58,6 +58,11 @@ int fftfilt_split_bin(int p);
 // (tw4096 = w_4096^k: when given, 8192 / 16384-point frames run as 2 / 4 sub-transforms of 4096 points)
 void launch_fft_frames(int log2n, const cf* in, cf* out, long nframes, const cf* tw, const cf* tw4096, hipStream_t s);
 
+// ... of any other size N, 2 N - 1 <= 2^log2m <= 4096, by Bluestein's chirp-z convolution on the filter tile:
+// chirp[n] = exp(-i pi n^2 / N), n < N;  hpos = FFT_M(b) / M in position order, b[m] = conj(chirp[|m|]) wrapped mod M.
+void launch_fft_bluestein(int log2m, const cf* in, cf* out, long nframes, int N, const cf* tw, const cf* hpos,
+                          const cf* chirp, hipStream_t s);
+
 // Fused FftFilter -> RationalResampler -> QuadratureDemod over the same virtual stream.
 struct FmChainArgs {
     long A;            // filtered samples emitted before this call

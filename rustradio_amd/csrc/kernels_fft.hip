@@ -882,6 +882,42 @@ void k_fft_frames(const cf* __restrict__ in, cf* __restrict__ out, long nframes,
     }
 }
 
+// Frames of any other size N <= F/2 + 1 (the reference plans every size with rustfft, fft_stream.rs:43-44): Bluestein's
+// chirp-z identity n k = (n^2 + k^2 - (k - n)^2) / 2 turns the N-point transform into a circular convolution of F
+// points, which is exactly the filter tile:  X[k] = c[k] * IFFT_F( FFT_F(x c zero-padded) * B )[k],
+// c[n] = exp(-i pi n^2 / N), B = FFT_F(b) / F with b[m] = conj(c[|m|]) wrapped.  chirp = c, hpos = B in position order.
+template <int LOG2F>
+__global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
+void k_fft_bluestein(const cf* __restrict__ in, cf* __restrict__ out, long nframes, int N, const cf* __restrict__ tw,
+                     const cf* __restrict__ hpos, const cf* __restrict__ chirp) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    const int t = threadIdx.x;
+    TileXform<LOG2F, 0> X;
+    X.init(t, tw, hpos);
+    const creg* ch = reinterpret_cast<const creg*>(chirp);
+    for (TileIter it(nframes); it.tile < it.end; it.tile += it.step) {
+        const creg* p = reinterpret_cast<const creg*>(in) + it.tile * N + t;
+        creg v[16];
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            const int idx = n * T + t;
+            v[n] = idx < N ? cmul(p[n * T], ch[idx]) : mk(0.0f, 0.0f);
+        }
+        RR_PHASE();
+        X.run(v, lds, 0, nullptr);
+        creg* po = reinterpret_cast<creg*>(out) + it.tile * N + t;
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            const int idx = n * T + t;
+            if (idx < N) po[n * T] = cmul(v[n], ch[idx]);
+        }
+        RR_PHASE();
+    }
+}
+
 // Frames of 2..512 points: radix-2 Stockham autosort in LDS, one butterfly per thread and stage, 512
 // points (512/N frames) per 256-thread workgroup.  Small transforms are not the hot path.
 __global__ __launch_bounds__(256) void k_fft_small(const cf* __restrict__ in, cf* __restrict__ out, long nframes,
@@ -999,6 +1035,26 @@ static void launch_frames_one(const cf* in, cf* out, long nframes, const cf* tw,
     hipLaunchKernelGGL((k_fft_frames<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, in, out, nframes, tw);
     RR_HIP(hipGetLastError());
 }
+template <int LOG2F>
+static void launch_bluestein_one(const cf* in, cf* out, long nframes, int N, const cf* tw, const cf* hpos, const cf* chirp,
+                                 hipStream_t s) {
+    constexpr int F = 1 << LOG2F, T = F / 16;
+    const size_t smem = sizeof(cf) * lds_elems(F);
+    const long grid = grid_for_tiles(k_fft_bluestein<LOG2F>, T, smem, nframes);
+    hipLaunchKernelGGL((k_fft_bluestein<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, in, out, nframes, N, tw, hpos, chirp);
+    RR_HIP(hipGetLastError());
+}
+void launch_fft_bluestein(int log2m, const cf* in, cf* out, long nframes, int N, const cf* tw, const cf* hpos,
+                          const cf* chirp, hipStream_t s) {
+    if (nframes <= 0) return;
+    switch (log2m) {
+    case 10: launch_bluestein_one<10>(in, out, nframes, N, tw, hpos, chirp, s); break;
+    case 11: launch_bluestein_one<11>(in, out, nframes, N, tw, hpos, chirp, s); break;
+    case 12: launch_bluestein_one<12>(in, out, nframes, N, tw, hpos, chirp, s); break;
+    default: throw Error("fft_bluestein: unsupported tile size");
+    }
+}
+
 void launch_fft_frames(int log2n, const cf* in, cf* out, long nframes, const cf* tw, const cf* tw4096, hipStream_t s) {
     if (nframes <= 0) return;
     if (log2n == 13 && tw4096) { launch_frames_split<2>(in, out, nframes, tw4096, tw, s); return; }

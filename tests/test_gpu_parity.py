@@ -322,9 +322,11 @@ def test_sync_blocks_bit_exact(rr, stream_bytes):
          xc, stream_bytes=4_096_000)
 
 
-@pytest.mark.parametrize("size", [2, 4, 8, 64, 256, 512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("size", [2, 4, 8, 64, 256, 512, 1024, 2048, 4096, 8192, 16384,
+                                  3, 5, 12, 100, 257, 511, 513, 1000, 1023, 1025, 1500, 2047])
 def test_fftstream(rr, size):
-    """FftStream: whole frames only, forward unnormalised transform in natural bin order"""
+    """FftStream: whole frames only, forward unnormalised transform in natural bin order; sizes that are not a power
+    of two (the reference plans any size with rustfft) run as Bluestein chirp-z convolutions on the filter tiles"""
     n = max(5 * size + 3, 40_000)
     x = rnd_c(n, size)
     e = both(rr, lambda m: [m.FftStream(size)], x)
@@ -337,7 +339,7 @@ def test_fftstream(rr, size):
 
 
 def test_fftstream_rejects(rr):
-    for bad in (0, 3, 1000, 32768):
+    for bad in (0, 1, 2049, 3000, 12000, 32768):
         with pytest.raises(Exception):
             rr.FftStream(bad)
     b = rr.FftStream(1024)

@@ -200,7 +200,7 @@ def test_fftstream_restatement():
     e^{-2 pi i kn/N}, unnormalised — SURVEY §8c), whole frames only, zero in -> zero out (fft.rs:65-85)."""
     import numpy as np
     from oracle import pyoracle as orc
-    for size in (2, 4, 16, 128, 1024, 8192):
+    for size in (2, 4, 16, 128, 1024, 8192, 3, 12, 100, 1000, 1500):     # (not a power of two: the defining sum in f64)
         rng = np.random.default_rng(size)
         x = (rng.standard_normal(3 * size + 1) + 1j * rng.standard_normal(3 * size + 1)).astype(np.complex64)
         st, c, p, need, out = orc.FftStream(size).work(x, 10 * size)
