@@ -293,7 +293,7 @@ def FastFM() -> Block:
 
 
 def FftStream(size: int) -> Block:
-    """FftStream::new(src, size) (src/fft_stream.rs:40-117); power-of-two sizes 2..16384."""
+    """FftStream::new(src, size) (src/fft_stream.rs:40-117); every size 2..2048 and the powers of two up to 16384."""
     h = lib().rr_fftstream_create(size)
     if not h:
         raise ValueError(last_error())
