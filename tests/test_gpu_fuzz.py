@@ -167,3 +167,72 @@ def test_fuzz_device_rings(rr, seed):
     yh = run_chain(mk(), x, stream_bytes=ring)
     yd = run_chain_device(rr, mk(), x, stream_bytes=ring)
     assert len(yh) == len(yd) and np.array_equal(yh, yd)
+
+
+_FIR_PATHS = [{}, {"RR_FIR_DIRECT": "1"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0", "RR_FIR_HALF": "0"},
+              {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "1"}]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_fir_every_path(rr, monkeypatch, seed):
+    """Random FirFilter shapes (Complex and Float streams, real and Complex taps, decimations incl. 4 / 8 / 16 and
+    other even ones) through every arithmetic path the block can take: automatic choice, direct form, overlap-save
+    tiles with a decimating store, half-size inverse, pruned inverse — identical protocol, outputs within 1e-5."""
+    rng = np.random.default_rng(5000 + seed)
+    for k, v in _FIR_PATHS[seed % len(_FIR_PATHS)].items():
+        monkeypatch.setenv(k, v)
+    L = int(rng.choice([1, 5, 16, 33, 64, 127, 200, 255, 401, 600, 601, 1000, 1025, 2049]))
+    d = int(rng.choice([1, 2, 2, 4, 4, 6, 8, 8, 10, 16, 16, 22, 3, 5]))
+    if seed % len(_FIR_PATHS) == 1 and L > 700:
+        L = 257                                       # (the direct form's fallback for long decimating filters is slow)
+    n = int(rng.integers(L + d, 200_000))
+    real_in = bool(rng.integers(0, 3) == 0)
+    es = 4 if real_in else 8
+    ring = int(rng.choice([4_096_000, es * (L + d + int(rng.integers(8, 9000)))]))
+    if real_in:
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        taps = (rng.uniform(-1, 1, L) / max(1, L // 8)).astype(np.float32)
+    else:
+        x = _c(rng, n)
+        taps = _c(rng, L) / max(1, L // 8)
+        if rng.integers(0, 2):
+            taps = taps.real.astype(np.complex64)
+    _both(rr, lambda m: [m.FirFilter(taps, deci=d)], x, ring)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_hilbert_fir_and_even_ratio_chains(rr, monkeypatch, seed):
+    """The fused Hilbert -> FirFilter block with random shapes (pruned-inverse tiles for deci 4 / 8 / 16 or direct form)
+    and the fused FM chain with 1:even ratios (half-size inverse where the tile allows) against the oracle chains."""
+    rng = np.random.default_rng(7000 + seed)
+    monkeypatch.setenv("RR_FIR_PRUNE", str(seed % 2))
+    hn = int(rng.choice([3, 17, 65, 129]))
+    L = int(rng.choice([1, 31, 100, 255, 500, 900]))
+    d = int(rng.choice([1, 4, 8, 16, 3, 6]))
+    n = int(rng.integers(4 * (L + hn + d), 250_000))
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    taps = _c(rng, L) / max(1, L // 8)
+    if rng.integers(0, 2):
+        taps = taps.real.astype(np.complex64)
+    ring = int(rng.choice([4_096_000, 4 * (L + d + int(rng.integers(8, 9000)))]))
+    yo = run_chain([orc.Hilbert(hn), orc.FirFilter(taps, deci=d)], x)
+    yg = run_chain([rr.HilbertFir(hn, taps, d)], x, stream_bytes=ring)
+    assert len(yg) == len(yo)
+    if len(yo):
+        assert max_norm_err(yg, yo) <= TOL
+    # fused chain, interp 1 / even decimation
+    Lc = int(rng.choice([101, 300, 463, 800]))
+    D = int(rng.choice([2, 4, 6, 10, 50]))
+    xc = _c(rng, int(rng.integers(5000, 150_000)))
+    tc = _c(rng, Lc) / max(1, Lc // 4)
+    yo = run_chain([orc.FftFilter(tc), orc.RationalResampler(1, D), orc.QuadratureDemod(1.0)], xc)
+    ro = run_chain([orc.FftFilter(tc), orc.RationalResampler(1, D)], xc)
+    yg = run_chain([rr.FmChain(tc, 1, D, 1.0)], xc, stream_bytes=int(rng.choice([4_096_000, 8 * 30_000])))
+    assert len(yg) == len(yo)
+    if len(yo):
+        eps = TOL * float(np.max(np.abs(ro)))
+        mag = np.abs(ro.astype(np.complex128))
+        bound = TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30)
+        dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
+        dd = np.minimum(dd, 2 * np.pi - dd)
+        assert np.all(dd <= bound[:len(dd)])
