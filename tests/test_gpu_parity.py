@@ -164,6 +164,22 @@ def test_fir_translate(rr, mode):
         assert max_norm_err(yg, yo) <= TOL
 
 
+@pytest.mark.parametrize("deci,f", [(1, 2.1e6), (2, -7e6), (4, 11e6), (8, -12.5e6), (16, 3e6), (6, 1e6)])
+def test_fir_translate_on_tiles(rr, deci, f):
+    """.translate() (pre-rotated taps + output rotator, fir.rs:430-473) on the FFT-tile paths: 255 taps at deci 1 (plain
+    tiles), 2 / 6 (half-size inverse), 4 / 8 / 16 (pruned inverse)."""
+    x = rnd_c(60000, 5 + deci)
+    taps = orc.low_pass_complex(100e6, 5e6, 943e3)
+    assert len(taps) == 255
+    lo, lg = [], []
+    yo = run_chain([orc.FirFilter(taps, deci=deci, translate=(100e6, f))], x, log=lo, stream_bytes=8 * 9000)
+    blk = rr.FirFilter(taps, deci=deci, translate=(100e6, f), rotator=rr.ROT_REPLAY)
+    assert rr.fir_uses_fft_tiles(blk)
+    yg = run_chain([blk], x, log=lg, stream_bytes=8 * 9000)
+    assert lo == lg and len(yo) == len(yg)
+    assert max_norm_err(yg, yo) <= TOL
+
+
 @pytest.mark.parametrize("L", [1, 2, 5, 193, 401, 463, 512, 513, 1025, 2467, 3100, 3300, 5000, 8193, 12000, 16383])
 def test_fftfilter(rr, L):
     n = 200_000 if L < 1025 else 400_000
