@@ -153,7 +153,11 @@ rr_block *rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_p
  * ntaps <= 4094. */
 rr_block *rr_fm_multi_create(const rr_c32 *taps, size_t nchan, size_t ntaps, size_t interp, size_t deci,
                              float gain, int atan2_mode);
-/* number of output windows of a block (1 except rr_fm_multi_create) */
+/* The same fed by the RTL-SDR byte stream: RtlSdrDecode (src/rtlsdr_decode.rs:9-47) fused in front of the Tee, as in
+ * rr_fm_chain_u8_create (input windows, `consumed` and the WAIT_SRC `need` count BYTES). */
+rr_block *rr_fm_multi_u8_create(const rr_c32 *taps, size_t nchan, size_t ntaps, size_t interp, size_t deci,
+                                float gain, int atan2_mode);
+/* number of output windows of a block (1 except rr_fm_multi[_u8]_create) */
 size_t rr_block_out_windows(const rr_block *b);
 
 void rr_block_destroy(rr_block *b);

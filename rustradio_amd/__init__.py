@@ -347,5 +347,15 @@ def FmMulti(taps_per_channel, interp: int, deci: int, gain: float = 1.0, mode: i
     return Block(h, np.complex64, np.float32)
 
 
+def FmMultiU8(taps_per_channel, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
+    """RtlSdrDecode -> Tee -> N x FmChain fused: RTL-SDR bytes in, N f32 windows out (windows, consumed and the
+    WAIT_SRC need count bytes)."""
+    t = np.ascontiguousarray(taps_per_channel, np.complex64)
+    if t.ndim != 2:
+        raise ValueError("taps_per_channel must be [nchan][ntaps]")
+    h = lib().rr_fm_multi_u8_create(_ptr(t), t.shape[0], t.shape[1], interp, deci, gain, mode)
+    return Block(h, np.uint8, np.float32)
+
+
 def Hilbert(ntaps: int, wtype: int = WIN_HAMMING, parm: float = 0.0) -> Block:
     return Block(lib().rr_hilbert_create(ntaps, wtype, parm), np.float32, np.complex64)

@@ -145,6 +145,10 @@ rr_block* rr_fm_multi_create(const rr_c32* taps, size_t nchan, size_t ntaps, siz
                              int atan2_mode) {
     return make_block([&] { return new rr::FmMulti(taps, nchan, ntaps, interp, deci, gain, atan2_mode); });
 }
+rr_block* rr_fm_multi_u8_create(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain,
+                                int atan2_mode) {
+    return make_block([&] { return new rr::FmMulti(taps, nchan, ntaps, interp, deci, gain, atan2_mode, true); });
+}
 size_t rr_block_out_windows(const rr_block* b) { return b ? b->b->out_windows() : 0; }
 void rr_block_destroy(rr_block* b) { delete b; }
 

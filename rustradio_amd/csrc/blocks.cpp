@@ -702,8 +702,9 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
 }
 
 // ---- N FM chains on one shared source ---------------------------------------------------------------------
-FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float g, int m)
-    : Block("Tee>N x (FftFilter>RationalResampler>QuadratureDemod)", 8, 4), C(nchan) {
+FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float g, int m, bool u8)
+    : Block(u8 ? "RtlSdrDecode>Tee>N x (FftFilter>RationalResampler>QuadratureDemod)" : "Tee>N x (FftFilter>RationalResampler>QuadratureDemod)",
+            u8 ? 1 : 8, 4), C(nchan), iq8(u8) {
     if (nchan == 0 || nchan > 4096) throw Error("FmMulti: channel count must be 1..4096");
     chain.reset(new FmChain(taps, ntaps, interp, deci, g, m, false, 12));   // bookkeeping, carry state, twiddles; 3-pass tiles
     const int lg = chain->f->log2f;
@@ -735,6 +736,14 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     FmChain& ch = *chain;
     FftFilter* f = ch.f.get();
     *consumed = *produced = *need = 0;
+    if (iq8) in_len /= 2;                          // whole I/Q pairs; an odd trailing byte is never consumed
+    bool packed = iq8;
+    if (iq8 && ((uintptr_t)in & 1)) {              // odd-addressed byte window: decode out of line
+        decoded.reserve(std::max<size_t>(in_len, 1));
+        launch_rtlsdr_decode(static_cast<const unsigned char*>(in), decoded.p, (long)in_len, s);
+        in = decoded.p;
+        packed = false;
+    }
     const uint64_t S = f->nsamples;
     const int64_t I = ch.I, D = ch.D;
     auto N2 = [&](uint64_t y) { return (uint64_t)(((__int128)y * I + D - 1) / D); };
@@ -757,12 +766,19 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     }
     const uint64_t n_y = k * S;
     VSrc<cf> src{f->prefix[f->cur].p, (long)(f->L - 1 + f->pend_len), static_cast<const cf*>(in), (long)in_len};
+    VSrcIQ8 src8{f->prefix[f->cur].p, (long)(f->L - 1 + f->pend_len), static_cast<const rr::iq8*>(in), (long)in_len};
     if (k) {
         FmChainArgs a;
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = ch.gain; a.mode = ch.mode;
         prof_begin(s);
-        if (half_ok)
+        if (half_ok && packed)
+            launch_fm_multi_half_iq8(f->log2f, src8, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_tw_half.p,
+                                     d_hpos_all.p, (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (packed)
+            launch_fm_multi_iq8(f->log2f, src8, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_hpos_all.p,
+                                (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (half_ok)
             launch_fm_multi_half(f->log2f, src, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_tw_half.p,
                                  d_hpos_all.p, (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else
@@ -772,12 +788,17 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
     }
     if (*consumed) {
-        launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
+        if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
+        else launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
         f->cur ^= 1;
         f->pend_len = new_pend;
     }
     *produced = N3(n1 + n_y) - o_old;
     ch.n1 += n_y;
+    if (iq8) {                                     // the input stream counts bytes
+        *consumed *= 2;
+        if (st == RR_WAIT_SRC) *need *= 2;
+    }
     return st;
 }
 

@@ -160,7 +160,10 @@ struct FmMulti : Block {
     bool half_ok = false;
     DevBuf<cf> last_r[2];             // [C]
     int cur_lr = 0;
-    FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain, int mode);
+    // iq8: RTL-SDR byte input, RtlSdrDecode fused in front (windows, `consumed` and WAIT_SRC `need` count BYTES)
+    bool iq8 = false;
+    DevBuf<cf> decoded;               // odd-addressed byte windows are decoded out of line
+    FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false);
     size_t out_windows() const override { return C; }
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
     int work_host(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*) override;

@@ -94,6 +94,11 @@ bool fm_multi_supported(int log2f);
 void launch_fm_multi(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
                      int nchan, const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 
+// ... with the RtlSdrDecode conversion fused in front (window = u8 I/Q pairs)
+void launch_fm_multi_iq8(int log2f, VSrcIQ8 src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
+                         int nchan, const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+void launch_fm_multi_half_iq8(int log2f, VSrcIQ8 src, float* out, long out_stride, int L, const cf* tw, const cf* tw_half,
+                              const cf* hpos_all, int nchan, const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 // interp 1 and an even decimation on 2048-point tiles: per channel a folded 1024-point inverse on one wave
 // (k_fm_multi_half); tw_half = w_(F/2)^k.
 bool fm_multi_half_supported(int log2f, long I, long D, int L);

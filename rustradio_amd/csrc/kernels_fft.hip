@@ -1201,9 +1201,9 @@ void k_fm_chain(SRC src, float* __restrict__ out, int L, long ntiles, const cf* 
 // FFT of a tile is computed once, parked in LDS, and each channel only pays H_c * X, the inverse
 // FFT and the resample/demod epilogue.  On-GPU fan-out is free: the input tile is read from HBM
 // once per workgroup, not once per channel.
-template <int LOG2F>
+template <int LOG2F, class SRC>
 __global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
-void k_fm_multi(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, long ntiles,
+void k_fm_multi(SRC src, float* __restrict__ out, long out_stride, int L, long ntiles,
                 const cf* __restrict__ tw, const cf* __restrict__ hpos_all, int nchan, FmArgs a,
                 const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
     constexpr int F = 1 << LOG2F;
@@ -1281,9 +1281,9 @@ void k_fm_multi(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, l
 // inverse is an F/2-point transform.  For F = 2048 that is a 1024-point tile of ONE wave: each of the two waves of
 // the workgroup takes every other channel and runs product, fold, inverse and the resample / demod epilogue without
 // a single barrier (the full-size version needs four per channel), on half the arithmetic.
-template <int LOG2F>
+template <int LOG2F, class SRC>
 __global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
-void k_fm_multi_half(VSrc<cf> src, float* __restrict__ out, long out_stride, int L, long ntiles, long Sp,
+void k_fm_multi_half(SRC src, float* __restrict__ out, long out_stride, int L, long ntiles, long Sp,
                      const cf* __restrict__ tw, const cf* __restrict__ tw_half, const cf* __restrict__ hpos_all,
                      int nchan, FmArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
     constexpr int F = 1 << LOG2F, T = F / 16, LH = LOG2F - 1, FH = F / 2, TH = T / 2;
@@ -2031,8 +2031,8 @@ void launch_fm_chain_split_iq8(int nsub, VSrcIQ8 src, float* out, int L, const c
     else launch_fm_split_one<4>(src, out, L, tw4096, hs, wk, h, last_in, last_out, s);
 }
 
-template <int LOG2F>
-static void launch_fm_multi_one(VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
+template <int LOG2F, class SRC>
+static void launch_fm_multi_one(SRC src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
                                 int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
@@ -2044,8 +2044,8 @@ static void launch_fm_multi_one(VSrc<cf> src, float* out, long out_stride, int L
     const long ntiles = (h.n_y + Sp - 1) / Sp;
     if (ntiles <= 0) return;
     const size_t smem = 2 * sizeof(cf) * lds_elems(F);
-    const long grid = grid_for_tiles(k_fm_multi<LOG2F>, T, smem, ntiles);
-    hipLaunchKernelGGL((k_fm_multi<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles,
+    const long grid = grid_for_tiles(k_fm_multi<LOG2F, SRC>, T, smem, ntiles);
+    hipLaunchKernelGGL((k_fm_multi<LOG2F, SRC>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles,
                        tw, hpos_all, nchan, a, last_in, last_out);
     RR_HIP(hipGetLastError());
 }
@@ -2054,8 +2054,9 @@ bool fm_multi_half_supported(int log2f, long I, long D, int L) {
     if (log2f != 11 || I != 1 || D < 2 || (D & 1)) return false;
     return (((1L << log2f) - L + 1) - D - 1) / 2 > 0;
 }
-void launch_fm_multi_half(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* tw_half,
-                          const cf* hpos_all, int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+template <class SRC>
+static void launch_fm_multi_half_t(int log2f, SRC src, float* out, long out_stride, int L, const cf* tw, const cf* tw_half,
+                                   const cf* hpos_all, int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
     constexpr int LOG2F = 11, F = 1 << LOG2F, T = F / 16;
     if (!fm_multi_half_supported(log2f, h.I, h.D, L)) throw Error("fm_multi_half: unsupported shape");
     FmArgs a;
@@ -2066,10 +2067,18 @@ void launch_fm_multi_half(int log2f, VSrc<cf> src, float* out, long out_stride, 
     const long ntiles = (h.n_y + Sp - 1) / Sp;
     if (ntiles <= 0) return;
     const size_t smem = sizeof(cf) * (2 * lds_elems(F) + 64);
-    const long grid = grid_for_tiles(k_fm_multi_half<LOG2F>, T, smem, ntiles);
-    hipLaunchKernelGGL((k_fm_multi_half<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles, Sp,
+    const long grid = grid_for_tiles(k_fm_multi_half<LOG2F, SRC>, T, smem, ntiles);
+    hipLaunchKernelGGL((k_fm_multi_half<LOG2F, SRC>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles, Sp,
                        tw, tw_half, hpos_all, nchan, a, last_in, last_out);
     RR_HIP(hipGetLastError());
+}
+void launch_fm_multi_half(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* tw_half,
+                          const cf* hpos_all, int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    launch_fm_multi_half_t(log2f, src, out, out_stride, L, tw, tw_half, hpos_all, nchan, h, last_in, last_out, s);
+}
+void launch_fm_multi_half_iq8(int log2f, VSrcIQ8 src, float* out, long out_stride, int L, const cf* tw, const cf* tw_half,
+                              const cf* hpos_all, int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    launch_fm_multi_half_t(log2f, src, out, out_stride, L, tw, tw_half, hpos_all, nchan, h, last_in, last_out, s);
 }
 
 template <class SRC>
@@ -2116,14 +2125,23 @@ void launch_fftfilt_half(VSrc<cf> src, cf* out, long n_out, int L, int d, const 
 
 bool fm_multi_supported(int log2f) { return log2f >= 10 && log2f <= 12; }
 
-void launch_fm_multi(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
-                     int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+template <class SRC>
+static void launch_fm_multi_t(int log2f, SRC src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
+                              int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
     switch (log2f) {
     case 10: launch_fm_multi_one<10>(src, out, out_stride, L, tw, hpos_all, nchan, h, last_in, last_out, s); break;
     case 11: launch_fm_multi_one<11>(src, out, out_stride, L, tw, hpos_all, nchan, h, last_in, last_out, s); break;
     case 12: launch_fm_multi_one<12>(src, out, out_stride, L, tw, hpos_all, nchan, h, last_in, last_out, s); break;
     default: throw Error("fm_multi: unsupported tile size");
     }
+}
+void launch_fm_multi(int log2f, VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
+                     int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    launch_fm_multi_t(log2f, src, out, out_stride, L, tw, hpos_all, nchan, h, last_in, last_out, s);
+}
+void launch_fm_multi_iq8(int log2f, VSrcIQ8 src, float* out, long out_stride, int L, const cf* tw, const cf* hpos_all,
+                         int nchan, const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    launch_fm_multi_t(log2f, src, out, out_stride, L, tw, hpos_all, nchan, h, last_in, last_out, s);
 }
 
 }  // namespace rr

@@ -654,6 +654,44 @@ def test_fm_multi_even_decimations(rr, L, D, nch):
         _demod_close(yg, yo, ro)
 
 
+@pytest.mark.parametrize("D,odd", [(6, False), (6, True), (5, False), (2, True)])
+def test_fm_multi_u8_shared_source(rr, D, odd):
+    """rr.FmMultiU8 (RtlSdrDecode fused in front of the multi-channel kernel) == RtlSdrDecode -> FftFilter(taps_c) ->
+    RationalResampler -> QuadratureDemod of the oracle per channel; byte-counted windows, odd-addressed windows."""
+    fs, n, nch = 2.4e6, 200_000, 3
+    proto = orc.low_pass_complex(fs, 100e3, 12.5e3)
+    k = np.arange(len(proto), dtype=np.float64)
+    taps = np.stack([(proto.astype(np.complex128) * np.exp(2j * np.pi * ((c - 1) * 30e3) * k / fs)).astype(np.complex64)
+                     for c in range(nch)])
+    z = fm_signal(n, fs, 0.0, 31 + D)
+    b = np.empty(2 * n, np.uint8)
+    b[0::2] = np.clip(np.round(z.real / 0.008 * 0.5 + 127), 0, 255).astype(np.uint8)
+    b[1::2] = np.clip(np.round(z.imag / 0.008 * 0.5 + 127), 0, 255).astype(np.uint8)
+    blk = rr.FmMultiU8(taps, 1, D, 1.0)
+    cap_in = 81_001 if odd else 4_096_000
+    outs = [[] for _ in range(nch)]
+    pos, ring = 0, np.zeros(0, np.uint8)
+    pad = np.zeros(1, np.uint8)
+    while True:
+        take = min(cap_in - len(ring), len(b) - pos)
+        ring = np.concatenate([ring, b[pos:pos + take]]); pos += take
+        win = np.concatenate([pad, ring])[1:] if odd else ring          # (odd: an odd-addressed view of the same bytes)
+        st, c, p, need, out = blk.work(win, 60_000)
+        ring = ring[c:]
+        out = out.reshape(nch, -1)
+        for ch in range(nch):
+            if p:
+                outs[ch].append(out[ch])
+        if take == 0 and c == 0 and p == 0:
+            break
+    for ch in range(nch):
+        yg = np.concatenate(outs[ch])
+        front = [orc.RtlSdrDecode(), orc.FftFilter(taps[ch]), orc.RationalResampler(1, D)]
+        yo = run_chain(front + [orc.QuadratureDemod(1.0)], b)
+        ro = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps[ch]), orc.RationalResampler(1, D)], b)
+        _demod_close(yg, yo, ro)
+
+
 def test_fm_multi_long_filters(rr):
     """FmMulti with the rtl_fm-sized filter (2467 taps -> 4096-point tiles); more than 4094 taps is refused"""
     fs, n = 1.024e6, 250_000
