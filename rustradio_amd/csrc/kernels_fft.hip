@@ -483,8 +483,8 @@ void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L,
 //   REAL2 = false: Complex stream (decimating FirFilter<Complex>, deci == D).
 //   REAL2 = true : real stream, Complex taps t = Gr + i Gi (the fused Hilbert -> FirFilter): two overlap-save
 //                  segments a, b ride in the re / im lanes (k_fftfilt_real); the real tap sets act on them as
-//                  Gr*a + i Gr*b and Gi*a + i Gi*b (two products, two sums, two tails), and the outputs are
-//                  y_a = (Gr*a) + i (Gi*a),  y_b = (Gr*b) + i (Gi*b).
+//                  Gr*a + i Gr*b and Gi*a + i Gi*b (two products, two sums; a batch is D/2 tiles x 2 responses, so
+//                  one park area and one tail), and the outputs are y_a = (Gr*a) + i (Gi*a), y_b = (Gr*b) + i (Gi*b).
 template <int T>
 __device__ __forceinline__ void prune_tail(creg* v, creg* park, int t, const creg* __restrict__ twb) {
     creg* own = park + 17 * t;                          // lds_pad(16 t + k) = 17 t + k
@@ -515,8 +515,8 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
     constexpr bool REAL2 = MODE != 0, TWO = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     creg* lds = reinterpret_cast<creg*>(smem_raw);
-    creg* park = lds + lds_elems(F);
-    creg* parkb = park + PARK;                          // MODE 1 only
+    creg* park = lds + lds_elems(F);                    // D slots of 256 values: D tiles, or (MODE 1) D/2 tiles x 2 responses
+    constexpr int BT = TWO ? D / 2 : D;                 // tiles per batch
     const int t = threadIdx.x;
     const int first = L - 1;
     const long fq = first / D;                          // kept samples in front of a tile's first valid one
@@ -527,7 +527,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
     // pass-1 twiddles w_16D^(k (t % D)) — 16 D distinct values — are read per tile from an LDS table; the second
     // response is re-read per tile (both sets of twiddles plus one response spill 80-110 B/lane, the LDS table
     // plus both responses 150 B/lane — and a spill waits on the whole in-order vmcnt queue).
-    creg* tw1tab = park + (TWO ? 2 : 1) * PARK;         // real streams only: w_16D^j, j < 16 D
+    creg* tw1tab = park + PARK;                         // real streams only: w_16D^j, j < 16 D
     creg hrA[16], hrB[16], tw0p[15];
     const int lo1 = PassGeom<LOG2F, 1>::lo(t);
     if constexpr (REAL2) {
@@ -540,11 +540,11 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
         X.init(t, tw, hpos2);
     }
     creg* out_reg = reinterpret_cast<creg*>(out);
-    const long nbatch = (ntiles + D - 1) / D;
+    const long nbatch = (ntiles + BT - 1) / BT;
     for (TileIter it(nbatch); it.tile < it.end; it.tile += it.step) {
-        const long tile0 = it.tile * D;
+        const long tile0 = it.tile * BT;
 #pragma unroll 1
-        for (int b = 0; b < D; b++) {
+        for (int b = 0; b < BT; b++) {
             const long tile = tile0 + b;
             creg v[16];
             if constexpr (REAL2) {
@@ -590,7 +590,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
                 creg z = cmul(v[u * D], h1[u * D]);
 #pragma unroll
                 for (int k = 1; k < D; k++) z = cadd(z, cmul(v[u * D + k], h1[u * D + k]));
-                park[lds_pad(256 * b + t + T * u)] = z;
+                park[lds_pad(256 * (TWO ? 2 * b : b) + t + T * u)] = z;
             }
             if constexpr (TWO) {
                 RR_PHASE();
@@ -600,7 +600,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
                     creg zb = cmul(v[u * D], hrB[u * D]);
 #pragma unroll
                     for (int k = 1; k < D; k++) zb = cadd(zb, cmul(v[u * D + k], hrB[u * D + k]));
-                    parkb[lds_pad(256 * b + t + T * u)] = zb;
+                    park[lds_pad(256 * (2 * b + 1) + t + T * u)] = zb;
                 }
             }
             RR_PHASE();
@@ -634,30 +634,26 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             for (int n1 = 0; n1 < 16; n1++)
                 if (16 * n1 >= lo && 16 * n1 < lim) po[16 * n1] = p[n1];
         } else {
-            // tail 0: (Gr*a) + i (Gr*b) = the real parts of y_a (segment 2 tile) and y_b (segment 2 tile + 1), stashed
-            // in the thread's own slots of the (now idle) exchange area; tail 1: (Gi*a) + i (Gi*b) = their imaginary
-            // parts; then whole Complex samples are stored (4-byte stores of the two parts cost 1.34x the write traffic)
-            const long ma = 2 * (tile0 + b) * Sd - fq + n2, mb = ma + Sd;
-            const long ra = n_out - ma, rb = n_out - mb;
-            const int lima = ra < hi ? (int)ra : hi, limb = rb < hi ? (int)rb : hi;
+            // slot = (tile b2, response c): c = 0 holds (Gr*a) + i (Gr*b), the real parts of y_a (segment 2 tile) and
+            // y_b (segment 2 tile + 1); c = 1 holds (Gi*a) + i (Gi*b), their imaginary parts.  The two threads of a
+            // pair (t ^ 16) swap results through the (now idle) exchange area; thread c then stores whole Complex
+            // samples of segment 2 tile + c (storing the parts with 4-byte strided stores costs 1.34x the write traffic).
+            const int b2 = b >> 1, c = b & 1;
+            creg p[16];
+            prune_tail<T>(p, park, t, twb);
             creg* stash = lds + 17 * t;
-            {
-                creg p[16];
-                prune_tail<T>(p, park, t, twb);
 #pragma unroll
-                for (int n1 = 0; n1 < 16; n1++) stash[n1] = p[n1];
-            }
-            {
-                creg p[16];
-                prune_tail<T>(p, parkb, t, twb);
-                creg* pa = out_reg + ma;
-                creg* pb = out_reg + mb;
+            for (int n1 = 0; n1 < 16; n1++) stash[n1] = p[n1];
+            tile_sync<T>();
+            const creg* other = lds + 17 * (t ^ 16);
+            const long m0 = (2 * (tile0 + b2) + c) * Sd - fq + n2;
+            const long room = n_out - m0;
+            const int lim = room < hi ? (int)room : hi;
+            creg* po = out_reg + m0;
 #pragma unroll
-                for (int n1 = 0; n1 < 16; n1++) {
-                    const creg q = stash[n1];
-                    if (16 * n1 >= lo && 16 * n1 < lima) pa[16 * n1] = mk(q.x, p[n1].x);
-                    if (16 * n1 >= lo && 16 * n1 < limb) pb[16 * n1] = mk(q.y, p[n1].y);
-                }
+            for (int n1 = 0; n1 < 16; n1++) {
+                const creg q = other[n1];
+                if (16 * n1 >= lo && 16 * n1 < lim) po[16 * n1] = c ? mk(q.y, p[n1].y) : mk(p[n1].x, q.x);
             }
         }
         tile_sync<T>();                                  // the next batch parks into the slots just read
@@ -1801,8 +1797,9 @@ static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_ou
     const long Sd = S / D;
     const long nseg = (n_out + Sd - 1) / Sd;
     const long ntiles = MODE ? (nseg + 1) / 2 : nseg;
-    const size_t smem = sizeof(cf) * (lds_elems(F) + (MODE == 1 ? 2 : 1) * lds_elems(256 * D) + (MODE ? 16 * D : 0));
-    const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, MODE>, T, smem, (ntiles + D - 1) / D);
+    const size_t smem = sizeof(cf) * (lds_elems(F) + lds_elems(256 * D) + (MODE ? 16 * D : 0));
+    constexpr int BT = MODE == 1 ? D / 2 : D;             // tiles per batch (MODE 1: two responses per tile)
+    const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, MODE>, T, smem, (ntiles + BT - 1) / BT);
     hipLaunchKernelGGL((k_fftfilt_prune<LOG2F, MODE>), dim3((unsigned)grid), dim3(T), smem, s, csrc, rsrc, out, n_out, L, S,
                        ntiles, tw, hpos2, hpos2b, twb);
     RR_HIP(hipGetLastError());
