@@ -1285,6 +1285,7 @@ void k_fm_multi_half(SRC src, float* __restrict__ out, long out_stride, int L, l
     constexpr int F = 1 << LOG2F, T = F / 16, LH = LOG2F - 1, FH = F / 2, TH = T / 2;
     constexpr int NP = Plan<LOG2F>::NP;
     constexpr int D3 = F / 256, DH = D3 / 2;             // last radix of the full / the half plan
+    constexpr int XROW = 256 + 8;                        // parked spectrum: D3 rows of 256 groups
     static_assert(NP == 3, "3-pass plans");
     static_assert(TH == 64, "one wave per half-size tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1314,7 +1315,12 @@ void k_fm_multi_half(SRC src, float* __restrict__ out, long out_stride, int L, l
             load_tile16<LOG2F>(v, src, ys, t, lds);
             RR_PHASE();
             XF.forward(v, lds);
-            lds_store<LOG2F, NP - 1>(v, t, ldsX);
+            // parked k3-major (rows of 256 groups + 8 slots of padding): both this store and the waves' reads below are
+            // lane-consecutive in the group index, i.e. conflict-free
+#pragma unroll
+            for (int u = 0; u < 16 / D3; u++)
+#pragma unroll
+                for (int k = 0; k < D3; k++) ldsX[k * XROW + t + T * u] = v[u * D3 + k];
         }
         tile_sync<T>();                                  // the spectrum is read by both waves
         const long y_lo = tile * Sp, y_hi = min((tile + 1) * Sp, a.n_y);
@@ -1341,10 +1347,10 @@ void k_fm_multi_half(SRC src, float* __restrict__ out, long out_stride, int L, l
                     for (int uu = 0; uu < 8 / DH; uu++) {
                         const int u = half * (8 / DH) + uu;
                         const int g = th + TH * u;           // group 16 k1 + k2, the same in both plans
-                        const creg* xx = ldsX + lds_pad(g * D3);   // (the D3 <= 16 slots of a group share one padding step)
+                        const creg* xx = ldsX + g;
 #pragma unroll
                         for (int k = 0; k < DH; k++)
-                            w[u * DH + k] = cadd(cmul(xx[k], h[uu * D3 + k]), cmul(xx[k + DH], h[uu * D3 + k + DH]));
+                            w[u * DH + k] = cadd(cmul(xx[k * XROW], h[uu * D3 + k]), cmul(xx[(k + DH) * XROW], h[uu * D3 + k + DH]));
                     }
                     RR_PHASE();
                 }
