@@ -263,6 +263,33 @@ def test_resampler_bit_exact(rr, I, D, dtype):
     both(rr, lambda m: [m.RationalResampler(I, D, dtype)], x, exact=True, stream_bytes=np.dtype(dtype).itemsize * 4001)
 
 
+def test_quaddemod_exact_atan2_accuracy(rr):
+    """The exact flavour's atan2 against f64 atan2 over all octants, axes, equal magnitudes, zeros, tiny and huge
+    magnitudes: <= 1e-6 rad; libm's special values (signed zeros, infinities, NaN)."""
+    rng = np.random.default_rng(99)
+    ang = np.concatenate([np.linspace(-np.pi, np.pi, 20001), np.arange(-8, 9) * np.pi / 4, rng.uniform(-np.pi, np.pi, 20000)])
+    mag = np.concatenate([np.ones(20001), np.ones(17), 10.0 ** rng.uniform(-15, 15, 20000)])
+    z = mag * np.exp(1j * ang)
+    # x[2i] = 1, x[2i+1] = z_i  ->  conj(1) * z = z at the even outputs
+    x = np.ones(2 * len(z), np.complex64)
+    x[1::2] = z.astype(np.complex64)
+    st, c, p, need, out = rr.QuadratureDemod(1.0, rr.ATAN2_EXACT).work(x, len(x))
+    got = out[0::2][:len(z)].astype(np.float64)
+    zz = x[1::2].astype(np.complex128)
+    ref = np.arctan2(zz.imag, zz.real)
+    d = np.abs(got - ref)
+    d = np.minimum(d, 2 * np.pi - d)
+    assert np.max(d) <= 1e-6, float(np.max(d))
+    # special values (the oracle is libm's atan2f)
+    sp = np.array([1, 0, 1, -1, 1, complex(0.0, 0.0), 1, complex(-1.0, 0.0), 1, complex(-1.0, -0.0), 1, complex(np.inf, np.inf),
+                   1, complex(-np.inf, np.inf), 1, complex(np.nan, 1.0), 1, complex(1e-40, 1e-40), 1, complex(3e38, -3e38)], np.complex64)
+    yo = orc.QuadratureDemod(1.0, orc.ATAN2_EXACT if hasattr(orc, "ATAN2_EXACT") else 0).work(sp, len(sp))[4]
+    yg = rr.QuadratureDemod(1.0, rr.ATAN2_EXACT).work(sp, len(sp))[4]
+    assert len(yo) == len(yg)
+    for a, b in zip(yo, yg):
+        assert (np.isnan(a) and np.isnan(b)) or abs(float(a) - float(b)) <= 1e-6, (a, b)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_quaddemod(rr, mode):
     x = rnd_c(300_000, 8)
