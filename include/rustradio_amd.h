@@ -124,7 +124,11 @@ rr_block *rr_hilbert_create(size_t ntaps, int window, float window_parm);
  * sequence (src/fft_filter.rs:290-354, src/rational_resampler.rs:155-206,
  * src/quadrature_demod.rs:46-113); the filtered and resampled streams never reach HBM.
  * work(): WAIT_DST(n) when the next filter block's outputs do not fit, else consumes like
- * FftFilter (whole pending block) and WAIT_SRC(nsamples - pending). */
+ * FftFilter (whole pending block) and WAIT_SRC(nsamples - pending).
+ * The output stream must be able to hold one filter block's worth of demodulated samples,
+ * ceil(nsamples * interp / deci) (the three separate blocks need only `nsamples` Complex slots in THEIR rings):
+ * with the reference's 4,096,000-byte streams that is any ratio up to interp/deci ~ 60 at 16384-point blocks; a
+ * smaller output window returns WAIT_DST(n) forever — use the three blocks there. */
 rr_block *rr_fm_chain_create(const rr_c32 *taps, size_t ntaps, size_t interp, size_t deci,
                              float gain, int atan2_mode);
 

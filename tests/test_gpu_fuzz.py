@@ -72,6 +72,8 @@ def test_fuzz_fftfilter_and_chain(rr, seed):
         blk = rr.FmChain(taps, I, D, 1.0)
     except Exception:
         return                                          # decimation too large for the tile: refused, not wrong
+    if ring // 4 < -(-nsamp * I // D) + 1:
+        return                                          # the fused block emits whole filter blocks: needs room for one (header)
     yg = run_chain([blk], x, stream_bytes=ring)
     assert len(yg) == len(yo)
     if len(yo):
