@@ -238,3 +238,60 @@ def test_fuzz_hilbert_fir_and_even_ratio_chains(rr, monkeypatch, seed):
         dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
         dd = np.minimum(dd, 2 * np.pi - dd)
         assert np.all(dd <= bound[:len(dd)])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_fftstream_float_filters_and_multi(rr, seed):
+    """FftStream of any size 2..2048 (Bluestein for sizes that are not a power of two), FftFilterFloat / FirFilter<Float>
+    of random lengths, and the multi-channel fused chain (Complex and RTL-SDR byte input, even and odd decimations)."""
+    rng = np.random.default_rng(9000 + seed)
+    size = int(rng.integers(2, 2049))
+    x = _c(rng, int(rng.integers(size, 12 * size + 5)))
+    _both(rr, lambda m: [m.FftStream(size)], x, int(rng.choice([4_096_000, 8 * (size + int(rng.integers(1, 3 * size)))])))
+    L = int(rng.choice([1, 3, 24, 65, 300, 1000, 3584, 3585, 5000]))
+    xf = rng.uniform(-1, 1, int(rng.integers(10, 200_000))).astype(np.float32)
+    tf = (rng.uniform(-1, 1, L) / max(1, L // 4)).astype(np.float32)
+    nsamp = 2 * (1 << int(np.ceil(np.log2(L)))) - L if L > 1 else 1
+    _both(rr, lambda m: [m.FftFilterFloat(tf)], xf, int(rng.choice([4_096_000, 4 * (nsamp + int(rng.integers(1, 4000)))])))
+    # multi-channel chain
+    Lm = int(rng.choice([100, 463, 700, 1500]))
+    D = int(rng.choice([2, 5, 6, 8, 30]))
+    nch = int(rng.integers(1, 5))
+    u8 = bool(rng.integers(0, 2))
+    n = int(rng.integers(20_000, 120_000))
+    taps = np.stack([_c(rng, Lm) / max(1, Lm // 4) for _ in range(nch)])
+    if u8:
+        src = rng.integers(0, 256, 2 * n).astype(np.uint8)
+        blk = rr.FmMultiU8(taps, 1, D, 1.0)
+        front = lambda c: [orc.RtlSdrDecode(), orc.FftFilter(taps[c]), orc.RationalResampler(1, D)]
+        cap_in = int(rng.choice([4_096_000, 2 * int(rng.integers(9000, 60000))]))
+    else:
+        src = _c(rng, n)
+        blk = rr.FmMulti(taps, 1, D, 1.0)
+        front = lambda c: [orc.FftFilter(taps[c]), orc.RationalResampler(1, D)]
+        cap_in = int(rng.choice([512_000, int(rng.integers(9000, 60000))]))
+    outs = [[] for _ in range(nch)]
+    pos, ring = 0, np.zeros(0, src.dtype)
+    while True:
+        take = min(cap_in - len(ring), len(src) - pos)
+        ring = np.concatenate([ring, src[pos:pos + take]]); pos += take
+        st, c, p, need, out = blk.work(ring, 1_024_000)
+        ring = ring[c:]
+        out = out.reshape(nch, -1)
+        for ch in range(nch):
+            if p:
+                outs[ch].append(out[ch])
+        if take == 0 and c == 0 and p == 0:
+            break
+    for ch in range(nch):
+        yg = np.concatenate(outs[ch]) if outs[ch] else np.zeros(0, np.float32)
+        yo = run_chain(front(ch) + [orc.QuadratureDemod(1.0)], src)
+        ro = run_chain(front(ch), src)
+        assert len(yg) == len(yo)
+        if len(yo):
+            eps = TOL * float(np.max(np.abs(ro)))
+            mag = np.abs(ro.astype(np.complex128))
+            bound = TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30)
+            dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
+            dd = np.minimum(dd, 2 * np.pi - dd)
+            assert np.all(dd <= bound[:len(dd)])

@@ -22,7 +22,8 @@ class MP:
 
 off, cnt = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 200
 fails = 0
-for name in ("test_fuzz_fir", "test_fuzz_fftfilter_and_chain", "test_fuzz_fir_every_path", "test_fuzz_hilbert_fir_and_even_ratio_chains"):
+names = [n for n in dir(F) if n.startswith("test_fuzz_")] if len(sys.argv) <= 3 else sys.argv[3:]
+for name in names:
     fn = getattr(F, name)
     takes_mp = "monkeypatch" in fn.__code__.co_varnames[:fn.__code__.co_argcount]
     for seed in range(off, off + cnt):
