@@ -1414,6 +1414,7 @@ void k_fm_chain_half(SRC src, float* __restrict__ out, int L, long ntiles, long 
     constexpr int F = 1 << LOG2F, T = F / 16, LH = LOG2F - 1, FH = F / 2, TH = T / 2;
     constexpr int NP = Plan<LOG2F>::NP;
     constexpr int D3 = F / 256, DH = D3 / 2, U = 16 / D3;
+    constexpr int YROW = 256 + 8;                        // parked folded spectrum: DH rows of 256 groups (DH * YROW <= lds_elems(FH))
     constexpr int N1 = PassGeom<LOG2F, 1>::R * PassGeom<LOG2F, 1>::P;      // 128: pass-1 twiddles of the full plan
     constexpr int N1H = PassGeom<LH, 1>::R * PassGeom<LH, 1>::P;          // 64: ... of the half plan
     static_assert(NP == 3 && TH == 64, "one wave per half-size tile");
@@ -1470,8 +1471,8 @@ void k_fm_chain_half(SRC src, float* __restrict__ out, int L, long ntiles, long 
             for (int u = 0; u < U; u++) {
                 const int g = t + T * u;                 // group 16 k1 + k2; its folded values sit at g * DH + k in the half plan
 #pragma unroll
-                for (int k = 0; k < DH; k++)
-                    py[lds_pad(g * DH + k)] = cadd(cmul(v[u * D3 + k], hreg[u * D3 + k]), cmul(v[u * D3 + k + DH], hreg[u * D3 + k + DH]));
+                for (int k = 0; k < DH; k++)         // parked k3-major: lane-consecutive (conflict-free) here and when read back
+                    py[k * YROW + g] = cadd(cmul(v[u * D3 + k], hreg[u * D3 + k]), cmul(v[u * D3 + k + DH], hreg[u * D3 + k + DH]));
             }
             RR_PHASE();
         }
@@ -1483,7 +1484,13 @@ void k_fm_chain_half(SRC src, float* __restrict__ out, int L, long ntiles, long 
             asm volatile("" : "+v"(th));
             creg* ldsH = lds + hg * lds_elems(FH);
             creg w[16], twl[15];
-            lds_load<LH, 2>(w, th, ldsY + hg * lds_elems(FH));
+            {
+                const creg* py = ldsY + hg * lds_elems(FH) + th;
+#pragma unroll
+                for (int u = 0; u < 16 / DH; u++)
+#pragma unroll
+                    for (int k = 0; k < DH; k++) w[u * DH + k] = py[k * YROW + TH * u];
+            }
             inv_pass<LH, 2>(w, twl);                     // (P == 1: no twiddles)
             RR_PHASE();
             lds_store<LH, 2>(w, th, ldsH);
