@@ -63,6 +63,29 @@ const char *rr_last_error(void);            /* thread-local message of the last 
 int         rr_device_count(void);          /* number of visible HIP devices (0 if none) */
 int         rr_set_device(int ordinal);     /* device used by blocks created afterwards on this thread */
 
+/* Path-selection overrides for ONE block: rr_next_create_options(&o) applies `o` to the next rr_*_create /
+ * rr_dstream_create call made on the calling thread and is cleared when that call returns (thread-local, so
+ * handles stay independent and nothing in the process environment changes what a block does).  A zeroed struct =
+ * every choice automatic.  Every path stays within the 1e-5 parity bar; the overrides exist so that the parity
+ * tests and A/B probes can reach each kernel. */
+enum rr_path { RR_PATH_AUTO = 0, RR_PATH_DIRECT = 1, RR_PATH_FFT = 2 };
+typedef struct {
+    int fir_path;           /* FirFilter / Hilbert>FirFilter: RR_PATH_DIRECT = direct-form kernels only,
+                               RR_PATH_FFT = overlap-save tiles for every shape they cover */
+    int fir_prune;          /* decimations 4 / 8 / 16: pruned inverse transform, > 0 on, < 0 off */
+    int fir_half;           /* other even decimations: half-size inverse, < 0 off */
+    int fir_cfg_plus1;      /* direct-form FIR tile shape 0..7, stored + 1 (0 = automatic) */
+    int fft_log2f;          /* FftFilter: overlap-save tile of 2^n points, n = 10..14 */
+    int fft_no_split;       /* tiles of 8192 / 16384 points as ONE workgroup instead of 2 / 4 sub-transforms */
+    int fftfloat_complex;   /* FftFilterFloat: the reference's f32 -> Complex -> FftFilter -> .re inner path */
+    int fm_full;            /* fused FM chains: full-size inverse transforms for 1:even ratios too */
+    int fm_poly;            /* fused FM chains: < 0 = no polyphase (decimate-first) tiles */
+    int dstream_no_vmm;     /* rr_dstream_create: the copying fallback ring instead of the double mapping */
+    int host_sync_copies;   /* rr_block_work: plain staged copies instead of the pinned, overlapped pipeline */
+    int reserved[5];
+} rr_build_opts;
+int rr_next_create_options(const rr_build_opts *opts);   /* NULL clears a pending override */
+
 /* ---- tap designers (setup time; host f32, same operation order as the reference) */
 float  rr_max_attenuation(int window);                                   /* src/window.rs:67-75 */
 int    rr_make_window(int window, float parm, size_t ntaps, float *out); /* src/window.rs:79-185 */
@@ -241,7 +264,7 @@ int rr_block_work_streams(rr_block *b, rr_dstream *src, rr_dstream *dst, size_t 
 int rr_block_set_profiling(rr_block *b, int on);
 int rr_block_profile(rr_block *b, double *total_ms, size_t *launches, int reset);
 
-/* Measurement builds only (make ABLATE=1, env RR_FFT_STAMPS=1): 16 s_memtime stamps taken at the
+/* Measurement builds only (make TIMING=1, env RR_FFT_STAMPS=1): 16 s_memtime stamps taken at the
  * phase boundaries of one FftFilter tile; returns 0 in product builds. */
 int rr_debug_fft_stamps(unsigned long long *out16);
 

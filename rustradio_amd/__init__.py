@@ -23,7 +23,9 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import lib, last_error, LIB_PATH  # noqa: F401
+import contextlib
+
+from ._lib import BuildOpts, lib as _raw_lib, last_error, LIB_PATH  # noqa: F401
 
 # BlockRet (src/block.rs:12-70)
 AGAIN, WAIT_SRC, WAIT_DST, EOF, PENDING, ERR = 0, 1, 2, 3, 4, -1
@@ -32,6 +34,56 @@ WIN_HAMMING, WIN_BLACKMAN, WIN_BLACKMAN_HARRIS, WIN_HAMMING_PARM = 0, 1, 2, 3
 ATAN2_EXACT, ATAN2_FAST = 0, 1
 ROT_MODEL, ROT_REPLAY = 0, 1
 DEFAULT_STREAM_SIZE = 4_096_000  # bytes, src/stream.rs:105
+
+
+# ---- per-block path overrides (rr_build_opts) ---------------------------------------------
+# `build_options(...)` is a context manager: every block / DeviceStream created inside it is built with these
+# overrides (each create call gets its own rr_next_create_options; nothing is read from the environment).
+PATH_AUTO, PATH_DIRECT, PATH_FFT = 0, 1, 2
+_build_opts: dict = {}
+_PATHS = {"auto": PATH_AUTO, "direct": PATH_DIRECT, "fft": PATH_FFT}
+
+
+@contextlib.contextmanager
+def build_options(**kw):
+    """fir_path='direct'|'fft', fir_prune=+-1, fir_half=-1, fir_cfg=0..7, fft_log2f=10..14, fft_no_split=1,
+    fftfloat_complex=1, fm_full=1, fm_poly=-1, dstream_no_vmm=1, host_sync_copies=1"""
+    global _build_opts
+    prev = _build_opts
+    _build_opts = dict(prev, **kw)
+    try:
+        yield
+    finally:
+        _build_opts = prev
+
+
+class _CreateProxy:
+    """the loaded library; rr_*_create / rr_dstream_create first hand the pending overrides to the C ABI"""
+
+    def __getattr__(self, name):
+        f = getattr(_raw_lib(), name)
+        if not (name.endswith("_create") and _build_opts):
+            return f
+
+        def create(*a):
+            o = BuildOpts()
+            for k, v in _build_opts.items():
+                if k == "fir_path":
+                    v = _PATHS.get(v, v)
+                if k == "fir_cfg":
+                    k, v = "fir_cfg_plus1", int(v) + 1
+                setattr(o, k, int(v))
+            if _raw_lib().rr_next_create_options(C.byref(o)) != 0:
+                raise ValueError(last_error())
+            return f(*a)
+        return create
+
+
+_proxy = _CreateProxy()
+
+
+def lib():
+    return _proxy
 
 
 def _ptr(a: np.ndarray):

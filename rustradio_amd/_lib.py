@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librustradio_amd.so")
 
 # every symbol include/rustradio_amd.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
-    "rr_abi_version", "rr_last_error", "rr_device_count", "rr_set_device",
+    "rr_abi_version", "rr_last_error", "rr_device_count", "rr_set_device", "rr_next_create_options",
     "rr_max_attenuation", "rr_make_window", "rr_compute_ntaps", "rr_low_pass", "rr_low_pass_complex",
     "rr_hilbert_taps", "rr_multiband",
     "rr_fir_c32_create", "rr_fir_f32_create", "rr_fftfilter_create", "rr_fftfilter_float_create",
@@ -27,6 +27,12 @@ SYMBOLS = [
 ]
 
 _lib = None
+
+
+class BuildOpts(C.Structure):
+    """rr_build_opts (include/rustradio_amd.h): path-selection overrides for the next create call"""
+    _fields_ = [(n, C.c_int) for n in ("fir_path", "fir_prune", "fir_half", "fir_cfg_plus1", "fft_log2f", "fft_no_split",
+                                        "fftfloat_complex", "fm_full", "fm_poly", "dstream_no_vmm", "host_sync_copies")] + [("reserved", C.c_int * 5)]
 
 
 def lib():
@@ -53,6 +59,7 @@ def lib():
     L.rr_last_error.restype = C.c_char_p
     L.rr_device_count.restype = i32
     L.rr_set_device.argtypes = [i32]; L.rr_set_device.restype = i32
+    L.rr_next_create_options.argtypes = [vp]; L.rr_next_create_options.restype = i32
     L.rr_max_attenuation.argtypes = [i32]; L.rr_max_attenuation.restype = f32
     L.rr_make_window.argtypes = [i32, f32, sz, vp]; L.rr_make_window.restype = i32
     L.rr_compute_ntaps.argtypes = [f32, f32, i32]; L.rr_compute_ntaps.restype = sz

@@ -17,12 +17,19 @@ struct rr_dstream {
 namespace rr {
 static thread_local std::string g_err;
 void set_last_error(const std::string& m) { g_err = m; }
+static thread_local BuildOpts g_opts;
+const BuildOpts& build_opts() { return g_opts; }
+void set_build_opts(const BuildOpts* o) { g_opts = o ? *o : BuildOpts(); }
+// the pending overrides belong to ONE create call: cleared when it returns, whether it succeeded or not
+struct OptsScope { ~OptsScope() { set_build_opts(nullptr); } };
 }  // namespace rr
 
 template <class F> static rr_block* make_block(F&& f) {
+    rr::OptsScope scope;
     try {
+        std::unique_ptr<rr::Block> b(f());         // a throwing constructor leaks nothing
         auto* h = new rr_block;
-        h->b.reset(f());
+        h->b = std::move(b);
         return h;
     } catch (const std::exception& e) {
         rr::set_last_error(e.what());
@@ -38,6 +45,20 @@ template <class F> static int guarded(F&& f) {
 extern "C" {
 
 int rr_abi_version(void) { return RR_ABI_VERSION; }
+int rr_next_create_options(const rr_build_opts* o) {
+    if (!o) { rr::set_build_opts(nullptr); return 0; }
+    rr::BuildOpts b;
+    b.fir_path = o->fir_path; b.fir_prune = o->fir_prune; b.fir_half = o->fir_half; b.fir_cfg = o->fir_cfg_plus1 - 1;
+    b.fft_log2f = o->fft_log2f; b.fft_no_split = o->fft_no_split; b.fftfloat_complex = o->fftfloat_complex;
+    b.fm_full = o->fm_full; b.fm_poly = o->fm_poly; b.dstream_no_vmm = o->dstream_no_vmm;
+    b.host_sync_copies = o->host_sync_copies;
+    if (b.fir_path < 0 || b.fir_path > 2 || b.fir_cfg > 7 || (b.fft_log2f != 0 && (b.fft_log2f < 10 || b.fft_log2f > 14))) {
+        rr::set_last_error("rr_next_create_options: value out of range");
+        return RR_ERR;
+    }
+    rr::set_build_opts(&b);
+    return 0;
+}
 const char* rr_last_error(void) { return rr::g_err.c_str(); }
 
 int rr_device_count(void) {
@@ -238,9 +259,11 @@ int rr_host_unregister(void* ptr) {
 
 // ---- device-resident streams ------------------------------------------------------------------------
 rr_dstream* rr_dstream_create(size_t elem_size, size_t capacity_bytes) {
+    rr::OptsScope scope;
     try {
+        std::unique_ptr<rr::DStream> d(new rr::DStream(elem_size, capacity_bytes));
         auto* h = new rr_dstream;
-        h->s.reset(new rr::DStream(elem_size, capacity_bytes));
+        h->s = std::move(d);
         return h;
     } catch (const std::exception& e) {
         rr::set_last_error(e.what());
@@ -258,6 +281,7 @@ size_t rr_dstream_read_buf(rr_dstream* s, const void** dev_ptr) {
 size_t rr_dstream_write_buf(rr_dstream* s, void** dev_ptr, void* hip_stream) {
     if (!s) return 0;
     try {
+        RR_HIP(hipSetDevice(s->s->device));        // write_ptr may enqueue the fallback ring's move
         void* p = s->s->write_ptr(static_cast<hipStream_t>(hip_stream));
         if (dev_ptr) *dev_ptr = p;
         return s->s->free();
@@ -279,9 +303,9 @@ int rr_dstream_copy_in(rr_dstream* s, size_t offset, const void* host, size_t n,
     return guarded([&] {
         rr::DStream& d = *s->s;
         auto st = static_cast<hipStream_t>(hip_stream);
+        RR_HIP(hipSetDevice(d.device));
         unsigned char* w = static_cast<unsigned char*>(d.write_ptr(st));
         if (offset + n > d.free()) throw rr::Error("dstream copy_in: beyond the write window");
-        RR_HIP(hipSetDevice(d.device));
         if (n) RR_HIP(hipMemcpyAsync(w + offset * d.es, host, n * d.es, hipMemcpyHostToDevice, st));
     });
 }
@@ -309,6 +333,7 @@ int rr_block_work_streams(rr_block* b, rr_dstream* src, rr_dstream* dst, size_t*
     int st = RR_ERR;
     const int rc = guarded([&] {
         auto hs = static_cast<hipStream_t>(hip_stream);
+        RR_HIP(hipSetDevice(dst->s->device));
         void* out = dst->s->write_ptr(hs);
         st = rr_block_work_dev(b, src->s->read_ptr(), src->s->used(), out, dst->s->free(), &c, &p, &nd, hip_stream);
         if (st == RR_ERR) return;

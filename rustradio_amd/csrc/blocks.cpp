@@ -31,9 +31,9 @@ Block::Block(const char* nm, size_t ies, size_t oes) : name(nm), in_es(ies), out
     RR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 }
 Block::~Block() {
+    (void)hipSetDevice(device);
     for (auto& e : prof_evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (stream) {
-        (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
         (void)hipStreamDestroy(stream);
     }
@@ -125,7 +125,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
             cur_x = ph0x; cur_y = ph0y;
         }
     }
-    pl.L = (int)ntaps; pl.d = (int)deci;
+    pl.L = (int)ntaps; pl.d = (int)deci; pl.cfg = build_opts().fir_cfg;
     h_taps = t;
     bool real_taps = true;
     for (auto& c : t) if (c.imag() != 0.0f) real_taps = false;
@@ -147,7 +147,8 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     // d = 1: overlap-save tiles cost a flat ~0.32 ms per 1e8 samples; the direct form stays at its 0.30 ms of
     // staging up to ~32 real / ~24 Complex taps and then grows by 0.004 / 0.007 ms per tap
     // (tools/fir_paths_probe.py on MI355X: 127 real taps 0.65 vs 0.32 ms, 127 Complex taps 1.09 vs 0.32 ms)
-    const bool force_direct = getenv("RR_FIR_DIRECT") != nullptr, force_fft = getenv("RR_FIR_FFT") != nullptr;
+    const BuildOpts& bo = build_opts();
+    const bool force_direct = bo.fir_path == RR_PATH_DIRECT, force_fft = bo.fir_path == RR_PATH_FFT;
     // d > 1: the same tiles with a decimating store (k_fftfilt_deci, k_fftfilt_split<.., true>).  The transform cost
     // per input sample does not shrink with d while the direct form's does, so the bar is on taps per output
     // phase; beyond ~320 taps the direct form's LDS tile no longer fits for most decimations and it collapses
@@ -160,7 +161,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     //  0.21, 401 taps /4 0.60 / 0.34 / 0.27, 1000 taps /16 98 / 0.45 / 0.29; short /8 filters stay direct: 127 taps 0.195 / 0.27 / 0.207)
     const size_t per_phase = ntaps / deci;
     const bool prune_default = deci == 4 ? per_phase >= 8 : deci == 8 ? per_phase >= (real_taps ? 28 : 16) : per_phase >= 4;
-    const bool prune_wins = getenv("RR_FIR_PRUNE") ? atoi(getenv("RR_FIR_PRUNE")) != 0 : prune_default;
+    const bool prune_wins = bo.fir_prune ? bo.fir_prune > 0 : prune_default;
     if (allow_fft && !force_direct && prune_wins && prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
         std::vector<std::complex<double>> td(ntaps);
         for (size_t i = 0; i < ntaps; i++) td[i] = {t[i].real(), t[i].imag()};
@@ -169,7 +170,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     }
     // other even decimations: 2048-point tiles, folded 1024-point inverse (k_fftfilt_half); same bar as the tiles with a
     // decimating store, which it replaces where it applies
-    const bool half_on = getenv("RR_FIR_HALF") ? atoi(getenv("RR_FIR_HALF")) != 0 : true;
+    const bool half_on = bo.fir_half >= 0;
     if (!prune && allow_fft && !force_direct && (force_fft || wins) && half_on && fftfilt_half_supported((int)std::min<size_t>(ntaps, 1 << 20), (long)std::min<size_t>(deci, 1 << 20))) {
         const size_t F = 2048;
         std::vector<rr_c32> ct(ntaps);
@@ -261,7 +262,7 @@ HilbertFir::HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c3
         const std::complex<double> r(fir->h_taps[ntaps - 1 - k].real(), fir->h_taps[ntaps - 1 - k].imag());
         for (size_t j = 0; j < hn; j++) G[k + j] += r * c[j];
     }
-    plG.L = (int)G.size(); plG.d = (int)deci; plG.complex_taps = true;
+    plG.L = (int)G.size(); plG.d = (int)deci; plG.complex_taps = true; plG.cfg = build_opts().fir_cfg;
     std::vector<cf> rev(G.size()), tp;
     for (size_t n = 0; n < G.size(); n++) rev[n] = mkcf((float)G[n].real(), (float)G[n].imag());
     build_poly(rev, plG.d, plG.qpad, tp);
@@ -271,7 +272,7 @@ HilbertFir::HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c3
     // (tools/prune_probe.py: 65 (*) 255 taps /8 0.219 -> 0.191 ms per 1e8 real samples, /4 0.37 -> 0.23, /16 a tie)
     const size_t g_per_phase = G.size() / std::max<size_t>(deci, 1);
     const bool prune_default = deci == 4 ? g_per_phase >= 8 : deci == 8 ? g_per_phase >= 24 : g_per_phase >= 24;
-    if (!getenv("RR_FIR_DIRECT") && (getenv("RR_FIR_PRUNE") ? atoi(getenv("RR_FIR_PRUNE")) != 0 : prune_default) &&
+    if (build_opts().fir_path != RR_PATH_DIRECT && (build_opts().fir_prune ? build_opts().fir_prune > 0 : prune_default) &&
         prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
         std::vector<std::complex<double>> td(G.size());
         for (size_t k = 0; k < G.size(); k++) td[k] = G[G.size() - 1 - k];
@@ -312,7 +313,7 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
     if (ntaps == 0) throw Error("FirFilter: empty taps");
     if (deci == 0) throw Error("FirFilter: decimation 0");
     if (ntaps > 0x3fffffff || deci > 0x3fffffff) throw Error("FirFilter: taps/deci too large");
-    pl.L = (int)ntaps; pl.d = (int)deci; pl.complex_taps = false;
+    pl.L = (int)ntaps; pl.d = (int)deci; pl.complex_taps = false; pl.cfg = build_opts().fir_cfg;
     std::vector<float> rev(ntaps), tp;
     for (size_t j = 0; j < ntaps; j++) rev[j] = taps[ntaps - 1 - j];
     build_poly(rev, pl.d, pl.qpad, tp);
@@ -322,12 +323,13 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
     // long filters on overlap-save tiles, two real segments per Complex tile (k_fftfilt_real): a flat ~0.148 ms per
     // 1e8 samples (8 B/sample -> 5.4 TB/s) against 0.15 + 0.002 ms per tap for the direct form
     // (tools/fir_float_probe.py: 65 taps 0.26 -> 0.147 ms, 463 taps 1.25 -> 0.17 ms, 2467 taps 5.96 -> 0.33 ms)
-    const bool force_direct = getenv("RR_FIR_DIRECT") != nullptr, force_fft = getenv("RR_FIR_FFT") != nullptr;
+    const BuildOpts& bo = build_opts();
+    const bool force_direct = bo.fir_path == RR_PATH_DIRECT, force_fft = bo.fir_path == RR_PATH_FFT;
     const bool fits = ntaps <= 3584 && deci <= 4096;
     const bool wins = deci == 1 ? ntaps >= 24 : (ntaps >= 320 || ntaps / deci >= 40);
     const size_t per_phase = ntaps / deci;
     const bool prune_default = deci == 4 ? per_phase >= 8 : deci == 8 ? per_phase >= 16 : per_phase >= 4;
-    const bool prune_wins = getenv("RR_FIR_PRUNE") ? atoi(getenv("RR_FIR_PRUNE")) != 0 : prune_default;
+    const bool prune_wins = bo.fir_prune ? bo.fir_prune > 0 : prune_default;
     if (!force_direct && prune_wins && prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
         std::vector<std::complex<double>> td(ntaps);
         for (size_t i = 0; i < ntaps; i++) td[i] = {(double)taps[i], 0.0};
@@ -486,9 +488,8 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
         if (log2f < 0 || c < best) { best = c; log2f = lg; }
     }
     if (log2f < 0) log2f = 15;                                        // -> refused below
-    if (const char* e = getenv("RR_FFT_LOG2F")) {          // tuning knob: force a tile size
-        const int v = atoi(e);
-        if (v >= 10 && v <= 14 && ((size_t)1 << v) >= L + 1) log2f = v;
+    if (const int v = build_opts().fft_log2f) {            // rr_build_opts: force a tile size
+        if (v >= 10 && v <= max_log2f && ((size_t)1 << v) >= L + 1) log2f = v;
     }
     if (!fftfilt_supported(log2f))
         throw Error("FftFilter: more than " + std::to_string(((size_t)1 << max_log2f) - 1) +
@@ -502,7 +503,7 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
     }
     d_hpos.upload(hpos.data(), F, stream);
     d_tw.upload(tw.data(), F, stream);
-    if (log2f >= 13 && !getenv("RR_FFT_NO_SPLIT")) {      // split-tile tables (thread-major order, see kernels.hpp)
+    if (log2f >= 13 && !build_opts().fft_no_split) {      // split-tile tables (thread-major order, see kernels.hpp)
         nsub = 1 << (log2f - 12);
         const size_t M = 4096;
         std::vector<std::complex<double>> H(F, 0.0);
@@ -603,13 +604,15 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     if (deci == 0) throw Error("RationalResampler created using deci 0");
     if (interp == 0) throw Error("RationalResampler created using interp 0");
     if (m != RR_ATAN2_EXACT && m != RR_ATAN2_FAST) throw Error("QuadratureDemod: bad atan2 mode");
-    if (interp > (size_t)1 << 40 || deci > (size_t)1 << 40) throw Error("FmChain: ratio out of range");
+    // the kernels index (A + y) * I and u * D in 64-bit: with the reduced ratio below 2^31 every product of a stream
+    // position (< 2^32 per call, rebased) stays far below 2^63
+    if (interp > (size_t)1 << 31 || deci > (size_t)1 << 31) throw Error("FmChain: interp and deci must be <= 2^31");
     const int64_t gg = gcd64((int64_t)deci, (int64_t)interp);
     D = (int64_t)deci / gg; I = (int64_t)interp / gg;
     f.reset(new FftFilter(taps, ntaps, true, max_log2f));
     const int64_t G = (D + I - 1) / I;
     if (G >= (int64_t)(((size_t)1 << f->log2f) - f->L + 1)) throw Error("FmChain: decimation too large for the FFT tile");
-    half_ok = !f->nsub && fm_multi_half_supported(f->log2f, I, D, (int)ntaps) && !getenv("RR_FM_CHAIN_FULL");
+    half_ok = !f->nsub && fm_multi_half_supported(f->log2f, I, D, (int)ntaps) && !build_opts().fm_full;
     if (half_ok) {
         const size_t FH = ((size_t)1 << f->log2f) / 2;
         std::vector<cf> th(FH);
@@ -716,7 +719,7 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
         std::copy(one.begin(), one.end(), all.begin() + c * F);
     }
     d_hpos_all.upload(all.data(), all.size(), stream);
-    half_ok = fm_multi_half_supported(lg, chain->I, chain->D, (int)ntaps) && !getenv("RR_FM_MULTI_FULL");
+    half_ok = fm_multi_half_supported(lg, chain->I, chain->D, (int)ntaps) && !build_opts().fm_full;
     if (half_ok) {
         std::vector<cf> th(F / 2);
         for (size_t k = 0; k < F / 2; k++) {
@@ -822,7 +825,7 @@ FftFilterFloat::FftFilterFloat(const float* taps, size_t ntaps) : Block("FftFilt
     if (ntaps == 0) throw Error("FftFilterFloat: empty taps");
     std::vector<rr_c32> ct(ntaps);
     for (size_t i = 0; i < ntaps; i++) ct[i] = rr_c32{taps[i], 0.0f};  // fft_filter.rs:398
-    real_inner = ntaps <= 3584 && !getenv("RR_FFTFLOAT_COMPLEX");       // (the knob keeps the three-kernel path testable)
+    real_inner = ntaps <= 3584 && !build_opts().fftfloat_complex;       // (the option keeps the three-kernel path testable)
     inner.reset(real_inner ? new FftFilter(ct.data(), ntaps, false, 12, true) : new FftFilter(ct.data(), ntaps));
     cap = 4096000 / sizeof(cf);                                         // inner streams: stream.rs:105,336-339
     if (real_inner) {
@@ -895,6 +898,8 @@ Resampler::Resampler(size_t interp, size_t deci, size_t es) : Block("RationalRes
     if (interp == 0) throw Error("RationalResampler created using interp 0");  // :133-135
     if (!(es == 1 || es == 2 || es == 4 || es == 8 || es == 16)) throw Error("RationalResampler: element size must be 1,2,4,8 or 16");
     if (interp > (size_t)INT64_MAX || deci > (size_t)INT64_MAX) throw Error("RationalResampler: ratio out of range");  // i64::try_from :142-143
+    // the gather kernel indexes m * D - c0 in 64-bit with m < 2^32 per call: the ratio has to stay below 2^31
+    if (interp > (size_t)1 << 31 || deci > (size_t)1 << 31) throw Error("RationalResampler: interp and deci must be <= 2^31 on the GPU");
     const int64_t g = gcd64((int64_t)deci, (int64_t)interp);
     D = (int64_t)deci / g; I = (int64_t)interp / g;
     d_pending.reserve(16);
@@ -1007,7 +1012,7 @@ FftStream::FftStream(size_t n) : Block("FftStream", 8, 8), size(n) {
         tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
     }
     d_tw.upload(tw.data(), n, stream);
-    if (n >= 8192 && !getenv("RR_FFT_NO_SPLIT")) {
+    if (n >= 8192 && !build_opts().fft_no_split) {
         std::vector<cf> t4(4096);
         for (size_t k = 0; k < 4096; k++) {
             const double a = -2.0 * 3.14159265358979323846 * (double)k / 4096.0;
@@ -1100,7 +1105,7 @@ Hilbert::Hilbert(size_t ntaps, int window, float parm) : Block("Hilbert", 4, 8) 
     std::vector<float> win, taps;
     if (!make_window(window, parm, ntaps, win)) throw Error("Hilbert: unknown window type");
     hilbert_taps(win.data(), ntaps, taps);                                      // :48
-    pl.L = (int)ntaps; pl.d = 1; pl.complex_taps = false;
+    pl.L = (int)ntaps; pl.d = 1; pl.complex_taps = false; pl.cfg = build_opts().fir_cfg;
     std::vector<float> rev(ntaps), tp;
     for (size_t j = 0; j < ntaps; j++) rev[j] = taps[ntaps - 1 - j];           // Fir::new, fir.rs:160
     build_poly(rev, 1, pl.qpad, tp);

@@ -17,6 +17,25 @@ struct Error : std::runtime_error {
 
 void set_last_error(const std::string& m);
 
+// Path-selection overrides of the block being constructed (include/rustradio_amd.h rr_build_opts): set by
+// rr_next_create_options() for the next rr_*_create call of this thread and cleared when that call returns.
+// All-zero = every choice automatic.  There are no environment switches in the product.
+struct BuildOpts {
+    int fir_path = 0;          // RR_PATH_AUTO / RR_PATH_DIRECT / RR_PATH_FFT
+    int fir_prune = 0;         // 0 auto, > 0 on, < 0 off
+    int fir_half = 0;          // 0 auto, < 0 off
+    int fir_cfg = -1;          // >= 0: direct-form tile shape
+    int fft_log2f = 0;         // 10..14: forced overlap-save tile
+    int fft_no_split = 0;
+    int fftfloat_complex = 0;
+    int fm_full = 0;
+    int fm_poly = 0;           // 0 auto, < 0 off: polyphase (decimate-first) tiles of the fused chains
+    int dstream_no_vmm = 0;
+    int host_sync_copies = 0;  // host-window work(): the simple staged path (no pinned double buffering)
+};
+const BuildOpts& build_opts();
+void set_build_opts(const BuildOpts* o);   // nullptr = reset
+
 #define RR_HIP(expr)                                                                          \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
@@ -39,9 +58,13 @@ template <class T> struct DevBuf {
         RR_HIP(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
         cap = n;
     }
+    // one-time setup tables: blocking, so the host vector may go out of scope right after the call
     void upload(const T* h, size_t n, hipStream_t s) {
         reserve(n);
-        if (n) RR_HIP(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+        if (n) {
+            RR_HIP(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+            RR_HIP(hipStreamSynchronize(s));
+        }
     }
 };
 

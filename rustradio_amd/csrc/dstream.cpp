@@ -8,7 +8,7 @@
 namespace rr {
 
 bool DStream::try_vmm() {
-    if (getenv("RR_DSTREAM_NO_VMM")) return false;
+    if (build_opts().dstream_no_vmm) return false;
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;

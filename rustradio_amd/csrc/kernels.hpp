@@ -116,6 +116,7 @@ struct FirPlan {             // host-prepared polyphase tap table
     int L = 0, d = 1;
     int qpad = 0;            // taps per phase, padded to a multiple of 8
     bool complex_taps = false;
+    int cfg = -1;            // >= 0: force tile shape cfg (rr_build_opts.fir_cfg, parity tests of every shape)
 };
 // y[m] = sum_k rev[k] * x[m*d + k], m < n_out  (rev = reversed taps), x = virtual stream.
 // tp = device polyphase table [d][qpad] (float if real taps else cf), rev = device reversed taps.

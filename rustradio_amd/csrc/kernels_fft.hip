@@ -1682,13 +1682,19 @@ int fft_read_stamps(unsigned long long* host16) {
 bool fftfilt_supported(int log2f) { return log2f >= 10 && log2f <= 14; }
 
 int device_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        RR_HIP(hipGetDevice(&dev));
+    // per device: one process may drive several GPUs (rr_set_device), first calls may race
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    RR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it == cus.end()) {
+        int n = 0;
         RR_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        it = cus.emplace(dev, n).first;
     }
-    return n;
+    return it->second;
 }
 
 template <class KFn> static long grid_for_tiles(KFn kfn, int T, size_t smem, long ntiles) {
@@ -1708,7 +1714,9 @@ template <class KFn> static long grid_for_tiles(KFn kfn, int T, size_t smem, lon
             int n = 0;
             RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, T, smem));
             if (n < 1) n = 1;
-            if (const char* e = getenv("RR_FFT_PERCU")) n = atoi(e) > 0 ? atoi(e) : n;   // measurement knob (tools/fft_percu.sh)
+#ifdef RR_MEASURE_KNOBS
+            if (const char* e = getenv("RR_FFT_PERCU")) n = atoi(e) > 0 ? atoi(e) : n;   // measurement builds only (tools/fft_percu.sh)
+#endif
             it = per_cu_of.emplace(key, n).first;
         }
         per_cu = it->second;

@@ -309,8 +309,7 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
     };
     int pick = -1;
     FirGeom g{};
-    const char* fe = getenv("RR_FIR_CFG");                                  // tuning / test knob
-    const int force = fe ? atoi(fe) : -1;
+    const int force = pl.cfg;                                               // rr_build_opts.fir_cfg
     if (force >= 0 && force < NCFG && !(HILBERT && cfgs[force].S > 1)) {
         const FirGeom gc = geom(force);
         if (gc.lds_bytes <= 64 * 1024) { pick = force; g = gc; }
@@ -347,16 +346,22 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
     const long by_waves = 32 / (NT / 64);
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
-    if (const char* pe = getenv("RR_FIR_PERCU")) per_cu = atoi(pe) > 0 ? atoi(pe) : per_cu;   // measurement knob
+#ifdef RR_MEASURE_KNOBS
+    if (const char* pe = getenv("RR_FIR_PERCU")) per_cu = atoi(pe) > 0 ? atoi(pe) : per_cu;   // measurement builds only
+#endif
     long grid = ntiles < (long)cus * per_cu ? ntiles : (long)cus * per_cu;
-    const char* qe = getenv("RR_FIR_QCOMPUTE");                             // measurement knob: taps actually multiplied
+#ifdef RR_MEASURE_KNOBS
+    const char* qe = getenv("RR_FIR_QCOMPUTE");                             // measurement builds only: taps actually multiplied
     const int qcomp = qe ? atoi(qe) : -1;
+#else
+    const int qcomp = -1;
+#endif
     const int qrun = qcomp >= 0 && qcomp < pl.qpad ? qcomp : pl.qpad;
     // the R = 8, S = 1 shapes (d = 1) stage <= 10 values per thread: a build with the shorter register
     // pipeline leaves room for the held outputs without spilling
     const long staged = ((long)g.np * pl.d + NT - 1) / NT;
     // d = 1, R = 8, S = 1 and up to 512 taps per phase: fixed row stride NT + 66 (== 2 mod 4: bank-friendly)
-    const bool fixed_rs = pick <= 2 && pl.d == 1 && staged <= 10 && pl.qpad / 8 + 1 <= 66 && !getenv("RR_FIR_NO_RSC");
+    const bool fixed_rs = pick <= 2 && pl.d == 1 && staged <= 10 && pl.qpad / 8 + 1 <= 66;
     if (fixed_rs) {
         g.rstride = NT + 66;
         g.pstride = 8 * g.rstride + 1;

@@ -110,3 +110,10 @@ def signal_source_complex_fast(samp_rate, freq, amplitude, n):
     rad = 2.0 * np.pi * float(np.float32(freq)) / float(np.float32(samp_rate))
     cur = np.mod(rad * np.arange(1, n + 1, dtype=np.float64), 2.0 * np.pi)
     return (np.float32(amplitude) * (np.sin(cur).astype(np.float32) + 1j * np.sin(cur - np.pi / 2).astype(np.float32))).astype(np.complex64)
+
+
+def knob(rr, monkeypatch, **opts):
+    """Build every block this test creates from now on with the given rr_build_opts overrides (rustradio_amd.build_options
+    keys: fir_path, fir_prune, fir_half, fir_cfg, fft_log2f, fft_no_split, fftfloat_complex, fm_full, fm_poly,
+    dstream_no_vmm, host_sync_copies); undone by monkeypatch at the end of the test.  The oracle ignores them."""
+    monkeypatch.setattr(rr, "_build_opts", dict(rr._build_opts, **opts))

@@ -5,7 +5,7 @@ cases that fixed parameter lists miss."""
 import numpy as np
 import pytest
 
-from harness import max_norm_err, run_chain
+from harness import knob, max_norm_err, run_chain
 from oracle import pyoracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -171,8 +171,8 @@ def test_fuzz_device_rings(rr, seed):
     assert len(yh) == len(yd) and np.array_equal(yh, yd)
 
 
-_FIR_PATHS = [{}, {"RR_FIR_DIRECT": "1"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0", "RR_FIR_HALF": "0"},
-              {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "1"}]
+_FIR_PATHS = [{}, {"fir_path": "direct"}, {"fir_path": "fft", "fir_prune": -1, "fir_half": -1},
+              {"fir_path": "fft", "fir_prune": -1}, {"fir_path": "fft", "fir_prune": 1}]
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -181,8 +181,7 @@ def test_fuzz_fir_every_path(rr, monkeypatch, seed):
     other even ones) through every arithmetic path the block can take: automatic choice, direct form, overlap-save
     tiles with a decimating store, half-size inverse, pruned inverse — identical protocol, outputs within 1e-5."""
     rng = np.random.default_rng(5000 + seed)
-    for k, v in _FIR_PATHS[seed % len(_FIR_PATHS)].items():
-        monkeypatch.setenv(k, v)
+    knob(rr, monkeypatch, **_FIR_PATHS[seed % len(_FIR_PATHS)])
     L = int(rng.choice([1, 5, 16, 33, 64, 127, 200, 255, 401, 600, 601, 1000, 1025, 2049]))
     d = int(rng.choice([1, 2, 2, 4, 4, 6, 8, 8, 10, 16, 16, 22, 3, 5]))
     if seed % len(_FIR_PATHS) == 1 and L > 700:
@@ -207,7 +206,7 @@ def test_fuzz_hilbert_fir_and_even_ratio_chains(rr, monkeypatch, seed):
     """The fused Hilbert -> FirFilter block with random shapes (pruned-inverse tiles for deci 4 / 8 / 16 or direct form)
     and the fused FM chain with 1:even ratios (half-size inverse where the tile allows) against the oracle chains."""
     rng = np.random.default_rng(7000 + seed)
-    monkeypatch.setenv("RR_FIR_PRUNE", str(seed % 2))
+    knob(rr, monkeypatch, fir_prune=1 if seed % 2 else -1)
     hn = int(rng.choice([3, 17, 65, 129]))
     L = int(rng.choice([1, 31, 100, 255, 500, 900]))
     d = int(rng.choice([1, 4, 8, 16, 3, 6]))

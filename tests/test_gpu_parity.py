@@ -6,7 +6,7 @@ RationalResampler is a pure copy and must be bit-exact."""
 import numpy as np
 import pytest
 
-from harness import AGAIN, WAIT_DST, WAIT_SRC, max_norm_err, run_chain
+from harness import AGAIN, WAIT_DST, WAIT_SRC, knob, max_norm_err, run_chain
 from oracle import pyoracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -59,8 +59,8 @@ def test_fir_complex(rr, L, deci, cplx):
 def test_fir_every_tile_shape(rr, monkeypatch, cfg, L, deci, cplx):
     """Every (threads, outputs/thread, phase split) tile shape of the FIR kernel, forced through the
     RR_FIR_CFG knob (the launcher otherwise picks by input size), incl. streams with boundary tiles."""
-    monkeypatch.setenv("RR_FIR_CFG", str(cfg))
-    monkeypatch.setenv("RR_FIR_DIRECT", "1")      # d = 1 filters would otherwise take the overlap-save tiles
+    knob(rr, monkeypatch, fir_cfg=cfg)
+    knob(rr, monkeypatch, fir_path="direct")      # d = 1 filters would otherwise take the overlap-save tiles
     x = rnd_c(40000, L * 11 + deci + cfg)
     taps = rnd_c(L, L + 1) / max(1, L // 8)
     if not cplx:
@@ -79,9 +79,9 @@ def test_fir_nondecimating_both_paths(rr, monkeypatch, path, L, cplx):
     (chosen automatically beyond a few taps): same work() protocol, both within 1e-5 of the oracle,
     whole windows and small rings (boundary tiles, windows shorter than a tile)."""
     if path == "direct":
-        monkeypatch.setenv("RR_FIR_DIRECT", "1")
+        knob(rr, monkeypatch, fir_path="direct")
     elif path == "fft":
-        monkeypatch.setenv("RR_FIR_FFT", "1")
+        knob(rr, monkeypatch, fir_path="fft")
     x = rnd_c(90000, L * 5 + 1)
     taps = rnd_c(L, L + 9) / max(1, L // 8)
     if not cplx:
@@ -101,16 +101,16 @@ def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
     """Decimating FirFilter through the direct-form kernel and through the overlap-save tiles with a decimating
     store: same protocol, same outputs (1e-5), incl. decimations beyond the tile's useful width and small rings."""
     if path == "direct":
-        monkeypatch.setenv("RR_FIR_DIRECT", "1")
+        knob(rr, monkeypatch, fir_path="direct")
     elif path == "fft":                               # overlap-save tiles with a decimating store
-        monkeypatch.setenv("RR_FIR_FFT", "1")
-        monkeypatch.setenv("RR_FIR_PRUNE", "0")
-        monkeypatch.setenv("RR_FIR_HALF", "0")
+        knob(rr, monkeypatch, fir_path="fft")
+        knob(rr, monkeypatch, fir_prune=-1)
+        knob(rr, monkeypatch, fir_half=-1)
     elif path == "prune":                             # deci 4 / 8 / 16: pruned inverse transform (else as "auto")
-        monkeypatch.setenv("RR_FIR_PRUNE", "1")
+        knob(rr, monkeypatch, fir_prune=1)
     elif path == "half":                              # even deci, <= 1025 taps: half-size inverse on 2048-point tiles
-        monkeypatch.setenv("RR_FIR_FFT", "1")
-        monkeypatch.setenv("RR_FIR_PRUNE", "0")
+        knob(rr, monkeypatch, fir_path="fft")
+        knob(rr, monkeypatch, fir_prune=-1)
     if path == "direct" and L >= 5000:
         pytest.skip("direct-form fallback at thousands of taps: covered by test_fir_complex history, slow")
     x = rnd_c(120000, L * 3 + deci)
@@ -216,7 +216,7 @@ def test_fftfilter_float(rr, monkeypatch, inner):
     """FftFilterFloat on the real-stream tile kernel (two overlap-save segments per Complex tile) and on the
     f32 -> Complex -> FftFilter -> .re path it replaces (kept for filters beyond 3584 taps)."""
     if inner == "complex":
-        monkeypatch.setenv("RR_FFTFLOAT_COMPLEX", "1")
+        knob(rr, monkeypatch, fftfloat_complex=1)
     x = rnd_f(300_000, 5)
     taps = orc.low_pass(200e3, 44.1e3, 500.0)
     both(rr, lambda m: [m.FftFilterFloat(taps)], x)
@@ -239,12 +239,12 @@ def test_fir_float_both_paths(rr, monkeypatch, path, L, deci):
     """FirFilter<Float> through the direct-form kernel, the real-stream overlap-save tiles (decimating store) and —
     deci 4 / 8 / 16 — the tiles with the pruned inverse transform."""
     if path == "direct":
-        monkeypatch.setenv("RR_FIR_DIRECT", "1")
+        knob(rr, monkeypatch, fir_path="direct")
     elif path == "fft":
-        monkeypatch.setenv("RR_FIR_FFT", "1")
-        monkeypatch.setenv("RR_FIR_PRUNE", "0")
+        knob(rr, monkeypatch, fir_path="fft")
+        knob(rr, monkeypatch, fir_prune=-1)
     elif path == "prune":
-        monkeypatch.setenv("RR_FIR_PRUNE", "1")
+        knob(rr, monkeypatch, fir_prune=1)
     x = rnd_f(150_000, L * 3 + deci)
     taps = rnd_f(L, L + deci) / max(1, L // 8)
     both(rr, lambda m: [m.FirFilter(taps, deci=deci)], x)
@@ -459,7 +459,7 @@ def test_hilbert_fir_fused_block(rr, monkeypatch, hn, L, deci, cplx, tr, stream_
     """rr.HilbertFir (one composite decimating FIR on the real input) == Hilbert -> FirFilter<Complex> of the
     oracle, whole stream, any chunking; with and without .translate().  prune = 1: decimations 4 / 8 / 16 run on
     real-stream overlap-save tiles with the pruned inverse transform (k_fftfilt_prune), 0: direct form."""
-    monkeypatch.setenv("RR_FIR_PRUNE", prune)
+    knob(rr, monkeypatch, fir_prune=1 if prune == "1" else -1)
     x = rnd_f(300_000, hn * 1000 + L + deci)
     if L == 255:
         taps = orc.low_pass_complex(100e6, 5e6, 943e3)
@@ -529,7 +529,7 @@ def test_fm_chain_fused_block(rr, monkeypatch, L, I, D, stream_bytes, kernel):
     for whole-stream output and any chunking.  kernel = half: reduced ratios 1:even on 2048-point tiles finish each
     tile with a folded 1024-point inverse on one wave (k_fm_chain_half); full: the full-size inverse everywhere."""
     if kernel == "full":
-        monkeypatch.setenv("RR_FM_CHAIN_FULL", "1")
+        knob(rr, monkeypatch, fm_full=1)
     fs = 2.4e6
     n = 400_000
     x = fm_signal(n, fs, 0.0, 77 + L)
@@ -618,7 +618,7 @@ def test_fm_multi_shared_source(rr, monkeypatch, stream_bytes, kernel):
     channel must equal its own oracle chain FftFilter(taps_c) -> RationalResampler -> QuadratureDemod.
     kernel = half: interp 1 / even deci on 2048-point tiles runs folded 1024-point inverses (k_fm_multi_half)."""
     if kernel == "full":
-        monkeypatch.setenv("RR_FM_MULTI_FULL", "1")
+        knob(rr, monkeypatch, fm_full=1)
     fs, n, nch = 2.4e6, 300_000, 5
     proto = orc.low_pass_complex(fs, 100e3, 12.5e3)
     k = np.arange(len(proto), dtype=np.float64)
@@ -766,7 +766,7 @@ def run_chain_device(rr, blocks, x, stream_bytes=4_096_000):
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 3_001])
 def test_device_streams_equal_host_windows(rr, monkeypatch, stream_bytes, no_vmm):
     if no_vmm:
-        monkeypatch.setenv("RR_DSTREAM_NO_VMM", "1")
+        knob(rr, monkeypatch, dstream_no_vmm=1)
     """chains over HBM-resident rings (small rings force the wrap-around move) produce bit-identical output
     to the same blocks driven through host windows"""
     fs = 2.4e6
@@ -789,7 +789,7 @@ def test_device_streams_equal_host_windows(rr, monkeypatch, stream_bytes, no_vmm
 @pytest.mark.parametrize("no_vmm", [False, True])
 def test_device_stream_ring_contract(rr, monkeypatch, no_vmm):
     if no_vmm:
-        monkeypatch.setenv("RR_DSTREAM_NO_VMM", "1")      # the linear fallback
+        knob(rr, monkeypatch, dstream_no_vmm=1)      # the linear fallback
     s = rr.DeviceStream(np.uint32, 4 * 10)
     assert s.double_mapped == (not no_vmm)
     assert s.capacity == 10 and s.readable() == 0 and s.free() == 10
