@@ -155,6 +155,22 @@ rr_block *rr_hilbert_create(size_t ntaps, int window, float window_parm);
 rr_block *rr_fm_chain_create(const rr_c32 *taps, size_t ntaps, size_t interp, size_t deci,
                              float gain, int atan2_mode);
 
+/* Graph-level fusion of FirFilter::<Complex>::builder(fir_taps).build(src) (deci 1, src/fir.rs:303-386) ->
+ * FftFilter::new(_, fft_taps) (src/fft_filter.rs:242-279) — the north star's "127-tap FIR + 1024-pt FftFilter chain" —
+ * as ONE convolution with the composite taps fir_taps (*) fft_taps (formed in f64, rounded once).  Whole-stream output
+ * equals the two blocks in sequence to f32 rounding, INCLUDING the start of the stream, where FftFilter sees zero
+ * history rather than a warm FIR: those fft_ntaps - 1 outputs are recomputed from the two-stage definition.
+ * work(): WAIT_DST(nsamples) when a block of the FftFilter stage does not fit (fft_filter.rs:294-303), WAIT_SRC(fir_ntaps)
+ * below the FIR's minimum (fir.rs:498-501); otherwise consumes len - (fir_ntaps - 1) samples like the FIR (its history
+ * stays in the caller's ring, fir.rs:537), emits whole blocks of nsamples = fft_size(fft_ntaps) - fft_ntaps and returns
+ * WAIT_SRC(nsamples - pending + fir_ntaps - 1) / WAIT_DST(nsamples). */
+rr_block *rr_fir_fftfilter_create(const rr_c32 *fir_taps, size_t fir_ntaps, const rr_c32 *fft_taps, size_t fft_ntaps);
+/* ... followed by RationalResampler(interp, deci) -> QuadratureDemod(gain): the metric's whole chain
+ * FIR + FftFilter + Resampler + QuadDemod as one kernel (rr_fm_chain_create with the composite filter and the same
+ * head fix).  Complex in, f32 out. */
+rr_block *rr_fir_fm_chain_create(const rr_c32 *fir_taps, size_t fir_ntaps, const rr_c32 *fft_taps, size_t fft_ntaps,
+                                 size_t interp, size_t deci, float gain, int atan2_mode);
+
 /* The same with RtlSdrDecode::new(src) (src/rtlsdr_decode.rs:9-47) fused in front, the receive chain of
  * examples/rtl_fm.rs:328-419 from the RTL-SDR byte stream onwards: u8 in, f32 out, 2 B instead of 8 B
  * read per sample.  Input windows, `consumed` and the WAIT_SRC `need` count BYTES; an odd trailing

@@ -185,6 +185,17 @@ class Block:
             return st, c.value, p.value, n.value, out.reshape(nw, max(out_cap, 1))[:, :p.value].copy()
         return st, c.value, p.value, n.value, out[:p.value]
 
+    def work_into(self, inp: np.ndarray, out: np.ndarray, out_cap: int):
+        """Block::work() over caller-owned host windows (no allocation, no copy on the Python side): exactly the
+        call the Rust shim makes with read_buf() / write_buf() slices -> (status, consumed, produced, need)"""
+        assert inp.dtype == self.in_dtype and out.dtype == self.out_dtype and inp.flags.c_contiguous and out.flags.c_contiguous
+        assert len(out) >= out_cap * lib().rr_block_out_windows(self._h)
+        c, p, n = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        st = lib().rr_block_work(self._h, _ptr(inp), len(inp), _ptr(out), out_cap, C.byref(c), C.byref(p), C.byref(n))
+        if st == ERR:
+            raise RuntimeError(last_error())
+        return st, c.value, p.value, n.value
+
     def work_dev(self, d_in: int, in_len: int, d_out: int, out_cap: int, stream: int = 0):
         """Block::work() over DEVICE windows (raw device pointers, e.g. tensor.data_ptr());
         asynchronous on `stream` (a hipStream_t handle used as given; 0 = the default stream, which is
@@ -273,6 +284,13 @@ class DeviceStream:
         n = min(len(x), self.free(stream))
         if n and (lib().rr_dstream_copy_in(self._h, 0, _ptr(x), n, C.c_void_p(stream)) != 0
                   or lib().rr_dstream_produce(self._h, n) != 0):
+            raise RuntimeError(last_error())
+        return n
+
+    def discard(self) -> int:
+        """consume everything readable without copying it anywhere (NullSink, src/null_sink.rs:15-25)"""
+        n = self.readable()
+        if n and lib().rr_dstream_consume(self._h, n) != 0:
             raise RuntimeError(last_error())
         return n
 
@@ -366,6 +384,23 @@ def FmChain(taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_E
     block / one kernel (examples/rtl_fm.rs:381-419 wiring); Complex in, f32 out."""
     t = np.ascontiguousarray(taps, np.complex64)
     return Block(lib().rr_fm_chain_create(_ptr(t), len(t), interp, deci, gain, mode), np.complex64, np.float32)
+
+
+def FirFftFilter(fir_taps, fft_taps) -> Block:
+    """FirFilter<Complex>(fir_taps) -> FftFilter(fft_taps) fused into one convolution with the composite taps
+    (rr_fir_fftfilter_create); whole-stream output == the two blocks, incl. FftFilter's zero-history start."""
+    t1 = np.ascontiguousarray(fir_taps, np.complex64)
+    t2 = np.ascontiguousarray(fft_taps, np.complex64)
+    return Block(lib().rr_fir_fftfilter_create(_ptr(t1), len(t1), _ptr(t2), len(t2)), np.complex64, np.complex64)
+
+
+def FirFmChain(fir_taps, fft_taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
+    """FirFilter(fir_taps) -> FftFilter(fft_taps) -> RationalResampler(interp, deci) -> QuadratureDemod(gain) as one
+    kernel (rr_fir_fm_chain_create): the metric's whole chain; Complex in, f32 out."""
+    t1 = np.ascontiguousarray(fir_taps, np.complex64)
+    t2 = np.ascontiguousarray(fft_taps, np.complex64)
+    return Block(lib().rr_fir_fm_chain_create(_ptr(t1), len(t1), _ptr(t2), len(t2), interp, deci, gain, mode),
+                 np.complex64, np.float32)
 
 
 def FmChainU8(taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:

@@ -162,6 +162,21 @@ rr_block* rr_hilbert_create(size_t ntaps, int window, float window_parm) {
 rr_block* rr_fm_chain_create(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int atan2_mode) {
     return make_block([&] { return new rr::FmChain(taps, ntaps, interp, deci, gain, atan2_mode); });
 }
+rr_block* rr_fir_fftfilter_create(const rr_c32* fir_taps, size_t fir_ntaps, const rr_c32* fft_taps, size_t fft_ntaps) {
+    return make_block([&] {
+        const std::vector<rr_c32> g = rr::FftFilter::composite(fir_taps, fir_ntaps, fft_taps, fft_ntaps);
+        std::unique_ptr<rr::FftFilter> f(new rr::FftFilter(g.data(), g.size(), false, 14, false, fir_ntaps - 1));
+        f->set_stage_taps(fir_taps, fir_ntaps, fft_taps, fft_ntaps);
+        return f.release();
+    });
+}
+rr_block* rr_fir_fm_chain_create(const rr_c32* fir_taps, size_t fir_ntaps, const rr_c32* fft_taps, size_t fft_ntaps,
+                                 size_t interp, size_t deci, float gain, int atan2_mode) {
+    return make_block([&] {
+        if (!fir_taps || fir_ntaps == 0) throw rr::Error("FirFilter: empty taps");
+        return new rr::FmChain(fft_taps, fft_ntaps, interp, deci, gain, atan2_mode, false, 14, fir_taps, fir_ntaps);
+    });
+}
 rr_block* rr_fm_multi_create(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain,
                              int atan2_mode) {
     return make_block([&] { return new rr::FmMulti(taps, nchan, ntaps, interp, deci, gain, atan2_mode); });

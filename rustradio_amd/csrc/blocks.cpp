@@ -456,9 +456,27 @@ bool PruneTables::build(const std::vector<std::complex<double>>& t, size_t d, bo
     return true;
 }
 
-FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int max_log2f, bool real)
-    : Block("FftFilter", real ? 4 : 8, real ? 4 : 8), real_stream(real) {
+std::vector<rr_c32> FftFilter::composite(const rr_c32* t1, size_t n1, const rr_c32* t2, size_t n2) {
+    if (n1 == 0 || n2 == 0) throw Error("FirFilter>FftFilter: empty taps");
+    if (n1 > 0x3fffff || n2 > 0x3fffff) throw Error("FirFilter>FftFilter: too many taps");
+    std::vector<std::complex<double>> g(n1 + n2 - 1);
+    for (size_t a = 0; a < n1; a++)
+        for (size_t b = 0; b < n2; b++)
+            g[a + b] += std::complex<double>(t1[a].re, t1[a].im) * std::complex<double>(t2[b].re, t2[b].im);
+    std::vector<rr_c32> out(g.size());
+    for (size_t i = 0; i < g.size(); i++) out[i] = rr_c32{(float)g[i].real(), (float)g[i].imag()};
+    return out;
+}
+void FftFilter::set_stage_taps(const rr_c32* t1, size_t n1, const rr_c32* t2, size_t n2) {
+    if (n1 != front + 1 || n1 + n2 - 1 != L) throw Error("FirFilter>FftFilter: stage taps do not match the composite");
+    d_t1.upload(reinterpret_cast<const cf*>(t1), n1, stream);
+    d_t2.upload(reinterpret_cast<const cf*>(t2), n2, stream);
+}
+
+FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int max_log2f, bool real, size_t front_)
+    : Block(front_ ? "FirFilter>FftFilter" : "FftFilter", real ? 4 : 8, real ? 4 : 8), real_stream(real), front(front_) {
     if (ntaps == 0) throw Error("FftFilter: empty taps");            // fft_filter.rs:146
+    if (front >= ntaps || (front && real)) throw Error("FftFilter: bad front-filter length");
     std::vector<rr_c32> real_taps;
     const rr_c32* taps = taps_in;
     if (real) {
@@ -468,8 +486,9 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
         taps = real_taps.data();
     }
     L = ntaps;
-    fft_size = calc_fft_size(ntaps);                                  // fft_filter.rs:261
-    nsamples = fft_size - ntaps;                                      // fft_filter.rs:262
+    hist = L - 1 - front;
+    fft_size = calc_fft_size(ntaps - front);                          // fft_filter.rs:261 (of the FftFilter stage)
+    nsamples = fft_size - (ntaps - front);                            // fft_filter.rs:262
     // GPU tile: overlap-save with any F > L - 1 (S' = F - L + 1 new outputs per F-point transform; results do
     // not depend on F beyond f32 rounding).  F is the one that minimises measured tile cost / S'
     // (tools/taps_sweep.py: relative cost of one tile of 1024 .. 16384 points on MI355X; the 8192- and
@@ -530,7 +549,7 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
         d_tw4096.upload(tw4.data(), tw4.size(), stream);
     }
     // prefix = [L-1 history samples][pending < nsamples]; zero history at stream start (A.4)
-    const size_t pcap = (L - 1) + nsamples + 1;
+    const size_t pcap = hist + nsamples + 1;
     for (auto& p : prefix) {
         p.reserve(pcap);
         RR_HIP(hipMemsetAsync(p.p, 0, pcap * sizeof(cf), stream));
@@ -552,7 +571,9 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     *consumed = *produced = *need = 0;
     const size_t S = nsamples;
     if (S > out_cap) { *need = S; return RR_WAIT_DST; }               // fft_filter.rs:294-303
-    const size_t total = pend_len + in_len;
+    if (front && in_len < front + 1) { *need = front + 1; return RR_WAIT_SRC; }   // the front FirFilter: fir.rs:498-501
+    const size_t av = avail(in_len);   // front FIR: its last L1 - 1 samples stay in the caller's window (fir.rs:537)
+    const size_t total = pend_len + av;
     const size_t k_in = total / S, k_out = out_cap / S;
     size_t k, new_pend;
     int st;
@@ -560,11 +581,11 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
         k = k_out; *consumed = k * S - pend_len; new_pend = 0;
         st = RR_WAIT_DST; *need = S;
     } else {                           // input runs out: everything is taken into `buf` (:306-314)
-        k = k_in; *consumed = in_len; new_pend = total - k * S;
-        st = RR_WAIT_SRC; *need = S - new_pend;                        // :323-326
+        k = k_in; *consumed = av; new_pend = total - k * S;
+        st = RR_WAIT_SRC; *need = S - new_pend + front;                // :323-326
     }
     const size_t n_out = k * S;
-    const long plen = (long)(L - 1 + pend_len);
+    const long plen = (long)(hist + pend_len);
     if (real_stream) {
         VSrc<float> rsrc{reinterpret_cast<const float*>(prefix[cur].p), plen, static_cast<const float*>(in), (long)in_len};
         if (k) {
@@ -573,7 +594,7 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
             prof_end(s);
         }
         if (*consumed) {
-            launch_vcopy_f32(rsrc, (long)n_out, reinterpret_cast<float*>(prefix[cur ^ 1].p), (long)(L - 1 + new_pend), s);
+            launch_vcopy_f32(rsrc, (long)n_out, reinterpret_cast<float*>(prefix[cur ^ 1].p), (long)(hist + new_pend), s);
             cur ^= 1;
             pend_len = new_pend;
         }
@@ -585,10 +606,17 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
         prof_begin(s);
         filter(src, static_cast<cf*>(out), (long)n_out, s);
         prof_end(s);
+        if (front && emitted == 0) {   // head fix: FftFilter's zero history under the first L2 - 1 outputs (n_out >= S > L2 - 1)
+            const long L2 = (long)(L - front);
+            d_zhead.reserve((size_t)L2);
+            launch_head_z(src, (long)hist, d_t1.p, (int)(front + 1), d_zhead.p, L2 - 1, s);
+            launch_head_y(d_zhead.p, d_t2.p, (int)L2, static_cast<cf*>(out), L2 - 1, s);
+        }
+        emitted += n_out;
     }
     if (*consumed) {
-        // new carry = last L-1 samples before the first unprocessed one, then the unprocessed tail
-        launch_vcopy_c32(src, (long)n_out, prefix[cur ^ 1].p, (long)(L - 1 + new_pend), s);
+        // new carry = last `hist` samples before the first unprocessed one, then the unprocessed tail
+        launch_vcopy_c32(src, (long)n_out, prefix[cur ^ 1].p, (long)(hist + new_pend), s);
         cur ^= 1;
         pend_len = new_pend;
     }
@@ -598,8 +626,10 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
 
 // ---- fused FM chain ------------------------------------------------------------------------------------
 static int64_t gcd64(int64_t a, int64_t b);
-FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float g, int m, bool u8, int max_log2f)
-    : Block(u8 ? "RtlSdrDecode>FftFilter>RationalResampler>QuadratureDemod" : "FftFilter>RationalResampler>QuadratureDemod",
+FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float g, int m, bool u8, int max_log2f,
+                 const rr_c32* fir_taps, size_t fir_ntaps)
+    : Block(fir_taps ? "FirFilter>FftFilter>RationalResampler>QuadratureDemod"
+            : u8 ? "RtlSdrDecode>FftFilter>RationalResampler>QuadratureDemod" : "FftFilter>RationalResampler>QuadratureDemod",
             u8 ? 1 : 8, 4), gain(g), mode(m), iq8(u8) {
     if (deci == 0) throw Error("RationalResampler created using deci 0");
     if (interp == 0) throw Error("RationalResampler created using interp 0");
@@ -609,7 +639,15 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     if (interp > (size_t)1 << 31 || deci > (size_t)1 << 31) throw Error("FmChain: interp and deci must be <= 2^31");
     const int64_t gg = gcd64((int64_t)deci, (int64_t)interp);
     D = (int64_t)deci / gg; I = (int64_t)interp / gg;
-    f.reset(new FftFilter(taps, ntaps, true, max_log2f));
+    if (fir_taps) {                      // front FirFilter fused in: composite taps, head fix at stream start
+        if (u8) throw Error("FmChain: the front FirFilter takes Complex input");
+        const std::vector<rr_c32> gt = FftFilter::composite(fir_taps, fir_ntaps, taps, ntaps);
+        f.reset(new FftFilter(gt.data(), gt.size(), true, max_log2f, false, fir_ntaps - 1));
+        f->set_stage_taps(fir_taps, fir_ntaps, taps, ntaps);
+        ntaps = gt.size();
+    } else {
+        f.reset(new FftFilter(taps, ntaps, true, max_log2f));
+    }
     const int64_t G = (D + I - 1) / I;
     if (G >= (int64_t)(((size_t)1 << f->log2f) - f->L + 1)) throw Error("FmChain: decimation too large for the FFT tile");
     half_ok = !f->nsub && fm_multi_half_supported(f->log2f, I, D, (int)ntaps) && !build_opts().fm_full;
@@ -644,7 +682,9 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     // like FftFilter::work (fft_filter.rs:294-303): room for one block's worth of output first
     const uint64_t need_next = N3(n1 + S) - o_old;
     if (need_next > out_cap) { *need = need_next; return RR_WAIT_DST; }
-    const uint64_t total = f->pend_len + in_len;
+    if (f->front && in_len < f->front + 1) { *need = f->front + 1; return RR_WAIT_SRC; }   // front FirFilter: fir.rs:498-501
+    const uint64_t av = f->avail(in_len);
+    const uint64_t total = f->pend_len + av;
     const uint64_t k_in = total / S;
     // largest k with N3(n1 + k S) - o_old <= out_cap  <=>  ceil((n1+kS) I / D) <= o_old + out_cap + 1
     const __int128 X = (__int128)(o_old + out_cap + 1) * D / I;        // (n1 + k S) <= X
@@ -656,11 +696,11 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         k = k_out; *consumed = k * S - f->pend_len; new_pend = 0;
         st = RR_WAIT_DST; *need = N3(n1 + (k + 1) * S) - N3(n1 + k * S);
     } else {
-        k = k_in; *consumed = in_len; new_pend = total - k * S;
-        st = RR_WAIT_SRC; *need = S - new_pend;
+        k = k_in; *consumed = av; new_pend = total - k * S;
+        st = RR_WAIT_SRC; *need = S - new_pend + f->front;
     }
     const uint64_t n_y = k * S;
-    const long plen = (long)(f->L - 1 + f->pend_len);
+    const long plen = (long)(f->hist + f->pend_len);
     VSrc<cf> src{f->prefix[f->cur].p, plen, static_cast<const cf*>(in), (long)in_len};
     VSrcIQ8 src8{f->prefix[f->cur].p, plen, static_cast<const rr::iq8*>(in), (long)in_len};
     if (k) {
@@ -687,11 +727,21 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
             launch_fm_chain(f->log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a,
                             last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         prof_end(s);
+        if (f->front && n1 == 0) {
+            // head fix (see FftFilter): every demodulated sample that touches y[n], n < L2 - 1, is recomputed from the
+            // two-stage definition.  n1 == 0: the whole head lies in this first emitting call (n_y >= S > L2 - 1).
+            const long L2 = (long)(f->L - f->front);
+            const long nz = std::min<long>((long)n_y, L2 - 1 + (long)((D + I - 1) / I) + 1);
+            f->d_zhead.reserve((size_t)nz);
+            launch_head_z(src, (long)f->hist, f->d_t1.p, (int)(f->front + 1), f->d_zhead.p, nz, s);
+            launch_head_demod(f->d_zhead.p, nz, f->d_t2.p, (int)L2, I, D, gain, mode, a.r_hi, static_cast<float*>(out),
+                              last_r[cur_lr ^ 1].p, s);
+        }
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
     }
     if (*consumed) {
-        if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
-        else launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
+        if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);
+        else launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);
         f->cur ^= 1;
         f->pend_len = new_pend;
     }
@@ -768,8 +818,8 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         st = RR_WAIT_SRC; *need = S - new_pend;
     }
     const uint64_t n_y = k * S;
-    VSrc<cf> src{f->prefix[f->cur].p, (long)(f->L - 1 + f->pend_len), static_cast<const cf*>(in), (long)in_len};
-    VSrcIQ8 src8{f->prefix[f->cur].p, (long)(f->L - 1 + f->pend_len), static_cast<const rr::iq8*>(in), (long)in_len};
+    VSrc<cf> src{f->prefix[f->cur].p, (long)(f->hist + f->pend_len), static_cast<const cf*>(in), (long)in_len};
+    VSrcIQ8 src8{f->prefix[f->cur].p, (long)(f->hist + f->pend_len), static_cast<const rr::iq8*>(in), (long)in_len};
     if (k) {
         FmChainArgs a;
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
@@ -791,8 +841,8 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
     }
     if (*consumed) {
-        if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
-        else launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->L - 1 + new_pend), s);
+        if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);
+        else launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);
         f->cur ^= 1;
         f->pend_len = new_pend;
     }

@@ -121,7 +121,21 @@ struct FftFilter : Block {
     // real_stream: f32 windows and real taps (imaginary parts ignored), two overlap-save segments per Complex tile
     // (k_fftfilt_real; tiles up to 4096 points, so <= 4094 taps); the carry prefix then holds floats
     bool real_stream = false;
-    FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain = false, int max_log2f = 14, bool real_stream = false);
+    // Front FirFilter fused in (rr_fir_fftfilter_create / rr_fir_fm_chain_create): `taps` are then the composite
+    // t1 (*) t2 of L1 + L2 - 1 taps and front = L1 - 1.  The block behaves like FirFilter(t1) -> FftFilter(t2):
+    // the FIR's L1 - 1 held-back samples stay in the caller's window (fir.rs:537), the carried history is L2 - 1
+    // samples, fft_size / nsamples are the reference's for L2 taps, and the first L2 - 1 outputs — where the two-block
+    // chain sees FftFilter's ZERO history instead of a warm FIR — are recomputed from their definition (head fix).
+    size_t front = 0, hist = 0;       // hist = L - 1 - front: history samples carried in `prefix`
+    DevBuf<cf> d_t1, d_t2, d_zhead;   // front > 0: caller-order taps of the two stages, z[0 .. L2 - 1 + G]
+    size_t emitted = 0;               // outputs emitted so far (the head fix applies while it is 0)
+    FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain = false, int max_log2f = 14, bool real_stream = false,
+              size_t front = 0);
+    // t1 (*) t2 in f64, rounded once
+    static std::vector<rr_c32> composite(const rr_c32* t1, size_t n1, const rr_c32* t2, size_t n2);
+    void set_stage_taps(const rr_c32* t1, size_t n1, const rr_c32* t2, size_t n2);
+    // samples of the window that can be filtered now (all of them without a front FIR)
+    size_t avail(size_t in_len) const { return front ? (in_len > front ? in_len - front : 0) : in_len; }
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
     // out[n] = sum_k t[k] src[n + L - 1 - k], n < n_out (the tile kernel of the chosen size)
     void filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s);
@@ -146,7 +160,7 @@ struct FmChain : Block {
     DevBuf<cf> d_tw_half;             // w_(F/2)^k: half-size inverse (interp 1, even deci, 2048-point tiles; k_fm_chain_half)
     bool half_ok = false;
     FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false,
-            int max_log2f = 14);
+            int max_log2f = 14, const rr_c32* fir_taps = nullptr, size_t fir_ntaps = 0);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 

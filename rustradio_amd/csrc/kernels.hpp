@@ -158,6 +158,16 @@ void launch_vcopy_f32(VSrc<float> src, long v0, float* dst, long n, hipStream_t 
 void launch_f32_to_c32(const float* in, cf* out, long n, hipStream_t s);
 void launch_c32_re(const cf* in, float* out, long n, hipStream_t s);
 
+// ---- head fix of the fused FirFilter -> FftFilter blocks (stream start only, a few hundred samples) ----------------
+// z[m] = sum_k t1[k] V[voff + m + L1 - 1 - k], m < n: the front FirFilter's first outputs (fir.rs:166-177) from the virtual stream
+void launch_head_z(VSrc<cf> V, long voff, const cf* t1, int L1, cf* z, long n, hipStream_t s);
+// y[i] = sum_{j <= min(i, L2 - 1)} t2[j] z[i - j], i < n: FftFilter's zero-history head (fft_filter.rs:332-348)
+void launch_head_y(const cf* z, const cf* t2, int L2, cf* y, long n, hipStream_t s);
+// the same head resampled (r[u] = y[floor(u D / I)]) and demodulated: rewrites out[u - 1] for every u < r_hi whose pair
+// touches y[n], n < L2 - 1, and *last_r when r[r_hi - 1] does (nz = valid entries of z)
+void launch_head_demod(const cf* z, long nz, const cf* t2, int L2, long I, long D, float gain, int mode, long r_hi, float* out,
+                       cf* last_r, hipStream_t s);
+
 int device_cu_count();
 
 }  // namespace rr

@@ -211,4 +211,68 @@ void launch_c32_re(const cf* in, float* out, long n, hipStream_t s) {
     RR_HIP(hipGetLastError());
 }
 
+// ---- head fix of the fused FirFilter -> FftFilter blocks ---------------------------------------------------------
+// Runs once per stream on a few hundred samples: plain one-thread-per-output sums.
+__global__ __launch_bounds__(256) void k_head_z(VSrc<cf> V, long voff, const cf* __restrict__ t1, int L1, cf* __restrict__ z, long n) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    float ar = 0.0f, ai = 0.0f;
+    for (int k = 0; k < L1; k++) {
+        const cf x = V.load(voff + m + L1 - 1 - k), t = t1[k];
+        ar += t.x * x.x - t.y * x.y;
+        ai += t.x * x.y + t.y * x.x;
+    }
+    z[m] = mkcf(ar, ai);
+}
+__device__ __forceinline__ cf head_y_at(const cf* __restrict__ z, const cf* __restrict__ t2, int L2, long i) {
+    float ar = 0.0f, ai = 0.0f;
+    const long jmax = i < L2 - 1 ? i : L2 - 1;
+    for (long j = 0; j <= jmax; j++) {
+        const cf x = z[i - j], t = t2[j];
+        ar += t.x * x.x - t.y * x.y;
+        ai += t.x * x.y + t.y * x.x;
+    }
+    return mkcf(ar, ai);
+}
+__global__ __launch_bounds__(256) void k_head_y(const cf* __restrict__ z, const cf* __restrict__ t2, int L2, cf* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = head_y_at(z, t2, L2, i);
+}
+__global__ __launch_bounds__(256) void k_head_demod(const cf* __restrict__ z, long nz, const cf* __restrict__ t2, int L2, long I, long D,
+                                                    float gain, int mode, long r_hi, float* __restrict__ out, cf* __restrict__ last_r) {
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;        // resampled sample r[u] = y[floor(u D / I)]
+    if (u >= r_hi) return;
+    const long su = (long)(((__int128)u * D) / I);
+    if (su >= nz) return;
+    if (u == r_hi - 1 && su < L2 - 1) last_r[0] = head_y_at(z, t2, L2, su);
+    if (u == 0) return;
+    const long sl = (long)(((__int128)(u - 1) * D) / I);
+    if (sl >= L2 - 1) return;                                        // neither sample touches the head
+    const cf rl = head_y_at(z, t2, L2, sl), ru = head_y_at(z, t2, L2, su);
+    const float na = -rl.y;
+    const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
+    const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
+    const float ang = mode == 0 ? atan2f(im, re) : fm_atan2(im, re);
+    out[u - 1] = mul_rn(gain, ang);
+}
+void launch_head_z(VSrc<cf> V, long voff, const cf* t1, int L1, cf* z, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_head_z, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, V, voff, t1, L1, z, n);
+    RR_HIP(hipGetLastError());
+}
+void launch_head_y(const cf* z, const cf* t2, int L2, cf* y, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_head_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, t2, L2, y, n);
+    RR_HIP(hipGetLastError());
+}
+void launch_head_demod(const cf* z, long nz, const cf* t2, int L2, long I, long D, float gain, int mode, long r_hi, float* out,
+                       cf* last_r, hipStream_t s) {
+    // u with floor((u - 1) D / I) < L2 - 1  <=>  u - 1 < ceil((L2 - 1) I / D)
+    long n = (long)((((__int128)(L2 - 1)) * I + D - 1) / D) + 2;
+    if (n > r_hi) n = r_hi;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_head_demod, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, nz, t2, L2, I, D, gain, mode, r_hi, out, last_r);
+    RR_HIP(hipGetLastError());
+}
+
 }  // namespace rr

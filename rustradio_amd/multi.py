@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import time
 
+import numpy as np
 import torch
 
 
@@ -24,6 +25,33 @@ def shard_channels(n_channels: int, world: int, rank: int) -> range:
 def channel_frequency(c: int, n_channels: int, spacing_hz: float) -> float:
     """Centre of channel c of a bank of n_channels spaced `spacing_hz` around DC."""
     return (c - n_channels // 2) * spacing_hz
+
+
+def channel_taps(proto, fs: float, f_c: float):
+    """Channel of a shared source: the low-pass prototype shifted to f_c (complex band-pass taps,
+    t[k] * exp(2 pi i f_c k / fs), formed in f64 and rounded once)."""
+    proto = np.asarray(proto)
+    if f_c == 0.0:
+        return proto.astype(np.complex64)
+    k = np.arange(len(proto), dtype=np.float64)
+    return (proto.astype(np.complex128) * np.exp(2j * np.pi * f_c * k / fs)).astype(np.complex64)
+
+
+CFG4_CHANNELS, CFG4_SPACING_HZ, CFG4_FS = 256, 8e3, 2.4e6
+
+
+def cfg4_taps(proto, chans, total: int = CFG4_CHANNELS, spacing_hz: float = CFG4_SPACING_HZ, fs: float = CFG4_FS):
+    """BASELINE configs[3]: taps of channels `chans` of the 256-channel bank, chain c =
+    the configs[2] low-pass shifted to f_c = (c - 128) * 8 kHz -> [len(chans)][ntaps] complex64."""
+    return np.stack([channel_taps(proto, fs, channel_frequency(c, total, spacing_hz)) for c in chans])
+
+
+def cfg5_translate_hz(rank: int, world: int, fs: float = 100e6) -> float:
+    """BASELINE configs[4], 8-GPU variant: GPU g runs channel offset f_g through
+    FirFilter::translate(fs, f_g) (src/fir.rs:476-486); the analytic band (0, fs/2) cut into `world` slices, 0 for a single GPU."""
+    if world <= 1:
+        return 0.0
+    return (rank + 0.5) * fs / (2.0 * world)       # the analytic signal occupies (0, fs/2): one slice per GPU
 
 
 def broadcast_source(dist, rank: int, make, device, src_rank: int = 0):
@@ -59,3 +87,90 @@ def aggregate(dist, units: float, seconds: float, device):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dist.all_reduce(uu, op=dist.ReduceOp.SUM)
     return float(uu.item()), float(tt.item())
+
+
+class TileFanout:
+    """Streaming fan-out of the shared IQ source, one tile per step (replaces the reference's
+    Tee tree, src/tee.rs:10-24): rank `src_rank` produces tile t+1 into one half of a double buffer and
+    broadcasts it (RCCL over xGMI on the GPU box, gloo in the CPU tests) on a COMMUNICATION stream while every
+    rank computes on tile t from the other half on its compute stream.  Two events per half order the streams:
+    `ready[h]` (broadcast of the tile in half h finished -> compute may read it) and `free[h]` (compute on
+    half h finished -> the next broadcast may overwrite it).  On CPU tensors (tests) the calls are synchronous.
+
+        fan = TileFanout(dist, rank, tile_elems, dtype, device, produce)   # produce(t, out) fills `out` on src_rank
+        fan.prefetch(0)
+        for t in range(steps):
+            fan.prefetch(t + 1)                 # broadcast of tile t+1 overlaps ...
+            x = fan.acquire(t, compute_stream)  # ... the compute on tile t
+            ... launch work on compute_stream reading x ...
+            fan.release(t, compute_stream)
+    """
+
+    def __init__(self, dist, rank, tile_elems, dtype, device, produce, src_rank=0):
+        self.dist, self.rank, self.src, self.produce = dist, rank, src_rank, produce
+        self.device = device
+        self.cuda = device.type == "cuda"
+        self.buf = [torch.empty(tile_elems, dtype=dtype, device=device) for _ in range(2)]
+        self.bytes_per_tile = tile_elems * self.buf[0].element_size()
+        self.issued = -1
+        self.n_bcast = 0
+        if self.cuda:
+            self.comm = torch.cuda.Stream(device=device)
+            self.ready = [torch.cuda.Event() for _ in range(2)]
+            self.free = [torch.cuda.Event() for _ in range(2)]
+            self.t_beg = []
+            self.t_end = []
+            self.used = [False, False]
+
+    def prefetch(self, t):
+        """enqueue production + broadcast of tile t (idempotent)"""
+        if t <= self.issued:
+            return
+        assert t == self.issued + 1
+        self.issued = t
+        h = t % 2
+        if not self.cuda:
+            if self.rank == self.src:
+                self.produce(t, self.buf[h])
+            if self.dist is not None:
+                self.dist.broadcast(self.buf[h], src=self.src)
+            self.n_bcast += 1
+            return
+        with torch.cuda.stream(self.comm):
+            if self.used[h]:
+                self.comm.wait_event(self.free[h])          # compute on the previous occupant of this half is done
+            if self.rank == self.src:
+                self.produce(t, self.buf[h])
+            if self.dist is not None:
+                b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                b.record(self.comm)
+                w = self.dist.broadcast(self.buf[h], src=self.src, async_op=True)
+                w.wait()                                     # the comm stream (not the host) waits for the collective
+                e.record(self.comm)
+                self.t_beg.append(b)
+                self.t_end.append(e)
+            self.ready[h].record(self.comm)
+        self.n_bcast += 1
+
+    def acquire(self, t, compute_stream=None):
+        self.prefetch(t)
+        h = t % 2
+        if self.cuda:
+            (compute_stream or torch.cuda.current_stream()).wait_event(self.ready[h])
+        return self.buf[h]
+
+    def release(self, t, compute_stream=None):
+        if self.cuda:
+            h = t % 2
+            self.free[h].record(compute_stream or torch.cuda.current_stream())
+            self.used[h] = True
+
+    def reset_timing(self):
+        if self.cuda:
+            self.t_beg, self.t_end = [], []
+
+    def broadcast_ms(self):
+        """-> (summed broadcast time in ms on the comm stream, broadcasts timed); call after a device sync"""
+        if not self.cuda or not self.t_beg:
+            return 0.0, 0
+        return sum(b.elapsed_time(e) for b, e in zip(self.t_beg, self.t_end)), len(self.t_beg)

@@ -803,3 +803,64 @@ def test_device_stream_ring_contract(rr, monkeypatch, no_vmm):
     assert got == list(range(len(got))) and len(got) == nxt
     with pytest.raises(Exception):
         rr.DeviceStream(np.uint32, 2)                      # smaller than one element
+
+
+# ---- FirFilter -> FftFilter fused into one convolution (the north star's "127-tap FIR + 1024-pt FftFilter chain") ----
+@pytest.mark.parametrize("L1,L2,cplx", [(127, 401, False), (1, 1, True), (5, 300, True), (64, 64, False), (200, 17, True),
+                                        (127, 2467, False), (33, 1000, True), (2, 512, True)])
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 9_000])
+def test_fir_fftfilter_fused_block(rr, L1, L2, cplx, stream_bytes):
+    """rr.FirFftFilter (ONE convolution with the composite taps) == FirFilter(t1) -> FftFilter(t2) of the oracle over the
+    whole stream for any chunking — including the first L2 - 1 outputs, where FftFilter starts from ZERO history while a
+    single long filter would see the FIR's warm output (the head fix)."""
+    if L1 == 127 and L2 == 401:
+        t1, t2 = orc.low_pass_complex(10e6, 1e6, 190e3), orc.low_pass_complex(10e6, 1e6, 60e3)
+    else:
+        t1 = rnd_c(L1, L1 + 3) / max(1, L1 // 8)
+        t2 = rnd_c(L2, L2 + 5) / max(1, L2 // 8)
+        if not cplx:
+            t1, t2 = t1.real.astype(np.complex64), t2.real.astype(np.complex64)
+    x = rnd_c(120_000, L1 * 31 + L2)
+    yo = run_chain([orc.FirFilter(t1), orc.FftFilter(t2)], x, stream_bytes=stream_bytes)
+    yg = run_chain([rr.FirFftFilter(t1, t2)], x, stream_bytes=stream_bytes)
+    assert len(yo) == len(yg) > 0
+    assert max_norm_err(yg, yo) <= TOL
+    # the head alone, against its own scale (the first outputs are small: the filter is still filling)
+    h = min(len(yo), L2 + 8)
+    assert max_norm_err(yg[:h], yo[:h], scale=max(float(np.max(np.abs(yo[:h]))), 1e-3 * float(np.max(np.abs(yo))))) <= 10 * TOL
+
+
+def test_fir_fftfilter_fused_protocol(rr):
+    t1, t2 = orc.low_pass_complex(10e6, 1e6, 190e3), orc.low_pass_complex(10e6, 1e6, 60e3)    # 127, 401 -> nsamples 623
+    b = rr.FirFftFilter(t1, t2)
+    x = rnd_c(5000, 1)
+    assert b.work(x[:100], 600)[:4] == (WAIT_DST, 0, 0, 623)            # FftFilter stage: room for one block first
+    assert b.work(x[:100], 1000)[:4] == (WAIT_SRC, 0, 0, 127)           # below the FIR's minimum
+    st, c, p, need, out = b.work(x[:1000], 5000)                        # 874 FIR outputs: one block + 251 pending
+    assert (st, c, p, need) == (WAIT_SRC, 874, 623, 623 - 251 + 126)
+    st, c, p, need, out = b.work(x[874:], 700)                          # output-limited: one more block, pending drained
+    assert (st, c, p, need) == (WAIT_DST, 623 - 251, 623, 623)
+    with pytest.raises(ValueError):
+        rr.FirFftFilter(np.zeros(0, np.complex64), t2)
+
+
+@pytest.mark.parametrize("L1,L2,I,D", [(127, 401, 1, 4), (127, 401, 1, 6), (31, 463, 1, 6), (64, 200, 3, 7), (9, 127, 25, 128), (127, 401, 1, 1),
+                                       (16, 300, 1, 250)])
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 20_000])
+def test_fir_fm_chain_fused_block(rr, L1, L2, I, D, stream_bytes):
+    """rr.FirFmChain (FirFilter -> FftFilter -> RationalResampler -> QuadratureDemod as ONE kernel: BASELINE.json's
+    metric chain) == the four oracle blocks, whole stream, any chunking, incl. the demodulated samples that touch
+    FftFilter's zero-history head."""
+    fs = 10e6
+    if (L1, L2) == (127, 401):
+        t1, t2 = orc.low_pass_complex(fs, 1e6, 190e3), orc.low_pass_complex(fs, 1e6, 60e3)
+    else:
+        t1 = (rnd_c(L1, L1) / max(1, L1 // 4)).astype(np.complex64)
+        t2 = (rnd_c(L2, L2 + 1) / max(1, L2 // 4)).astype(np.complex64)
+    x = fm_signal(150_000, fs, 0.0, L1 + L2 + D)
+    gain = 0.7
+    front = [orc.FirFilter(t1), orc.FftFilter(t2), orc.RationalResampler(I, D)]
+    yo = run_chain([orc.FirFilter(t1), orc.FftFilter(t2), orc.RationalResampler(I, D), orc.QuadratureDemod(gain)], x, stream_bytes=max(stream_bytes, 8 * 20_000))
+    ro = run_chain(front, x, stream_bytes=max(stream_bytes, 8 * 20_000))
+    yg = run_chain([rr.FirFmChain(t1, t2, I, D, gain)], x, stream_bytes=stream_bytes)
+    _demod_close(yg / gain, yo / gain, ro)
