@@ -390,18 +390,19 @@ def make_fm_chain_unfused(dev, rank, world, shared_src):
     return make_fm_chain(dev, rank, world, shared_src, fused=False)
 
 
-def make_fm_multi(dev, rank, world, shared_src, per_gpu=32, total=256):
-    """BASELINE configs[3]: 256 FM channels of configs[2] on one shared IQ source, 32 per GPU.
-    Channel c uses the configs[2] low-pass shifted to f_c = (c - 128) * 8 kHz (complex band-pass, multi.cfg4_taps);
-    rank r owns channels r*32 .. r*32+31 (multi.shard_channels).  `value` counts
-    channel-samples: input samples x channels processed."""
+def make_fm_multi(dev, rank, world, shared_src, per_gpu=32):
+    """BASELINE configs[3]: 256 FM channels of configs[2] on one shared IQ source, 32 per GPU (weak scaling: N GPUs run
+    the first 32 N channels of the bank; 8 GPUs = all 256).  Channel c uses the configs[2] low-pass shifted to
+    f_c = (c - 128) * 8 kHz (complex band-pass, multi.cfg4_taps); rank r owns channels r*32 .. r*32+31
+    (multi.shard_channels).  `value` counts channel-samples: input samples x channels processed."""
     w = Workload()
     fs, n = 2.4e6, 2_400_000
     taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
-    chans = list(multi.shard_channels(total if world > 1 else per_gpu, world, rank))
+    total = multi.CFG4_CHANNELS
+    chans = list(multi.shard_channels(per_gpu * world, world, rank))
     w.name = (f"configs[3]: {len(chans)} FM channels/GPU (FftFilter 463 taps->RationalResampler 1:6->QuadratureDemod, fused, "
               f"rr.FmMulti) on one shared 2.4 Msps IQ source, {n:,} samples/step/channel"
-              + (f"; channels {chans[0]}..{chans[-1]} of {total}" if world > 1 else ""))
+              + (f"; this rank: channels {chans[0]}..{chans[-1]} of the {total}-channel bank, {per_gpu * world} in the job" if world > 1 else ""))
     src = shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0004), 2 * n, torch.float32)
     taps_all = multi.cfg4_taps(taps, chans, total)
     blk = rr.FmMulti(taps_all, 1, 6, 1.0, rr.ATAN2_EXACT)     # one kernel: forward FFT shared by all channels
@@ -529,44 +530,13 @@ def run_timed(w, steps, warmup, dist, stream, fan=None):
 
 # ---- CPU baseline (the oracle; test infrastructure used here as the reported baseline only) ----------------------
 def _cpu_chain(kind, taps):
-    from oracle import pyoracle as orc
-    if kind == "channelizer":
-        return [orc.Hilbert(65), orc.FirFilter(taps, deci=8)]
-    if kind == "FirFilterFloat":
-        return [orc.FirFilter(taps)]
-    if kind == "fir_fft_chain":
-        return [orc.FirFilter(taps[0]), orc.FftFilter(taps[1])]
-    if kind == "full_chain":
-        return [orc.FirFilter(taps[0]), orc.FftFilter(taps[1]), orc.RationalResampler(1, 4), orc.QuadratureDemod(1.0)]
-    if kind == "rtl_fm_example":
-        return [orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(200000, 1024000), orc.QuadratureDemod(1.0)]
-    if kind == "rtl_fm_chain":
-        return [orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(1, 6), orc.QuadratureDemod(1.0)]
-    return {"FftFilter": lambda: [orc.FftFilter(taps)],
-            "FirFilter": lambda: [orc.FirFilter(taps)],
-            "fm_chain": lambda: [orc.FftFilter(taps), orc.RationalResampler(1, 6), orc.QuadratureDemod(1.0)]}[kind]()
+    from oracle import cpu_worker
+    return cpu_worker.chain_for(kind, taps)
 
 
 def _cpu_graph_1thread(chain, host, win, in_mult, seconds):
-    """Graph (src/graph.rs:113): every block's work() on ONE thread, 4,096,000-byte rings -> (samples fed, seconds)"""
-    nwin = len(host) // win
-    rings = [np.zeros(0, b.in_dtype) for b in chain]
-    t0 = time.perf_counter()
-    fed = i = 0
-    while time.perf_counter() - t0 < seconds:
-        chunk = host[(i % nwin) * win:(i % nwin + 1) * win]
-        i += 1
-        rings[0] = np.concatenate([rings[0], chunk])
-        fed += len(chunk) // in_mult
-        for j, b in enumerate(chain):
-            while True:
-                st, c, p, need, out = b.work(rings[j], 4_096_000 // b.out_dtype.itemsize)
-                rings[j] = rings[j][c:]
-                if j + 1 < len(chain):
-                    rings[j + 1] = np.concatenate([rings[j + 1], out])
-                if st == 1 or (c == 0 and p == 0):      # WAIT_SRC, or no progress (the output is drained every call)
-                    break
-    return fed, time.perf_counter() - t0
+    from oracle import cpu_worker
+    return cpu_worker.graph_1thread(chain, host, win, in_mult, seconds)
 
 
 def _cpu_mtgraph(chain, host, win, in_mult, seconds):
@@ -642,19 +612,35 @@ def cpu_baseline(w, seconds=8.0):
     if len(chain) > 1:
         f2, d2 = _cpu_mtgraph(chain, host, win, w.in_mult, seconds / 2)
         modes["mtgraph_thread_per_block"] = {"msamples_per_s": round(f2 / d2 / 1e6, 3), "threads": len(chain) + 1}
+    # one independent chain per core on all cores: child processes (they never touch the GPU), each with 2 windows of
+    # the same input
     cores = os.cpu_count() or 1
-    res = [None] * cores
-
-    def one(k):
-        res[k] = _cpu_graph_1thread(_cpu_chain(kind, taps), host, win, w.in_mult, seconds / 2)
-    th = [threading.Thread(target=one, args=(k,)) for k in range(cores)]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt_all = time.perf_counter() - t0
-    modes["one_chain_per_core_all_cores"] = {"msamples_per_s": round(sum(r[0] for r in res) / dt_all / 1e6, 3), "threads": cores}
+    import tempfile
+    tmp = tempfile.NamedTemporaryFile(suffix=".npz", dir="/dev/shm" if os.path.isdir("/dev/shm") else None, delete=False)
+    tmp.close()
+    try:
+        arrs = {"host": host[:2 * win], "kind": np.array(kind), "win": np.array(win), "in_mult": np.array(w.in_mult)}
+        if isinstance(taps, tuple):
+            arrs["taps0"], arrs["taps1"] = taps
+        else:
+            arrs["taps0"] = taps
+        np.savez(tmp.name, **arrs)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), tmp.name, str(seconds / 2)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for _ in range(cores)]
+        tot = 0.0
+        ok = 0
+        for pr in procs:
+            o, _ = pr.communicate(timeout=seconds * 10 + 120)
+            try:
+                f_, d_ = o.decode().split()
+                tot += float(f_) / float(d_)
+                ok += 1
+            except Exception:
+                pass
+        modes["one_chain_per_core_all_cores"] = {"msamples_per_s": round(tot / 1e6, 3), "processes": ok}
+    finally:
+        os.unlink(tmp.name)
     return {"value": round(base, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
             "sample": f"{fed} input samples of the same synthetic stream in {win}-sample work() windows, {dt:.1f} s, 1 thread, gcc -O2 strict f32 (own scalar radix-4 FFT, not rustfft's SIMD kernels)",
             "host_cores": cores, "modes": modes}

@@ -280,9 +280,9 @@ int rr_block_work_streams(rr_block *b, rr_dstream *src, rr_dstream *dst, size_t 
 int rr_block_set_profiling(rr_block *b, int on);
 int rr_block_profile(rr_block *b, double *total_ms, size_t *launches, int reset);
 
-/* Measurement builds only (make TIMING=1, env RR_FFT_STAMPS=1): 16 s_memtime stamps taken at the
- * phase boundaries of one FftFilter tile; returns 0 in product builds. */
-int rr_debug_fft_stamps(unsigned long long *out16);
+/* Measurement builds only (make TIMING=1): 32 s_memtime stamps taken at the phase boundaries of one tile of the
+ * last stamped kernel (out must hold 32 values); returns 0 in product builds. */
+int rr_debug_fft_stamps(unsigned long long *out32);
 
 /* ---- per-block knobs / introspection ------------------------------------------- */
 /* FftFilter: reference fft_size and nsamples (src/fft_filter.rs:261-262) and the

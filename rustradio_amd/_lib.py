@@ -9,7 +9,9 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librustradio_amd.so")
+# RR_LIB_PATH: measurement tools load a differently-built library (tools/*.sh: ablation / timing builds) without ever
+# overwriting the product .so
+LIB_PATH = os.environ.get("RR_LIB_PATH") or os.path.join(_HERE, "lib", "librustradio_amd.so")
 
 # every symbol include/rustradio_amd.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [

@@ -473,6 +473,32 @@ void FftFilter::set_stage_taps(const rr_c32* t1, size_t n1, const rr_c32* t2, si
     d_t2.upload(reinterpret_cast<const cf*>(t2), n2, stream);
 }
 
+bool PolyTables::build(const rr_c32* taps, size_t C, size_t L, size_t D, bool multi, hipStream_t s) {
+    if (!fm_poly_supported(1, (long)D, (int)std::min<size_t>(L, 1 << 24), multi)) return false;
+    const size_t F = 1024;
+    std::vector<cf> h(C * D * F), tw(F);
+    std::vector<std::complex<double>> H(F);
+    for (size_t c = 0; c < C; c++)
+        for (size_t p = 0; p < D; p++) {
+            std::fill(H.begin(), H.end(), std::complex<double>(0.0, 0.0));
+            for (size_t j = 0; D * j + p < L; j++) H[j] = {taps[c * L + D * j + p].re, taps[c * L + D * j + p].im};
+            fft64(H);
+            cf* dst = h.data() + (c * D + p) * F;
+            for (int j = 0; j < 16; j++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const auto v = H[(size_t)fm_poly_bin(j, lane)] / (double)F;
+                    dst[j * 64 + lane] = mkcf((float)v.real(), (float)v.imag());
+                }
+        }
+    for (size_t k = 0; k < F; k++) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)F;
+        tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+    }
+    d_h.upload(h.data(), h.size(), s);
+    d_tw.upload(tw.data(), F, s);
+    return true;
+}
+
 FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int max_log2f, bool real, size_t front_)
     : Block(front_ ? "FirFilter>FftFilter" : "FftFilter", real ? 4 : 8, real ? 4 : 8), real_stream(real), front(front_) {
     if (ntaps == 0) throw Error("FftFilter: empty taps");            // fft_filter.rs:146
@@ -660,6 +686,14 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
         }
         d_tw_half.upload(th.data(), th.size(), stream);
     }
+    if (build_opts().fm_poly >= 0 && !build_opts().fm_full && I == 1 && D >= 2) {
+        // decimate-first tiles: D phase transforms + one inverse per 1024 OUTPUT-rate positions (kernels_poly.hip)
+        std::vector<rr_c32> ct(f->L);
+        if (fir_taps) ct = FftFilter::composite(fir_taps, fir_ntaps, taps, f->L - (fir_ntaps - 1));
+        else std::copy(taps, taps + f->L, ct.begin());
+        poly.reset(new PolyTables());
+        if (!poly->build(ct.data(), 1, f->L, (size_t)D, false, stream)) poly.reset();
+    }
     for (auto& b : last_r) { b.reserve(1); RR_HIP(hipMemsetAsync(b.p, 0, sizeof(cf), stream)); }
     RR_HIP(hipStreamSynchronize(stream));
 }
@@ -708,7 +742,11 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = gain; a.mode = mode;
         prof_begin(s);
-        if (f->nsub && packed)
+        if (poly && packed)
+            launch_fm_chain_poly_iq8(src8, static_cast<float*>(out), (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (poly)
+            launch_fm_chain_poly(src, static_cast<float*>(out), (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (f->nsub && packed)
             launch_fm_chain_split_iq8(f->nsub, src8, static_cast<float*>(out), (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
                                       last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (f->nsub)
@@ -778,6 +816,10 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
         }
         d_tw_half.upload(th.data(), th.size(), stream);
     }
+    if (build_opts().fm_poly >= 0 && !build_opts().fm_full && chain->I == 1) {
+        poly.reset(new PolyTables());
+        if (!poly->build(taps, C, ntaps, (size_t)chain->D, true, stream)) poly.reset();
+    }
     for (auto& b : last_r) { b.reserve(C); RR_HIP(hipMemsetAsync(b.p, 0, C * sizeof(cf), stream)); }
     RR_HIP(hipStreamSynchronize(stream));
 }
@@ -825,7 +867,13 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = ch.gain; a.mode = ch.mode;
         prof_begin(s);
-        if (half_ok && packed)
+        if (poly && packed)
+            launch_fm_multi_poly_iq8(src8, static_cast<float*>(out), (long)out_cap, (int)f->L, poly->d_tw.p, poly->d_h.p, (int)C, a,
+                                     last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (poly)
+            launch_fm_multi_poly(src, static_cast<float*>(out), (long)out_cap, (int)f->L, poly->d_tw.p, poly->d_h.p, (int)C, a,
+                                 last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (half_ok && packed)
             launch_fm_multi_half_iq8(f->log2f, src8, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_tw_half.p,
                                      d_hpos_all.p, (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (packed)

@@ -51,6 +51,13 @@ struct PruneTables {
     // false when (L, d) is not covered.
     bool build(const std::vector<std::complex<double>>& t, size_t d, bool split, hipStream_t s);
 };
+// Tables of the decimate-first (polyphase) fused chains (kernels_poly.hip): per channel c and phase p the response of
+// the taps t[D j + p] on 1024-point tiles, in the register order of the kernels.
+struct PolyTables {
+    DevBuf<cf> d_tw, d_h;
+    // taps = [C][L] caller-order taps; false when (D, L) is not covered
+    bool build(const rr_c32* taps, size_t C, size_t L, size_t D, bool multi, hipStream_t s);
+};
 struct FirC32 : Block {
     FirPlan pl;
     // Non-decimating filters beyond a few taps run as overlap-save FFT tiles (the FftFilter kernel on a window
@@ -159,6 +166,7 @@ struct FmChain : Block {
     DevBuf<cf> decoded;               // only for odd-addressed byte windows (decoded out of line)
     DevBuf<cf> d_tw_half;             // w_(F/2)^k: half-size inverse (interp 1, even deci, 2048-point tiles; k_fm_chain_half)
     bool half_ok = false;
+    std::unique_ptr<PolyTables> poly; // interp 1, integer deci: decimate-first tiles (k_fm_chain_poly)
     FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false,
             int max_log2f = 14, const rr_c32* fir_taps = nullptr, size_t fir_ntaps = 0);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
@@ -172,6 +180,7 @@ struct FmMulti : Block {
     DevBuf<cf> d_hpos_all;            // [C][F]
     DevBuf<cf> d_tw_half;             // w_(F/2)^k: half-size inverse transforms (interp 1, even deci; k_fm_multi_half)
     bool half_ok = false;
+    std::unique_ptr<PolyTables> poly; // interp 1, deci 2..8: decimate-first tiles (k_fm_multi_poly)
     DevBuf<cf> last_r[2];             // [C]
     int cur_lr = 0;
     // iq8: RTL-SDR byte input, RtlSdrDecode fused in front (windows, `consumed` and WAIT_SRC `need` count BYTES)

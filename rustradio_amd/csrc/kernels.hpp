@@ -111,6 +111,20 @@ void launch_fm_chain_half(VSrc<cf> src, float* out, int L, const cf* tw, const c
 void launch_fm_chain_half_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, const cf* tw_half, const cf* hpos,
                               const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 
+// ---- kernels_poly.hip: fused FM chains with an integer decimation on decimate-first (polyphase) tiles ----------------
+// tw = w_1024^k; hreg = per channel and phase p the response FFT_1024(t[D j + p]) / 1024, register-major:
+// hreg[((c D + p) 16 + j) 64 + lane] = H_{c,p}[fm_poly_bin(j, lane)].  a.I must be 1.
+bool fm_poly_supported(long I, long D, int L, bool multi);
+int fm_poly_bin(int j, int lane);
+void launch_fm_chain_poly(VSrc<cf> src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& a, const cf* last_in,
+                          cf* last_out, hipStream_t s);
+void launch_fm_chain_poly_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& a, const cf* last_in,
+                              cf* last_out, hipStream_t s);
+void launch_fm_multi_poly(VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
+                          const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+void launch_fm_multi_poly_iq8(VSrcIQ8 src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
+                              const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
+
 // ---- kernels_fir.hip ---------------------------------------------------------------
 struct FirPlan {             // host-prepared polyphase tap table
     int L = 0, d = 1;

@@ -17,6 +17,7 @@
 #include <utility>
 
 #include "kernels.hpp"
+#include "tile_common.hpp"
 
 // Measurement builds (never shipped; make ABLATE=<bits> / TIMING=1 OUT=../lib_ablate):
 //   -DRR_FFT_ABLATE_BITS=<bits>  compile-time phase ablation: 1 no input loads, 2 no output stores,
@@ -57,30 +58,7 @@ template <int LOG2F, int VAR> struct KCfg {
     static constexpr int WAVES_PER_SIMD = VAR == 0 ? 2 : ((T / 64 + 3) / 4 < 2 ? 2 : (T / 64 + 3) / 4);
 };
 
-// Exchange synchronisation.  __syncthreads() also drains vmcnt (it is a fence), which would
-// serialise outstanding global traffic behind every LDS exchange.  A one-wave workgroup needs
-// no barrier at all (a wave's LDS operations execute in order); larger tiles wait for their
-// own LDS writes only and then meet at a raw s_barrier.
-template <int T> __device__ __forceinline__ void tile_sync() {
-    if constexpr (T > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("" ::: "memory");
-}
 
-// Workgroup b -> tile sequence.  The dispatcher places workgroup b on XCD b % 8 (observed,
-// used for speed only): each XCD gets one contiguous eighth of the tiles and its
-// workgroups sweep it together, so the L-1 samples two neighbouring tiles share are
-// fetched from HBM once and re-read from that XCD's L2.
-struct TileIter {
-    long tile, end, step;
-    __device__ __forceinline__ TileIter(long ntiles) {
-        const int b = blockIdx.x, g = gridDim.x;
-        const int nx = g < 8 ? g : 8;                  // partitions (XCDs that have a workgroup)
-        const int xcd = b % nx, slot = b / nx;
-        const int gx = (g - xcd + nx - 1) / nx;        // workgroups in this partition
-        const long lo = ntiles * xcd / nx, hi = ntiles * (xcd + 1) / nx;
-        tile = lo + slot; end = hi; step = gx;
-    }
-};
 
 // Per-thread constants of a kernel instance + the transform of one tile held in v[16]:
 // forward FFT, multiply by H, inverse FFT.  On entry v[n] = x[n*T + t]; on exit
@@ -1073,24 +1051,6 @@ void launch_fft_frames(int log2n, const cf* in, cf* out, long nframes, const cf*
 }
 
 // ---- fused FftFilter -> RationalResampler -> QuadratureDemod ------------------------------------------
-// fast-math 0.1.1 atan2 restated from its published algorithm (crate not vendored: parity-unpinned
-// flavour); same code as k_quaddemod in kernels_misc.hip.
-__device__ __forceinline__ float fmc_flip_sign(float v, float s) {
-    return __uint_as_float(__float_as_uint(v) ^ (__float_as_uint(s) & 0x80000000u));
-}
-__device__ __forceinline__ float fmc_atan_raw(float x) {
-    return mul_rn(sub_rn(add_rn(0.78539816339744830962f, 0.273f), mul_rn(0.273f, fabsf(x))), x);
-}
-__device__ __forceinline__ float fmc_atan2(float y, float x) {
-    if (fabsf(y) < fabsf(x)) {
-        const float bias = x > 0.0f ? 0.0f : 3.14159265358979323846f;
-        return add_rn(fmc_flip_sign(bias, y), fmc_atan_raw(__fdiv_rn(y, x)));
-    } else if (x == 0.0f) {
-        if (y == 0.0f) return 0.0f;
-        return fmc_flip_sign(1.57079632679489661923f, y);
-    }
-    return sub_rn(fmc_flip_sign(1.57079632679489661923f, y), fmc_atan_raw(__fdiv_rn(x, y)));
-}
 
 struct FmArgs {
     long A;          // filtered samples emitted before this call (global index of y at tile-space 0)
@@ -1658,13 +1618,14 @@ void k_fftfilt_half(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d
     }
 }
 
-// measurement builds: 16 s_memtime stamps of one tile (see RR_STAMP); nullptr otherwise
-static unsigned long long* fft_stamp_buffer() {
+// measurement builds (make TIMING=1): 32 s_memtime stamps of one tile (see RR_STAMP; the two-wave kernels of
+// kernels_poly.hip use 16 per wave); nullptr otherwise
+unsigned long long* fft_stamp_buffer() {
 #ifdef RR_FFT_TIMING_BUILD
     static unsigned long long* p = nullptr;
-    if (!p && getenv("RR_FFT_STAMPS")) {
-        RR_HIP(hipMalloc(reinterpret_cast<void**>(&p), 16 * sizeof(unsigned long long)));
-        RR_HIP(hipMemset(p, 0, 16 * sizeof(unsigned long long)));
+    if (!p) {
+        RR_HIP(hipMalloc(reinterpret_cast<void**>(&p), 32 * sizeof(unsigned long long)));
+        RR_HIP(hipMemset(p, 0, 32 * sizeof(unsigned long long)));
     }
     return p;
 #else
@@ -1675,8 +1636,8 @@ int fft_read_stamps(unsigned long long* host16) {
     unsigned long long* p = fft_stamp_buffer();
     if (!p) return 0;
     RR_HIP(hipDeviceSynchronize());
-    RR_HIP(hipMemcpy(host16, p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return 16;
+    RR_HIP(hipMemcpy(host16, p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 32;
 }
 
 bool fftfilt_supported(int log2f) { return log2f >= 10 && log2f <= 14; }
@@ -1697,33 +1658,6 @@ int device_cu_count() {
     return it->second;
 }
 
-template <class KFn> static long grid_for_tiles(KFn kfn, int T, size_t smem, long ntiles) {
-    // launch setup (shared-memory attribute, occupancy) is per kernel AND per device: a process may drive several
-    // GPUs (rr_set_device); first launches may come from several host threads at once
-    static std::mutex mu;
-    static std::map<std::pair<const void*, int>, int> per_cu_of;
-    int dev = 0;
-    RR_HIP(hipGetDevice(&dev));
-    const std::pair<const void*, int> key(reinterpret_cast<const void*>(kfn), dev);
-    int per_cu;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        auto it = per_cu_of.find(key);
-        if (it == per_cu_of.end()) {
-            RR_HIP(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            int n = 0;
-            RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, T, smem));
-            if (n < 1) n = 1;
-#ifdef RR_MEASURE_KNOBS
-            if (const char* e = getenv("RR_FFT_PERCU")) n = atoi(e) > 0 ? atoi(e) : n;   // measurement builds only (tools/fft_percu.sh)
-#endif
-            it = per_cu_of.emplace(key, n).first;
-        }
-        per_cu = it->second;
-    }
-    long grid = (long)device_cu_count() * per_cu;
-    return grid > ntiles ? ntiles : grid;
-}
 
 template <int LOG2F, int VAR>
 static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s) {

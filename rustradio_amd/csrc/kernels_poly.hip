@@ -1,0 +1,414 @@
+// kernels_poly.hip — fused FM receive chains with an INTEGER decimation, decimate-first ("polyphase") tiles.
+//
+// FftFilter -> RationalResampler(1, D) keeps r[u] = y[u D] (rational_resampler.rs:183-198 with interp 1): of every D
+// filtered samples D - 1 are thrown away.  Splitting the taps and the input into their D phases,
+//     r[u] = sum_{p < D} (h_p * x_p)[u],    h_p[j] = t[D j + p],    x_p[u] = x[D u - p],
+// turns the L-tap filter at the input rate into D filters of ceil(L / D) taps at the OUTPUT rate, and in the frequency
+// domain the sum over the phases is taken BEFORE the inverse transform:
+//     R = IFFT_F( sum_p H_p . FFT_F(x_p) ),   H_p = FFT_F(h_p) / F
+// — per F low-rate positions D forward transforms and ONE inverse of F points, instead of a forward transform over D F
+// input samples, the product, and an inverse whose output is then decimated.  For BASELINE configs[2] / [3] (463 taps,
+// 1:6; 78 taps per phase) a 1024-point tile yields 946 demodulated samples from 5676 inputs with 7 transforms of 1024
+// points; the 2048-point tiles of kernels_fft.hip spend a 2048- plus a 1024-point transform on 1536 inputs.  (A radix-3
+// tile plan, F = 3 * 2^k, would prune the inverse by the same 6 but still pay the full-rate forward transform, and 16
+// values per thread do not divide into radix-3 / 6 / 12 groups; the phase transforms are all powers of two.)
+//
+// One 1024-point transform = ONE WAVE (64 lanes x 16 values, Plan<10> = 16 x 16 x 4; LDS exchanges inside a wave need
+// no barrier).  The phases of a tile interleave in memory (x_p[u] = x[D u - p]): lane-consecutive loads of one phase are
+// strided by D samples, so the waves that share a tile load their phases at the same time and the cache lines they share
+// are fetched once (a wave working through all D phases alone would come back to every line D times, tile-sized reuse
+// distances apart).
+//   k_fm_chain_poly: one chain.  A workgroup = 2 waves = one tile: wave 0 transforms phases [0, ceil(D/2)), wave 1 the
+//     rest, each accumulating its share of sum_p H_p X_p in registers; wave 1 hands its partial sum over through LDS,
+//     wave 0 runs the inverse, both demodulate (alternate rounds of 64 outputs).
+//   k_fm_multi_poly: N channels on one input (configs[3]).  A workgroup = 8 waves: waves 0 .. D-1 transform one phase
+//     each and park the D spectra in LDS (the forward work is shared by all channels, as in k_fm_multi); then every wave
+//     takes every 8th channel: sum_p H_{c,p} X_p from the parked spectra, inverse, demodulation.
+#include "kernels.hpp"
+#include "tile_common.hpp"
+
+namespace rr {
+
+constexpr int PLG = 10, PF = 1 << PLG, PT = PF / 16;      // tile: 1024 low-rate positions on 64 lanes
+constexpr int PLE = lds_elems(PF);
+
+struct PolyArgs {
+    long off;            // virtual-stream index of global input sample i is i + off  (off = L - 1 - A)
+    long r_lo, r_hi;     // resampled samples of this call: r[u] = y[u D], u in [r_lo, r_hi)
+    long o_base;         // demodulated samples emitted before this call
+    int Ls;              // taps per phase, ceil(L / D)
+    float gain;
+    int mode;            // RR_ATAN2_*
+};
+
+#ifdef RR_FFT_TIMING_BUILD
+#define PSTAMP(i) do { if (stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void wave_fence() { asm volatile("" ::: "memory"); }   // a wave's LDS operations execute in order
+
+// acc + a * w (complex): the product's two halves as packed FMAs (see cmul in fft_core.hpp)
+__device__ __forceinline__ creg cmac(creg acc, creg a, creg w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    creg t = a * __builtin_shufflevector(w, w, 0, 0) + acc, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+#else
+    return cadd(acc, cmul(a, w));
+#endif
+}
+
+__device__ __forceinline__ creg poly_elem(const VSrc<cf>& s, long i) { return reinterpret_cast<const creg*>(s.in)[i]; }
+__device__ __forceinline__ creg poly_elem(const VSrcIQ8& s, long i) {
+    return to_reg(VSrcIQ8::decode(reinterpret_cast<const unsigned short*>(s.in)[i]));
+}
+
+// Boundary tiles (touching the carry prefix, the start of the stream or the end of the window) are staged through
+// the wave's exchange area by an out-of-line routine, so that their index arithmetic costs the steady-state path nothing.
+template <class SRC>
+__device__ __attribute__((noinline)) void poly_stage_slow(creg* ex, SRC src, long vbase, int D, int p, int t) {
+    for (int n = 0; n < 16; n++) {
+        const long vi = vbase + (long)D * (PT * n + t) - p;
+        ex[lds_pad(PT * n + t)] = vi >= 0 ? to_reg(src.load(vi)) : mk(0.0f, 0.0f);
+    }
+}
+// v[n] = V[vbase + D (64 n + t) - p]: phase p of the tile whose position 0 is the low-rate sample at vbase / D.
+// interior (wave-uniform): the whole tile, all phases, lies inside the caller's window.
+template <int D, class SRC>
+__device__ __forceinline__ void poly_load(creg* v, const SRC& src, long vbase, int p, int t, bool interior, creg* ex) {
+    if (interior) {
+        const long i0 = vbase - src.plen - p + (long)D * t;
+#pragma unroll
+        for (int n = 0; n < 16; n++) v[n] = poly_elem(src, i0 + (long)D * PT * n);
+    } else {
+        poly_stage_slow(ex, src, vbase, D, p, t);
+        wave_fence();
+        lds_load<PLG, 0>(v, t, ex);                      // (own slots: each lane reads back what it wrote)
+        wave_fence();
+    }
+}
+
+// forward 1024-point transform of one wave, exchanges in `ex`; pass-1 twiddles w_64^(k (t % 4)) from the LDS table
+__device__ __forceinline__ void poly_forward(creg* v, int t, creg* ex, const creg* tw0, const creg* tab1) {
+    creg twl[15];
+    fwd_pass<PLG, 0>(v, tw0);
+    lds_store<PLG, 0>(v, t, ex);
+    wave_fence();
+    lds_load<PLG, 1>(v, t, ex);
+#pragma unroll
+    for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<PLG, 1>::lo(t)];
+    fwd_pass<PLG, 1>(v, twl);
+    lds_store<PLG, 1>(v, t, ex);
+    wave_fence();
+    lds_load<PLG, 2>(v, t, ex);
+    fwd_pass<PLG, 2>(v, twl);                        // (P == 1: no twiddles)
+}
+// inverse: spectrum in the pass-2 layout -> v[n] = tile position 64 n + t
+__device__ __forceinline__ void poly_inverse(creg* v, int t, creg* ex, const creg* tw0, const creg* tab1) {
+    creg twl[15];
+    inv_pass<PLG, 2>(v, twl);
+    lds_store<PLG, 2>(v, t, ex);
+    wave_fence();
+    lds_load<PLG, 1>(v, t, ex);
+#pragma unroll
+    for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<PLG, 1>::lo(t)];
+    inv_pass<PLG, 1>(v, twl);
+    lds_store<PLG, 1>(v, t, ex);
+    wave_fence();
+    lds_load<PLG, 0>(v, t, ex);
+    inv_pass<PLG, 0>(v, tw0);
+}
+
+// Phases [P0, P0 + NPH) of one tile on this wave: z += sum_p H_p X_p.  Loaded in batches of up to 3 phases — the lines
+// a batch shares are then touched by back-to-back loads (one fetch per line and wave) and there is one memory latency
+// per batch; hreg = this channel's responses, register-major [p][16][64].  Register budget (256 at 2 waves / SIMD): a
+// batch 96 + z 32 + pass-0 twiddles 30 + one pass's temporaries; H is fetched during the last (twiddle-free) pass.
+template <int D, int P0, int NPH, class SRC>
+__device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase, bool interior, int t, creg* ex,
+                                            const creg* tw0, const creg* tab1, const creg* __restrict__ hreg) {
+    constexpr int NB = NPH <= 3 ? NPH : 2;
+#pragma unroll
+    for (int pb = 0; pb < NPH; pb += NB) {
+        creg v[NB][16];
+        if (interior) {
+            // position-major: the NB loads of one n touch the same cache lines back to back (phase-major order would
+            // come back to every line of the 48 KB tile NB times, a whole tile apart: the L1 does not hold a tile)
+            const long i0 = vbase - src.plen - (P0 + pb) + (long)D * t;
+#pragma unroll
+            for (int n = 0; n < 16; n++)
+#pragma unroll
+                for (int i = 0; i < NB; i++)
+                    if (pb + i < NPH) v[i][n] = poly_elem(src, i0 - i + (long)D * PT * n);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; i++)
+                if (pb + i < NPH) poly_load<D>(v[i], src, vbase, P0 + pb + i, t, false, ex);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            if (pb + i < NPH) {
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    creg twl[15];
+                    fwd_pass<PLG, 0>(v[i], tw0);
+                    lds_store<PLG, 0>(v[i], t, ex);
+                    wave_fence();
+                    lds_load<PLG, 1>(v[i], t, ex);
+#pragma unroll
+                    for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<PLG, 1>::lo(t)];
+                    fwd_pass<PLG, 1>(v[i], twl);
+                    lds_store<PLG, 1>(v[i], t, ex);
+                    wave_fence();
+                    lds_load<PLG, 2>(v[i], t, ex);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                creg h[16];
+                const creg* hp = hreg + (long)(P0 + pb + i) * 16 * PT + t;
+#pragma unroll
+                for (int j = 0; j < 16; j++) h[j] = hp[j * PT];
+                fwd_pass<PLG, 2>(v[i], nullptr);         // (P == 1: no twiddles)
+#pragma unroll
+                for (int j = 0; j < 16; j++) z[j] = cmac(z[j], v[i][j], h[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// Demodulation of one tile: tile position Ls + i holds r[u0 + i]; lanes `lane0, lane0 + stride, ...` of the tile's
+// outputs.  Everything that does not depend on i is hoisted: the loop body is two LDS reads, the conj-multiply, atan2
+// and one store; the three special samples (r[0] has no partner, the first pair of a call takes its lower sample from the
+// previous call, the last r of a call is carried) are patched outside the loop by the lane that owns them.
+__device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int stride, long u0, int Sa, const PolyArgs& a,
+                                                float* __restrict__ out, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    const long left = a.r_hi - u0;
+    const int nv = left < Sa ? (int)left : Sa;                          // valid samples of this tile
+    float* o = out + ((u0 - 1) - a.o_base);                              // o[i] = demodulated pair (r[u0 + i - 1], r[u0 + i])
+    const creg* rp = ldsR;
+    const int Ls = a.Ls;
+    for (int i = lane0; i < nv; i += stride) {
+        const int q = Ls + i;
+        const creg ru = rp[lds_pad(q)];
+        creg rl = rp[lds_pad(q - 1)];
+        if (i == 0) {
+            if (u0 == a.r_lo) rl = to_reg(last_r_in[0]);                  // lower sample from the previous call
+            if (u0 == 0) continue;                                       // r[0] has no lower partner
+        }
+        o[i] = demod_pair<true>(rl, ru, a.gain, a.mode);
+    }
+    if (left <= Sa && ((nv - 1 - lane0) % stride) == 0 && nv - 1 >= lane0)
+        last_r_out[0] = from_reg(rp[lds_pad(Ls + nv - 1)]);              // r[r_hi - 1]: carry for the next call
+}
+
+template <int D, class SRC>
+__global__ __launch_bounds__(128, 2)
+void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
+                     PolyArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg) {
+    constexpr int PHA = (D + 1) / 2, PHB = D - PHA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    creg* exB = lds + PLE;                               // wave 1's exchanges, then its partial sum (register-major)
+    creg* ldsR = lds + 2 * PLE;                          // the tile's resampled samples, natural order
+    creg* tab1 = lds + 3 * PLE;                          // w_64^j
+    const int w = threadIdx.x >> 6, t_ = threadIdx.x & 63;
+    creg* ex = lds + w * PLE;
+    creg tw0[15];
+    load_twiddles<PLG, 0>(tw0, t_, tw);
+    if (w == 0) tab1[t_] = to_reg(tw[t_ * (PF / 64)]);
+    tile_sync<128>();
+    const int Sa = PF - a.Ls;                            // demodulated samples per tile
+    const creg* hr = reinterpret_cast<const creg*>(hreg);
+
+    int iter = 0;
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step, iter++) {
+#ifdef RR_FFT_TIMING_BUILD
+        unsigned long long* stamps = (dbg && blockIdx.x == 0 && t_ == 0 && iter == 2) ? dbg + 16 * w : nullptr;
+#else
+        (void)dbg; (void)iter;
+#endif
+        PSTAMP(0);
+        const long u0 = a.r_lo + it.tile * Sa;           // tile position Ls holds r[u0]
+        const long vbase = (u0 - a.Ls) * D + a.off;
+        const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
+        creg z[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) z[j] = mk(0.0f, 0.0f);
+        int t = t_;                                      // opaque per tile: keeps the tile body's LDS / table addresses from
+        asm volatile("" : "+v"(t));                      // being hoisted out of the loop into persistent VGPRs
+        if (w == 0) {
+            poly_phases<D, 0, PHA>(z, src, vbase, interior, t, ex, tw0, tab1, hr);
+        } else {
+            if constexpr (PHB > 0) poly_phases<D, PHA, PHB>(z, src, vbase, interior, t, ex, tw0, tab1, hr);
+#pragma unroll
+            for (int j = 0; j < 16; j++) exB[j * PT + t] = z[j];
+        }
+        PSTAMP(1);
+        tile_sync<128>();
+        PSTAMP(2);
+        if (w == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) z[j] = cadd(z[j], exB[j * PT + t]);
+            poly_inverse(z, t, ex, tw0, tab1);
+            lds_store<PLG, 0>(z, t, ldsR);
+        }
+        PSTAMP(3);
+        tile_sync<128>();
+        PSTAMP(4);
+        poly_demod_tile(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        PSTAMP(5);
+        // (the next tile rewrites exB / ldsR only after its first barrier, which both waves reach after these reads)
+    }
+}
+
+// ---- N channels on one input -------------------------------------------------------------------------------------
+template <int D, class SRC>
+__global__ __launch_bounds__(512, 1)
+void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long ntiles, const cf* __restrict__ tw,
+                     const cf* __restrict__ hreg, int nchan, PolyArgs a, const cf* __restrict__ last_r_in,
+                     cf* __restrict__ last_r_out) {
+    static_assert(D <= 8, "one phase per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    creg* park = lds + 8 * PLE;                          // D spectra, register-major [p][16][64]
+    creg* tab1 = park + D * PF;
+    const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
+    creg* ex = lds + w * PLE;
+    creg tw0[15];
+    load_twiddles<PLG, 0>(tw0, t, tw);
+    if (w == 0) tab1[t] = to_reg(tw[t * (PF / 64)]);
+    tile_sync<512>();
+    const int Sa = PF - a.Ls;
+    const creg* hr = reinterpret_cast<const creg*>(hreg);
+
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long u0 = a.r_lo + it.tile * Sa;
+        const long vbase = (u0 - a.Ls) * D + a.off;
+        const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
+        if (w < D) {
+            creg v[16];
+            poly_load<D>(v, src, vbase, w, t, interior, ex);
+            poly_forward(v, t, ex, tw0, tab1);
+#pragma unroll
+            for (int j = 0; j < 16; j++) park[(w * 16 + j) * PT + t] = v[j];
+        }
+        tile_sync<512>();
+#pragma unroll 1
+        for (int c = w; c < nchan; c += 8) {
+            const creg* hc = hr + (long)c * D * 16 * PT + t;
+            creg z[16], h[2][16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) z[j] = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < 16; j++) h[0][j] = hc[j * PT];
+#pragma unroll
+            for (int p = 0; p < D; p++) {                    // phase p + 1's response is in flight while phase p is multiplied
+                if (p + 1 < D) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) h[(p + 1) & 1][j] = hc[((p + 1) * 16 + j) * PT];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; j++) z[j] = cmac(z[j], park[(p * 16 + j) * PT + t], h[p & 1][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            poly_inverse(z, t, ex, tw0, tab1);
+            lds_store<PLG, 0>(z, t, ex);                 // natural order in the wave's own area
+            wave_fence();
+            float* oc = out + (long)c * out_stride;
+            poly_demod_tile(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+            wave_fence();
+        }
+        tile_sync<512>();                                // every wave is done with the parked spectra
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------------
+bool fm_poly_supported(long I, long D, int L, bool multi) {
+    if (I != 1) return false;
+    const bool dok = multi ? (D >= 2 && D <= 8) : (D == 2 || D == 3 || D == 4 || D == 5 || D == 6 || D == 7 || D == 8 || D == 10 || D == 12 || D == 16);
+    if (!dok || L < 1) return false;
+    const long Ls = (L + D - 1) / D;
+    return Ls <= 448;                                    // at least 576 of the 1024 positions of a tile are output
+}
+int fm_poly_bin(int j, int t) {                          // frequency bin held by register j of lane t after the forward transform
+    using G = PassGeom<PLG, 2>;
+    return bin_of_pos<PLG>(G::pos(t + G::T * (j / G::R), j % G::R));
+}
+
+static PolyArgs poly_args(const FmChainArgs& h, int L) {
+    PolyArgs a;
+    a.off = (long)(L - 1) - h.A;
+    a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
+    a.Ls = (int)((L + h.D - 1) / h.D);
+    a.gain = h.gain; a.mode = h.mode;
+    return a;
+}
+
+template <int D, class SRC>
+static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& h, const cf* last_in,
+                                cf* last_out, hipStream_t s) {
+    const PolyArgs a = poly_args(h, L);
+    const long Sa = PF - a.Ls, nr = a.r_hi - a.r_lo;
+    if (nr <= 0) return;
+    const long ntiles = (nr + Sa - 1) / Sa;
+    const size_t smem = sizeof(cf) * (3 * PLE + 64);
+    const long grid = grid_for_tiles(k_fm_chain_poly<D, SRC>, 128, smem, ntiles);
+    hipLaunchKernelGGL((k_fm_chain_poly<D, SRC>), dim3((unsigned)grid), dim3(128), smem, s, src, out, ntiles, tw, hreg, a, last_in, last_out,
+                       fft_stamp_buffer());
+    RR_HIP(hipGetLastError());
+}
+template <class SRC>
+static void launch_chain_poly_t(SRC src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& h, const cf* last_in,
+                                cf* last_out, hipStream_t s) {
+    switch (h.D) {
+#define RR_POLY_CASE(DV) case DV: launch_chain_poly_d<DV>(src, out, L, tw, hreg, h, last_in, last_out, s); break
+    RR_POLY_CASE(2); RR_POLY_CASE(3); RR_POLY_CASE(4); RR_POLY_CASE(5); RR_POLY_CASE(6); RR_POLY_CASE(7); RR_POLY_CASE(8);
+    RR_POLY_CASE(10); RR_POLY_CASE(12); RR_POLY_CASE(16);
+#undef RR_POLY_CASE
+    default: throw Error("fm_chain_poly: unsupported decimation");
+    }
+}
+void launch_fm_chain_poly(VSrc<cf> src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& a, const cf* last_in,
+                          cf* last_out, hipStream_t s) {
+    launch_chain_poly_t(src, out, L, tw, hreg, a, last_in, last_out, s);
+}
+void launch_fm_chain_poly_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& a, const cf* last_in,
+                              cf* last_out, hipStream_t s) {
+    launch_chain_poly_t(src, out, L, tw, hreg, a, last_in, last_out, s);
+}
+
+template <int D, class SRC>
+static void launch_multi_poly_d(SRC src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
+                                const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    const PolyArgs a = poly_args(h, L);
+    const long Sa = PF - a.Ls, nr = a.r_hi - a.r_lo;
+    if (nr <= 0) return;
+    const long ntiles = (nr + Sa - 1) / Sa;
+    const size_t smem = sizeof(cf) * (8 * PLE + D * PF + 64);
+    const long grid = grid_for_tiles(k_fm_multi_poly<D, SRC>, 512, smem, ntiles);
+    hipLaunchKernelGGL((k_fm_multi_poly<D, SRC>), dim3((unsigned)grid), dim3(512), smem, s, src, out, out_stride, ntiles, tw, hreg,
+                       nchan, a, last_in, last_out);
+    RR_HIP(hipGetLastError());
+}
+template <class SRC>
+static void launch_multi_poly_t(SRC src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
+                                const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
+    switch (h.D) {
+#define RR_POLY_CASE(DV) case DV: launch_multi_poly_d<DV>(src, out, out_stride, L, tw, hreg, nchan, h, last_in, last_out, s); break
+    RR_POLY_CASE(2); RR_POLY_CASE(3); RR_POLY_CASE(4); RR_POLY_CASE(5); RR_POLY_CASE(6); RR_POLY_CASE(7); RR_POLY_CASE(8);
+#undef RR_POLY_CASE
+    default: throw Error("fm_multi_poly: unsupported decimation");
+    }
+}
+void launch_fm_multi_poly(VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
+                          const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s) {
+    launch_multi_poly_t(src, out, out_stride, L, tw, hreg, nchan, a, last_in, last_out, s);
+}
+void launch_fm_multi_poly_iq8(VSrcIQ8 src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
+                              const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s) {
+    launch_multi_poly_t(src, out, out_stride, L, tw, hreg, nchan, a, last_in, last_out, s);
+}
+
+}  // namespace rr

@@ -521,15 +521,20 @@ def _demod_close(yg, yo, ro):
 
 
 @pytest.mark.parametrize("L,I,D", [(463, 1, 6), (401, 1, 1), (127, 25, 128), (33, 3, 2), (463, 200000, 1024000), (5, 1, 40),
-                                   (463, 1, 2), (400, 1, 6), (600, 1, 100), (463, 3, 18)])
+                                   (463, 1, 2), (400, 1, 6), (600, 1, 100), (463, 3, 18), (463, 1, 3), (461, 1, 5), (200, 1, 7),
+                                   (463, 1, 8), (464, 1, 12), (1000, 1, 16), (462, 1, 10), (2467, 1, 6), (1, 1, 4), (7, 1, 6)])
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 20_000])
-@pytest.mark.parametrize("kernel", ["half", "full"])
+@pytest.mark.parametrize("kernel", ["poly", "half", "full"])
 def test_fm_chain_fused_block(rr, monkeypatch, L, I, D, stream_bytes, kernel):
     """rr.FmChain (one fused kernel) == FftFilter -> RationalResampler -> QuadratureDemod of the oracle,
-    for whole-stream output and any chunking.  kernel = half: reduced ratios 1:even on 2048-point tiles finish each
-    tile with a folded 1024-point inverse on one wave (k_fm_chain_half); full: the full-size inverse everywhere."""
+    for whole-stream output and any chunking.  kernel = poly (the default): integer decimations run on decimate-first
+    tiles (k_fm_chain_poly: D phase transforms + one inverse per 1024 output-rate positions); half: reduced ratios 1:even
+    on 2048-point tiles finish each tile with a folded 1024-point inverse on one wave (k_fm_chain_half); full: the
+    full-size inverse everywhere."""
     if kernel == "full":
         knob(rr, monkeypatch, fm_full=1)
+    elif kernel == "half":
+        knob(rr, monkeypatch, fm_poly=-1)
     fs = 2.4e6
     n = 400_000
     x = fm_signal(n, fs, 0.0, 77 + L)
@@ -612,13 +617,15 @@ def test_fm_chain_fused_protocol(rr):
 
 
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 30_000])
-@pytest.mark.parametrize("kernel", ["half", "full"])
+@pytest.mark.parametrize("kernel", ["poly", "half", "full"])
 def test_fm_multi_shared_source(rr, monkeypatch, stream_bytes, kernel):
     """rr.FmMulti: N channels on one shared input (forward FFT computed once per tile) — every
     channel must equal its own oracle chain FftFilter(taps_c) -> RationalResampler -> QuadratureDemod.
     kernel = half: interp 1 / even deci on 2048-point tiles runs folded 1024-point inverses (k_fm_multi_half)."""
     if kernel == "full":
         knob(rr, monkeypatch, fm_full=1)
+    elif kernel == "half":
+        knob(rr, monkeypatch, fm_poly=-1)
     fs, n, nch = 2.4e6, 300_000, 5
     proto = orc.low_pass_complex(fs, 100e3, 12.5e3)
     k = np.arange(len(proto), dtype=np.float64)
@@ -649,11 +656,16 @@ def test_fm_multi_shared_source(rr, monkeypatch, stream_bytes, kernel):
             assert np.max(d[len(proto) // 6 + 2:]) <= TOL * np.pi
 
 
-@pytest.mark.parametrize("L,D,nch", [(463, 2, 1), (463, 4, 2), (400, 10, 3), (300, 64, 2), (513, 6, 4), (463, 200, 1), (700, 6, 2)])
-def test_fm_multi_even_decimations(rr, L, D, nch):
-    """FmMulti with interp 1 and even decimations (half-size inverse transforms on 2048-point tiles where the tile
-    choice allows), odd and even filter lengths (the reference's nsamples, hence the parity of every call's start,
-    alternates), 1..4 channels, small windows."""
+@pytest.mark.parametrize("kernel", ["auto", "half"])
+@pytest.mark.parametrize("L,D,nch", [(463, 2, 1), (463, 4, 2), (400, 10, 3), (300, 64, 2), (513, 6, 4), (463, 200, 1), (700, 6, 2),
+                                     (463, 3, 2), (461, 5, 3), (300, 7, 2), (463, 8, 9), (2467, 6, 2), (3, 6, 2)])
+def test_fm_multi_even_decimations(rr, monkeypatch, L, D, nch, kernel):
+    """FmMulti with interp 1 and integer decimations — auto: decimations 2..8 on decimate-first tiles (k_fm_multi_poly), the
+    others as half: even decimations with half-size inverse transforms on 2048-point tiles where the tile choice allows,
+    else full-size inverses; odd and even filter lengths (the reference's nsamples, hence the parity of every call's
+    start, alternates), 1..9 channels, small windows."""
+    if kernel == "half":
+        knob(rr, monkeypatch, fm_poly=-1)
     fs, n = 2.4e6, 200_000
     proto = (rnd_c(L, L + D) / max(1, L // 8)).astype(np.complex64)
     k = np.arange(L, dtype=np.float64)
