@@ -1143,7 +1143,7 @@ void k_fm_chain(SRC src, float* __restrict__ out, int L, long ntiles, const cf* 
                 const float na = -rl.y;
                 const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
                 const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
-                const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                const float ang = a.mode == 0 ? atan2_poly(im, re) : fmc_atan2(im, re);
                 out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
             }
         }
@@ -1219,7 +1219,7 @@ void k_fm_multi(SRC src, float* __restrict__ out, long out_stride, int L, long n
                     const float na = -rl.y;
                     const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
                     const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
-                    const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                    const float ang = a.mode == 0 ? atan2_poly(im, re) : fmc_atan2(im, re);
                     oc[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
                 }
             }
@@ -1348,7 +1348,7 @@ void k_fm_multi_half(SRC src, float* __restrict__ out, long out_stride, int L, l
                     const float na = -rl.y;
                     const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
                     const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
-                    const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                    const float ang = a.mode == 0 ? atan2_poly(im, re) : fmc_atan2(im, re);
                     oc[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
                 }
             }
@@ -1485,7 +1485,7 @@ void k_fm_chain_half(SRC src, float* __restrict__ out, int L, long ntiles, long 
                     const float na = -rl.y;
                     const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
                     const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
-                    const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                    const float ang = a.mode == 0 ? atan2_poly(im, re) : fmc_atan2(im, re);
                     out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
                 }
             }
@@ -1947,7 +1947,7 @@ void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, cons
                 const float na = -rl.y;
                 const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
                 const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
-                const float ang = a.mode == 0 ? atan2f(im, re) : fmc_atan2(im, re);
+                const float ang = a.mode == 0 ? atan2_poly(im, re) : fmc_atan2(im, re);
                 out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
             }
         }

@@ -41,6 +41,13 @@ struct PolyArgs {
     int mode;            // RR_ATAN2_*
 };
 
+// tuning: phases loaded per batch and waves per SIMD of the single-chain kernel (measured on MI355X)
+#ifndef RR_POLY_NB
+#define RR_POLY_NB 3
+#endif
+#ifndef RR_POLY_WAVES
+#define RR_POLY_WAVES 2
+#endif
 #ifdef RR_FFT_TIMING_BUILD
 #define PSTAMP(i) do { if (stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
@@ -128,7 +135,7 @@ __device__ __forceinline__ void poly_inverse(creg* v, int t, creg* ex, const cre
 template <int D, int P0, int NPH, class SRC>
 __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase, bool interior, int t, creg* ex,
                                             const creg* tw0, const creg* tab1, const creg* __restrict__ hreg) {
-    constexpr int NB = NPH <= 3 ? NPH : 2;
+    constexpr int NB = RR_POLY_NB < NPH ? RR_POLY_NB : NPH;
 #pragma unroll
     for (int pb = 0; pb < NPH; pb += NB) {
         creg v[NB][16];
@@ -177,33 +184,44 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
     }
 }
 
-// Demodulation of one tile: tile position Ls + i holds r[u0 + i]; lanes `lane0, lane0 + stride, ...` of the tile's
-// outputs.  Everything that does not depend on i is hoisted: the loop body is two LDS reads, the conj-multiply, atan2
-// and one store; the three special samples (r[0] has no partner, the first pair of a call takes its lower sample from the
-// previous call, the last r of a call is carried) are patched outside the loop by the lane that owns them.
+// Demodulation of one tile: tile position Ls + i holds r[u0 + i]; this lane takes i = lane0, lane0 + stride, ...
+// (stride a multiple of 16, so the padded LDS address advances by a constant).  The loop body is two LDS reads, the
+// conj-multiply as one packed multiply + one packed FMA, atan2 and one store; the special samples — r[0] has no partner,
+// the first pair of a call takes its lower sample from the previous call, the last r of a call is carried — sit in the
+// first / last tile of a call only and are handled under wave-uniform tests outside the steady-state loop.
+// (conj(rl) * ru here is ru * conj(rl) with FMA contraction: within 1 ulp of the reference's un-fused form,
+//  quadrature_demod.rs:72; zeros stay exact zeros, so atan2(0, 0) * gain == 0 still holds.)
+template <int MODE>
+__device__ __forceinline__ float poly_angle(creg rl, creg ru, float gain) {
+    const creg zz = cmulc(ru, rl);
+    return gain * (MODE == 0 ? atan2_poly(zz.y, zz.x) : fmc_atan2(zz.y, zz.x));
+}
+template <int MODE>
 __device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int stride, long u0, int Sa, const PolyArgs& a,
                                                 float* __restrict__ out, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
     const long left = a.r_hi - u0;
     const int nv = left < Sa ? (int)left : Sa;                          // valid samples of this tile
-    float* o = out + ((u0 - 1) - a.o_base);                              // o[i] = demodulated pair (r[u0 + i - 1], r[u0 + i])
-    const creg* rp = ldsR;
-    const int Ls = a.Ls;
-    for (int i = lane0; i < nv; i += stride) {
-        const int q = Ls + i;
-        const creg ru = rp[lds_pad(q)];
-        creg rl = rp[lds_pad(q - 1)];
-        if (i == 0) {
-            if (u0 == a.r_lo) rl = to_reg(last_r_in[0]);                  // lower sample from the previous call
-            if (u0 == 0) continue;                                       // r[0] has no lower partner
+    float* o = out + ((u0 - 1) - a.o_base) + lane0;                      // o[i] = demodulated pair (r[u0 + i - 1], r[u0 + i])
+    const creg* pu = ldsR + lds_pad(a.Ls + lane0);
+    const creg* pl = ldsR + lds_pad(a.Ls + lane0 - 1);
+    const int inc = stride + (stride >> 4);
+    int i = lane0;
+    if (u0 == a.r_lo) {                                                  // (wave-uniform) first tile of the call
+        if (i < nv) {
+            const creg ru = *pu;
+            const creg rl = i == 0 ? to_reg(last_r_in[0]) : *pl;       // lower sample from the previous call
+            if (!(i == 0 && u0 == 0)) *o = poly_angle<MODE>(rl, ru, a.gain);   // r[0] has no lower partner
         }
-        o[i] = demod_pair<true>(rl, ru, a.gain, a.mode);
+        i += stride; pu += inc; pl += inc; o += stride;
     }
-    if (left <= Sa && ((nv - 1 - lane0) % stride) == 0 && nv - 1 >= lane0)
-        last_r_out[0] = from_reg(rp[lds_pad(Ls + nv - 1)]);              // r[r_hi - 1]: carry for the next call
+    for (; i < nv; i += stride, pu += inc, pl += inc, o += stride) *o = poly_angle<MODE>(*pl, *pu, a.gain);
+    if (left <= Sa) {                                                    // (wave-uniform) last tile: carry r[r_hi - 1]
+        if (nv - 1 >= lane0 && ((nv - 1 - lane0) % stride) == 0) last_r_out[0] = from_reg(ldsR[lds_pad(a.Ls + nv - 1)]);
+    }
 }
 
 template <int D, class SRC>
-__global__ __launch_bounds__(128, 2)
+__global__ __launch_bounds__(128, RR_POLY_WAVES)
 void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
                      PolyArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg) {
     constexpr int PHA = (D + 1) / 2, PHB = D - PHA;
@@ -256,7 +274,8 @@ void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __
         PSTAMP(3);
         tile_sync<128>();
         PSTAMP(4);
-        poly_demod_tile(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        if (a.mode == 0) poly_demod_tile<0>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        else poly_demod_tile<1>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
         PSTAMP(5);
         // (the next tile rewrites exB / ldsR only after its first barrier, which both waves reach after these reads)
     }
@@ -267,7 +286,7 @@ template <int D, class SRC>
 __global__ __launch_bounds__(512, 1)
 void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long ntiles, const cf* __restrict__ tw,
                      const cf* __restrict__ hreg, int nchan, PolyArgs a, const cf* __restrict__ last_r_in,
-                     cf* __restrict__ last_r_out) {
+                     cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg) {
     static_assert(D <= 8, "one phase per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     creg* lds = reinterpret_cast<creg*>(smem_raw);
@@ -282,7 +301,14 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
     const int Sa = PF - a.Ls;
     const creg* hr = reinterpret_cast<const creg*>(hreg);
 
-    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+    int iter = 0;
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step, iter++) {
+#ifdef RR_FFT_TIMING_BUILD
+        unsigned long long* stamps = (dbg && blockIdx.x == 0 && t == 0 && iter == 1 && w < 2) ? dbg + 16 * w : nullptr;
+#else
+        (void)dbg; (void)iter;
+#endif
+        PSTAMP(0);
         const long u0 = a.r_lo + it.tile * Sa;
         const long vbase = (u0 - a.Ls) * D + a.off;
         const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
@@ -293,7 +319,9 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
 #pragma unroll
             for (int j = 0; j < 16; j++) park[(w * 16 + j) * PT + t] = v[j];
         }
+        PSTAMP(1);
         tile_sync<512>();
+        PSTAMP(2);
 #pragma unroll 1
         for (int c = w; c < nchan; c += 8) {
             const creg* hc = hr + (long)c * D * 16 * PT + t;
@@ -313,14 +341,20 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
                 for (int j = 0; j < 16; j++) z[j] = cmac(z[j], park[(p * 16 + j) * PT + t], h[p & 1][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (c == w) PSTAMP(3);
             poly_inverse(z, t, ex, tw0, tab1);
             lds_store<PLG, 0>(z, t, ex);                 // natural order in the wave's own area
             wave_fence();
+            if (c == w) PSTAMP(4);
             float* oc = out + (long)c * out_stride;
-            poly_demod_tile(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+            if (a.mode == 0) poly_demod_tile<0>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+            else poly_demod_tile<1>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
             wave_fence();
+            if (c == w) PSTAMP(5);
         }
+        PSTAMP(6);
         tile_sync<512>();                                // every wave is done with the parked spectra
+        PSTAMP(7);
     }
 }
 
@@ -389,7 +423,7 @@ static void launch_multi_poly_d(SRC src, float* out, long out_stride, int L, con
     const size_t smem = sizeof(cf) * (8 * PLE + D * PF + 64);
     const long grid = grid_for_tiles(k_fm_multi_poly<D, SRC>, 512, smem, ntiles);
     hipLaunchKernelGGL((k_fm_multi_poly<D, SRC>), dim3((unsigned)grid), dim3(512), smem, s, src, out, out_stride, ntiles, tw, hreg,
-                       nchan, a, last_in, last_out);
+                       nchan, a, last_in, last_out, fft_stamp_buffer());
     RR_HIP(hipGetLastError());
 }
 template <class SRC>
