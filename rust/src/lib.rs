@@ -3,18 +3,23 @@
 //! `FftFilter::new(prev, taps)` for `GpuFftFilter::new(prev, taps)` and nothing else.
 //!
 //! SOURCE ONLY: the build image has no cargo/rustc, so this file is not compiled in CI.
-//! It binds the C ABI of `include/rustradio_amd.h` one to one; the C++ mirror
-//! `rustradio_amd/host/rustradio.hpp` implements the same shim logic and IS tested
-//! (`tests/cpp/test_host_api.cpp`).
+//! It binds the C ABI of `include/rustradio_amd.h` one to one — `tests/test_rust_shim.py` parses the
+//! `extern "C"` block below and checks every declaration (name, arity, argument and return types)
+//! against the header — and the C++ mirror `rustradio_amd/host/rustradio.hpp` implements the same shim
+//! logic and IS tested (`tests/cpp/test_host_api.cpp`).
 use std::ffi::{c_int, c_void, CStr};
 
 use rustradio::block::{Block, BlockEOF, BlockName, BlockRet};
-use rustradio::stream::{new_stream, ReadStream, Tag, WriteStream};
+use rustradio::stream::{new_stream, ReadStream, Tag, TagValue, WriteStream};
 use rustradio::window::WindowType;
 use rustradio::{Complex, Error, Float, Result, Sample};
 
 #[repr(C)]
 pub struct RrBlock {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct RrDStream {
     _private: [u8; 0],
 }
 
@@ -38,10 +43,37 @@ unsafe extern "C" {
     fn rr_fastfm_create() -> *mut RrBlock;
     fn rr_fm_chain_create(taps: *const Complex, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_fm_chain_u8_create(taps: *const Complex, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
+    fn rr_fir_fftfilter_create(fir_taps: *const Complex, fir_ntaps: usize, fft_taps: *const Complex, fft_ntaps: usize) -> *mut RrBlock;
+    fn rr_fir_fm_chain_create(fir_taps: *const Complex, fir_ntaps: usize, fft_taps: *const Complex, fft_ntaps: usize,
+                              interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
+    fn rr_hilbert_fir_create(hilbert_ntaps: usize, window: c_int, window_parm: f32, taps: *const Complex, ntaps: usize,
+                             deci: usize, translate: c_int, samp_rate: f32, freq: f32) -> *mut RrBlock;
+    fn rr_fm_multi_create(taps: *const Complex, nchan: usize, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
+    fn rr_fm_multi_u8_create(taps: *const Complex, nchan: usize, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
+    fn rr_fftstream_create(size: usize) -> *mut RrBlock;
+    fn rr_multiply_const_c32_create(re: f32, im: f32) -> *mut RrBlock;
+    fn rr_block_out_windows(b: *const RrBlock) -> usize;
     fn rr_block_destroy(b: *mut RrBlock);
     fn rr_block_work(b: *mut RrBlock, inp: *const c_void, in_len: usize, out: *mut c_void, out_cap: usize,
                      consumed: *mut usize, produced: *mut usize, need: *mut usize) -> c_int;
     fn rr_block_eof(b: *mut RrBlock, src_eof: c_int) -> c_int;
+    fn rr_block_work_dev(b: *mut RrBlock, d_in: *const c_void, in_len: usize, d_out: *mut c_void, out_cap: usize,
+                         consumed: *mut usize, produced: *mut usize, need: *mut usize, hip_stream: *mut c_void) -> c_int;
+    fn rr_block_sync(b: *mut RrBlock) -> c_int;
+    fn rr_fir_set_rotator_mode(b: *mut RrBlock, mode: c_int) -> c_int;
+    fn rr_host_register(ptr: *mut c_void, bytes: usize) -> c_int;
+    fn rr_host_unregister(ptr: *mut c_void) -> c_int;
+    fn rr_dstream_create(elem_size: usize, capacity_bytes: usize) -> *mut RrDStream;
+    fn rr_dstream_destroy(s: *mut RrDStream);
+    fn rr_dstream_capacity(s: *const RrDStream) -> usize;
+    fn rr_dstream_read_buf(s: *mut RrDStream, dev_ptr: *mut *const c_void) -> usize;
+    fn rr_dstream_write_buf(s: *mut RrDStream, dev_ptr: *mut *mut c_void, hip_stream: *mut c_void) -> usize;
+    fn rr_dstream_consume(s: *mut RrDStream, n: usize) -> c_int;
+    fn rr_dstream_produce(s: *mut RrDStream, n: usize) -> c_int;
+    fn rr_dstream_copy_in(s: *mut RrDStream, offset: usize, host: *const c_void, n: usize, hip_stream: *mut c_void) -> c_int;
+    fn rr_dstream_copy_out(s: *mut RrDStream, offset: usize, host: *mut c_void, n: usize, hip_stream: *mut c_void) -> c_int;
+    fn rr_block_work_streams(b: *mut RrBlock, src: *mut RrDStream, dst: *mut RrDStream, consumed: *mut usize,
+                             produced: *mut usize, need: *mut usize, hip_stream: *mut c_void) -> c_int;
 }
 
 fn last_error() -> Error {
@@ -280,10 +312,363 @@ impl<I: Sample, O: Sample> Block for GpuMap<I, O> {
     }
 }
 
-// The Complex-input fused chain (rr_fm_chain_create), the fused Hilbert -> FirFilter (rr_hilbert_fir_create),
-// Hilbert (tags with `pos < n` kept), FftFilterFloat and FftStream (frame tags added from `produced`) follow
-// the same patterns: see the C++ mirror for the exact work() bodies — rustradio_amd/host/rustradio.hpp — and
-// INTEGRATION.md.
+/// `Hilbert::new(src, ntaps, &window_type)` (src/hilbert.rs:38-129): f32 in, analytic Complex out; tags with
+/// `pos < n` are forwarded unchanged (hilbert.rs:119-123).
+pub struct GpuHilbert {
+    h: Handle,
+    src: ReadStream<Float>,
+    dst: WriteStream<Complex>,
+}
+impl GpuHilbert {
+    pub fn new(src: ReadStream<Float>, ntaps: usize, window_type: &WindowType) -> Result<(Self, ReadStream<Complex>)> {
+        let (w, parm) = window_code(window_type);
+        // SAFETY: plain values.
+        let h = Handle::new(unsafe { rr_hilbert_create(ntaps, w, parm) })?;
+        let (dst, dr) = new_stream();
+        Ok((Self { h, src, dst }, dr))
+    }
+}
+impl BlockName for GpuHilbert { fn block_name(&self) -> &str { "GpuHilbert" } }
+impl BlockEOF for GpuHilbert { fn eof(&mut self) -> bool { self.src.eof() } }
+impl Block for GpuHilbert {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let (input, mut tags) = self.src.read_buf()?;
+        let mut out = self.dst.write_buf()?;
+        let (st, consumed, produced, need) = self.h.work(input.slice(), out.slice())?;
+        tags.retain(|t| t.pos() < produced);
+        input.consume(consumed);
+        out.produce(produced, &tags);
+        Ok(match st {
+            RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need),
+            RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
+            _ => BlockRet::Again,
+        })
+    }
+}
+
+/// `FftFilterFloat::new(src, taps)` (src/fft_filter.rs:365-491).  The reference drops tags at the f32 -> Complex lift
+/// of its inner stream (fft_filter.rs:431-445); so does this block.
+pub struct GpuFftFilterFloat {
+    h: Handle,
+    src: ReadStream<Float>,
+    dst: WriteStream<Float>,
+}
+impl GpuFftFilterFloat {
+    pub fn new(src: ReadStream<Float>, taps: &[Float]) -> Result<(Self, ReadStream<Float>)> {
+        // SAFETY: taps is a live slice.
+        let h = Handle::new(unsafe { rr_fftfilter_float_create(taps.as_ptr(), taps.len()) })?;
+        let (dst, dr) = new_stream();
+        Ok((Self { h, src, dst }, dr))
+    }
+}
+impl BlockName for GpuFftFilterFloat { fn block_name(&self) -> &str { "GpuFftFilterFloat" } }
+impl BlockEOF for GpuFftFilterFloat { fn eof(&mut self) -> bool { self.src.eof() } }
+impl Block for GpuFftFilterFloat {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let (input, _tags) = self.src.read_buf()?;
+        let mut out = self.dst.write_buf()?;
+        let (st, consumed, produced, need) = self.h.work(input.slice(), out.slice())?;
+        input.consume(consumed);
+        out.produce(produced, &[]);
+        Ok(match st {
+            RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need),
+            RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
+            _ => BlockRet::Again,
+        })
+    }
+}
+
+/// `FftStream::new(src, size)` (src/fft_stream.rs:40-117): frame tags are rebuilt from `produced` exactly as
+/// fft_stream.rs:98-111 (input tags are dropped there too).
+pub const TAG_FRAME: &str = "FftStream::frame";
+pub const TAG_FRAME_SIZE: &str = "FftStream::frame_size";
+pub struct GpuFftStream {
+    h: Handle,
+    size: usize,
+    src: ReadStream<Complex>,
+    dst: WriteStream<Complex>,
+}
+impl GpuFftStream {
+    pub fn new(src: ReadStream<Complex>, size: usize) -> Result<(Self, ReadStream<Complex>)> {
+        // SAFETY: plain value.
+        let h = Handle::new(unsafe { rr_fftstream_create(size) })?;
+        let (dst, dr) = new_stream();
+        Ok((Self { h, size, src, dst }, dr))
+    }
+}
+impl BlockName for GpuFftStream { fn block_name(&self) -> &str { "GpuFftStream" } }
+impl BlockEOF for GpuFftStream { fn eof(&mut self) -> bool { self.src.eof() } }
+impl Block for GpuFftStream {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let (input, _tags) = self.src.read_buf()?;
+        let mut out = self.dst.write_buf()?;
+        let (st, consumed, produced, need) = self.h.work(input.slice(), out.slice())?;
+        let mut tags = Vec::with_capacity((produced / self.size) * 3);
+        for pos in (0..produced).step_by(self.size) {
+            tags.push(Tag::new(pos, TAG_FRAME_SIZE, TagValue::U64(self.size as u64)));
+            tags.push(Tag::new(pos, TAG_FRAME, TagValue::Bool(true)));
+            tags.push(Tag::new(pos + self.size - 1, TAG_FRAME, TagValue::Bool(false)));
+        }
+        input.consume(consumed);
+        out.produce(produced, &tags);
+        Ok(match st {
+            RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need),
+            RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
+            _ => BlockRet::Again,
+        })
+    }
+}
+
+/// Blocks whose tags are all dropped and that map one Complex / f32 input stream to one output stream through a fused
+/// kernel: `GpuFused::fm_chain` = FftFilter -> RationalResampler -> QuadratureDemod (rr_fm_chain_create,
+/// examples/rtl_fm.rs:381-419), `fir_fm_chain` = FirFilter -> FftFilter -> RationalResampler -> QuadratureDemod
+/// (rr_fir_fm_chain_create), `fir_fftfilter` = FirFilter -> FftFilter (rr_fir_fftfilter_create; tags travel with their
+/// sample as in GpuFftFilter when only those two blocks are fused — dropped here for simplicity, both reference blocks
+/// forward them), `hilbert_fir` = Hilbert -> FirFilter (rr_hilbert_fir_create, examples/ax25-1200-rx.rs:238-247).
+pub struct GpuFused<I: Sample, O: Sample> {
+    h: Handle,
+    name: &'static str,
+    src: ReadStream<I>,
+    dst: WriteStream<O>,
+}
+impl<I: Sample, O: Sample> GpuFused<I, O> {
+    fn wrap(h: *mut RrBlock, name: &'static str, src: ReadStream<I>) -> Result<(Self, ReadStream<O>)> {
+        let h = Handle::new(h)?;
+        let (dst, dr) = new_stream();
+        Ok((Self { h, name, src, dst }, dr))
+    }
+}
+impl GpuFused<Complex, Float> {
+    pub fn fm_chain(src: ReadStream<Complex>, taps: &[Complex], interp: usize, deci: usize, gain: Float, fast_math: bool)
+        -> Result<(Self, ReadStream<Float>)> {
+        // SAFETY: taps is a live slice of repr(C) Complex<f32>.
+        Self::wrap(unsafe { rr_fm_chain_create(taps.as_ptr(), taps.len(), interp, deci, gain, fast_math as c_int) }, "GpuFmChain", src)
+    }
+    pub fn fir_fm_chain(src: ReadStream<Complex>, fir_taps: &[Complex], fft_taps: &[Complex], interp: usize, deci: usize,
+                        gain: Float, fast_math: bool) -> Result<(Self, ReadStream<Float>)> {
+        // SAFETY: live slices.
+        Self::wrap(unsafe {
+            rr_fir_fm_chain_create(fir_taps.as_ptr(), fir_taps.len(), fft_taps.as_ptr(), fft_taps.len(), interp, deci, gain,
+                                   fast_math as c_int)
+        }, "GpuFirFmChain", src)
+    }
+}
+impl GpuFused<Complex, Complex> {
+    pub fn fir_fftfilter(src: ReadStream<Complex>, fir_taps: &[Complex], fft_taps: &[Complex]) -> Result<(Self, ReadStream<Complex>)> {
+        // SAFETY: live slices.
+        Self::wrap(unsafe { rr_fir_fftfilter_create(fir_taps.as_ptr(), fir_taps.len(), fft_taps.as_ptr(), fft_taps.len()) },
+                   "GpuFirFftFilter", src)
+    }
+    /// `MultiplyConst::<Complex>::new(src, val)` (src/multiply_const.rs:6-23)
+    pub fn multiply_const(src: ReadStream<Complex>, val: Complex) -> Result<(Self, ReadStream<Complex>)> {
+        Self::wrap(unsafe { rr_multiply_const_c32_create(val.re, val.im) }, "GpuMultiplyConst", src)
+    }
+}
+impl GpuFused<Float, Complex> {
+    /// `translate` = `Some((samp_rate, freq))` for `.translate()`; `replay_rotator` selects the bit-faithful f32 rotator
+    /// recurrence (RR_ROT_REPLAY) instead of the closed-form model.
+    pub fn hilbert_fir(src: ReadStream<Float>, hilbert_ntaps: usize, window_type: &WindowType, taps: &[Complex], deci: usize,
+                       translate: Option<(Float, Float)>, replay_rotator: bool) -> Result<(Self, ReadStream<Complex>)> {
+        let (w, parm) = window_code(window_type);
+        let (fs, f) = translate.unwrap_or((0.0, 0.0));
+        // SAFETY: live slice, plain values.
+        let p = unsafe { rr_hilbert_fir_create(hilbert_ntaps, w, parm, taps.as_ptr(), taps.len(), deci, translate.is_some() as c_int, fs, f) };
+        if !p.is_null() && translate.is_some() {
+            // SAFETY: p is a valid handle.
+            unsafe { rr_fir_set_rotator_mode(p, replay_rotator as c_int) };
+        }
+        Self::wrap(p, "GpuHilbertFir", src)
+    }
+}
+impl<I: Sample, O: Sample> BlockName for GpuFused<I, O> { fn block_name(&self) -> &str { self.name } }
+impl<I: Sample, O: Sample> BlockEOF for GpuFused<I, O> { fn eof(&mut self) -> bool { self.src.eof() } }
+impl<I: Sample, O: Sample> Block for GpuFused<I, O> {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let (input, _tags) = self.src.read_buf()?;
+        let mut out = self.dst.write_buf()?;
+        let (st, consumed, produced, need) = self.h.work(input.slice(), out.slice())?;
+        input.consume(consumed);
+        out.produce(produced, &[]);
+        Ok(match st {
+            RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need),
+            RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
+            _ => BlockRet::Again,
+        })
+    }
+}
+
+/// `Tee` + N x (FftFilter -> RationalResampler -> QuadratureDemod) on ONE input (rr_fm_multi_create; the reference needs
+/// a Tee tree, src/tee.rs:10-24): N output streams.  The C ABI takes the N output windows as one buffer of N x out_cap
+/// elements, so the block stages them in `scratch` and copies each channel into its own stream (4 B per output sample).
+pub struct GpuFmMulti {
+    h: Handle,
+    nchan: usize,
+    src: ReadStream<Complex>,
+    dsts: Vec<WriteStream<Float>>,
+    scratch: Vec<Float>,
+}
+impl GpuFmMulti {
+    /// `taps[c]` = channel c's filter (all of one length).
+    pub fn new(src: ReadStream<Complex>, taps: &[Vec<Complex>], interp: usize, deci: usize, gain: Float, fast_math: bool)
+        -> Result<(Self, Vec<ReadStream<Float>>)> {
+        let nchan = taps.len();
+        let ntaps = taps.first().map_or(0, Vec::len);
+        if taps.iter().any(|t| t.len() != ntaps) { return Err(Error::msg("GpuFmMulti: all channels need the same number of taps")); }
+        let flat: Vec<Complex> = taps.iter().flatten().copied().collect();
+        // SAFETY: flat is a live [nchan][ntaps] array.
+        let h = Handle::new(unsafe { rr_fm_multi_create(flat.as_ptr(), nchan, ntaps, interp, deci, gain, fast_math as c_int) })?;
+        debug_assert_eq!(unsafe { rr_block_out_windows(h.0) }, nchan);
+        let (dsts, drs): (Vec<_>, Vec<_>) = (0..nchan).map(|_| new_stream()).unzip();
+        Ok((Self { h, nchan, src, dsts, scratch: Vec::new() }, drs))
+    }
+}
+impl BlockName for GpuFmMulti { fn block_name(&self) -> &str { "GpuFmMulti" } }
+impl BlockEOF for GpuFmMulti { fn eof(&mut self) -> bool { self.src.eof() } }
+impl Block for GpuFmMulti {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let (input, _tags) = self.src.read_buf()?;
+        let mut outs = Vec::with_capacity(self.nchan);
+        for d in &self.dsts { outs.push(d.write_buf()?); }
+        let cap = outs.iter_mut().map(|o| o.slice().len()).min().unwrap_or(0);
+        self.scratch.resize(self.nchan * cap.max(1), 0.0);
+        let (mut c, mut p, mut need) = (0usize, 0usize, 0usize);
+        // SAFETY: scratch holds nchan windows of `cap` elements; input is a live window.
+        let st = unsafe {
+            rr_block_work(self.h.0, input.slice().as_ptr().cast(), input.slice().len(), self.scratch.as_mut_ptr().cast(), cap,
+                          &mut c, &mut p, &mut need)
+        };
+        if st == RR_ERR { return Err(last_error()); }
+        for (ch, mut o) in outs.into_iter().enumerate() {
+            o.slice()[..p].copy_from_slice(&self.scratch[ch * cap..ch * cap + p]);
+            o.produce(p, &[]);
+        }
+        input.consume(c);
+        Ok(if st == RR_WAIT_DST { BlockRet::WaitForStream(&self.dsts[0], need) } else { BlockRet::WaitForStream(&self.src, need) })
+    }
+}
+
+// ---- device-resident streams (include/rustradio_amd.h rr_dstream_*) ---------------------------------------
+/// A stream ring in HBM with the reference's window contract (everything readable / all free space, contiguous).
+/// GPU blocks chained through `GpuStream`s never cross PCIe; `GpuUpload` / `GpuDownload` are the two ends.
+pub struct GpuStream<T: Sample> {
+    s: *mut RrDStream,
+    _t: std::marker::PhantomData<T>,
+}
+// SAFETY: the ring has no thread affinity; it is driven by one block at a time like the reference's streams.
+unsafe impl<T: Sample> Send for GpuStream<T> {}
+impl<T: Sample> Drop for GpuStream<T> {
+    fn drop(&mut self) {
+        // SAFETY: created by rr_dstream_create, destroyed once.
+        unsafe { rr_dstream_destroy(self.s) }
+    }
+}
+impl<T: Sample> GpuStream<T> {
+    /// `new_stream()` in HBM (src/stream.rs:336-339); `capacity_bytes` as `DEFAULT_STREAM_SIZE`.
+    pub fn new(capacity_bytes: usize) -> Result<Self> {
+        // SAFETY: plain values.
+        let s = unsafe { rr_dstream_create(std::mem::size_of::<T>(), capacity_bytes) };
+        if s.is_null() { Err(last_error()) } else { Ok(Self { s, _t: std::marker::PhantomData }) }
+    }
+    #[must_use] pub fn capacity(&self) -> usize { unsafe { rr_dstream_capacity(self.s) } }
+    #[must_use] pub fn readable(&self) -> usize { unsafe { rr_dstream_read_buf(self.s, std::ptr::null_mut()) } }
+    #[must_use] pub fn free(&self) -> usize { unsafe { rr_dstream_write_buf(self.s, std::ptr::null_mut(), std::ptr::null_mut()) } }
+}
+fn check(rc: c_int) -> Result<()> { if rc == RR_ERR { Err(last_error()) } else { Ok(()) } }
+
+/// Host ring -> HBM ring (graph edge): `fill_from_slice` + `produce` across PCIe.  Register the host ring once with
+/// `register_ring` (the reference's ring is one stable mapping) and the copies run as direct DMA.
+pub struct GpuUpload<T: Sample> {
+    src: ReadStream<T>,
+    dst: std::sync::Arc<std::sync::Mutex<GpuStream<T>>>,
+}
+impl<T: Sample> GpuUpload<T> {
+    pub fn new(src: ReadStream<T>, dst: std::sync::Arc<std::sync::Mutex<GpuStream<T>>>) -> Self { Self { src, dst } }
+}
+impl<T: Sample> BlockName for GpuUpload<T> { fn block_name(&self) -> &str { "GpuUpload" } }
+impl<T: Sample> BlockEOF for GpuUpload<T> { fn eof(&mut self) -> bool { self.src.eof() } }
+impl<T: Sample> Block for GpuUpload<T> {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let (input, _tags) = self.src.read_buf()?;
+        let d = self.dst.lock().map_err(|_| Error::msg("GpuUpload: poisoned stream lock"))?;
+        let n = input.slice().len().min(d.free());
+        if n == 0 { return Ok(BlockRet::WaitForStream(&self.src, 1)); }
+        // SAFETY: input is a live window of n elements; the ring has room for n.
+        check(unsafe { rr_dstream_copy_in(d.s, 0, input.slice().as_ptr().cast(), n, std::ptr::null_mut()) })?;
+        check(unsafe { rr_dstream_produce(d.s, n) })?;
+        input.consume(n);
+        Ok(BlockRet::Again)
+    }
+}
+/// HBM ring -> host ring (graph edge).
+pub struct GpuDownload<T: Sample> {
+    src: std::sync::Arc<std::sync::Mutex<GpuStream<T>>>,
+    dst: WriteStream<T>,
+}
+impl<T: Sample> GpuDownload<T> {
+    pub fn new(src: std::sync::Arc<std::sync::Mutex<GpuStream<T>>>) -> (Self, ReadStream<T>) {
+        let (dst, dr) = new_stream();
+        (Self { src, dst }, dr)
+    }
+}
+impl<T: Sample> BlockName for GpuDownload<T> { fn block_name(&self) -> &str { "GpuDownload" } }
+impl<T: Sample> BlockEOF for GpuDownload<T> { fn eof(&mut self) -> bool { false } }
+impl<T: Sample> Block for GpuDownload<T> {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let mut out = self.dst.write_buf()?;
+        let s = self.src.lock().map_err(|_| Error::msg("GpuDownload: poisoned stream lock"))?;
+        let n = out.slice().len().min(s.readable());
+        if n == 0 { return Ok(BlockRet::WaitForStream(&self.dst, 1)); }
+        // SAFETY: out is a live window with room for n elements; the ring holds n readable elements.
+        check(unsafe { rr_dstream_copy_out(s.s, 0, out.slice().as_mut_ptr().cast(), n, std::ptr::null_mut()) })?;
+        check(unsafe { rr_dstream_consume(s.s, n) })?;
+        out.produce(n, &[]);
+        Ok(BlockRet::Again)
+    }
+}
+/// One GPU block between two HBM rings: `Block::work()` without a PCIe hop (rr_block_work_streams).
+pub struct GpuResident<I: Sample, O: Sample> {
+    h: Handle,
+    name: &'static str,
+    src: std::sync::Arc<std::sync::Mutex<GpuStream<I>>>,
+    dst: std::sync::Arc<std::sync::Mutex<GpuStream<O>>>,
+}
+impl<I: Sample, O: Sample> GpuResident<I, O> {
+    /// `create` = any `rr_*_create` call, e.g. `|| unsafe { rr_fftfilter_create(taps.as_ptr(), taps.len()) }`.
+    pub fn new(create: impl FnOnce() -> *mut RrBlock, name: &'static str, src: std::sync::Arc<std::sync::Mutex<GpuStream<I>>>,
+               dst: std::sync::Arc<std::sync::Mutex<GpuStream<O>>>) -> Result<Self> {
+        Ok(Self { h: Handle::new(create())?, name, src, dst })
+    }
+}
+impl<I: Sample, O: Sample> BlockName for GpuResident<I, O> { fn block_name(&self) -> &str { self.name } }
+impl<I: Sample, O: Sample> BlockEOF for GpuResident<I, O> { fn eof(&mut self) -> bool { false } }
+impl<I: Sample, O: Sample> Block for GpuResident<I, O> {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        let s = self.src.lock().map_err(|_| Error::msg("GpuResident: poisoned stream lock"))?;
+        let d = self.dst.lock().map_err(|_| Error::msg("GpuResident: poisoned stream lock"))?;
+        let (mut c, mut p, mut need) = (0usize, 0usize, 0usize);
+        // SAFETY: valid handles; counts are final on return (they depend on lengths only), kernels run asynchronously.
+        let st = unsafe { rr_block_work_streams(self.h.0, s.s, d.s, &mut c, &mut p, &mut need, std::ptr::null_mut()) };
+        check(st)?;
+        Ok(if c > 0 || p > 0 || st == RR_AGAIN { BlockRet::Again } else { BlockRet::Pending })
+    }
+}
+
+/// Page-lock a host ring the blocks will be handed windows of (rr_host_register): once per stream, at creation.
+pub fn register_ring(base: *mut u8, bytes: usize) -> Result<()> { check(unsafe { rr_host_register(base.cast(), bytes) }) }
+pub fn unregister_ring(base: *mut u8) -> Result<()> { check(unsafe { rr_host_unregister(base.cast()) }) }
+/// Wait for everything a handle enqueued (device-pointer work is asynchronous).
+pub fn sync_block(h: *mut RrBlock) -> Result<()> { check(unsafe { rr_block_sync(h) }) }
+/// `Block::work()` on raw device windows (rr_block_work_dev), for graphs that manage their own device memory.
+///
+/// # Safety
+/// `d_in` / `d_out` must be device pointers to `in_len` / `out_cap` elements of the block's element types.
+pub unsafe fn work_dev(h: *mut RrBlock, d_in: *const c_void, in_len: usize, d_out: *mut c_void, out_cap: usize,
+                       hip_stream: *mut c_void) -> Result<(c_int, usize, usize, usize)> {
+    let (mut c, mut p, mut need) = (0usize, 0usize, 0usize);
+    let st = unsafe { rr_block_work_dev(h, d_in, in_len, d_out, out_cap, &mut c, &mut p, &mut need, hip_stream) };
+    if st == RR_ERR { Err(last_error()) } else { Ok((st, c, p, need)) }
+}
+
 pub fn window_code(w: &WindowType) -> (c_int, f32) {
     match w {
         WindowType::Hamming => (0, 0.0),

@@ -686,8 +686,13 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
         }
         d_tw_half.upload(th.data(), th.size(), stream);
     }
-    if (build_opts().fm_poly >= 0 && !build_opts().fm_full && I == 1 && D >= 2) {
-        // decimate-first tiles: D phase transforms + one inverse per 1024 OUTPUT-rate positions (kernels_poly.hip)
+    // decimate-first tiles: D phase transforms + one inverse per 1024 OUTPUT-rate positions (kernels_poly.hip).  Where they
+    // win (tools/poly_probe.py on MI355X, ms per 2.4e7 samples, poly / best other kernel): 463 taps 1:2 0.084 / 0.102, 1:4
+    // 0.065 / 0.087, 1:6 0.067 / 0.085, 1:7 0.083 / 0.095, 1:8 0.096 / 0.083; 2467 taps 1:6 0.086 / 0.157, 1:10 0.113 / 0.152,
+    // 1:12 0.159 / 0.149 — every decimation up to 6 (7 phases and more run in two register batches per wave), and up to
+    // 10 for filters long enough to push the other kernels onto 4096-point or split tiles.  fm_poly > 0 forces them.
+    const bool poly_wins = D <= 6 || (D <= 10 && f->L >= 800);
+    if ((build_opts().fm_poly > 0 || (build_opts().fm_poly == 0 && poly_wins)) && !build_opts().fm_full && I == 1 && D >= 2) {
         std::vector<rr_c32> ct(f->L);
         if (fir_taps) ct = FftFilter::composite(fir_taps, fir_ntaps, taps, f->L - (fir_ntaps - 1));
         else std::copy(taps, taps + f->L, ct.begin());

@@ -535,6 +535,8 @@ def test_fm_chain_fused_block(rr, monkeypatch, L, I, D, stream_bytes, kernel):
         knob(rr, monkeypatch, fm_full=1)
     elif kernel == "half":
         knob(rr, monkeypatch, fm_poly=-1)
+    else:
+        knob(rr, monkeypatch, fm_poly=1)          # (decimations beyond 6 are otherwise left to the other kernels)
     fs = 2.4e6
     n = 400_000
     x = fm_signal(n, fs, 0.0, 77 + L)
