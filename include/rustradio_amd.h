@@ -54,7 +54,12 @@ enum rr_atan2 { RR_ATAN2_EXACT = 0, RR_ATAN2_FAST = 1 };
  * RR_ROT_MODEL  = closed form phase0 * step^m evaluated in f64 from the SAME
  *                 f32-rounded phase0/step the reference uses (parallel, default);
  * RR_ROT_REPLAY = bit-faithful replay of the reference's sequential f32
- *                 recurrence on the host (slow; for parity over long streams). */
+ *                 recurrence, one device lane per block walking the chain from
+ *                 the carried phase (~5 ns per output, no host involvement).
+ * The two differ by the recurrence's accumulated rounding only: <= 1e-7 * n in
+ * n outputs (tests/test_gpu_edges_fullsize.py::test_rotator_drift_vs_length),
+ * i.e. MODEL stays within the 1e-5 parity bar for ~1e2 .. 1e5 outputs depending on
+ * the step, REPLAY for any length. */
 enum rr_rotator { RR_ROT_MODEL = 0, RR_ROT_REPLAY = 1 };
 
 /* ---- library / device ------------------------------------------------------ */
@@ -177,6 +182,14 @@ rr_block *rr_fir_fm_chain_create(const rr_c32 *fir_taps, size_t fir_ntaps, const
  * byte stays unconsumed (rtlsdr_decode.rs:23).  Whole-stream output == RtlSdrDecode -> rr_fm_chain. */
 rr_block *rr_fm_chain_u8_create(const rr_c32 *taps, size_t ntaps, size_t interp, size_t deci,
                                 float gain, int atan2_mode);
+
+/* Graph-level fusion of the audio stage of examples/rtl_fm.rs:398-418:
+ *   FftFilterFloat::new(src, taps) -> RationalResampler::new(_, interp, deci) -> MultiplyConst::new(_, scale)
+ * (src/fft_filter.rs:365-491, src/rational_resampler.rs:125-206, src/multiply_const.rs:6-23) as ONE real-valued kernel:
+ * f32 in, f32 out; whole-stream output equals the three blocks in sequence.  work() like rr_fm_chain_create: WAIT_DST(n)
+ * when the next filter block's resampled samples do not fit, else consumes like FftFilter (whole pending block) and
+ * WAIT_SRC(nsamples - pending).  ntaps <= 3584 (NULL beyond: use the three blocks). */
+rr_block *rr_audio_chain_create(const float *taps, size_t ntaps, size_t interp, size_t deci, float scale);
 
 /* Graph-level fusion of Hilbert::new(src, hilbert_ntaps, &window) (src/hilbert.rs:38-61) ->
  * FirFilter::<Complex>::builder(taps).deci(deci)[.translate(samp_rate, freq)].build(_) (src/fir.rs:303-386,476-486)

@@ -43,6 +43,7 @@ unsafe extern "C" {
     fn rr_fastfm_create() -> *mut RrBlock;
     fn rr_fm_chain_create(taps: *const Complex, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_fm_chain_u8_create(taps: *const Complex, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
+    fn rr_audio_chain_create(taps: *const f32, ntaps: usize, interp: usize, deci: usize, scale: f32) -> *mut RrBlock;
     fn rr_fir_fftfilter_create(fir_taps: *const Complex, fir_ntaps: usize, fft_taps: *const Complex, fft_ntaps: usize) -> *mut RrBlock;
     fn rr_fir_fm_chain_create(fir_taps: *const Complex, fir_ntaps: usize, fft_taps: *const Complex, fft_ntaps: usize,
                               interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
@@ -451,6 +452,13 @@ impl GpuFused<Complex, Float> {
             rr_fir_fm_chain_create(fir_taps.as_ptr(), fir_taps.len(), fft_taps.as_ptr(), fft_taps.len(), interp, deci, gain,
                                    fast_math as c_int)
         }, "GpuFirFmChain", src)
+    }
+}
+impl GpuFused<Float, Float> {
+    /// `FftFilterFloat -> RationalResampler -> MultiplyConst` (the audio stage of examples/rtl_fm.rs:398-418) as one kernel
+    pub fn audio_chain(src: ReadStream<Float>, taps: &[Float], interp: usize, deci: usize, scale: Float) -> Result<(Self, ReadStream<Float>)> {
+        // SAFETY: taps is a live slice.
+        Self::wrap(unsafe { rr_audio_chain_create(taps.as_ptr(), taps.len(), interp, deci, scale) }, "GpuAudioChain", src)
     }
 }
 impl GpuFused<Complex, Complex> {

@@ -403,6 +403,13 @@ def FirFmChain(fir_taps, fft_taps, interp: int, deci: int, gain: float = 1.0, mo
                  np.complex64, np.float32)
 
 
+def AudioChain(taps, interp: int, deci: int, scale: float = 1.0) -> Block:
+    """FftFilterFloat(taps) -> RationalResampler(interp, deci) -> MultiplyConst(scale) fused into one real-valued kernel
+    (rr_audio_chain_create; the audio stage of examples/rtl_fm.rs:398-418); f32 in, f32 out."""
+    t = np.ascontiguousarray(taps, np.float32)
+    return Block(lib().rr_audio_chain_create(_ptr(t), len(t), interp, deci, scale), np.float32, np.float32)
+
+
 def FmChainU8(taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2_EXACT) -> Block:
     """RtlSdrDecode -> FmChain fused (examples/rtl_fm.rs:328-419): RTL-SDR bytes in, f32 out; windows,
     consumed and the WAIT_SRC need count bytes."""

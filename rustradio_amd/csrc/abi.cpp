@@ -177,6 +177,9 @@ rr_block* rr_fir_fm_chain_create(const rr_c32* fir_taps, size_t fir_ntaps, const
         return new rr::FmChain(fft_taps, fft_ntaps, interp, deci, gain, atan2_mode, false, 14, fir_taps, fir_ntaps);
     });
 }
+rr_block* rr_audio_chain_create(const float* taps, size_t ntaps, size_t interp, size_t deci, float scale) {
+    return make_block([&] { return new rr::AudioChain(taps, ntaps, interp, deci, scale); });
+}
 rr_block* rr_fm_multi_create(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain,
                              int atan2_mode) {
     return make_block([&] { return new rr::FmMulti(taps, nchan, ntaps, interp, deci, gain, atan2_mode); });

@@ -122,7 +122,6 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
             rot_on = true;
             ph0x = (float)std::cos(first); ph0y = (float)std::sin(first);
             stx = (float)std::cos(ostep); sty = (float)std::sin(ostep);
-            cur_x = ph0x; cur_y = ph0y;
         }
     }
     pl.L = (int)ntaps; pl.d = (int)deci; pl.cfg = build_opts().fir_cfg;
@@ -228,16 +227,17 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
 void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
     if (rot_on) {                                                    // fir.rs:464-473
         if (rot_mode == RR_ROT_REPLAY) {
-            h_tab.resize(out_n);
-            for (size_t i = 0; i < out_n; i++) {                     // the reference's f32 recurrence
-                h_tab[i] = mkcf(cur_x, cur_y);
-                const float nx = cur_x * stx - cur_y * sty, ny = cur_x * sty + cur_y * stx;
-                cur_x = nx; cur_y = ny;
+            // the reference's f32 recurrence replayed ON THE DEVICE from the carried phase: no host loop, no upload, no
+            // synchronisation (a device-resident chain stays asynchronous)
+            if (!d_phase.p) {
+                d_phase.reserve(1);
+                const cf p0 = mkcf(ph0x, ph0y);
+                RR_HIP(hipMemcpyAsync(d_phase.p, &p0, sizeof(cf), hipMemcpyHostToDevice, s));
+                RR_HIP(hipStreamSynchronize(s));                     // (p0 is a stack variable; once per block)
             }
             d_tab.reserve(out_n * sizeof(cf));
-            RR_HIP(hipMemcpyAsync(d_tab.p, h_tab.data(), out_n * sizeof(cf), hipMemcpyHostToDevice, s));
+            launch_rotor_replay(d_phase.p, stx, sty, reinterpret_cast<cf*>(d_tab.p), (long)out_n, s);
             launch_rotate_table(static_cast<cf*>(out), (long)out_n, reinterpret_cast<const cf*>(d_tab.p), s);
-            RR_HIP(hipStreamSynchronize(s));                         // h_tab is reused by the next call
         } else {
             launch_rotate_model(static_cast<cf*>(out), (long)out_n, ph0x, ph0y, stx, sty, (long)n_rot, s);
         }
@@ -794,6 +794,63 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         *consumed *= 2;
         if (st == RR_WAIT_SRC) *need *= 2;
     }
+    return st;
+}
+
+// ---- fused audio stage: FftFilterFloat -> RationalResampler -> MultiplyConst --------------------------------------------
+AudioChain::AudioChain(const float* taps, size_t ntaps, size_t interp, size_t deci, float sc)
+    : Block("FftFilterFloat>RationalResampler>MultiplyConst", 4, 4), scale(sc) {
+    if (ntaps == 0) throw Error("FftFilterFloat: empty taps");
+    if (deci == 0) throw Error("RationalResampler created using deci 0");
+    if (interp == 0) throw Error("RationalResampler created using interp 0");
+    if (interp > (size_t)1 << 31 || deci > (size_t)1 << 31) throw Error("AudioChain: interp and deci must be <= 2^31");
+    if (ntaps > 3584) throw Error("AudioChain: at most 3584 taps (real-stream tiles of up to 4096 points); use the three blocks");
+    const int64_t gg = gcd64((int64_t)deci, (int64_t)interp);
+    D = (int64_t)deci / gg; I = (int64_t)interp / gg;
+    std::vector<rr_c32> ct(ntaps);
+    for (size_t i = 0; i < ntaps; i++) ct[i] = rr_c32{taps[i], 0.0f};  // fft_filter.rs:398
+    f.reset(new FftFilter(ct.data(), ntaps, false, 12, true));
+}
+
+// Bookkeeping as FmChain's without the demodulator's one-sample lag: a call emits whole filter blocks and every resampled
+// sample whose source lies in them.
+int AudioChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed, size_t* produced,
+                         size_t* need, hipStream_t s) {
+    *consumed = *produced = *need = 0;
+    const uint64_t S = f->nsamples;
+    auto N2 = [&](uint64_t y) { return (uint64_t)(((__int128)y * I + D - 1) / D); };
+    const uint64_t o_old = N2(n1);
+    const uint64_t need_next = N2(n1 + S) - o_old;                     // room for one filter block's outputs first
+    if (need_next > out_cap) { *need = need_next; return RR_WAIT_DST; }
+    const uint64_t total = f->pend_len + in_len, k_in = total / S;
+    const __int128 X = (__int128)(o_old + out_cap) * D / I;            // N2(n1 + k S) <= o_old + out_cap
+    uint64_t k_out = X >= (__int128)n1 ? (uint64_t)((X - n1) / S) : 0;
+    while (k_out > 0 && N2(n1 + k_out * S) - o_old > out_cap) k_out--;
+    uint64_t k, new_pend;
+    int st;
+    if (k_in > k_out) {
+        k = k_out; *consumed = k * S - f->pend_len; new_pend = 0;
+        st = RR_WAIT_DST; *need = N2(n1 + (k + 1) * S) - N2(n1 + k * S);
+    } else {
+        k = k_in; *consumed = in_len; new_pend = total - k * S;
+        st = RR_WAIT_SRC; *need = S - new_pend;
+    }
+    const uint64_t n_y = k * S;
+    VSrc<float> src{reinterpret_cast<const float*>(f->prefix[f->cur].p), (long)(f->hist + f->pend_len),
+                    static_cast<const float*>(in), (long)in_len};
+    if (k) {
+        AudioChainArgs a{(long)n1, (long)n_y, (long)o_old, (long)N2(n1 + n_y), I, D, scale};
+        prof_begin(s);
+        launch_audio_chain(f->log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a, s);
+        prof_end(s);
+    }
+    if (*consumed) {
+        launch_vcopy_f32(src, (long)n_y, reinterpret_cast<float*>(f->prefix[f->cur ^ 1].p), (long)(f->hist + new_pend), s);
+        f->cur ^= 1;
+        f->pend_len = new_pend;
+    }
+    *produced = N2(n1 + n_y) - o_old;
+    n1 += n_y;
     return st;
 }
 

@@ -73,9 +73,8 @@ struct FirC32 : Block {
     bool rot_on = false;
     int rot_mode = RR_ROT_MODEL;
     float ph0x = 1, ph0y = 0, stx = 1, sty = 0;   // f32-rounded phase0 / step (fir.rs:453-461)
-    float cur_x = 1, cur_y = 0;                   // REPLAY state
+    DevBuf<cf> d_phase;                           // REPLAY state: the carried f32 phase, on the device
     size_t n_rot = 0;                             // outputs rotated so far
-    std::vector<cf> h_tab;
     std::vector<std::complex<float>> h_taps;      // caller-order taps after the translate pre-rotation
     // allow_fft = false: bookkeeping / direct form only (HilbertFir's inner object)
     FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq, bool allow_fft = true);
@@ -169,6 +168,19 @@ struct FmChain : Block {
     std::unique_ptr<PolyTables> poly; // interp 1, integer deci: decimate-first tiles (k_fm_chain_poly)
     FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false,
             int max_log2f = 14, const rr_c32* fir_taps = nullptr, size_t fir_ntaps = 0);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+};
+
+// FftFilterFloat(taps) -> RationalResampler(interp, deci) -> MultiplyConst(scale) fused (the audio stage of
+// examples/rtl_fm.rs:398-418): f32 in, f32 out, one real-stream tile kernel (k_audio_chain).  Whole-stream output = the
+// three reference blocks in sequence: after N input samples N1 = floor(N / nsamples) * nsamples filtered,
+// ceil(N1 * I / D) resampled and scaled.
+struct AudioChain : Block {
+    std::unique_ptr<FftFilter> f;     // real-stream filter: tables, history / pending prefix, tile choice
+    int64_t I = 1, D = 1;
+    float scale;
+    uint64_t n1 = 0;                  // filtered samples emitted so far
+    AudioChain(const float* taps, size_t ntaps, size_t interp, size_t deci, float scale);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 

@@ -25,6 +25,15 @@ void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, in
 void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
                          hipStream_t s);
 
+// FftFilterFloat -> RationalResampler(I:D) -> MultiplyConst fused on the real-stream tiles: out[m - r_lo] = scale *
+// y[floor(m D / I)] for the resampled samples m in [r_lo, r_hi) whose source lies in this call's y[A .. A + n_y).
+struct AudioChainArgs {
+    long A, n_y, r_lo, r_hi, I, D;
+    float scale;
+};
+void launch_audio_chain(int log2f, VSrc<float> src, float* out, int L, const cf* tw, const cf* hpos, const AudioChainArgs& a,
+                        hipStream_t s);
+
 // Decimation by D = F / 256 (4 / 8 / 16 on tiles of 1024 / 2048 / 4096 points) with a pruned inverse transform
 // (k_fftfilt_prune): out[m] = y[m D], m < n_out.  Tables (see the kernel): hpos2 = H in position order with the
 // factors w_D^(-c k3) w_16D^(-c k2), c = (L - 1) % D, folded in; twb[n2 * 16 + k1] = exp(+2 pi i k1 (n2 D + c) / F).
@@ -150,6 +159,8 @@ bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src
 // y[m] *= phase0 * step^(m0 + m) evaluated in f64 (RR_ROT_MODEL)
 void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, double sy, long m0,
                          hipStream_t s);
+// table[i] = phase_i, phase_{i+1} = phase_i * step in f32 (the reference's recurrence), phase_0 = *state; *state <- phase_n
+void launch_rotor_replay(cf* state, float stx, float sty, cf* table, long n, hipStream_t s);
 // y[m] *= table[m]
 void launch_rotate_table(cf* y, long n, const cf* table, hipStream_t s);
 

@@ -1090,6 +1090,89 @@ struct SrcWalk {
     }
 };
 
+// ---- FftFilterFloat -> RationalResampler -> MultiplyConst fused (the rtl_fm audio stage, examples/rtl_fm.rs:398-418) ----
+// The real-stream tile above (two overlap-save segments per Complex tile); instead of storing the filtered segments
+// the tile parks them in LDS in stream order and every thread picks resampled samples out[m] = scale * y[floor(m D / I)]
+// (rational_resampler.rs:183-198; multiply_const.rs:6-23: one f32 multiply), lane-consecutive in m: 4 B in and
+// 4 I / D B out per sample instead of 8 + (4 + 4 I / D) + 8 I / D through three kernels.
+struct AudioArgs {
+    long A;            // filtered samples emitted before this call (stream index of this call's y[0])
+    long n_y;          // filtered samples of this call
+    long r_lo, r_hi;   // resampled samples whose source lies in this call
+    long I, D;         // reduced interp / deci
+    float scale;
+};
+template <int LOG2F>
+__global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
+void k_audio_chain(VSrc<float> src, float* __restrict__ out, int L, long ntiles, const cf* __restrict__ tw,
+                   const cf* __restrict__ hpos, AudioArgs a) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    float* ybuf = reinterpret_cast<float*>(smem_raw);    // 2 S filtered samples in stream order (after the transform)
+    const int t = threadIdx.x;
+    const long S = F - L + 1;
+    const int first = L - 1;
+    const long qs = ((long)T * a.D) / a.I, rs = ((long)T * a.D) % a.I;      // SrcWalk step of T outputs
+    TileXform<LOG2F, 0> X;
+    X.init(t, tw, hpos);
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long va = 2 * it.tile * S, vb = va + S;       // virtual index of position 0 of the two segments
+        creg v[16];
+        if (va >= src.plen && vb - src.plen + F <= src.in_len) {
+            const float* pa = src.in + (va - src.plen) + t;
+#pragma unroll
+            for (int n = 0; n < 16; n++) v[n] = mk(pa[n * T], pa[S + n * T]);
+        } else {
+            stage_pair_slow<T>(lds, src, va, vb, t);
+            tile_sync<T>();
+            lds_load<LOG2F, 0>(v, t, lds);
+        }
+        RR_PHASE();
+        X.run(v, lds, 0, nullptr);
+        tile_sync<T>();                                      // the last exchange is read everywhere
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            const int p = n * T + t - first;                 // y_rel[va + p] (segment a), y_rel[vb + p] (segment b)
+            if (p >= 0) { ybuf[p] = v[n].x; ybuf[S + p] = v[n].y; }
+        }
+        tile_sync<T>();
+        // resampled samples with their source in [va, min(va + 2 S, n_y)) (relative to A)
+        const long y_lo = va, y_hi = min(va + 2 * S, a.n_y);
+        long u_lo = ((a.A + y_lo) * a.I + a.D - 1) / a.D;
+        long u_hi = ((a.A + y_hi) * a.I + a.D - 1) / a.D;
+        if (u_lo < a.r_lo) u_lo = a.r_lo;
+        if (u_hi > a.r_hi) u_hi = a.r_hi;
+        SrcWalk wu;
+        wu.init(u_lo + t, a.I, a.D);
+        for (long u = u_lo + t; u < u_hi; u += T, wu.step(qs, rs, a.I))
+            out[u - a.r_lo] = mul_rn(a.scale, ybuf[wu.q - a.A - va]);
+        tile_sync<T>();                                      // before the next tile's exchanges overwrite ybuf
+    }
+}
+template <int LOG2F>
+static void launch_audio_one(VSrc<float> src, float* out, int L, const cf* tw, const cf* hpos, const AudioChainArgs& h, hipStream_t s) {
+    constexpr int F = 1 << LOG2F, T = F / 16;
+    const long S = F - L + 1;
+    if (h.n_y <= 0) return;
+    const long ntiles = (h.n_y + 2 * S - 1) / (2 * S);
+    AudioArgs a{h.A, h.n_y, h.r_lo, h.r_hi, h.I, h.D, h.scale};
+    const size_t smem = sizeof(cf) * lds_elems(F);
+    const long grid = grid_for_tiles(k_audio_chain<LOG2F>, T, smem, ntiles);
+    hipLaunchKernelGGL((k_audio_chain<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, L, ntiles, tw, hpos, a);
+    RR_HIP(hipGetLastError());
+}
+void launch_audio_chain(int log2f, VSrc<float> src, float* out, int L, const cf* tw, const cf* hpos, const AudioChainArgs& a,
+                        hipStream_t s) {
+    switch (log2f) {
+    case 10: launch_audio_one<10>(src, out, L, tw, hpos, a, s); break;
+    case 11: launch_audio_one<11>(src, out, L, tw, hpos, a, s); break;
+    case 12: launch_audio_one<12>(src, out, L, tw, hpos, a, s); break;
+    default: throw Error("audio_chain: unsupported tile size");
+    }
+}
+
 // Tile j transforms y[A + j*Sp - G .. + S') and owns every demod output o[u-1] whose UPPER
 // sample r[u] has its source in [A + j*Sp, A + (j+1)*Sp), Sp = S' - G; the lower sample r[u-1]
 // then lies in the same tile — or is the last r of the previous call (`last_r`).

@@ -612,6 +612,26 @@ void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, doubl
     hipLaunchKernelGGL(k_rotate_model, dim3(grid), dim3(256), 0, s, y, n, p0x, p0y, sx, sy, m0, gx, gy);
     RR_HIP(hipGetLastError());
 }
+// The reference's rotator (fir.rs:464-473) is a sequential f32 recurrence, phase <- phase * step once per output and
+// never renormalised; replaying it bit for bit is inherently serial (every step rounds).  One lane walks the chain for
+// the outputs of this window from the phase carried in *state (device memory, so a chain of device-resident blocks never
+// synchronises with the host) and leaves the table for k_rotate_table: ~5 ns per output.
+__global__ void k_rotor_replay(cf* __restrict__ state, float stx, float sty, cf* __restrict__ tab, long n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float x = state->x, y = state->y;
+    for (long i = 0; i < n; i++) {
+        tab[i] = mkcf(x, y);
+        const float nx = sub_rn(mul_rn(x, stx), mul_rn(y, sty));      // num-complex order, un-contracted
+        const float ny = add_rn(mul_rn(x, sty), mul_rn(y, stx));
+        x = nx; y = ny;
+    }
+    state->x = x; state->y = y;
+}
+void launch_rotor_replay(cf* state, float stx, float sty, cf* table, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rotor_replay, dim3(1), dim3(64), 0, s, state, stx, sty, table, n);
+    RR_HIP(hipGetLastError());
+}
 void launch_rotate_table(cf* y, long n, const cf* table, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_rotate_table, dim3(rot_grid(n)), dim3(256), 0, s, y, n, table);

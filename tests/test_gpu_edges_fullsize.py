@@ -214,3 +214,52 @@ def test_windows_beyond_2_31_elements(rr):
     skip = 2 * len(ct)                                               # zero history of the tail run
     a, r = yc[2 * start + skip: 2 * p], y2[skip: 2 * p2]
     assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
+
+
+def test_rotator_drift_vs_length(rr):
+    """FirFilter::translate's rotator (fir.rs:464-473) is an un-renormalised f32 recurrence.  The default RR_ROT_MODEL
+    evaluates phase0 * step^m in f64 from the same f32-rounded phase0 / step: it reproduces the recurrence's systematic
+    drift (|step| != 1 after rounding) but not its accumulated rounding noise.  This pins the bound the header states:
+    |model - replay| <= 1e-7 * n after n outputs (measured ~3e-8 * n), so MODEL is inside the 1e-5 parity bar for about
+    1e2 outputs in the worst case and REPLAY (bit-faithful, on the device) is there for long streams."""
+    fs, f = 1.0e6, 123_456.7
+    one = np.ones(1, np.complex64)                                # a 1-tap filter: the output IS the rotator (times x)
+    n = 1_000_000
+    x = np.ones(n, np.complex64)
+    ym = run_chain([rr.FirFilter(one, translate=(fs, f), rotator=rr.ROT_MODEL)], x)
+    yr = run_chain([rr.FirFilter(one, translate=(fs, f), rotator=rr.ROT_REPLAY)], x)
+    yo = run_chain([orc.FirFilter(one, translate=(fs, f))], x)
+    assert len(ym) == len(yr) == len(yo) == n
+    assert np.array_equal(yr, yo)                                 # the replay is the reference's recurrence, bit for bit
+    d = np.abs(ym.astype(np.complex128) - yr.astype(np.complex128))
+    idx = np.arange(1, n + 1)
+    assert np.all(d <= 1e-7 * idx + 2e-7), float(np.max(d / idx))
+    print("rotator drift: max |model - replay| / n =", float(np.max(d / idx)), " at n = 1e6:", float(d[-1]))
+
+
+def test_nan_locality_is_bounded_by_one_tile(rr):
+    """DESIGN.md "known deviations": on the overlap-save tile paths one non-finite input sample poisons up to one TILE of
+    outputs where the reference's direct form poisons the ntaps outputs whose window contains it.  Pinned here: (a) every
+    output the reference poisons is poisoned, (b) nothing farther than one tile (4096 points at most for these filters) from
+    the sample is touched, (c) the direct-form path (rr_build_opts.fir_path = DIRECT) keeps the reference's locality up to
+    its zero-padded groups of 8 taps."""
+    L, pos, n = 127, 50_000, 120_000
+    taps = orc.low_pass_complex(10e6, 1e6, 190e3)
+    x = rnd_c(n, 11)
+    x[pos] = np.nan
+    yo = run_chain([orc.FirFilter(taps)], x)
+    bad_o = np.flatnonzero(~np.isfinite(yo.real) | ~np.isfinite(yo.imag))
+    assert bad_o[0] == pos - (L - 1) and bad_o[-1] == pos and len(bad_o) == L
+    for blocks, width in (([rr.FirFilter(taps)], 4096), ([rr.FftFilter(taps)], 4096)):
+        yg = run_chain(blocks, x)
+        bad_g = np.flatnonzero(~np.isfinite(yg.real) | ~np.isfinite(yg.imag))
+        off = 0 if len(yg) == len(yo) else L - 1                 # FftFilter's output index is the FIR's + L - 1
+        assert set(bad_o + off) <= set(bad_g)
+        assert bad_g[0] >= pos - width and bad_g[-1] <= pos + width
+        good = np.ones(len(yg), bool); good[bad_g] = False
+        ref = run_chain([orc.FftFilter(taps)] if off else [orc.FirFilter(taps)], np.nan_to_num(x))
+        assert max_norm_err(yg[good], ref[:len(yg)][good]) <= TOL     # everything else is untouched
+    with rr.build_options(fir_path="direct"):
+        yd = run_chain([rr.FirFilter(taps)], x)
+    bad_d = np.flatnonzero(~np.isfinite(yd.real) | ~np.isfinite(yd.imag))
+    assert set(bad_o) <= set(bad_d) and bad_d[0] >= bad_o[0] - 8 and bad_d[-1] <= bad_o[-1] + 8

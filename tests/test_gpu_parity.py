@@ -878,3 +878,54 @@ def test_fir_fm_chain_fused_block(rr, L1, L2, I, D, stream_bytes):
     ro = run_chain(front, x, stream_bytes=max(stream_bytes, 8 * 20_000))
     yg = run_chain([rr.FirFmChain(t1, t2, I, D, gain)], x, stream_bytes=stream_bytes)
     _demod_close(yg / gain, yo / gain, ro)
+
+
+# ---- fused audio stage: FftFilterFloat -> RationalResampler -> MultiplyConst as one kernel --------------
+@pytest.mark.parametrize("L,I,D", [(963, 48000, 200000), (963, 44100, 200000), (65, 1, 1), (127, 1, 4), (401, 3, 2), (1, 5, 7), (3584, 1, 5),
+                                   (500, 7, 3)])
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 4 * 30_000])
+def test_audio_chain_fused_block(rr, L, I, D, stream_bytes):
+    """rr.AudioChain (one real-valued kernel) == FftFilterFloat -> RationalResampler -> MultiplyConst of the oracle
+    (examples/rtl_fm.rs:398-418: low_pass(200 kHz, 44.1 kHz, 500 Hz) = 963 taps, 200000 -> 48000, volume), whole stream,
+    any chunking."""
+    if L == 963:
+        taps = orc.low_pass(200_000.0, 44_100.0, 500.0)
+        assert len(taps) == 963
+    else:
+        taps = rnd_f(L, L + 2) / max(1, L // 8)
+    x = rnd_f(250_000, L + I + D)
+    vol = 0.35
+    yo = run_chain([orc.FftFilterFloat(taps), orc.RationalResampler(I, D, np.float32), orc.MultiplyConst(vol)], x, stream_bytes=max(stream_bytes, 4 * 30_000))
+    yg = run_chain([rr.AudioChain(taps, I, D, vol)], x, stream_bytes=stream_bytes)
+    assert len(yo) == len(yg) > 0
+    assert max_norm_err(yg, yo) <= TOL
+
+
+def test_audio_chain_protocol(rr):
+    taps = orc.low_pass(200_000.0, 44_100.0, 500.0)           # 963 taps -> nsamples 2048 - 963 = 1085
+    b = rr.AudioChain(taps, 48000, 200000, 1.0)                 # 6 : 25
+    x = rnd_f(5000, 2)
+    assert b.work(x[:100], 200)[:4] == (WAIT_DST, 0, 0, 261)   # ceil(1085 * 6 / 25) outputs of the first block must fit
+    assert b.work(x[:100], 1000)[:4] == (WAIT_SRC, 100, 0, 985)
+    st, c, p, need, out = b.work(x[100:3000], 1000)             # 3000 = 2 blocks + 830
+    assert (st, c, p, need) == (WAIT_SRC, 2900, 521, 1085 - 830)
+    with pytest.raises(ValueError):
+        rr.AudioChain(taps, 0, 5)
+    with pytest.raises(ValueError):
+        rr.AudioChain(np.ones(4000, np.float32), 1, 5)
+
+
+# ---- .translate(): the exact rotator replay on the device, and the model's drift against it --------------------------
+def test_translate_replay_on_device_matches_the_oracle_bit_for_bit_rotator(rr):
+    """RR_ROT_REPLAY walks the reference's f32 recurrence (fir.rs:464-473) on the device from the phase carried between
+    calls: the rotator itself is then bit-identical to the oracle's for ANY stream length, so a long translated stream
+    (600,000 outputs through many windows) stays inside the FIR's own 1e-5, where the closed-form model has drifted."""
+    fs, f, d = 2.4e6, 312_345.0, 2
+    taps = orc.low_pass_complex(fs, 100e3, 25e3)
+    x = rnd_c(1_200_400, 99)
+    mk = lambda m, **kw: [m.FirFilter(taps, deci=d, translate=(fs, f), **kw)]
+    yo = run_chain(mk(orc), x, stream_bytes=8 * 40_000)
+    yg = run_chain(mk(rr, rotator=rr.ROT_REPLAY), x, stream_bytes=8 * 40_000)
+    assert len(yo) == len(yg) >= 600_000
+    assert max_norm_err(yg, yo) <= TOL
+    assert max_norm_err(yg[-50_000:], yo[-50_000:]) <= TOL      # no growth towards the end of the stream
