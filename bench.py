@@ -390,7 +390,7 @@ def make_fm_chain_unfused(dev, rank, world, shared_src):
     return make_fm_chain(dev, rank, world, shared_src, fused=False)
 
 
-def make_fm_multi(dev, rank, world, shared_src, per_gpu=32):
+def make_fm_multi(dev, rank, world, shared_src, per_gpu=32, u8=False):
     """BASELINE configs[3]: 256 FM channels of configs[2] on one shared IQ source, 32 per GPU (weak scaling: N GPUs run
     the first 32 N channels of the bank; 8 GPUs = all 256).  Channel c uses the configs[2] low-pass shifted to
     f_c = (c - 128) * 8 kHz (complex band-pass, multi.cfg4_taps); rank r owns channels r*32 .. r*32+31
@@ -403,17 +403,24 @@ def make_fm_multi(dev, rank, world, shared_src, per_gpu=32):
     w.name = (f"configs[3]: {len(chans)} FM channels/GPU (FftFilter 463 taps->RationalResampler 1:6->QuadratureDemod, fused, "
               f"rr.FmMulti) on one shared 2.4 Msps IQ source, {n:,} samples/step/channel"
               + (f"; this rank: channels {chans[0]}..{chans[-1]} of the {total}-channel bank, {per_gpu * world} in the job" if world > 1 else ""))
-    src = shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0004), 2 * n, torch.float32)
+    if u8:      # the RTL-SDR wire format as the fan-out format: 2 B instead of 8 B per sample over xGMI, decoded in the kernel
+        src = shared_src(lambda: torch.clamp(torch.round(synth_fm(n, fs, dev, 0x5EED0004) / 0.008 + 127.0), 0, 255).to(torch.uint8),
+                         2 * n, torch.uint8)
+        w.in_mult, w.dtype = 2, "u8->f32"
+        w.name = w.name.replace("one shared 2.4 Msps IQ source", "one shared 2.4 Msps RTL-SDR byte stream (rr.FmMultiU8)")
+    else:
+        src = shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0004), 2 * n, torch.float32)
     taps_all = multi.cfg4_taps(taps, chans, total)
-    blk = rr.FmMulti(taps_all, 1, 6, 1.0, rr.ATAN2_EXACT)     # one kernel: forward FFT shared by all channels
+    blk = (rr.FmMultiU8 if u8 else rr.FmMulti)(taps_all, 1, 6, 1.0, rr.ATAN2_EXACT)     # one kernel: forward FFT shared by all channels
     w.blocks = [blk]
     w.n = n
     cap = n // 6 + 1024
     w.outs = torch.empty(len(chans) * cap, dtype=torch.float32, device=dev)
     nch = len(chans)
     w.units_per_sample = nch
-    w.alg_bytes_per_sample = 8.0 / nch + 4.0 / 6.0       # shared read: 8/N B in + 0.67 B out per channel-sample
-    w.dominant, w.dominant_bytes_per_unit = 0, (8.0 / nch + 4.0 / 6.0) * nch
+    bin_ = 2.0 if u8 else 8.0
+    w.alg_bytes_per_sample = bin_ / nch + 4.0 / 6.0       # shared read: 8/N (2/N) B in + 0.67 B out per channel-sample
+    w.dominant, w.dominant_bytes_per_unit = 0, (bin_ / nch + 4.0 / 6.0) * nch
     # vector-FP32-bound: per channel and input sample the reference's filter work (two 1024-point transforms + product
     # per 561 samples) + demod, the forward transform shared by the channels of one GPU
     w.bound = "vector_fp32"
@@ -423,11 +430,17 @@ def make_fm_multi(dev, rank, world, shared_src, per_gpu=32):
     w.bufs = [src]
 
     def step(stream, src_ptr=None):
-        st, c, p, need = blk.work_dev(src.data_ptr() if src_ptr is None else src_ptr, n, w.outs.data_ptr(), cap, stream)
+        st, c, p, need = blk.work_dev(src.data_ptr() if src_ptr is None else src_ptr, n * w.in_mult, w.outs.data_ptr(), cap, stream)
+        c //= w.in_mult
         w.dom_units += c
         return c * nch
     w.step = step
     return w
+
+
+def make_fm_multi_u8(dev, rank, world, shared_src):
+    """configs[3] with the fan-out in the RTL-SDR wire format: the broadcast moves 2 B per sample"""
+    return make_fm_multi(dev, rank, world, shared_src, u8=True)
 
 
 def make_channelizer(dev, rank, world, shared_src, fused=True):
@@ -470,7 +483,8 @@ def make_channelizer_unfused(dev, rank, world, shared_src):
 
 
 WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
-             "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "channelizer": make_channelizer,
+             "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "fm_multi_u8": make_fm_multi_u8,
+             "channelizer": make_channelizer,
              "rtl_fm_chain": make_rtl_fm_chain, "channelizer_unfused": make_channelizer_unfused,
              "fir_fft_chain": make_fir_fft_chain, "fir_fft_chain_unfused": make_fir_fft_chain_unfused,
              "full_chain": make_full_chain, "full_chain_fused": make_full_chain_fused,
@@ -831,31 +845,46 @@ def main():
     stream = torch.cuda.current_stream()
     with rr.build_options(**opts):
         w = WORKLOADS[wname](dev, rank, world, shared_src)
-    fan = None
-    if world > 1:
-        store = w.bufs[0]
+    def make_fan(wl):
+        """the streaming fan-out of wl's shared source (resident on rank 0): one tile = one step's input"""
+        if world == 1:
+            return None
+        store = wl.bufs[0]
         meta = torch.tensor([store.numel() if rank == 0 else 0], dtype=torch.int64, device=dev)
         dist.broadcast(meta, src=0)
-        tile_elems = int(meta.item())
-        sdtype = torch.uint8 if w.in_mult == 2 else torch.float32
+        sdtype = torch.uint8 if wl.in_mult == 2 else torch.float32
 
         def produce(t, out):                  # rank 0: the source block writes tile t into the ring half
             out.copy_(store, non_blocking=True)
-        fan = multi.TileFanout(dist, rank, tile_elems, sdtype, dev, produce)
+        return multi.TileFanout(dist, rank, int(meta.item()), sdtype, dev, produce)
+
+    def collective_report(fan_, kms_, steps_, wall_ms):
+        bms_sum, bn = fan_.broadcast_ms()
+        bms = bms_sum / max(bn, 1)
+        kstep = kms_ / max(steps_, 1)
+        return {"backend": "rccl" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
+                "devices_visible": ndev, "tile_bytes": fan_.bytes_per_tile, "broadcasts_timed": bn,
+                "broadcast_ms_per_tile": round(bms, 4),
+                "source_broadcast_gbs": round(fan_.bytes_per_tile / (bms * 1e-3) / 1e9, 1) if bms > 0 else None,
+                "kernel_ms_per_step": round(kstep, 4),
+                "overlap": round(max(0.0, min(1.0, (bms + kstep - wall_ms) / max(min(bms, kstep), 1e-9))), 3)}
+
+    fan = make_fan(w)
     units, dt, kms, launches, dom_units, step_ms = run_timed(w, args.steps, args.warmup, dist, stream, fan)
-    bc_ms, bc_n = fan.broadcast_ms() if fan is not None else (0.0, 0)
 
     # max over ranks of the wall time, sum over ranks of the units
     units_all, dt = multi.aggregate(dist, units, dt, dev)
 
     others = {}
     if not args.no_others:
-        names = [n for n in WORKLOADS if n != wname] if world == 1 else (["channelizer"] if wname != "channelizer" else [])
+        names = [n for n in WORKLOADS if n != wname] if world == 1 else [n for n in ("fm_multi_u8", "channelizer") if n != wname]
         for name in names:
+            streamed = world > 1 and name.startswith("fm_multi")
             with rr.build_options(**opts):
-                wo = WORKLOADS[name](dev, rank, world, lambda gen, numel, dtype: gen())
+                wo = WORKLOADS[name](dev, rank, world, shared_src if streamed else (lambda gen, numel, dtype: gen()))
             k = max(3, min(args.steps, 10)) if name != "fir" else 200
-            u, t, km, ln, du, sm = run_timed(wo, k, 2, dist, stream)
+            fo = make_fan(wo) if streamed else None
+            u, t, km, ln, du, sm = run_timed(wo, k, 2, dist, stream, fo)
             ua, ta = multi.aggregate(dist, u, t, dev)
             avg_s = km / max(ln, 1) * 1e-3
             ach = (wo.dominant_bytes_per_unit * du / max(ln, 1)) / avg_s / 1e9 if km > 0 else None
@@ -868,8 +897,12 @@ def main():
                             "dominant_kernel_hbm_frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
                             "dominant_kernel_tflops": None if fl is None else round(fl, 2),
                             "dominant_kernel_fp32_frac": None if fl is None else round(fl / FP32_PEAK_TFLOPS, 4)}
-            if world > 1:
+            if world > 1 and streamed:
+                others[name]["source"] = "streamed: rank 0 broadcasts every step's tile (double-buffered) inside the timed region"
+                others[name]["collective"] = collective_report(fo, km, k, ta / k * 1e3)
+            elif world > 1:
                 others[name]["source"] = "resident on every rank (a 400 MB f32 tile per 0.14 ms step cannot stream over xGMI)"
+            del fo
             del wo
             torch.cuda.empty_cache()
         if world == 1 and not args.no_dropin:
@@ -913,15 +946,7 @@ def main():
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),
         }
         if world > 1:
-            bms = bc_ms / max(bc_n, 1)
-            kms_step = kms / max(args.steps, 1)
-            wall = dt / args.steps * 1e3
-            line["collective"] = {"backend": "rccl" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
-                                  "devices_visible": ndev, "tile_bytes": fan.bytes_per_tile, "broadcasts_timed": bc_n,
-                                  "broadcast_ms_per_tile": round(bms, 4),
-                                  "source_broadcast_gbs": round(fan.bytes_per_tile / (bms * 1e-3) / 1e9, 1) if bms > 0 else None,
-                                  "kernel_ms_per_step": round(kms_step, 4),
-                                  "overlap": round(max(0.0, min(1.0, (bms + kms_step - wall) / max(min(bms, kms_step), 1e-9))), 3)}
+            line["collective"] = collective_report(fan, kms, args.steps, dt / args.steps * 1e3)
             line["source_broadcast_gbs"] = line["collective"]["source_broadcast_gbs"]
         if others:
             line["others"] = others

@@ -3,9 +3,23 @@
 HBM bytes per launch = FETCH_SIZE[KB]*1024*2 + WRITE_SIZE[KB]*1024: FETCH_SIZE on gfx950 counts a
 coalesced streaming read at half its bytes (MI355X_MICROARCH.md §HBM); WRITE_SIZE matched the
 known output size exactly (800,000,xxx B for 1e8 complex samples)."""
+import hashlib
 import json
+import os
 import re
 import sys
+
+
+def sources_hash():
+    """the same hash bench.py computes: traffic is only valid for the kernel sources it was collected on"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    d = os.path.join(root, "rustradio_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
 
 summary, workload, kernel = sys.argv[1], sys.argv[2], sys.argv[3]
 vals, cur = {}, None
@@ -22,6 +36,7 @@ except Exception:
     d = {}
 d[workload] = {"hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
                "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"],
-               "kernel": kernel, "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes"}
+               "kernel": kernel, "sources_sha16": sources_hash(),
+               "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes"}
 json.dump(d, open(out_path, "w"), indent=1)
 print(d[workload])
