@@ -65,6 +65,20 @@ RR_HD creg cmulc(creg a, creg w) {
         : "=v"(r) : "v"(a), "v"(w), "v"(t));
     return r;
 }
+// the same with a compile-time constant w: the pair rides in SGPRs (one constant-bus operand) instead of two VGPRs that
+// the compiler would hoist out of the tile loop and keep for the whole kernel
+RR_HD creg cmul_k(creg a, creg w) {
+    creg t = a * __builtin_shufflevector(w, w, 0, 0), r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+RR_HD creg cmulc_k(creg a, creg w) {
+    creg t = a * __builtin_shufflevector(w, w, 0, 0), r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
 RR_HD creg to_reg(cf a) { return mk(a.x, a.y); }
 RR_HD cf from_reg(creg a) { cf r; r.x = a.x; r.y = a.y; return r; }
 #else
@@ -76,8 +90,16 @@ RR_HD creg add_mj(creg a, creg b) { return mk(a.x + b.y, a.y - b.x); }
 RR_HD creg add_pj(creg a, creg b) { return mk(a.x - b.y, a.y + b.x); }
 RR_HD creg cmul(creg a, creg b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 RR_HD creg cmulc(creg a, creg b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+RR_HD creg cmul_k(creg a, creg b) { return cmul(a, b); }
+RR_HD creg cmulc_k(creg a, creg b) { return cmulc(a, b); }
 RR_HD creg to_reg(cf a) { return a; }
 RR_HD cf from_reg(creg a) { return a; }
+#endif
+
+// RR_LDS_Q = volatile keeps hipcc from fusing neighbouring 8-byte LDS accesses into
+// ds_read2_b64 / ds_write2_b64 (a tuning experiment; see DESIGN.md).
+#ifndef RR_LDS_Q
+#define RR_LDS_Q
 #endif
 
 constexpr float kSqrtHalf = 0.70710678118654752440f;
@@ -115,7 +137,7 @@ template <int M, bool INV> RR_HD creg mul_w16(creg a) {
         constexpr float s = (m == 1 || m == 7) ? kSin8 : (m == 3 || m == 5) ? kCos8
                           : (m == 9 || m == 15) ? -kSin8 : -kCos8;            // m == 11, 13
         const creg w = mk(c, -s);
-        return INV ? cmulc(a, w) : cmul(a, w);
+        return INV ? cmulc_k(a, w) : cmul_k(a, w);
     }
 }
 
@@ -259,11 +281,6 @@ template <int LOG2F, int I> RR_HD void inv_pass(creg* v, const creg* twl) {
 #pragma unroll
     for (int u = 0; u < G::U; u++) Dft<G::R, true>::run(v + u * G::R);
 }
-// RR_LDS_Q = volatile keeps hipcc from fusing neighbouring 8-byte LDS accesses into
-// ds_read2_b64 / ds_write2_b64 (a tuning experiment; see DESIGN.md).
-#ifndef RR_LDS_Q
-#define RR_LDS_Q
-#endif
 
 // LDS addressing of a pass layout, split into ONE per-thread base and compile-time
 // offsets so that every ds_read/ds_write uses base VGPR + immediate:

@@ -264,7 +264,7 @@ template <int LOG2F, int VAR>
 __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
 void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles,
                   const cf* __restrict__ tw, const cf* __restrict__ hpos, int ablate,
-                  unsigned long long* __restrict__ dbg) {
+                  unsigned long long* __restrict__ dbg, long tile_base) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -278,7 +278,7 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
 
     int iter = 0;
     for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step, iter++) {
-        const long tile = it.tile;
+        const long tile = tile_base + it.tile;           // (tile_base: a sub-range of the tiles, see launch_fftfilt_t32)
 #ifdef RR_FFT_TIMING_BUILD
         unsigned long long* stamps = (dbg && blockIdx.x == 0 && t == 0 && iter == 2) ? dbg : nullptr;
 #else
@@ -1743,17 +1743,18 @@ int device_cu_count() {
 
 
 template <int LOG2F, int VAR>
-static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s) {
+static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s, long tile_lo = 0, long tile_hi = -1) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     const long S = F - L + 1;
-    const long ntiles = (n_out + S - 1) / S;
+    if (tile_hi < 0) tile_hi = (n_out + S - 1) / S;     // all tiles
+    const long ntiles = tile_hi - tile_lo;
     if (ntiles <= 0) return;
     const size_t smem = sizeof(cf) * lds_elems(F);
     const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR>, T, smem, ntiles);
     const int ablate = 0;
     hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L,
-                       ntiles, tw, hpos, ablate, fft_stamp_buffer());
+                       ntiles, tw, hpos, ablate, fft_stamp_buffer(), tile_lo);
     RR_HIP(hipGetLastError());
 }
 
