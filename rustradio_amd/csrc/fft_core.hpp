@@ -65,6 +65,25 @@ RR_HD creg cmulc(creg a, creg w) {
         : "=v"(r) : "v"(a), "v"(w), "v"(t));
     return r;
 }
+// Two independent products issued interleaved (mul, mul, fma, fma): a packed FMA that reads the result of the packed
+// multiply right before it costs a wait state (hipcc puts an s_nop between them — 88 of the 787 issue slots of a 2048-point
+// tile); with the partner's multiply in between there is nothing to wait for.
+RR_HD void cmul2(creg& a0, creg w0, creg& a1, creg w1) {
+    creg t0 = a0 * __builtin_shufflevector(w0, w0, 0, 0);
+    creg t1 = a1 * __builtin_shufflevector(w1, w1, 0, 0);
+    creg r0, r1;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r0) : "v"(a0), "v"(w0), "v"(t0));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r1) : "v"(a1), "v"(w1), "v"(t1));
+    a0 = r0; a1 = r1;
+}
+RR_HD void cmulc2(creg& a0, creg w0, creg& a1, creg w1) {
+    creg t0 = a0 * __builtin_shufflevector(w0, w0, 0, 0);
+    creg t1 = a1 * __builtin_shufflevector(w1, w1, 0, 0);
+    creg r0, r1;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r0) : "v"(a0), "v"(w0), "v"(t0));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r1) : "v"(a1), "v"(w1), "v"(t1));
+    a0 = r0; a1 = r1;
+}
 // the same with a compile-time constant w: the pair rides in SGPRs (one constant-bus operand) instead of two VGPRs that
 // the compiler would hoist out of the tile loop and keep for the whole kernel
 RR_HD creg cmul_k(creg a, creg w) {
@@ -79,6 +98,9 @@ RR_HD creg cmulc_k(creg a, creg w) {
         : "=v"(r) : "v"(a), "s"(w), "v"(t));
     return r;
 }
+// a * k (real constant): ONE packed multiply (this file is compiled without SLP vectorisation, which would otherwise
+// be the only thing fusing the two scalar products)
+RR_HD creg cscale(creg a, float k) { return a * k; }
 RR_HD creg to_reg(cf a) { return mk(a.x, a.y); }
 RR_HD cf from_reg(creg a) { cf r; r.x = a.x; r.y = a.y; return r; }
 #else
@@ -90,6 +112,9 @@ RR_HD creg add_mj(creg a, creg b) { return mk(a.x + b.y, a.y - b.x); }
 RR_HD creg add_pj(creg a, creg b) { return mk(a.x - b.y, a.y + b.x); }
 RR_HD creg cmul(creg a, creg b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 RR_HD creg cmulc(creg a, creg b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+RR_HD creg cscale(creg a, float k) { return mk(a.x * k, a.y * k); }
+RR_HD void cmul2(creg& a0, creg w0, creg& a1, creg w1) { a0 = cmul(a0, w0); a1 = cmul(a1, w1); }
+RR_HD void cmulc2(creg& a0, creg w0, creg& a1, creg w1) { a0 = cmulc(a0, w0); a1 = cmulc(a1, w1); }
 RR_HD creg cmul_k(creg a, creg b) { return cmul(a, b); }
 RR_HD creg cmulc_k(creg a, creg b) { return cmulc(a, b); }
 RR_HD creg to_reg(cf a) { return a; }
@@ -120,16 +145,16 @@ template <int M, bool INV> RR_HD creg mul_w16(creg a) {
     else if constexpr (m == 12) return sub_w4<INV>(zero, a);
     else if constexpr (m == 2) {   // (1 -+ j)/sqrt2 : (a + w4 a) / sqrt2
         creg t = add_w4<INV>(a, a);
-        return mk(t.x * kSqrtHalf, t.y * kSqrtHalf);
+        return cscale(t, kSqrtHalf);
     } else if constexpr (m == 6) { // (-1 -+ j)/sqrt2 : (w4 a - a) / sqrt2 = -(a - w4 a)/sqrt2
         creg t = sub_w4<INV>(a, a);
-        return mk(t.x * -kSqrtHalf, t.y * -kSqrtHalf);
+        return cscale(t, -kSqrtHalf);
     } else if constexpr (m == 10) {
         creg t = add_w4<INV>(a, a);
-        return mk(t.x * -kSqrtHalf, t.y * -kSqrtHalf);
+        return cscale(t, -kSqrtHalf);
     } else if constexpr (m == 14) {
         creg t = sub_w4<INV>(a, a);
-        return mk(t.x * kSqrtHalf, t.y * kSqrtHalf);
+        return cscale(t, kSqrtHalf);
     } else {
         // generic: forward w = (c, -s), s = sin(pi m / 8), c = cos(pi m / 8)
         constexpr float c = (m == 1 || m == 15) ? kCos8 : (m == 3 || m == 13) ? kSin8
@@ -267,16 +292,18 @@ template <int LOG2F, int I> RR_HD void fwd_pass(creg* v, const creg* twl) {
 #pragma unroll
     for (int u = 0; u < G::U; u++) Dft<G::R, false>::run(v + u * G::R);
     if constexpr (G::P > 1) {
+        v[1] = cmul(v[1], twl[0]);
 #pragma unroll
-        for (int k = 1; k < 16; k++) v[k] = cmul(v[k], twl[k - 1]);
+        for (int k = 2; k < 16; k += 2) cmul2(v[k], twl[k - 1], v[k + 1], twl[k]);
     }
 }
 // Mirror: conj twiddle first, then inverse DFT of the digit.
 template <int LOG2F, int I> RR_HD void inv_pass(creg* v, const creg* twl) {
     using G = PassGeom<LOG2F, I>;
     if constexpr (G::P > 1) {
+        v[1] = cmulc(v[1], twl[0]);
 #pragma unroll
-        for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], twl[k - 1]);
+        for (int k = 2; k < 16; k += 2) cmulc2(v[k], twl[k - 1], v[k + 1], twl[k]);
     }
 #pragma unroll
     for (int u = 0; u < G::U; u++) Dft<G::R, true>::run(v + u * G::R);
@@ -324,7 +351,7 @@ template <int LOG2F, int I> RR_HD void load_h(creg* h, int t, const cf* __restri
 }
 RR_HD void apply_h(creg* v, const creg* h) {
 #pragma unroll
-    for (int n = 0; n < 16; n++) v[n] = cmul(v[n], h[n]);
+    for (int n = 0; n < 16; n += 2) cmul2(v[n], h[n], v[n + 1], h[n + 1]);
 }
 
 }  // namespace rr
