@@ -642,6 +642,53 @@ public:
     }
 };
 
+// ---- graph-level fusions (one block, one kernel; whole-stream output = the reference blocks in sequence) ------------------
+// All of them drop tags (as RationalResampler / QuadratureDemod / FftFilterFloat's inner lift do in the reference).
+template <class In, class Out> class Fused : public Block {
+    detail::Handle h_;
+    ReadStream<In> src_;
+    WriteStream<Out> dst_;
+public:
+    Fused(rr_block* h, ReadStream<In> src, WriteStream<Out> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)) {}
+    const char* block_name() const override { return rr_block_name(h_.h); }
+    bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
+    BlockRet work() override {
+        auto [input, tags] = src_.read_buf();
+        (void)tags;
+        auto out = dst_.write_buf();
+        auto w = detail::work(h_.h, input, out);
+        input.consume(w.consumed);
+        out.produce(w.produced, {});
+        if (w.st == RR_AGAIN) return BlockRet::again();
+        return w.st == RR_WAIT_DST ? BlockRet::wait(dst_.wait_handle(), w.need) : BlockRet::wait(src_.wait_handle(), w.need);
+    }
+    template <class MakeHandle> static std::pair<std::unique_ptr<Fused>, ReadStream<Out>> make(ReadStream<In> src, MakeHandle&& mk) {
+        auto [w, r] = new_stream<Out>();
+        return {std::make_unique<Fused>(mk(), std::move(src), std::move(w)), std::move(r)};
+    }
+};
+inline const rr_c32* c32(const std::vector<Complex>& v) { return reinterpret_cast<const rr_c32*>(v.data()); }
+// FftFilter -> RationalResampler -> QuadratureDemod (examples/rtl_fm.rs:381-419)
+inline auto FmChain(ReadStream<Complex> src, const std::vector<Complex>& taps, size_t interp, size_t deci, Float gain, bool exact_atan2 = true) {
+    return Fused<Complex, Float>::make(std::move(src), [&] { return rr_fm_chain_create(c32(taps), taps.size(), interp, deci, gain, exact_atan2 ? RR_ATAN2_EXACT : RR_ATAN2_FAST); });
+}
+// FirFilter -> FftFilter as one convolution (the north star's pair)
+inline auto FirFftFilter(ReadStream<Complex> src, const std::vector<Complex>& fir_taps, const std::vector<Complex>& fft_taps) {
+    return Fused<Complex, Complex>::make(std::move(src), [&] { return rr_fir_fftfilter_create(c32(fir_taps), fir_taps.size(), c32(fft_taps), fft_taps.size()); });
+}
+// FirFilter -> FftFilter -> RationalResampler -> QuadratureDemod (BASELINE's metric chain)
+inline auto FirFmChain(ReadStream<Complex> src, const std::vector<Complex>& fir_taps, const std::vector<Complex>& fft_taps, size_t interp,
+                       size_t deci, Float gain, bool exact_atan2 = true) {
+    return Fused<Complex, Float>::make(std::move(src), [&] {
+        return rr_fir_fm_chain_create(c32(fir_taps), fir_taps.size(), c32(fft_taps), fft_taps.size(), interp, deci, gain,
+                                      exact_atan2 ? RR_ATAN2_EXACT : RR_ATAN2_FAST);
+    });
+}
+// FftFilterFloat -> RationalResampler -> MultiplyConst (examples/rtl_fm.rs:398-418)
+inline auto AudioChain(ReadStream<Float> src, const std::vector<Float>& taps, size_t interp, size_t deci, Float scale) {
+    return Fused<Float, Float>::make(std::move(src), [&] { return rr_audio_chain_create(taps.data(), taps.size(), interp, deci, scale); });
+}
+
 // ---- Hilbert (src/hilbert.rs) ----------------------------------------------------------------------------------------------
 class Hilbert : public Block {
     detail::Handle h_;

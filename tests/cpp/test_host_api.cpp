@@ -216,6 +216,106 @@ static void graph_fm_chain() {
     CHECK(worst < 1e-4);
 }
 
+// Graph-level fusions against the blocks they replace, both through Graph on the GPU: FirFilter -> FftFilter as one
+// convolution, the metric's four-block chain as one kernel, the rtl_fm audio stage as one kernel.
+template <class T> static double max_rel(const std::vector<T>& a, const std::vector<T>& b, double floor_ = 0.0) {
+    double e = 0, m = floor_;
+    for (size_t i = 0; i < b.size(); i++) m = std::max(m, (double)std::abs(b[i]));
+    for (size_t i = 0; i < std::min(a.size(), b.size()); i++) e = std::max(e, (double)std::abs(a[i] - b[i]));
+    return m > 0 ? e / m : e;
+}
+static void fused_blocks_equal_their_chains() {
+    const size_t n = 300000;
+    std::vector<Complex> x(n);
+    uint64_t st = 12345;
+    auto rnd = [&] { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return (float)((st >> 40) / 8388608.0 - 1.0); };
+    for (auto& v : x) v = Complex(rnd(), rnd());
+    auto t1 = fir::low_pass_complex(10e6f, 1e6f, 190e3f, WindowType::Hamming());
+    auto t2 = fir::low_pass_complex(10e6f, 1e6f, 60e3f, WindowType::Hamming());
+    CHECK(t1.size() == 127 && t2.size() == 401);
+    auto run_c = [&](bool fused) {
+        auto [src, s0] = VectorSource<Complex>::new_(x);
+        Graph g;
+        g.add(std::move(src));
+        ReadStream<Complex> last = std::move(s0);
+        if (fused) {
+            auto [b, s1] = FirFftFilter(std::move(last), t1, t2);
+            g.add(std::move(b)); last = std::move(s1);
+        } else {
+            auto [a, s1] = FirFilter<Complex>::builder(t1).build(std::move(last));
+            auto [b, s2] = FftFilter::new_(std::move(s1), t2);
+            g.add(std::move(a)); g.add(std::move(b)); last = std::move(s2);
+        }
+        auto sink = std::make_unique<VectorSink<Complex>>(std::move(last));
+        auto hook = sink->hook();
+        g.add(std::move(sink));
+        g.run();
+        return *hook;
+    };
+    auto yu = run_c(false), yf = run_c(true);
+    CHECK(yu.size() == yf.size() && yu.size() > 290000);
+    CHECK(max_rel(yf, yu) < 2e-5);
+    auto run_f = [&](bool fused) {
+        auto [src, s0] = VectorSource<Complex>::new_(x);
+        Graph g;
+        g.add(std::move(src));
+        ReadStream<Float> out;
+        if (fused) {
+            auto [b, s1] = FirFmChain(std::move(s0), t1, t2, 1, 4, 0.5f);
+            g.add(std::move(b)); out = std::move(s1);
+        } else {
+            auto [a, s1] = FirFilter<Complex>::builder(t1).build(std::move(s0));
+            auto [b, s2] = FftFilter::new_(std::move(s1), t2);
+            auto [c, s3] = RationalResampler<Complex>::new_(std::move(s2), 1, 4);
+            auto [d, s4] = QuadratureDemod::new_(std::move(s3), 0.5f);
+            g.add(std::move(a)); g.add(std::move(b)); g.add(std::move(c)); g.add(std::move(d)); out = std::move(s4);
+        }
+        auto sink = std::make_unique<VectorSink<Float>>(std::move(out));
+        auto hook = sink->hook();
+        g.add(std::move(sink));
+        g.run();
+        return *hook;
+    };
+    auto du = run_f(false), df = run_f(true);
+    CHECK(du.size() == df.size() && du.size() > 70000);
+    // noise input filtered to |r| ~ 0.3: angle errors stay far below 1e-3 rad except where |r| is tiny; compare robustly
+    size_t bad = 0;
+    for (size_t i = 0; i < du.size(); i++) {
+        double d = std::fabs((double)du[i] - (double)df[i]);
+        d = std::min(d, 2 * M_PI * 0.5 - d);
+        if (d > 1e-3) bad++;
+    }
+    CHECK(bad < du.size() / 1000);
+    // audio stage
+    std::vector<Float> xr(n);
+    for (auto& v : xr) v = rnd();
+    auto ta = fir::low_pass(200000.0f, 44100.0f, 500.0f, WindowType::Hamming());
+    CHECK(ta.size() == 963);
+    auto run_a = [&](bool fused) {
+        auto [src, s0] = VectorSource<Float>::new_(xr);
+        Graph g;
+        g.add(std::move(src));
+        ReadStream<Float> out;
+        if (fused) {
+            auto [b, s1] = AudioChain(std::move(s0), ta, 48000, 200000, 0.25f);
+            g.add(std::move(b)); out = std::move(s1);
+        } else {
+            auto [a, s1] = FftFilterFloat::new_(std::move(s0), ta);
+            auto [b, s2] = RationalResampler<Float>::new_(std::move(s1), 48000, 200000);
+            auto [c, s3] = MultiplyConst<Float>::new_(std::move(s2), 0.25f);
+            g.add(std::move(a)); g.add(std::move(b)); g.add(std::move(c)); out = std::move(s3);
+        }
+        auto sink = std::make_unique<VectorSink<Float>>(std::move(out));
+        auto hook = sink->hook();
+        g.add(std::move(sink));
+        g.run();
+        return *hook;
+    };
+    auto au = run_a(false), af = run_a(true);
+    CHECK(au.size() == af.size() && au.size() > 70000);
+    CHECK(max_rel(af, au) < 2e-5);
+}
+
 // The same Graph, rings in host memory vs rings in HBM: identical samples and tags.
 template <class F> static auto with_memory(Memory m, F&& f) {
     const Memory old = default_memory();
@@ -447,7 +547,7 @@ static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
     fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
-    device_resident_graph(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests(); handles_on_concurrent_threads();
+    device_resident_graph(); fused_blocks_equal_their_chains(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests(); handles_on_concurrent_threads();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }
