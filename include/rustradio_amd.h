@@ -117,8 +117,9 @@ rr_block *rr_fir_c32_create(const rr_c32 *taps, size_t ntaps, size_t deci,
                             int translate, float samp_rate, float freq);
 /* FirFilter::<Float> (same generic block, src/fir.rs:343-386; long filters on real-stream overlap-save tiles). */
 rr_block *rr_fir_f32_create(const float *taps, size_t ntaps, size_t deci);
-/* FftFilter::new(src, taps) (src/fft_filter.rs:242-279).  1 <= ntaps <= 16383 (the largest LDS-resident
- * overlap-save tile is 16384 points; the reference has no limit) — NULL beyond. */
+/* FftFilter::new(src, taps) (src/fft_filter.rs:242-279).  Up to 16383 taps run on LDS-resident overlap-save tiles; longer
+ * filters (up to 524,288 taps; the reference has no limit) as overlap-save frames of 2^m >= 2 ntaps points through the
+ * any-size transform (plain HBM-streaming passes). */
 rr_block *rr_fftfilter_create(const rr_c32 *taps, size_t ntaps);
 /* FftFilterFloat::new(src, taps) (src/fft_filter.rs:391-426). */
 rr_block *rr_fftfilter_float_create(const float *taps, size_t ntaps);
@@ -134,9 +135,15 @@ rr_block *rr_rtlsdr_decode_create(void);
 /* FftStream::new(src, size) (src/fft_stream.rs:40-117): the forward, unnormalised FFT of every consecutive
  * `size`-sample frame, natural bin order; work(): WAIT_SRC(size) / WAIT_DST(size), else whole frames of
  * min(in, out), RR_AGAIN.  The frame tags (TAG_FRAME, TAG_FRAME_SIZE) are added by the shim from
- * `produced`.  GPU sizes: every size 2..2048 (sizes that are not a power of two as Bluestein chirp-z convolutions) and
- * the powers of two up to 16384 (NULL otherwise; rustfft plans any size). */
+ * `produced`.  ANY size from 2 to the stream capacity (512,000; rustfft plans any size): one tile kernel up to 16384 = 2^14
+ * points and for every size up to 2048 (Bluestein chirp-z on a filter tile), the four-step decomposition for larger powers
+ * of two, Bluestein on a power of two M >= 2 size - 1 for everything else. */
 rr_block *rr_fftstream_create(size_t size);
+/* Fft::from_fft_size(prev, size) (src/fft.rs:19-56): the message (PDU) form — one Vec<Complex> of exactly `size` samples
+ * in, its forward FFT out.  The handle is an rr_fftstream_create(size) block; rr_fft_process transforms ONE message held in
+ * host memory (n != size: RR_ERR, "FFT expected {size} samples, got {n}" as fft.rs:46-52).  The shim pops the message from
+ * its NCReadStream, calls this, pushes the result with the message's tags. */
+int rr_fft_process(rr_block *fftstream, const rr_c32 *msg, size_t n, rr_c32 *out);
 /* MultiplyConst::<Float|Complex>::new(src, val) (src/multiply_const.rs:6-23) and FastFM::new(src)
  * (src/quadrature_demod.rs:144-165): #[rustradio(sync)] blocks — work() maps min(input, output space)
  * samples and returns WaitForStream(src|dst, 1) (rustradio_macros_code/src/lib.rs:458-515).  Bit-exact. */

@@ -52,6 +52,7 @@ unsafe extern "C" {
     fn rr_fm_multi_create(taps: *const Complex, nchan: usize, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_fm_multi_u8_create(taps: *const Complex, nchan: usize, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_fftstream_create(size: usize) -> *mut RrBlock;
+    fn rr_fft_process(fftstream: *mut RrBlock, msg: *const Complex, n: usize, out: *mut Complex) -> c_int;
     fn rr_multiply_const_c32_create(re: f32, im: f32) -> *mut RrBlock;
     fn rr_block_out_windows(b: *const RrBlock) -> usize;
     fn rr_block_destroy(b: *mut RrBlock);
@@ -417,6 +418,38 @@ impl Block for GpuFftStream {
             RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
             _ => BlockRet::Again,
         })
+    }
+}
+
+/// `Fft::from_fft_size(prev, size)` (src/fft.rs:19-56): the message (PDU) form — one `Vec<Complex>` of exactly `size`
+/// samples in, its forward FFT out, tags passed along; a wrong-sized message is a fatal `Err` as in fft.rs:46-52.
+pub struct GpuFft {
+    h: Handle,
+    src: rustradio::stream::NCReadStream<Vec<Complex>>,
+    dst: rustradio::stream::NCWriteStream<Vec<Complex>>,
+}
+impl GpuFft {
+    pub fn from_fft_size(src: rustradio::stream::NCReadStream<Vec<Complex>>, size: usize)
+        -> Result<(Self, rustradio::stream::NCReadStream<Vec<Complex>>)> {
+        if size == 0 { return Err(Error::msg("FFT called with size 0")); }
+        // SAFETY: plain value.
+        let h = Handle::new(unsafe { rr_fftstream_create(size) })?;
+        let (dst, dr) = rustradio::stream::new_nocopy_stream();
+        Ok((Self { h, src, dst }, dr))
+    }
+}
+impl BlockName for GpuFft { fn block_name(&self) -> &str { "GpuFft" } }
+impl BlockEOF for GpuFft { fn eof(&mut self) -> bool { self.src.eof() } }
+impl Block for GpuFft {
+    fn work(&mut self) -> Result<BlockRet<'_>> {
+        loop {
+            if self.dst.remaining() == 0 { return Ok(BlockRet::WaitForStream(&self.dst, 1)); }
+            let Some((msg, tags)) = self.src.pop() else { return Ok(BlockRet::WaitForStream(&self.src, 1)); };
+            let mut out = vec![Complex::default(); msg.len()];
+            // SAFETY: msg and out are live slices of msg.len() repr(C) Complex<f32>.
+            check(unsafe { rr_fft_process(self.h.0, msg.as_ptr(), msg.len(), out.as_mut_ptr()) })?;
+            self.dst.push(out, tags);
+        }
     }
 }
 

@@ -363,11 +363,29 @@ def FastFM() -> Block:
 
 
 def FftStream(size: int) -> Block:
-    """FftStream::new(src, size) (src/fft_stream.rs:40-117); every size 2..2048 and the powers of two up to 16384."""
+    """FftStream::new(src, size) (src/fft_stream.rs:40-117); any size from 2 to the stream capacity (512,000)."""
     h = lib().rr_fftstream_create(size)
     if not h:
         raise ValueError(last_error())
     return Block(h, np.complex64, np.complex64)
+
+
+class Fft:
+    """Fft::from_fft_size(prev, size) (src/fft.rs:19-56): the message (PDU) form of the forward FFT —
+    `process(msg)` takes one array of exactly `size` Complex samples and returns its transform."""
+
+    def __init__(self, size: int):
+        if size == 0:
+            raise ValueError("FFT called with size 0")                    # fft.rs:24-26
+        self.size = size
+        self._blk = FftStream(size)
+
+    def process(self, msg) -> np.ndarray:
+        m = np.ascontiguousarray(msg, np.complex64)
+        out = np.empty(len(m), np.complex64) if len(m) else np.empty(1, np.complex64)
+        if lib().rr_fft_process(self._blk._h, _ptr(m), len(m), _ptr(out)) != 0:
+            raise ValueError(last_error())
+        return out[:len(m)]
 
 
 def RtlSdrDecode() -> Block:

@@ -19,7 +19,7 @@ SYMBOLS = [
     "rr_max_attenuation", "rr_make_window", "rr_compute_ntaps", "rr_low_pass", "rr_low_pass_complex",
     "rr_hilbert_taps", "rr_multiband",
     "rr_fir_c32_create", "rr_fir_f32_create", "rr_fftfilter_create", "rr_fftfilter_float_create",
-    "rr_resampler_create", "rr_quaddemod_create", "rr_rtlsdr_decode_create", "rr_fftstream_create", "rr_multiply_const_f32_create", "rr_multiply_const_c32_create", "rr_fastfm_create", "rr_hilbert_create", "rr_fm_chain_create", "rr_fm_chain_u8_create", "rr_fir_fftfilter_create", "rr_fir_fm_chain_create", "rr_audio_chain_create", "rr_hilbert_fir_create", "rr_fm_multi_create", "rr_fm_multi_u8_create", "rr_block_out_windows", "rr_block_destroy",
+    "rr_resampler_create", "rr_quaddemod_create", "rr_rtlsdr_decode_create", "rr_fftstream_create", "rr_fft_process", "rr_multiply_const_f32_create", "rr_multiply_const_c32_create", "rr_fastfm_create", "rr_hilbert_create", "rr_fm_chain_create", "rr_fm_chain_u8_create", "rr_fir_fftfilter_create", "rr_fir_fm_chain_create", "rr_audio_chain_create", "rr_hilbert_fir_create", "rr_fm_multi_create", "rr_fm_multi_u8_create", "rr_block_out_windows", "rr_block_destroy",
     "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_in_elem_size",
     "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_fft_tile", "rr_fir_set_rotator_mode",
     "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps",
@@ -80,6 +80,7 @@ def lib():
     L.rr_multiply_const_c32_create.argtypes = [f32, f32]; L.rr_multiply_const_c32_create.restype = vp
     L.rr_fastfm_create.argtypes = []; L.rr_fastfm_create.restype = vp
     L.rr_fftstream_create.argtypes = [sz]; L.rr_fftstream_create.restype = vp
+    L.rr_fft_process.argtypes = [vp, vp, sz, vp]; L.rr_fft_process.restype = i32
     L.rr_hilbert_create.argtypes = [sz, i32, f32]; L.rr_hilbert_create.restype = vp
     L.rr_fm_chain_create.argtypes = [vp, sz, sz, sz, f32, i32]; L.rr_fm_chain_create.restype = vp
     L.rr_fir_fftfilter_create.argtypes = [vp, sz, vp, sz]; L.rr_fir_fftfilter_create.restype = vp

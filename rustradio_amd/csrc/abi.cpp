@@ -141,6 +141,17 @@ rr_block* rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_p
 rr_block* rr_fftstream_create(size_t size) {
     return make_block([&] { return new rr::FftStream(size); });
 }
+int rr_fft_process(rr_block* b, const rr_c32* msg, size_t n, rr_c32* out) {
+    auto* f = b ? dynamic_cast<rr::FftStream*>(b->b.get()) : nullptr;
+    if (!f || !msg || !out) { rr::set_last_error("rr_fft_process: not an FftStream handle / null argument"); return RR_ERR; }
+    if (n != f->size) {                                                   // fft.rs:46-52
+        rr::set_last_error("FFT expected " + std::to_string(f->size) + " samples, got " + std::to_string(n));
+        return RR_ERR;
+    }
+    size_t c = 0, p = 0, need = 0;
+    const int st = rr_block_work(b, msg, n, out, n, &c, &p, &need);
+    return st == RR_ERR ? RR_ERR : (p == n ? 0 : RR_ERR);
+}
 rr_block* rr_multiply_const_f32_create(float val) {
     return make_block([&] { return new rr::MultiplyConst(4, val, 0.0f); });
 }

@@ -532,13 +532,35 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
         const double c = (cost_a[lg - 10] + cost_b[lg - 10] * Sc) / Sc;
         if (log2f < 0 || c < best) { best = c; log2f = lg; }
     }
-    if (log2f < 0) log2f = 15;                                        // -> refused below
+    if (log2f < 0) log2f = 15;                                        // -> the any-size path (or refused) below
     if (const int v = build_opts().fft_log2f) {            // rr_build_opts: force a tile size
         if (v >= 10 && v <= max_log2f && ((size_t)1 << v) >= L + 1) log2f = v;
     }
-    if (!fftfilt_supported(log2f))
-        throw Error("FftFilter: more than " + std::to_string(((size_t)1 << max_log2f) - 1) +
-                    " taps is not supported by the LDS-resident tile kernel");
+    if (!fftfilt_supported(log2f)) {
+        // more than 16383 taps (the reference has no limit, fft_filter.rs:36-42): overlap-save frames of M = 2^m >= 2 L
+        // points, every frame one any-size transform (four-step beyond 16384 points) — plain HBM-streaming passes
+        if (real || for_chain || max_log2f < 14 || L > ((size_t)1 << 19))
+            throw Error("FftFilter: more than " + std::to_string(((size_t)1 << max_log2f) - 1) +
+                        " taps is not supported by this block's tile kernels");
+        bigM = 1;
+        while (bigM < 2 * L) bigM <<= 1;
+        log2f = 0;
+        while (((size_t)1 << log2f) < bigM) log2f++;
+        big.reset(new AnyFft(bigM, stream));
+        std::vector<std::complex<double>> H(bigM, 0.0);
+        for (size_t i = 0; i < ntaps; i++) H[i] = {taps[i].re, taps[i].im};
+        fft64(H);
+        std::vector<cf> hb(bigM);
+        for (size_t k = 0; k < bigM; k++) hb[k] = mkcf((float)(H[k].real() / (double)bigM), (float)(H[k].imag() / (double)bigM));
+        d_hbig.upload(hb.data(), bigM, stream);
+        const size_t pcap = hist + nsamples + 1;
+        for (auto& p : prefix) {
+            p.reserve(pcap);
+            RR_HIP(hipMemsetAsync(p.p, 0, pcap * sizeof(cf), stream));
+        }
+        RR_HIP(hipStreamSynchronize(stream));
+        return;
+    }
     const size_t F = (size_t)1 << log2f;
     std::vector<cf> hpos, tw(F);
     compute_hpos(taps, ntaps, log2f, hpos);
@@ -584,6 +606,23 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
 }
 
 void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s) {
+    if (big) {
+        // y = conj(FFT_M(conj(FFT_M(frame) H))) per overlap-save frame, in chunks of <= 2^24 elements of work space
+        const long M = (long)bigM, S = M - (long)L + 1;
+        const long nfr = (n_out + S - 1) / S;
+        const long per = std::max<long>(1, ((long)1 << 24) / M);
+        bframes.reserve((size_t)std::min(per, nfr) * M);
+        bspec.reserve((size_t)std::min(per, nfr) * M);
+        for (long f0 = 0; f0 < nfr; f0 += per) {
+            const long nf = std::min(per, nfr - f0);
+            launch_ols_gather(src, bframes.p, S, M, f0, nf, s);
+            big->forward(bframes.p, bspec.p, nf, s);
+            launch_mul_conj(bspec.p, d_hbig.p, M, nf, s);
+            big->forward(bspec.p, bframes.p, nf, s);
+            launch_ols_scatter(bframes.p, out, S, M, (long)L, f0, nf, n_out, s);
+        }
+        return;
+    }
     if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s);
     else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s);
 }
@@ -674,6 +713,7 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     } else {
         f.reset(new FftFilter(taps, ntaps, true, max_log2f));
     }
+    if (f->big) throw Error("FmChain: at most 16383 taps (the fused kernels run on LDS-resident tiles)");
     const int64_t G = (D + I - 1) / I;
     if (G >= (int64_t)(((size_t)1 << f->log2f) - f->L + 1)) throw Error("FmChain: decimation too large for the FFT tile");
     half_ok = !f->nsub && fm_multi_half_supported(f->log2f, I, D, (int)ntaps) && !build_opts().fm_full;
@@ -1130,56 +1170,105 @@ int QuadDemod::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
 }
 
 // ---- FftStream (fft_stream.rs:26-117) ------------------------------------------------------------------------
-FftStream::FftStream(size_t n) : Block("FftStream", 8, 8), size(n) {
-    if (n == 0) throw Error("FFT size must be nonzero");                                   // :42
-    if (n > 4096000 / sizeof(cf)) throw Error("FFT size must be no bigger than stream size");   // :46-50
-    if (n < 2 || n > 16384 || ((n & (n - 1)) != 0 && n > 2048))
-        throw Error("FftStream: the GPU block transforms sizes 2..2048 and the powers of two up to 16384 (the reference plans any size with rustfft)");
-    if ((n & (n - 1)) != 0) {                             // Bluestein on a filter tile of M >= 2 n - 1 points
+static void fill_tw(std::vector<cf>& tw, size_t n) {
+    tw.resize(n);
+    for (size_t k = 0; k < n; k++) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)n;
+        tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+    }
+}
+// c[k] = exp(-i pi k^2 / n), k^2 reduced mod 2 n in integers (exact phase for any n), and b[m] = conj(c[|m|]) wrapped mod M
+static void bluestein_tables(size_t n, size_t M, std::vector<std::complex<double>>& c, std::vector<std::complex<double>>& B) {
+    c.resize(n);
+    B.assign(M, 0.0);
+    for (size_t k = 0; k < n; k++) {
+        const unsigned __int128 q = ((unsigned __int128)k * k) % (2 * n);
+        c[k] = std::polar(1.0, -3.14159265358979323846 * (double)(size_t)q / (double)n);
+    }
+    B[0] = std::conj(c[0]);
+    for (size_t m = 1; m < n; m++) B[m] = B[M - m] = std::conj(c[m]);
+    fft64(B);
+    for (auto& h : B) h /= (double)M;
+}
+
+AnyFft::AnyFft(size_t n, hipStream_t s) : N(n) {
+    if (n < 2) throw Error("FFT size must be at least 2");
+    const bool pow2 = (n & (n - 1)) == 0;
+    if (n > ((size_t)1 << 20) || (!pow2 && n > ((size_t)1 << 19))) throw Error("FFT size beyond 524288 (2^20 for powers of two) is not supported");
+    std::vector<cf> tw;
+    if (pow2 && n <= 16384) {
+        while (((size_t)1 << log2n) < n) log2n++;
+        fill_tw(tw, n);
+        d_tw.upload(tw.data(), n, s);
+        if (n >= 8192 && !build_opts().fft_no_split) {
+            fill_tw(tw, 4096);
+            d_tw4096.upload(tw.data(), 4096, s);
+        }
+    } else if (pow2) {                                    // four-step: N1 >= N2, both <= 1024
+        int lg = 0;
+        while (((size_t)1 << lg) < n) lg++;
+        N1 = (size_t)1 << ((lg + 1) / 2); N2 = n / N1;
+        f1.reset(new AnyFft(N1, s));
+        f2.reset(new AnyFft(N2, s));
+        fill_tw(tw, n);
+        d_twN.upload(tw.data(), n, s);
+    } else if (n <= 2048) {                               // Bluestein fused into one filter tile of M >= 2 n - 1 points
         log2m = 10;
         while (((size_t)1 << log2m) < 2 * n - 1) log2m++;
-        const size_t M = (size_t)1 << log2m;
-        std::vector<std::complex<double>> c(n), B(M, 0.0);
-        for (size_t k = 0; k < n; k++) {                  // c[k] = exp(-i pi k^2 / n), k^2 reduced mod 2 n
-            const size_t q = (k * k) % (2 * n);
-            c[k] = std::polar(1.0, -3.14159265358979323846 * (double)q / (double)n);
-        }
-        B[0] = std::conj(c[0]);
-        for (size_t m = 1; m < n; m++) B[m] = B[M - m] = std::conj(c[m]);
-        fft64(B);
-        for (auto& h : B) h /= (double)M;
-        std::vector<cf> hpos, tw(M), chirp(n);
+        const size_t Mt = (size_t)1 << log2m;
+        std::vector<std::complex<double>> c, B;
+        bluestein_tables(n, Mt, c, B);
+        std::vector<cf> hpos, chirp(n);
         switch (log2m) {
         case 10: fill_hpos<10>(B, hpos); break;
         case 11: fill_hpos<11>(B, hpos); break;
         default: fill_hpos<12>(B, hpos); break;
         }
-        for (size_t k = 0; k < M; k++) {
-            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)M;
-            tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
-        }
+        fill_tw(tw, Mt);
         for (size_t k = 0; k < n; k++) chirp[k] = mkcf((float)c[k].real(), (float)c[k].imag());
-        d_tw.upload(tw.data(), M, stream);
-        d_bh.upload(hpos.data(), M, stream);
-        d_chirp.upload(chirp.data(), n, stream);
-        RR_HIP(hipStreamSynchronize(stream));
+        d_tw.upload(tw.data(), Mt, s);
+        d_bh.upload(hpos.data(), Mt, s);
+        d_chirp.upload(chirp.data(), n, s);
+    } else {                                              // Bluestein on M points through the power-of-two engine
+        M = 1;
+        while (M < 2 * n - 1) M <<= 1;
+        fm.reset(new AnyFft(M, s));
+        std::vector<std::complex<double>> c, B;
+        bluestein_tables(n, M, c, B);
+        std::vector<cf> bn(M), chirp(n);
+        for (size_t k = 0; k < M; k++) bn[k] = mkcf((float)B[k].real(), (float)B[k].imag());
+        for (size_t k = 0; k < n; k++) chirp[k] = mkcf((float)c[k].real(), (float)c[k].imag());
+        d_b.upload(bn.data(), M, s);
+        d_chirp.upload(chirp.data(), n, s);
+    }
+}
+
+void AnyFft::forward(const cf* in, cf* out, long nf, hipStream_t s) {
+    if (nf <= 0) return;
+    if (log2n) { launch_fft_frames(log2n, in, out, nf, d_tw.p, d_tw4096.p, s); return; }
+    if (log2m) { launch_fft_bluestein(log2m, in, out, nf, (int)N, d_tw.p, d_bh.p, d_chirp.p, s); return; }
+    if (N1) {                                             // n = N2 n1 + n2, k = k1 + N1 k2
+        t1.reserve((size_t)nf * N); t2.reserve((size_t)nf * N);
+        launch_transpose_tw(in, t1.p, (int)N1, (int)N2, nf, nullptr, s);            // [n1][n2] -> [n2][n1]
+        f1->forward(t1.p, t2.p, nf * (long)N2, s);                                   // over n1 -> [n2][k1]
+        launch_transpose_tw(t2.p, t1.p, (int)N2, (int)N1, nf, d_twN.p, s);          // * w_N^(n2 k1), -> [k1][n2]
+        f2->forward(t1.p, t2.p, nf * (long)N1, s);                                   // over n2 -> [k1][k2]
+        launch_transpose_tw(t2.p, out, (int)N1, (int)N2, nf, nullptr, s);           // -> [k2][k1] = natural order
         return;
     }
-    while (((size_t)1 << log2n) < n) log2n++;
-    std::vector<cf> tw(n);
-    for (size_t k = 0; k < n; k++) {
-        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)n;
-        tw[k] = mkcf((float)std::cos(a), (float)std::sin(a));
-    }
-    d_tw.upload(tw.data(), n, stream);
-    if (n >= 8192 && !build_opts().fft_no_split) {
-        std::vector<cf> t4(4096);
-        for (size_t k = 0; k < 4096; k++) {
-            const double a = -2.0 * 3.14159265358979323846 * (double)k / 4096.0;
-            t4[k] = mkcf((float)std::cos(a), (float)std::sin(a));
-        }
-        d_tw4096.upload(t4.data(), t4.size(), stream);
-    }
+    t1.reserve((size_t)nf * M); t2.reserve((size_t)nf * M);
+    launch_chirp_pre(in, t1.p, (long)N, (long)M, nf, d_chirp.p, s);
+    fm->forward(t1.p, t2.p, nf, s);
+    launch_mul_conj(t2.p, d_b.p, (long)M, nf, s);
+    fm->forward(t2.p, t1.p, nf, s);
+    launch_chirp_post(t1.p, out, (long)N, (long)M, nf, d_chirp.p, s);
+}
+
+FftStream::FftStream(size_t n) : Block("FftStream", 8, 8), size(n) {
+    if (n == 0) throw Error("FFT size must be nonzero");                                   // :42
+    if (n > 4096000 / sizeof(cf)) throw Error("FFT size must be no bigger than stream size");   // :46-50
+    if (n < 2) throw Error("FftStream: size 1 is the identity (not a GPU block)");
+    fft.reset(new AnyFft(n, stream));
     RR_HIP(hipStreamSynchronize(stream));
 }
 int FftStream::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
@@ -1190,8 +1279,7 @@ int FftStream::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     size_t len = std::min(in_len, out_cap);                                    // :82-83
     len -= len % size;
     prof_begin(s);
-    if (log2m) launch_fft_bluestein(log2m, static_cast<const cf*>(in), static_cast<cf*>(out), (long)(len / size), (int)size, d_tw.p, d_bh.p, d_chirp.p, s);
-    else launch_fft_frames(log2n, static_cast<const cf*>(in), static_cast<cf*>(out), (long)(len / size), d_tw.p, d_tw4096.p, s);
+    fft->forward(static_cast<const cf*>(in), static_cast<cf*>(out), (long)(len / size), s);
     prof_end(s);
     *consumed = *produced = len;
     return RR_AGAIN;                                                           // :116

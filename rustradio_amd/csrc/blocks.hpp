@@ -42,6 +42,26 @@ struct Block {
     void prof_read(double* total_ms, size_t* launches, bool reset);
 };
 
+// Forward, unnormalised FFT of consecutive N-sample frames in natural bin order for ANY N >= 2 (rustfft plans any size:
+// fft_stream.rs:43-44, fft.rs:27-32).  One tile kernel up to 16384 = 2^14 points and for every size up to 2048; beyond
+// that the four-step decomposition (powers of two) or Bluestein's chirp-z on a power of two M >= 2 N - 1 (kernels_misc.hip).
+struct AnyFft {
+    size_t N = 0;
+    int log2n = 0;                    // one tile: power of two <= 16384 (k_fft_frames / k_fft_small)
+    DevBuf<cf> d_tw, d_tw4096;
+    int log2m = 0;                    // one tile: any size <= 2048 (fused k_fft_bluestein on a 2^log2m-point filter tile)
+    DevBuf<cf> d_bh, d_chirp;
+    size_t N1 = 0, N2 = 0;            // four-step: N = N1 N2, both powers of two
+    std::unique_ptr<AnyFft> f1, f2;
+    DevBuf<cf> d_twN;                 // w_N^m, m < N
+    size_t M = 0;                     // generic Bluestein on M points
+    std::unique_ptr<AnyFft> fm;
+    DevBuf<cf> d_b;                   // FFT_M(conj chirp, wrapped) / M in natural order
+    DevBuf<cf> t1, t2;                // work frames (grow on demand)
+    AnyFft(size_t n, hipStream_t s);
+    void forward(const cf* in, cf* out, long nframes, hipStream_t s);
+};
+
 struct FftFilter;
 // Tables of k_fftfilt_prune (decimation by the last radix of the tile plan: 4 / 8 / 16 on 1024 / 2048 / 4096 points).
 struct PruneTables {
@@ -119,6 +139,10 @@ struct FftFilter : Block {
     // >= 8192-point tiles as nsub interleaved 4096-point sub-transforms (kernels_fft.hip k_fftfilt_split)
     int nsub = 0;
     DevBuf<cf> d_tw4096, d_hs, d_wk;
+    // more than 16383 taps: overlap-save frames of M = 2^m >= 2 L points through the any-size transform (AnyFft)
+    std::unique_ptr<AnyFft> big;
+    size_t bigM = 0;
+    DevBuf<cf> d_hbig, bframes, bspec;
     DevBuf<cf> prefix[2];
     int cur = 0;
     size_t pend_len = 0;
@@ -237,11 +261,7 @@ struct QuadDemod : Block {
 // FftStream (fft_stream.rs:26-117): forward FFT of consecutive `size`-sample frames (power-of-two sizes here).
 struct FftStream : Block {
     size_t size = 0;
-    int log2n = 0;
-    DevBuf<cf> d_tw, d_tw4096;
-    // sizes that are not a power of two (3..2048): Bluestein on a 2^log2m-point filter tile
-    int log2m = 0;
-    DevBuf<cf> d_bh, d_chirp;
+    std::unique_ptr<AnyFft> fft;
     explicit FftStream(size_t size);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };

@@ -193,6 +193,14 @@ void launch_head_y(const cf* z, const cf* t2, int L2, cf* y, long n, hipStream_t
 void launch_head_demod(const cf* z, long nz, const cf* t2, int L2, long I, long D, float gain, int mode, long r_hi, float* out,
                        cf* last_r, hipStream_t s);
 
+// ---- glue of the any-size transforms (kernels_misc.hip; see AnyFft in blocks.hpp) --------------------------------------
+void launch_transpose_tw(const cf* in, cf* out, int rows, int cols, long nframes, const cf* tw, hipStream_t s);
+void launch_chirp_pre(const cf* in, cf* a, long N, long M, long nframes, const cf* chirp, hipStream_t s);
+void launch_mul_conj(cf* a, const cf* b, long M, long nframes, hipStream_t s);
+void launch_chirp_post(const cf* y, cf* out, long N, long M, long nframes, const cf* chirp, hipStream_t s);
+void launch_ols_gather(VSrc<cf> src, cf* frames, long S, long M, long f0, long nframes, hipStream_t s);
+void launch_ols_scatter(const cf* frames, cf* out, long S, long M, long L, long f0, long nframes, long n_out, hipStream_t s);
+
 int device_cu_count();
 
 }  // namespace rr

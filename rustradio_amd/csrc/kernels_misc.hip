@@ -275,4 +275,125 @@ void launch_head_demod(const cf* z, long nz, const cf* t2, int L2, long I, long 
     RR_HIP(hipGetLastError());
 }
 
+// ---- transforms of ANY size (FftStream / Fft beyond one LDS tile, FftFilter beyond 16383 taps) ---------------------------
+// Sizes up to 16384 = 2^14 (and every size up to 2048) are one tile kernel (kernels_fft.hip).  Beyond that:
+//   power of two N = N1 N2: the four-step transform — transpose, N2 x FFT_N1, twiddle w_N^(n2 k1) fused into the second
+//       transpose, N1 x FFT_N2, last transpose to natural order (every pass a plain HBM stream of 16 B per sample);
+//   any other N: Bluestein's chirp-z on a power-of-two M >= 2 N - 1 (n k = (n^2 + k^2 - (k - n)^2) / 2), the inverse
+//       transform as conj(FFT(conj(.))).
+// These are the small glue kernels; rustfft plans any size (fft_stream.rs:43-44, fft.rs:27-32) and so does the block now.
+
+// out[f][c][r] = in[f][r][c] * (tw ? tw[(r * c) % (rows * cols)] : 1)      (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void k_transpose_tw(const cf* __restrict__ in, cf* __restrict__ out, int rows, int cols,
+                                                      const cf* __restrict__ tw) {
+    __shared__ cf tile[32][33];
+    const long f = blockIdx.z;
+    const cf* pin = in + f * (long)rows * cols;
+    cf* pout = out + f * (long)rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        if (r < rows && c < cols) {
+            cf v = pin[(long)r * cols + c];
+            if (tw) {
+                const cf w = tw[((long)r * c) % ((long)rows * cols)];
+                v = mkcf(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            }
+            tile[j][tx] = v;
+        }
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < rows && c < cols) pout[(long)c * rows + r] = tile[tx][j];
+    }
+}
+void launch_transpose_tw(const cf* in, cf* out, int rows, int cols, long nframes, const cf* tw, hipStream_t s) {
+    if (nframes <= 0) return;
+    for (long f0 = 0; f0 < nframes; f0 += 65535) {                   // gridDim.z limit
+        const long nf = nframes - f0 < 65535 ? nframes - f0 : 65535;
+        dim3 grid((cols + 31) / 32, (rows + 31) / 32, (unsigned)nf);
+        hipLaunchKernelGGL(k_transpose_tw, grid, dim3(256), 0, s, in + f0 * (long)rows * cols, out + f0 * (long)rows * cols, rows, cols, tw);
+    }
+    RR_HIP(hipGetLastError());
+}
+// Bluestein glue (frames of N samples in, M-point work frames)
+__global__ __launch_bounds__(256) void k_chirp_pre(const cf* __restrict__ in, cf* __restrict__ a, long N, long M, long total,
+                                                   const cf* __restrict__ chirp) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long f = i / M, n = i - f * M;
+        cf v = mkcf(0.0f, 0.0f);
+        if (n < N) {
+            const cf x = in[f * N + n], c = chirp[n];
+            v = mkcf(x.x * c.x - x.y * c.y, x.x * c.y + x.y * c.x);
+        }
+        a[i] = v;
+    }
+}
+// a[f][k] = conj(a[f][k] * b[k])   (b: M values; the conjugate sets up the inverse transform as a forward one)
+__global__ __launch_bounds__(256) void k_mul_conj(cf* __restrict__ a, const cf* __restrict__ b, long M, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const cf x = a[i], w = b[i % M];
+        a[i] = mkcf(x.x * w.x - x.y * w.y, -(x.x * w.y + x.y * w.x));
+    }
+}
+__global__ __launch_bounds__(256) void k_chirp_post(const cf* __restrict__ y, cf* __restrict__ out, long N, long M, long total,
+                                                    const cf* __restrict__ chirp) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long f = i / N, k = i - f * N;
+        const cf v = y[f * M + k], c = chirp[k];
+        out[i] = mkcf(v.x * c.x + v.y * c.y, v.x * c.y - v.y * c.x);       // conj(v) * c
+    }
+}
+void launch_chirp_pre(const cf* in, cf* a, long N, long M, long nframes, const cf* chirp, hipStream_t s) {
+    const long total = nframes * M;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_chirp_pre, dim3(grid_for(total, 256)), dim3(256), 0, s, in, a, N, M, total, chirp);
+    RR_HIP(hipGetLastError());
+}
+void launch_mul_conj(cf* a, const cf* b, long M, long nframes, hipStream_t s) {
+    const long total = nframes * M;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_mul_conj, dim3(grid_for(total, 256)), dim3(256), 0, s, a, b, M, total);
+    RR_HIP(hipGetLastError());
+}
+void launch_chirp_post(const cf* y, cf* out, long N, long M, long nframes, const cf* chirp, hipStream_t s) {
+    const long total = nframes * N;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_chirp_post, dim3(grid_for(total, 256)), dim3(256), 0, s, y, out, N, M, total, chirp);
+    RR_HIP(hipGetLastError());
+}
+// overlap-save frames of a long filter: frames[f][i] = V[f S + i], i < M   (V = carry prefix ++ window, zero beyond)
+__global__ __launch_bounds__(256) void k_ols_gather(VSrc<cf> src, cf* __restrict__ frames, long S, long M, long f0, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long f = i / M, n = i - f * M;
+        frames[i] = src.load((f0 + f) * S + n);
+    }
+}
+// out[(f0 + f) S + j] = conj(frames[f][L - 1 + j]), j < S, below n_out
+__global__ __launch_bounds__(256) void k_ols_scatter(const cf* __restrict__ frames, cf* __restrict__ out, long S, long M, long L, long f0,
+                                                     long n_out, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long f = i / S, j = i - f * S;
+        const long o = (f0 + f) * S + j;
+        if (o < n_out) {
+            const cf v = frames[f * M + L - 1 + j];
+            out[o] = mkcf(v.x, -v.y);
+        }
+    }
+}
+void launch_ols_gather(VSrc<cf> src, cf* frames, long S, long M, long f0, long nframes, hipStream_t s) {
+    const long total = nframes * M;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_ols_gather, dim3(grid_for(total, 256)), dim3(256), 0, s, src, frames, S, M, f0, total);
+    RR_HIP(hipGetLastError());
+}
+void launch_ols_scatter(const cf* frames, cf* out, long S, long M, long L, long f0, long nframes, long n_out, hipStream_t s) {
+    const long total = nframes * S;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_ols_scatter, dim3(grid_for(total, 256)), dim3(256), 0, s, frames, out, S, M, L, f0, n_out, total);
+    RR_HIP(hipGetLastError());
+}
+
 }  // namespace rr

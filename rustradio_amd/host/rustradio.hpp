@@ -599,6 +599,27 @@ public:
     }
 };
 
+// ---- Fft (src/fft.rs:19-56): the message (PDU) form; process() is what work() does to each popped message ---------------------
+class Fft {
+    detail::Handle h_;
+    size_t size_;
+    static rr_block* make(size_t size) {
+        if (!size) throw Error("FFT called with size 0");                                        // :24-26
+        return rr_fftstream_create(size);
+    }
+public:
+    explicit Fft(size_t size) : h_(make(size)), size_(size) {}
+    std::vector<Complex> process(const std::vector<Complex>& msg) {                              // :41-55
+        std::vector<Complex> out(msg.size());
+        Complex dummy{};
+        if (rr_fft_process(h_.h, reinterpret_cast<const rr_c32*>(msg.empty() ? &dummy : msg.data()), msg.size(),
+                           reinterpret_cast<rr_c32*>(msg.empty() ? &dummy : out.data())) != 0)
+            throw Error(rr_last_error());                                                        // "FFT expected {} samples, got {}"
+        return out;
+    }
+    size_t size() const { return size_; }
+};
+
 // ---- #[rustradio(sync)] blocks: MultiplyConst (src/multiply_const.rs), FastFM (src/quadrature_demod.rs:144-165) ----------
 // work() per rustradio_macros_code/src/lib.rs:458-515; a tag at position pos < n passes through at pos.
 template <class In, class Out> class SyncBlock : public Block {

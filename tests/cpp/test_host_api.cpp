@@ -224,6 +224,21 @@ template <class T> static double max_rel(const std::vector<T>& a, const std::vec
     for (size_t i = 0; i < std::min(a.size(), b.size()); i++) e = std::max(e, (double)std::abs(a[i] - b[i]));
     return m > 0 ? e / m : e;
 }
+// fft.rs:58-105 — the reference's own two tests of the message block, plus one DC check
+static void fft_message_block() {
+    Fft f(1024);
+    auto z = f.process(std::vector<Complex>(1024));
+    for (auto v : z) CHECK(v == Complex(0, 0));
+    auto dc = f.process(std::vector<Complex>(1024, Complex(1, 0)));
+    CHECK(std::abs(dc[0] - Complex(1024, 0)) < 1e-2f && std::abs(dc[1]) < 1e-3f);
+    bool threw = false;
+    try { Fft(4).process(std::vector<Complex>(3)); } catch (const Error& e) { threw = std::string(e.what()).find("FFT expected 4 samples, got 3") != std::string::npos; }
+    CHECK(threw);
+    threw = false;
+    try { Fft bad(0); } catch (const Error&) { threw = true; }
+    CHECK(threw);
+}
+
 static void fused_blocks_equal_their_chains() {
     const size_t n = 300000;
     std::vector<Complex> x(n);
@@ -547,7 +562,7 @@ static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
     fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
-    device_resident_graph(); fused_blocks_equal_their_chains(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests(); handles_on_concurrent_threads();
+    device_resident_graph(); fused_blocks_equal_their_chains(); fft_message_block(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests(); handles_on_concurrent_threads();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }

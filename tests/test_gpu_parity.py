@@ -206,9 +206,11 @@ def test_fftfilter_chunked_and_small_outputs(rr):
 
 def test_fftfilter_rejects_too_many_taps(rr):
     with pytest.raises(ValueError):
-        rr.FftFilter(np.ones(16384, np.complex64))          # no 16384-point tile leaves room for new samples
+        rr.FftFilter(np.ones((1 << 19) + 1, np.complex64))  # frames of 2^m >= 2 L points beyond the any-size transform's 2^20
     with pytest.raises(ValueError):
         rr.FftFilter(np.ones(0, np.complex64))
+    with pytest.raises(ValueError):                          # the fused chains run on LDS tiles only
+        rr.FmChain(np.ones(16384, np.complex64), 1, 6, 1.0)
 
 
 @pytest.mark.parametrize("inner", ["real", "complex"])
@@ -381,8 +383,55 @@ def test_fftstream(rr, size):
     assert np.array_equal(rr.FftStream(size).work(np.zeros(size, np.complex64), size)[4], np.zeros(size, np.complex64))
 
 
+@pytest.mark.parametrize("size", [2049, 3000, 4097, 8191, 12000, 16385, 32768, 65536, 100_000, 131_072, 262_144, 500_001, 512_000])
+def test_fftstream_any_size(rr, size):
+    """FftStream sizes beyond one LDS tile (rustfft plans any size, fft_stream.rs:43-44): the four-step decomposition for
+    powers of two above 16384, Bluestein on a power of two M >= 2 size - 1 for everything else above 2048 — against
+    numpy's f64 FFT (the oracle's defining sum is O(n^2)), whole frames only, work() protocol of the reference."""
+    nfr = 2 if size <= 200_000 else 1
+    x = rnd_c(nfr * size + 5, size % 1000)
+    b = rr.FftStream(size)
+    st, c, p, need, out = b.work(x, 512_000)
+    assert (st, c, p) == (AGAIN, nfr * size, nfr * size)
+    ref = np.fft.fft(x[:nfr * size].astype(np.complex128).reshape(nfr, size), axis=1).reshape(-1)
+    assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) <= TOL
+    assert b.work(x[:size - 1], 512_000)[:4] == (WAIT_SRC, 0, 0, size)
+    assert b.work(x, size - 1)[:4] == (WAIT_DST, 0, 0, size)
+
+
+def test_fft_message_block(rr):
+    """Fft (src/fft.rs:19-56), the PDU form: one message in, its transform out; the reference's `zeroes` and
+    `rejects_wrong_size` tests, plus random messages of tile, four-step and Bluestein sizes against numpy."""
+    f = rr.Fft(1024)
+    assert np.array_equal(f.process(np.zeros(1024, np.complex64)), np.zeros(1024, np.complex64))      # fft.rs:65-85
+    with pytest.raises(ValueError, match="FFT expected 4 samples, got 3"):                            # fft.rs:87-104
+        rr.Fft(4).process(np.zeros(3, np.complex64))
+    with pytest.raises(ValueError):
+        rr.Fft(0)
+    for size in (4, 1000, 1024, 5000, 32768):
+        x = rnd_c(size, size)
+        ref = np.fft.fft(x.astype(np.complex128))
+        assert np.max(np.abs(rr.Fft(size).process(x) - ref)) / np.max(np.abs(ref)) <= TOL
+
+
+@pytest.mark.parametrize("L", [16384, 20_000, 40_000, 100_000])
+def test_fftfilter_beyond_16383_taps(rr, L):
+    """The reference has no limit on FftFilter's taps (fft_filter.rs:36-42): beyond the largest LDS-resident tile the
+    block runs overlap-save frames of 2^m >= 2 L points through the any-size transform; same work() protocol and outputs."""
+    taps = rnd_c(L, L) / (L // 8)
+    x = rnd_c(2 * (2 * (1 << int(np.ceil(np.log2(L)))) - L) + 1000, 3)
+    both(rr, lambda m: [m.FftFilter(taps)], x)
+
+
+def test_fftfilter_float_beyond_16383_taps(rr):
+    L = 20_000
+    taps = (rnd_c(L, 1).real / (L // 8)).astype(np.float32)
+    x = rnd_c(2 * (65536 - L) + 1000, 4).real.astype(np.float32)
+    both(rr, lambda m: [m.FftFilterFloat(taps)], x)
+
+
 def test_fftstream_rejects(rr):
-    for bad in (0, 1, 2049, 3000, 12000, 32768):
+    for bad in (0, 1, 512_001):
         with pytest.raises(Exception):
             rr.FftStream(bad)
     b = rr.FftStream(1024)
