@@ -188,3 +188,49 @@ def test_two_ranks_drive_real_blocks_on_streamed_tiles():
             assert np.all(d <= bound[:len(d)]), (c, float(np.max(d - bound[:len(d)])))
             seen.append(c)
     assert sorted(seen) == list(range(124, 132))                # the union of the two shards: every channel once
+
+
+# ---- the RCCL code path itself, as far as one GPU allows: a one-rank "nccl" group -------------------------------------
+def _rccl_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # exactly bench.py's call
+    n = 1 << 20
+    store = torch.arange(8 * n, dtype=torch.float32, device=dev)
+
+    def produce(t, out):
+        out.copy_(store[t * n:(t + 1) * n], non_blocking=True)
+
+    fan = multi.TileFanout(dist, rank, n, torch.float32, dev, produce)
+    stream = torch.cuda.current_stream()
+    sums = []
+    fan.prefetch(0)
+    for t in range(8):
+        if t + 1 < 8:
+            fan.prefetch(t + 1)
+        x = fan.acquire(t, stream)
+        sums.append(x.double().sum())                       # compute-stream work on the tile
+        fan.release(t, stream)
+    torch.cuda.synchronize()
+    ms, nb = fan.broadcast_ms()
+    units, secs = multi.aggregate(dist, 3.0, 0.25, dev)
+    q.put((rank, [float(v) for v in sums], ms, nb, units, secs, dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_tile_fanout_on_a_one_rank_rccl_group():
+    """bench.py's N > 1 path runs over RCCL, which wants one GPU per rank; on the one-GPU box this drives the same calls
+    (init_process_group("nccl", device_id=...), async broadcast on the communication stream, event hand-over, all_reduce)
+    through a one-rank RCCL group: tiles arrive intact and in order, every broadcast is timed."""
+    (rank, sums, ms, nb, units, secs, backend), = _run(1, _rccl_worker)
+    n = 1 << 20
+    for t, v in enumerate(sums):
+        lo = t * n
+        assert v == float(n) * lo + n * (n - 1) / 2
+    assert backend == "nccl" and nb == 8 and ms > 0
+    assert (units, secs) == (3.0, 0.25)
