@@ -801,6 +801,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-window (drop-in path) measurements")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--fanout", choices=("torch", "abi"), default="torch",
+                    help="N > 1: the source fan-out through torch.distributed (default) or through the library's own "
+                         "rr_fanout_* entry points (RCCL bound by the C ABI; what a Rust graph would call)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="rr_build_opts override for every block built (e.g. fft_log2f=11, fir_path=direct)")
     args = ap.parse_args()
@@ -856,13 +859,17 @@ def main():
 
         def produce(t, out):                  # rank 0: the source block writes tile t into the ring half
             out.copy_(store, non_blocking=True)
+        if args.fanout == "abi":
+            if backend != "nccl":
+                raise SystemExit("bench.py --fanout abi: rr_fanout_* binds RCCL, which needs one GPU per rank")
+            return multi.AbiFanout(rr, dist, rank, int(meta.item()), sdtype, dev, produce)
         return multi.TileFanout(dist, rank, int(meta.item()), sdtype, dev, produce)
 
     def collective_report(fan_, kms_, steps_, wall_ms):
         bms_sum, bn = fan_.broadcast_ms()
         bms = bms_sum / max(bn, 1)
         kstep = kms_ / max(steps_, 1)
-        return {"backend": "rccl" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
+        return {"backend": "rccl" if backend == "nccl" else backend, "fanout": args.fanout, "ranks": dist.get_world_size(),
                 "devices_visible": ndev, "tile_bytes": fan_.bytes_per_tile, "broadcasts_timed": bn,
                 "broadcast_ms_per_tile": round(bms, 4),
                 "source_broadcast_gbs": round(fan_.bytes_per_tile / (bms * 1e-3) / 1e9, 1) if bms > 0 else None,

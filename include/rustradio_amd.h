@@ -294,6 +294,38 @@ int         rr_dstream_copy_out(rr_dstream *s, size_t offset, void *host, size_t
 int rr_block_work_streams(rr_block *b, rr_dstream *src, rr_dstream *dst, size_t *consumed, size_t *produced,
                           size_t *need, void *hip_stream);
 
+/* ---- multi-GPU fan-out of a shared source ------------------------------------------------------------------
+ * One process per GPU, chains sharded by channel; the only exchange is the source, which the reference fans out with a Tee
+ * tree inside one process (src/tee.rs:10-24).  An rr_fanout is a double buffer of `tile_bytes` in HBM on every rank plus a
+ * communication stream: the owning rank's source block writes tile t into one half, an RCCL broadcast (xGMI) delivers it
+ * into the same half on every other rank while the blocks of every rank still read tile t - 1 from the other half.  All
+ * ordering is by HIP events between the caller's streams and the communication stream; no call blocks the host.
+ *
+ *     id:  rank src calls rr_fanout_unique_id and ships the 128 bytes to the other processes (file, socket, MPI, env)
+ *     f = rr_fanout_create(id, rank, world, src, tile_bytes, 0)                  -- collective: every rank calls it
+ *     per tile t = 0, 1, 2 …, on every rank, in order:
+ *         rank src:  p = rr_fanout_produce_buf(f, t, s_src);  … enqueue the source's writes of tile t to p on s_src …
+ *         rr_fanout_submit(f, t, s_src)                      -- collective: broadcast of tile t on the communication stream
+ *         x = rr_fanout_acquire(f, t, s_blk);  rr_block_work_dev(b, x, …, s_blk) …;  rr_fanout_release(f, t, s_blk)
+ *     submit(t + 1) may (and for overlap should) be called before acquire(t); tile t + 2 needs release(t) first.
+ * A one-rank fan-out (world 1) needs neither an id nor RCCL and keeps the same calls, so a graph is written once.
+ * RCCL is bound at run time (dlopen), the library itself does not depend on it. */
+typedef struct rr_fanout rr_fanout;
+#define RR_FANOUT_ID_BYTES 128
+enum rr_fanout_flags {
+    RR_FANOUT_TIMING      = 1,  /* time every broadcast with HIP events on the communication stream (rr_fanout_stats) */
+    RR_FANOUT_RCCL_ALWAYS = 2   /* run a one-rank group through RCCL as well (tests of the RCCL path on a one-GPU machine) */
+};
+int         rr_fanout_unique_id(void *id128);
+rr_fanout  *rr_fanout_create(const void *id128, int rank, int world, int src_rank, size_t tile_bytes, int flags);
+void        rr_fanout_destroy(rr_fanout *f);
+void       *rr_fanout_produce_buf(rr_fanout *f, unsigned long long t, void *producer_stream);   /* NULL + rr_last_error */
+int         rr_fanout_submit(rr_fanout *f, unsigned long long t, void *producer_stream);        /* non-owning ranks: stream unused */
+const void *rr_fanout_acquire(rr_fanout *f, unsigned long long t, void *compute_stream);        /* NULL + rr_last_error */
+int         rr_fanout_release(rr_fanout *f, unsigned long long t, void *compute_stream);
+/* waits for the communication stream; summed duration and number of the broadcasts timed since the last call */
+int         rr_fanout_stats(rr_fanout *f, double *broadcast_ms, size_t *broadcasts);
+
 /* Measurement aid: when enabled, every work call brackets the block's dominant kernel
  * with HIP events on the stream it is launched on; rr_block_profile waits for them and
  * returns the summed kernel time and the number of launches (reset != 0 clears them). */

@@ -22,6 +22,10 @@ pub struct RrBlock {
 pub struct RrDStream {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct RrFanout {
+    _private: [u8; 0],
+}
 
 // enum rr_status (include/rustradio_amd.h)
 const RR_AGAIN: c_int = 0;
@@ -51,6 +55,14 @@ unsafe extern "C" {
                              deci: usize, translate: c_int, samp_rate: f32, freq: f32) -> *mut RrBlock;
     fn rr_fm_multi_create(taps: *const Complex, nchan: usize, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
     fn rr_fm_multi_u8_create(taps: *const Complex, nchan: usize, ntaps: usize, interp: usize, deci: usize, gain: f32, atan2_mode: c_int) -> *mut RrBlock;
+    fn rr_fanout_unique_id(id128: *mut c_void) -> c_int;
+    fn rr_fanout_create(id128: *const c_void, rank: c_int, world: c_int, src_rank: c_int, tile_bytes: usize, flags: c_int) -> *mut RrFanout;
+    fn rr_fanout_destroy(f: *mut RrFanout);
+    fn rr_fanout_produce_buf(f: *mut RrFanout, t: u64, producer_stream: *mut c_void) -> *mut c_void;
+    fn rr_fanout_submit(f: *mut RrFanout, t: u64, producer_stream: *mut c_void) -> c_int;
+    fn rr_fanout_acquire(f: *mut RrFanout, t: u64, compute_stream: *mut c_void) -> *const c_void;
+    fn rr_fanout_release(f: *mut RrFanout, t: u64, compute_stream: *mut c_void) -> c_int;
+    fn rr_fanout_stats(f: *mut RrFanout, broadcast_ms: *mut f64, broadcasts: *mut usize) -> c_int;
     fn rr_fftstream_create(size: usize) -> *mut RrBlock;
     fn rr_fft_process(fftstream: *mut RrBlock, msg: *const Complex, n: usize, out: *mut Complex) -> c_int;
     fn rr_multiply_const_c32_create(re: f32, im: f32) -> *mut RrBlock;
@@ -691,6 +703,71 @@ impl<I: Sample, O: Sample> Block for GpuResident<I, O> {
         let st = unsafe { rr_block_work_streams(self.h.0, s.s, d.s, &mut c, &mut p, &mut need, std::ptr::null_mut()) };
         check(st)?;
         Ok(if c > 0 || p > 0 || st == RR_AGAIN { BlockRet::Again } else { BlockRet::Pending })
+    }
+}
+
+// ---- multi-GPU fan-out (include/rustradio_amd.h rr_fanout_*) --------------------------------------------------
+/// The shared source of a channel-sharded graph, one process per GPU: replaces the in-process `Tee` tree
+/// (src/tee.rs:10-24) by a double buffer in HBM on every rank and an RCCL broadcast per tile on a communication stream.
+/// The owning rank's source writes tile `t` (`produce_buf` / `submit`), every rank's blocks read it
+/// (`acquire` / `release`) while tile `t + 1` is in flight.
+pub struct GpuFanout {
+    f: *mut RrFanout,
+    next: u64,
+}
+// SAFETY: the handle has no thread affinity; it is driven by one graph thread.
+unsafe impl Send for GpuFanout {}
+impl Drop for GpuFanout {
+    fn drop(&mut self) {
+        // SAFETY: created by rr_fanout_create, destroyed once.
+        unsafe { rr_fanout_destroy(self.f) }
+    }
+}
+impl GpuFanout {
+    /// The 128-byte group id: made on the owning rank, shipped to the other processes by the application.
+    pub fn unique_id() -> Result<[u8; 128]> {
+        let mut id = [0u8; 128];
+        // SAFETY: 128 writable bytes.
+        check(unsafe { rr_fanout_unique_id(id.as_mut_ptr().cast()) })?;
+        Ok(id)
+    }
+    /// Collective: every rank of the group calls it (`id` may be `None` for a one-rank group).
+    pub fn new(id: Option<&[u8; 128]>, rank: usize, world: usize, src_rank: usize, tile_bytes: usize) -> Result<Self> {
+        let p = id.map_or(std::ptr::null(), |i| i.as_ptr().cast());
+        // SAFETY: p is null or 128 readable bytes.
+        let f = unsafe { rr_fanout_create(p, rank as c_int, world as c_int, src_rank as c_int, tile_bytes, 0) };
+        if f.is_null() { Err(last_error()) } else { Ok(Self { f, next: 0 }) }
+    }
+    /// Owning rank: device pointer the source writes the next tile to (its stream waits for the half to be free).
+    pub fn produce_buf(&mut self, producer_stream: *mut c_void) -> Result<*mut c_void> {
+        // SAFETY: valid handle.
+        let p = unsafe { rr_fanout_produce_buf(self.f, self.next, producer_stream) };
+        if p.is_null() { Err(last_error()) } else { Ok(p) }
+    }
+    /// Collective, once per tile in order: the broadcast of the next tile; returns its index.
+    pub fn submit(&mut self, producer_stream: *mut c_void) -> Result<u64> {
+        // SAFETY: valid handle.
+        check(unsafe { rr_fanout_submit(self.f, self.next, producer_stream) })?;
+        self.next += 1;
+        Ok(self.next - 1)
+    }
+    /// Device pointer of tile `t`; `compute_stream` waits for its broadcast.
+    pub fn acquire(&mut self, t: u64, compute_stream: *mut c_void) -> Result<*const c_void> {
+        // SAFETY: valid handle.
+        let p = unsafe { rr_fanout_acquire(self.f, t, compute_stream) };
+        if p.is_null() { Err(last_error()) } else { Ok(p) }
+    }
+    /// The blocks' reads of tile `t` are enqueued on `compute_stream`: its half may be overwritten after them.
+    pub fn release(&mut self, t: u64, compute_stream: *mut c_void) -> Result<()> {
+        // SAFETY: valid handle.
+        check(unsafe { rr_fanout_release(self.f, t, compute_stream) })
+    }
+    /// (summed broadcast ms, broadcasts timed) since the last call; waits for the communication stream.
+    pub fn stats(&mut self) -> Result<(f64, usize)> {
+        let (mut ms, mut n) = (0f64, 0usize);
+        // SAFETY: valid handle, two writable scalars.
+        check(unsafe { rr_fanout_stats(self.f, &mut ms, &mut n) })?;
+        Ok((ms, n))
     }
 }
 

@@ -305,6 +305,61 @@ class DeviceStream:
         return out
 
 
+FANOUT_TIMING, FANOUT_RCCL_ALWAYS, FANOUT_ID_BYTES = 1, 2, 128
+
+
+def fanout_unique_id() -> bytes:
+    """rr_fanout_unique_id: the 128-byte group id, made on the owning rank and shipped to the others"""
+    buf = C.create_string_buffer(FANOUT_ID_BYTES)
+    if lib().rr_fanout_unique_id(buf) != 0:
+        raise RuntimeError(last_error())
+    return buf.raw
+
+
+class Fanout:
+    """rr_fanout (include/rustradio_amd.h): the double-buffered streaming fan-out of a shared source across GPUs, one
+    process per GPU, broadcast over RCCL on a communication stream (replaces the reference's in-process Tee tree,
+    src/tee.rs:10-24).  Streams are raw HIP stream handles (0 = the default stream)."""
+
+    def __init__(self, group_id, rank: int, world: int, tile_bytes: int, src_rank: int = 0, flags: int = 0):
+        self.rank, self.world, self.src, self.tile_bytes = rank, world, src_rank, tile_bytes
+        self._h = lib().rr_fanout_create(group_id, rank, world, src_rank, tile_bytes, flags)
+        if not self._h:
+            raise RuntimeError(last_error())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().rr_fanout_destroy(h)
+
+    def produce_buf(self, t: int, stream: int = 0) -> int:
+        p = lib().rr_fanout_produce_buf(self._h, t, C.c_void_p(stream))
+        if not p:
+            raise RuntimeError(last_error())
+        return p
+
+    def submit(self, t: int, stream: int = 0) -> None:
+        if lib().rr_fanout_submit(self._h, t, C.c_void_p(stream)) != 0:
+            raise RuntimeError(last_error())
+
+    def acquire(self, t: int, stream: int = 0) -> int:
+        p = lib().rr_fanout_acquire(self._h, t, C.c_void_p(stream))
+        if not p:
+            raise RuntimeError(last_error())
+        return p
+
+    def release(self, t: int, stream: int = 0) -> None:
+        if lib().rr_fanout_release(self._h, t, C.c_void_p(stream)) != 0:
+            raise RuntimeError(last_error())
+
+    def stats(self):
+        """-> (summed broadcast ms, broadcasts timed) since the last call (FANOUT_TIMING)"""
+        ms, n = C.c_double(0), C.c_size_t(0)
+        if lib().rr_fanout_stats(self._h, C.byref(ms), C.byref(n)) != 0:
+            raise RuntimeError(last_error())
+        return ms.value, n.value
+
+
 def FirFilter(taps, deci: int = 1, translate=None, rotator: int = ROT_MODEL) -> Block:
     """FirFilter::builder(taps).deci(deci).translate(samp_rate, freq).build(src)."""
     if np.iscomplexobj(np.asarray(taps)):

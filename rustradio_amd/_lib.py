@@ -26,6 +26,8 @@ SYMBOLS = [
     "rr_host_register", "rr_host_unregister",
     "rr_dstream_create", "rr_dstream_destroy", "rr_dstream_capacity", "rr_dstream_is_double_mapped", "rr_dstream_read_buf", "rr_dstream_write_buf",
     "rr_dstream_consume", "rr_dstream_produce", "rr_dstream_copy_in", "rr_dstream_copy_out", "rr_block_work_streams",
+    "rr_fanout_unique_id", "rr_fanout_create", "rr_fanout_destroy", "rr_fanout_produce_buf", "rr_fanout_submit",
+    "rr_fanout_acquire", "rr_fanout_release", "rr_fanout_stats",
 ]
 
 _lib = None
@@ -117,6 +119,15 @@ def lib():
     L.rr_dstream_copy_in.argtypes = [vp, sz, vp, sz, vp]; L.rr_dstream_copy_in.restype = i32
     L.rr_dstream_copy_out.argtypes = [vp, sz, vp, sz, vp]; L.rr_dstream_copy_out.restype = i32
     L.rr_block_work_streams.argtypes = [vp, vp, vp, psz, psz, psz, vp]; L.rr_block_work_streams.restype = i32
+    u64 = C.c_ulonglong
+    L.rr_fanout_unique_id.argtypes = [vp]; L.rr_fanout_unique_id.restype = i32
+    L.rr_fanout_create.argtypes = [vp, i32, i32, i32, sz, i32]; L.rr_fanout_create.restype = vp
+    L.rr_fanout_destroy.argtypes = [vp]; L.rr_fanout_destroy.restype = None
+    L.rr_fanout_produce_buf.argtypes = [vp, u64, vp]; L.rr_fanout_produce_buf.restype = vp
+    L.rr_fanout_submit.argtypes = [vp, u64, vp]; L.rr_fanout_submit.restype = i32
+    L.rr_fanout_acquire.argtypes = [vp, u64, vp]; L.rr_fanout_acquire.restype = vp
+    L.rr_fanout_release.argtypes = [vp, u64, vp]; L.rr_fanout_release.restype = i32
+    L.rr_fanout_stats.argtypes = [vp, C.POINTER(C.c_double), psz]; L.rr_fanout_stats.restype = i32
     L.rr_block_set_profiling.argtypes = [vp, i32]; L.rr_block_set_profiling.restype = i32
     L.rr_block_profile.argtypes = [vp, C.POINTER(C.c_double), psz, i32]; L.rr_block_profile.restype = i32
     _lib = L

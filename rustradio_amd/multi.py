@@ -174,3 +174,64 @@ class TileFanout:
         if not self.cuda or not self.t_beg:
             return 0.0, 0
         return sum(b.elapsed_time(e) for b, e in zip(self.t_beg, self.t_end)), len(self.t_beg)
+
+
+class _DevMem:
+    """a raw device allocation presented through __cuda_array_interface__, so torch can alias it (no copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class AbiFanout:
+    """The same fan-out through the C ABI (`rr_fanout_*`, include/rustradio_amd.h — what a Rust graph binds) behind
+    TileFanout's interface, so bench.py can run either (`--fanout abi`).  The 128-byte group id travels over the
+    torch.distributed group that launched the ranks; the double buffer, the communication stream, the events and the
+    RCCL broadcasts are the library's.  `produce(t, out)` fills the torch alias of the half on the owning rank."""
+
+    def __init__(self, rr, dist, rank, tile_elems, dtype, device, produce, src_rank=0, rccl_always=False):
+        self.rank, self.src, self.produce, self.dtype, self.device = rank, src_rank, produce, dtype, device
+        self.bytes_per_tile = tile_elems * torch.empty(0, dtype=dtype).element_size()
+        world = dist.get_world_size() if dist is not None else 1
+        gid = [rr.fanout_unique_id() if (rank == src_rank and (world > 1 or rccl_always)) else None]
+        if dist is not None and world > 1:
+            dist.broadcast_object_list(gid, src=src_rank)
+        flags = rr.FANOUT_TIMING | (rr.FANOUT_RCCL_ALWAYS if rccl_always else 0)
+        self.fan = rr.Fanout(gid[0], rank, world, self.bytes_per_tile, src_rank, flags)
+        self.pstream = torch.cuda.Stream(device=device)      # the source block's stream on the owning rank
+        self.views = {}
+        self.issued = -1
+        self.n_bcast = 0
+
+    def _view(self, ptr):
+        v = self.views.get(ptr)
+        if v is None:
+            v = torch.as_tensor(_DevMem(ptr, self.bytes_per_tile), device=self.device).view(self.dtype)
+            self.views[ptr] = v
+        return v
+
+    def prefetch(self, t):
+        if t <= self.issued:
+            return
+        assert t == self.issued + 1
+        self.issued = t
+        sh = self.pstream.cuda_stream
+        if self.rank == self.src:
+            out = self._view(self.fan.produce_buf(t, sh))
+            with torch.cuda.stream(self.pstream):
+                self.produce(t, out)
+        self.fan.submit(t, sh)
+        self.n_bcast += 1
+
+    def acquire(self, t, compute_stream=None):
+        self.prefetch(t)
+        return self._view(self.fan.acquire(t, (compute_stream or torch.cuda.current_stream()).cuda_stream))
+
+    def release(self, t, compute_stream=None):
+        self.fan.release(t, (compute_stream or torch.cuda.current_stream()).cuda_stream)
+
+    def reset_timing(self):
+        self.fan.stats()
+
+    def broadcast_ms(self):
+        return self.fan.stats()

@@ -15,6 +15,7 @@ C2RUST = {
     "rr_dstream *": "*mut RrDStream", "const rr_dstream *": "*const RrDStream",
     "const void **": "*mut *const c_void", "void **": "*mut *mut c_void", "double *": "*mut f64",
     "unsigned long long *": "*mut u64", "const rr_build_opts *": "*const RrBuildOpts",
+    "unsigned long long": "u64", "rr_fanout *": "*mut RrFanout",
 }
 
 
