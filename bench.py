@@ -804,6 +804,9 @@ def main():
     ap.add_argument("--fanout", choices=("torch", "abi"), default="torch",
                     help="N > 1: the source fan-out through torch.distributed (default) or through the library's own "
                          "rr_fanout_* entry points (RCCL bound by the C ABI; what a Rust graph would call)")
+    ap.add_argument("--fanout-algo", choices=("auto", "bcast", "scatter_allgather"), default="auto",
+                    help="N > 1, --fanout torch: one broadcast per tile, scatter + all-gather over the xGMI mesh, or (default) "
+                         "whichever is faster on this job's fabric, timed before the run")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="rr_build_opts override for every block built (e.g. fft_log2f=11, fir_path=direct)")
     args = ap.parse_args()
@@ -862,14 +865,22 @@ def main():
         if args.fanout == "abi":
             if backend != "nccl":
                 raise SystemExit("bench.py --fanout abi: rr_fanout_* binds RCCL, which needs one GPU per rank")
-            return multi.AbiFanout(rr, dist, rank, int(meta.item()), sdtype, dev, produce)
-        return multi.TileFanout(dist, rank, int(meta.item()), sdtype, dev, produce)
+            return multi.AbiFanout(rr, dist, rank, int(meta.item()), sdtype, dev, produce,
+                                   mesh=args.fanout_algo == "scatter_allgather")
+        try:
+            return multi.TileFanout(dist, rank, int(meta.item()), sdtype, dev, produce, algo=args.fanout_algo)
+        except RuntimeError as e:             # a backend without scatter / all-gather on device tensors: the broadcast always works
+            if rank == 0:
+                print(f"bench.py: fan-out algorithm {args.fanout_algo!r} unavailable ({e}); using bcast", file=sys.stderr)
+            return multi.TileFanout(dist, rank, int(meta.item()), sdtype, dev, produce, algo="bcast")
 
     def collective_report(fan_, kms_, steps_, wall_ms):
         bms_sum, bn = fan_.broadcast_ms()
         bms = bms_sum / max(bn, 1)
         kstep = kms_ / max(steps_, 1)
-        return {"backend": "rccl" if backend == "nccl" else backend, "fanout": args.fanout, "ranks": dist.get_world_size(),
+        return {"backend": "rccl" if backend == "nccl" else backend, "fanout": args.fanout,
+                "algorithm": getattr(fan_, "algo", "bcast"), "calibration_ms_per_tile": getattr(fan_, "calibration", None),
+                "ranks": dist.get_world_size(),
                 "devices_visible": ndev, "tile_bytes": fan_.bytes_per_tile, "broadcasts_timed": bn,
                 "broadcast_ms_per_tile": round(bms, 4),
                 "source_broadcast_gbs": round(fan_.bytes_per_tile / (bms * 1e-3) / 1e9, 1) if bms > 0 else None,

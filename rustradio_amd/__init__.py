@@ -305,7 +305,7 @@ class DeviceStream:
         return out
 
 
-FANOUT_TIMING, FANOUT_RCCL_ALWAYS, FANOUT_ID_BYTES = 1, 2, 128
+FANOUT_TIMING, FANOUT_RCCL_ALWAYS, FANOUT_MESH, FANOUT_ID_BYTES = 1, 2, 4, 128
 
 
 def fanout_unique_id() -> bytes:

@@ -32,6 +32,8 @@ struct Rccl {
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Scatter)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;       // rccl.h:767 (RCCL extension)
+    int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;          // rccl.h:678
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
     std::string why;
@@ -50,6 +52,8 @@ const Rccl& rccl() {
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
         x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(dlsym(h, "ncclBroadcast"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        x.Scatter = reinterpret_cast<decltype(x.Scatter)>(dlsym(h, "ncclScatter"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(h, "ncclAllGather"));
         x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.Broadcast && x.GetErrorString;
         if (!x.ok) x.why = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast";
         return x;
@@ -64,8 +68,8 @@ constexpr int kNcclUint8 = 1;                                            // rccl
 
 struct Fanout {
     int rank, world, src, device = 0;
-    size_t tile_bytes;
-    bool timing;
+    size_t tile_bytes, piece;                                            // piece: bytes per rank of the scattered form
+    bool timing, mesh;
     Comm comm = nullptr;
     void* buf[2] = {nullptr, nullptr};
     hipStream_t cs = nullptr;                                            // the communication stream
@@ -75,14 +79,17 @@ struct Fanout {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;                // one per timed broadcast
 
     Fanout(const void* id, int rank_, int world_, int src_, size_t bytes, int flags)
-        : rank(rank_), world(world_), src(src_), tile_bytes(bytes), timing((flags & RR_FANOUT_TIMING) != 0) {
+        : rank(rank_), world(world_), src(src_), tile_bytes(bytes), piece(0), timing((flags & RR_FANOUT_TIMING) != 0),
+          mesh((flags & RR_FANOUT_MESH) != 0) {
         if (world < 1 || rank < 0 || rank >= world || src < 0 || src >= world) throw Error("rr_fanout_create: rank / world / src_rank out of range");
         if (bytes == 0) throw Error("rr_fanout_create: tile_bytes must be nonzero");
+        piece = (bytes + (size_t)world - 1) / (size_t)world;
         device = thread_device();
         RR_HIP(hipSetDevice(device));
         if (world > 1 || (flags & RR_FANOUT_RCCL_ALWAYS)) {
             if (!id) throw Error("rr_fanout_create: a group of more than one rank needs the id of rr_fanout_unique_id");
             if (!rccl().ok) throw Error(rccl().why);
+            if (mesh && !(rccl().Scatter && rccl().AllGather)) throw Error("RR_FANOUT_MESH: this librccl has no ncclScatter / ncclAllGather");
             UniqueId u;
             std::memcpy(u.internal, id, sizeof u.internal);
             nccl_check(rccl().CommInitRank(&comm, world, u, rank), "ncclCommInitRank");
@@ -90,7 +97,7 @@ struct Fanout {
         try {
             RR_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             for (int h = 0; h < 2; h++) {
-                RR_HIP(hipMalloc(&buf[h], bytes));
+                RR_HIP(hipMalloc(&buf[h], piece * (size_t)world));
                 RR_HIP(hipEventCreateWithFlags(&ready[h], hipEventDisableTiming));
                 RR_HIP(hipEventCreateWithFlags(&freed[h], hipEventDisableTiming));
                 RR_HIP(hipEventCreateWithFlags(&written[h], hipEventDisableTiming));
@@ -148,7 +155,15 @@ struct Fanout {
                 RR_HIP(hipEventCreate(&e));
                 RR_HIP(hipEventRecord(b, cs));
             }
-            nccl_check(rccl().Broadcast(buf[h], buf[h], tile_bytes, kNcclUint8, src, comm, cs), "ncclBroadcast");
+            if (mesh) {
+                // the full mesh instead of one link: 1/world of the tile from the owner to every rank (each into its own
+                // slot), then an in-place all-gather between the receivers
+                char* own = static_cast<char*>(buf[h]) + (size_t)rank * piece;
+                nccl_check(rccl().Scatter(buf[h], own, piece, kNcclUint8, src, comm, cs), "ncclScatter");
+                nccl_check(rccl().AllGather(own, buf[h], piece, kNcclUint8, comm, cs), "ncclAllGather");
+            } else {
+                nccl_check(rccl().Broadcast(buf[h], buf[h], tile_bytes, kNcclUint8, src, comm, cs), "ncclBroadcast");
+            }
             if (timed) {
                 RR_HIP(hipEventRecord(e, cs));
                 spans.emplace_back(b, e);

@@ -92,28 +92,50 @@ def aggregate(dist, units: float, seconds: float, device):
 class TileFanout:
     """Streaming fan-out of the shared IQ source, one tile per step (replaces the reference's
     Tee tree, src/tee.rs:10-24): rank `src_rank` produces tile t+1 into one half of a double buffer and
-    broadcasts it (RCCL over xGMI on the GPU box, gloo in the CPU tests) on a COMMUNICATION stream while every
+    fans it out (RCCL over xGMI on the GPU box, gloo in the CPU tests) on a COMMUNICATION stream while every
     rank computes on tile t from the other half on its compute stream.  Two events per half order the streams:
-    `ready[h]` (broadcast of the tile in half h finished -> compute may read it) and `free[h]` (compute on
-    half h finished -> the next broadcast may overwrite it).  On CPU tensors (tests) the calls are synchronous.
+    `ready[h]` (fan-out of the tile in half h finished -> compute may read it) and `free[h]` (compute on
+    half h finished -> the next fan-out may overwrite it).  On CPU tensors (tests) the calls are synchronous.
+
+    Two fan-out algorithms, same result:
+      "bcast"              one `broadcast` of the tile: every byte leaves the source GPU once per ring / tree edge —
+                           bounded by ONE xGMI link (~153 GB/s) however many links the source has;
+      "scatter_allgather"  the source scatters 1/world of the tile to each rank, then every rank all-gathers the
+                           pieces: the source's 7 links each carry 1/8 of the tile, and the rest moves over the
+                           links BETWEEN the receivers, which a broadcast leaves idle.  xGMI is a full mesh, so the
+                           tile arrives in ~2/world of the single-link time (plus one more collective's latency);
+      "auto"               times both on this job's actual fabric before the run (`calibrate`) and keeps the
+                           faster — all ranks decide on the same max-over-ranks numbers.
 
         fan = TileFanout(dist, rank, tile_elems, dtype, device, produce)   # produce(t, out) fills `out` on src_rank
         fan.prefetch(0)
         for t in range(steps):
-            fan.prefetch(t + 1)                 # broadcast of tile t+1 overlaps ...
+            fan.prefetch(t + 1)                 # fan-out of tile t+1 overlaps ...
             x = fan.acquire(t, compute_stream)  # ... the compute on tile t
             ... launch work on compute_stream reading x ...
             fan.release(t, compute_stream)
     """
 
-    def __init__(self, dist, rank, tile_elems, dtype, device, produce, src_rank=0):
+    ALGOS = ("bcast", "scatter_allgather")
+
+    def __init__(self, dist, rank, tile_elems, dtype, device, produce, src_rank=0, algo="bcast"):
         self.dist, self.rank, self.src, self.produce = dist, rank, src_rank, produce
         self.device = device
         self.cuda = device.type == "cuda"
-        self.buf = [torch.empty(tile_elems, dtype=dtype, device=device) for _ in range(2)]
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.n = tile_elems
+        self.piece = -(-tile_elems // self.world)                      # elements per rank in the scattered form
+        self.full = [torch.empty(self.piece * self.world, dtype=dtype, device=device) for _ in range(2)]
+        self.buf = [f[:tile_elems] for f in self.full]                 # what producer and consumers see
+        self.part = [torch.empty(self.piece, dtype=dtype, device=device) for _ in range(2)]
         self.bytes_per_tile = tile_elems * self.buf[0].element_size()
         self.issued = -1
         self.n_bcast = 0
+        self.calibration = None
+        backend = dist.get_backend() if dist is not None else None
+        # gloo moves CUDA tensors for broadcast / all_reduce only: the one-GPU fallback of bench.py stays on "bcast"
+        self.can_scatter = dist is not None and self.world > 1 and not (self.cuda and backend != "nccl")
+        self.into_tensor = backend == "nccl"
         if self.cuda:
             self.comm = torch.cuda.Stream(device=device)
             self.ready = [torch.cuda.Event() for _ in range(2)]
@@ -121,9 +143,55 @@ class TileFanout:
             self.t_beg = []
             self.t_end = []
             self.used = [False, False]
+        if algo == "auto":
+            algo = self.calibrate() if self.can_scatter else "bcast"
+        if algo not in self.ALGOS:
+            raise ValueError(f"TileFanout: unknown algorithm {algo!r}")
+        if algo == "scatter_allgather" and not self.can_scatter:
+            algo = "bcast"
+        self.algo = algo
+
+    # ---- the collective(s) of one tile, on the current stream ------------------------------------------------------
+    def _fan(self, h, algo):
+        d = self.dist
+        if algo == "bcast":
+            w = d.broadcast(self.full[h], src=self.src, async_op=True)
+            w.wait()                                             # the current (comm) stream waits, not the host
+            return
+        pieces = list(self.full[h].chunk(self.world)) if self.rank == self.src else None
+        w = d.scatter(self.part[h], scatter_list=pieces, src=self.src, async_op=True)
+        w.wait()
+        if self.into_tensor:
+            w = d.all_gather_into_tensor(self.full[h], self.part[h], async_op=True)
+        else:
+            w = d.all_gather(list(self.full[h].chunk(self.world)), self.part[h], async_op=True)
+        w.wait()
+
+    def calibrate(self, tiles=6):
+        """time both algorithms on this job's fabric (no compute alongside) -> the faster; identical on every rank"""
+        res = {}
+        for algo in self.ALGOS:
+            for k in range(tiles + 2):                           # two untimed: connection set-up
+                if k == 2:
+                    if self.cuda:
+                        torch.cuda.synchronize()
+                    self.dist.barrier()
+                    t0 = time.perf_counter()
+                if self.cuda:
+                    with torch.cuda.stream(self.comm):
+                        self._fan(k % 2, algo)
+                else:
+                    self._fan(k % 2, algo)
+            if self.cuda:
+                torch.cuda.synchronize()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(dt, op=self.dist.ReduceOp.MAX)
+            res[algo] = float(dt.item()) / tiles * 1e3
+        self.calibration = {k: round(v, 4) for k, v in res.items()}
+        return min(self.ALGOS, key=lambda a: res[a])
 
     def prefetch(self, t):
-        """enqueue production + broadcast of tile t (idempotent)"""
+        """enqueue production + fan-out of tile t (idempotent)"""
         if t <= self.issued:
             return
         assert t == self.issued + 1
@@ -133,7 +201,7 @@ class TileFanout:
             if self.rank == self.src:
                 self.produce(t, self.buf[h])
             if self.dist is not None:
-                self.dist.broadcast(self.buf[h], src=self.src)
+                self._fan(h, self.algo)
             self.n_bcast += 1
             return
         with torch.cuda.stream(self.comm):
@@ -144,8 +212,7 @@ class TileFanout:
             if self.dist is not None:
                 b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 b.record(self.comm)
-                w = self.dist.broadcast(self.buf[h], src=self.src, async_op=True)
-                w.wait()                                     # the comm stream (not the host) waits for the collective
+                self._fan(h, self.algo)
                 e.record(self.comm)
                 self.t_beg.append(b)
                 self.t_end.append(e)
@@ -170,7 +237,7 @@ class TileFanout:
             self.t_beg, self.t_end = [], []
 
     def broadcast_ms(self):
-        """-> (summed broadcast time in ms on the comm stream, broadcasts timed); call after a device sync"""
+        """-> (summed fan-out time in ms on the comm stream, fan-outs timed); call after a device sync"""
         if not self.cuda or not self.t_beg:
             return 0.0, 0
         return sum(b.elapsed_time(e) for b, e in zip(self.t_beg, self.t_end)), len(self.t_beg)
@@ -189,14 +256,16 @@ class AbiFanout:
     torch.distributed group that launched the ranks; the double buffer, the communication stream, the events and the
     RCCL broadcasts are the library's.  `produce(t, out)` fills the torch alias of the half on the owning rank."""
 
-    def __init__(self, rr, dist, rank, tile_elems, dtype, device, produce, src_rank=0, rccl_always=False):
+    def __init__(self, rr, dist, rank, tile_elems, dtype, device, produce, src_rank=0, rccl_always=False, mesh=False):
         self.rank, self.src, self.produce, self.dtype, self.device = rank, src_rank, produce, dtype, device
         self.bytes_per_tile = tile_elems * torch.empty(0, dtype=dtype).element_size()
         world = dist.get_world_size() if dist is not None else 1
         gid = [rr.fanout_unique_id() if (rank == src_rank and (world > 1 or rccl_always)) else None]
         if dist is not None and world > 1:
             dist.broadcast_object_list(gid, src=src_rank)
-        flags = rr.FANOUT_TIMING | (rr.FANOUT_RCCL_ALWAYS if rccl_always else 0)
+        flags = rr.FANOUT_TIMING | (rr.FANOUT_RCCL_ALWAYS if rccl_always else 0) | (rr.FANOUT_MESH if mesh else 0)
+        self.algo = "scatter_allgather" if mesh else "bcast"
+        self.calibration = None
         self.fan = rr.Fanout(gid[0], rank, world, self.bytes_per_tile, src_rank, flags)
         self.pstream = torch.cuda.Stream(device=device)      # the source block's stream on the owning rank
         self.views = {}

@@ -49,11 +49,13 @@ def test_one_rank_fanout_is_a_double_buffer(rr, two_streams):
     assert fan.stats() == (0.0, 0)                               # no communicator, nothing timed
 
 
-def test_one_rank_fanout_through_rccl(rr):
-    n = 1 << 20
+@pytest.mark.parametrize("mesh", [False, True])
+def test_one_rank_fanout_through_rccl(rr, mesh):
+    """ncclBroadcast, and (mesh) ncclScatter + in-place ncclAllGather, on a one-rank group"""
+    n = (1 << 20) + 3
     gid = rr.fanout_unique_id()
     assert len(gid) == rr.FANOUT_ID_BYTES and any(gid)
-    fan = rr.Fanout(gid, 0, 1, 4 * n, flags=rr.FANOUT_RCCL_ALWAYS | rr.FANOUT_TIMING)
+    fan = rr.Fanout(gid, 0, 1, 4 * n, flags=rr.FANOUT_RCCL_ALWAYS | rr.FANOUT_TIMING | (rr.FANOUT_MESH if mesh else 0))
     _drive(rr, fan, 7, n, torch.cuda.current_stream(), True)
     ms, nb = fan.stats()
     assert nb == 7 and ms > 0

@@ -23,7 +23,7 @@ def _tile(t, n):
     return torch.rand(n, generator=g, dtype=torch.float32)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, algo="bcast"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -44,7 +44,7 @@ def _worker(rank, world, port, q):
         produced.append(t)
         out.copy_(_tile(t, out.numel()))
 
-    fan = multi.TileFanout(dist, rank, 50_000, torch.float32, dev, produce)
+    fan = multi.TileFanout(dist, rank, 50_000, torch.float32, dev, produce, algo=algo)
     sums = []
     fan.prefetch(0)
     for t in range(6):
@@ -54,7 +54,8 @@ def _worker(rank, world, port, q):
         sums.append([float((x * (c + 1)).sum()) for c in chans])
         fan.release(t)
     units, secs = multi.aggregate(dist, len(chans) * src.numel(), 0.5 + rank, dev)
-    q.put((rank, made, chans, float(src.sum()), sums, produced, units, secs, gbs is not None, fan.n_bcast))
+    q.put((rank, made, chans, float(src.sum()), sums, produced, units, secs, gbs is not None, fan.n_bcast, fan.algo,
+           fan.calibration))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,7 +75,9 @@ def _run(world, target, *extra):
 
 
 def test_two_rank_channel_sharding_and_streaming_fanout():
-    (r0, made0, ch0, s0, sums0, prod0, u0, t0, b0, n0), (r1, made1, ch1, s1, sums1, prod1, u1, t1, b1, n1) = _run(2, _worker)
+    ((r0, made0, ch0, s0, sums0, prod0, u0, t0, b0, n0, a0, c0),
+     (r1, made1, ch1, s1, sums1, prod1, u1, t1, b1, n1, a1, c1)) = _run(2, _worker)
+    assert a0 == a1 == "bcast" and c0 is None
     assert made0 == [0] and made1 == []            # only the owning rank synthesises the source
     assert s0 == s1                                # identical source on every rank after the broadcast
     assert sorted(ch0 + ch1) == [0, 1, 2, 3, 4] and not set(ch0) & set(ch1)
@@ -89,6 +92,30 @@ def test_two_rank_channel_sharding_and_streaming_fanout():
     assert u0 == u1 == 5 * 100_000                 # units: sum over ranks
     assert t0 == t1 == 1.5                         # wall time: max over ranks
     assert b0 and b1
+
+
+@pytest.mark.parametrize("world,algo", [(2, "scatter_allgather"), (3, "scatter_allgather"), (3, "auto")])
+def test_fanout_by_scatter_and_allgather(world, algo):
+    """the full-mesh fan-out: 1/world of the tile to each rank, then an all-gather between the receivers — same tiles on
+    every rank as the broadcast, also when the tile does not divide by the number of ranks (50,000 over 3); "auto" times
+    both and every rank keeps the same one"""
+    res = _run(world, _worker, algo)
+    algos = {r[10] for r in res}
+    assert len(algos) == 1 and algos <= {"bcast", "scatter_allgather"}
+    if algo != "auto":
+        assert algos == {algo}
+    else:
+        cal = [r[11] for r in res]
+        assert all(c == cal[0] and set(c) == {"bcast", "scatter_allgather"} for c in cal)
+    assert [r[5] for r in res] == [list(range(7))] + [[]] * (world - 1)      # produced on rank 0 only
+    owned = []
+    for r in res:
+        for t in range(6):
+            ref = _tile(t, 50_000)
+            for c, v in zip(r[2], r[4][t]):
+                assert v == float((ref * (c + 1)).sum())
+        owned += r[2]
+    assert sorted(owned) == [0, 1, 2, 3, 4]
 
 
 def test_shard_channels_properties():
