@@ -893,6 +893,20 @@ def main():
     # max over ranks of the wall time, sum over ranks of the units
     units_all, dt = multi.aggregate(dist, units, dt, dev)
 
+    # N > 1: the same step on every rank at once with the tile ALREADY on the rank (no fan-out) — what channel sharding
+    # alone scales to; value / this = what the fan-out costs.  (N = 1 of the driver's scaling run is a different
+    # workload, configs[1]: this is the same-workload reference for the N > 1 lines.)
+    resident = None
+    if fan is not None:
+        torch.cuda.synchronize()
+        keep, w.bufs[0] = w.bufs[0], fan.buf[0] if hasattr(fan, "buf") else fan.acquire(fan.issued, stream)
+        u1, t1, _, _, _, sm1 = run_timed(w, args.steps, 2, dist, stream, None)
+        w.bufs[0] = keep
+        u1a, t1a = multi.aggregate(dist, u1, t1, dev)
+        resident = {"value": round(u1a / t1a / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(t1a / args.steps * 1e3, 4),
+                    "ms_per_step_median": round(statistics.median(sm1), 4),
+                    "what": "the same N-rank step with the source tile already resident on every rank (no fan-out in the step)"}
+
     others = {}
     if not args.no_others:
         names = [n for n in WORKLOADS if n != wname] if world == 1 else [n for n in ("fm_multi_u8", "channelizer") if n != wname]
@@ -966,6 +980,8 @@ def main():
         if world > 1:
             line["collective"] = collective_report(fan, kms, args.steps, dt / args.steps * 1e3)
             line["source_broadcast_gbs"] = line["collective"]["source_broadcast_gbs"]
+            line["resident_source"] = resident
+            line["fanout_efficiency"] = round(value / resident["value"], 4) if resident and resident["value"] > 0 else None
         if others:
             line["others"] = others
         if world == 1 and not args.no_cpu:

@@ -24,6 +24,8 @@
 //   k_fm_multi_poly: N channels on one input (configs[3]).  A workgroup = 8 waves: waves 0 .. D-1 transform one phase
 //     each and park the D spectra in LDS (the forward work is shared by all channels, as in k_fm_multi); then every wave
 //     takes every 8th channel: sum_p H_{c,p} X_p from the parked spectra, inverse, demodulation.
+#include <type_traits>
+
 #include "kernels.hpp"
 #include "tile_common.hpp"
 
@@ -48,6 +50,16 @@ struct PolyArgs {
 #ifndef RR_POLY_WAVES
 #define RR_POLY_WAVES 2
 #endif
+#ifndef RR_POLY_WIDE
+#define RR_POLY_WIDE 1
+#endif
+// measurement builds only (make EXTRA=-DRR_POLY_ABLATE=<bits>, wrong results): 1 no input loads, 2 no atan2, 4 no output
+// stores, 8 no H loads, 16 no LDS exchanges inside the transforms
+#ifndef RR_POLY_ABLATE
+#define RR_POLY_ABLATE 0
+#endif
+typedef float creg2 __attribute__((ext_vector_type(4)));
+typedef creg2 creg2u __attribute__((aligned(8)));                        // two adjacent Complex samples, 8-byte aligned
 #ifdef RR_FFT_TIMING_BUILD
 #define PSTAMP(i) do { if (stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
@@ -101,30 +113,30 @@ __device__ __forceinline__ void poly_load(creg* v, const SRC& src, long vbase, i
 __device__ __forceinline__ void poly_forward(creg* v, int t, creg* ex, const creg* tw0, const creg* tab1) {
     creg twl[15];
     fwd_pass<PLG, 0>(v, tw0);
-    lds_store<PLG, 0>(v, t, ex);
+    if constexpr (!(RR_POLY_ABLATE & 16)) lds_store<PLG, 0>(v, t, ex);
     wave_fence();
-    lds_load<PLG, 1>(v, t, ex);
+    if constexpr (!(RR_POLY_ABLATE & 16)) lds_load<PLG, 1>(v, t, ex);
 #pragma unroll
     for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<PLG, 1>::lo(t)];
     fwd_pass<PLG, 1>(v, twl);
-    lds_store<PLG, 1>(v, t, ex);
+    if constexpr (!(RR_POLY_ABLATE & 16)) lds_store<PLG, 1>(v, t, ex);
     wave_fence();
-    lds_load<PLG, 2>(v, t, ex);
+    if constexpr (!(RR_POLY_ABLATE & 16)) lds_load<PLG, 2>(v, t, ex);
     fwd_pass<PLG, 2>(v, twl);                        // (P == 1: no twiddles)
 }
 // inverse: spectrum in the pass-2 layout -> v[n] = tile position 64 n + t
 __device__ __forceinline__ void poly_inverse(creg* v, int t, creg* ex, const creg* tw0, const creg* tab1) {
     creg twl[15];
     inv_pass<PLG, 2>(v, twl);
-    lds_store<PLG, 2>(v, t, ex);
+    if constexpr (!(RR_POLY_ABLATE & 16)) lds_store<PLG, 2>(v, t, ex);
     wave_fence();
-    lds_load<PLG, 1>(v, t, ex);
+    if constexpr (!(RR_POLY_ABLATE & 16)) lds_load<PLG, 1>(v, t, ex);
 #pragma unroll
     for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<PLG, 1>::lo(t)];
     inv_pass<PLG, 1>(v, twl);
-    lds_store<PLG, 1>(v, t, ex);
+    if constexpr (!(RR_POLY_ABLATE & 16)) lds_store<PLG, 1>(v, t, ex);
     wave_fence();
-    lds_load<PLG, 0>(v, t, ex);
+    if constexpr (!(RR_POLY_ABLATE & 16)) lds_load<PLG, 0>(v, t, ex);
     inv_pass<PLG, 0>(v, tw0);
 }
 
@@ -143,11 +155,40 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
             // position-major: the NB loads of one n touch the same cache lines back to back (phase-major order would
             // come back to every line of the 48 KB tile NB times, a whole tile apart: the L1 does not hold a tile)
             const long i0 = vbase - src.plen - (P0 + pb) + (long)D * t;
+            const int nbv = NPH - pb < NB ? NPH - pb : NB;            // phases of this batch (a constant once unrolled)
+            if constexpr ((RR_POLY_ABLATE & 1) != 0) {
 #pragma unroll
-            for (int n = 0; n < 16; n++)
+                for (int n = 0; n < 16; n++)
 #pragma unroll
-                for (int i = 0; i < NB; i++)
-                    if (pb + i < NPH) v[i][n] = poly_elem(src, i0 - i + (long)D * PT * n);
+                    for (int i = 0; i < NB; i++)
+                        if (pb + i < NPH) v[i][n] = mk((float)(t + n) * 1e-3f, (float)(i0 & 255) * 1e-3f);
+            } else if constexpr (std::is_same<SRC, VSrc<cf>>::value && RR_POLY_WIDE) {
+                // the batch's phases are NBV ADJACENT samples per lane: fetched as 16-byte pairs (+ one 8-byte rest) — every
+                // load instruction of a 48-byte lane stride looks up the same 24 cache lines whatever its width, so two
+                // loads per position instead of three are a third fewer L1 look-ups
+                const creg* base = reinterpret_cast<const creg*>(src.in) + i0;
+#pragma unroll
+                for (int n = 0; n < 16; n++) {
+                    const creg* q = base + (long)D * PT * n;
+#pragma unroll
+                    for (int k = 0; k < (NB + 1) / 2; k++) {
+                        const int i = nbv - 1 - 2 * k;
+                        if (i >= 1) {
+                            const creg2u w = *reinterpret_cast<const creg2u*>(q - i);
+                            v[i][n] = mk(w.x, w.y);
+                            v[i - 1][n] = mk(w.z, w.w);
+                        } else if (i == 0) {
+                            v[0][n] = q[0];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 16; n++)
+#pragma unroll
+                    for (int i = 0; i < NB; i++)
+                        if (pb + i < NPH) v[i][n] = poly_elem(src, i0 - i + (long)D * PT * n);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < NB; i++)
@@ -160,21 +201,21 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
                 {
                     creg twl[15];
                     fwd_pass<PLG, 0>(v[i], tw0);
-                    lds_store<PLG, 0>(v[i], t, ex);
+                    if constexpr (!(RR_POLY_ABLATE & 16)) lds_store<PLG, 0>(v[i], t, ex);
                     wave_fence();
-                    lds_load<PLG, 1>(v[i], t, ex);
+                    if constexpr (!(RR_POLY_ABLATE & 16)) lds_load<PLG, 1>(v[i], t, ex);
 #pragma unroll
                     for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<PLG, 1>::lo(t)];
                     fwd_pass<PLG, 1>(v[i], twl);
-                    lds_store<PLG, 1>(v[i], t, ex);
+                    if constexpr (!(RR_POLY_ABLATE & 16)) lds_store<PLG, 1>(v[i], t, ex);
                     wave_fence();
-                    lds_load<PLG, 2>(v[i], t, ex);
+                    if constexpr (!(RR_POLY_ABLATE & 16)) lds_load<PLG, 2>(v[i], t, ex);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 creg h[16];
                 const creg* hp = hreg + (long)(P0 + pb + i) * 16 * PT + t;
 #pragma unroll
-                for (int j = 0; j < 16; j++) h[j] = hp[j * PT];
+                for (int j = 0; j < 16; j++) h[j] = (RR_POLY_ABLATE & 8) ? mk(1.0f + j, (float)t) : hp[j * PT];
                 fwd_pass<PLG, 2>(v[i], nullptr);         // (P == 1: no twiddles)
 #pragma unroll
                 for (int j = 0; j < 16; j++) z[j] = cmac(z[j], v[i][j], h[j]);
@@ -194,6 +235,7 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
 template <int MODE>
 __device__ __forceinline__ float poly_angle(creg rl, creg ru, float gain) {
     const creg zz = cmulc(ru, rl);
+    if constexpr ((RR_POLY_ABLATE & 2) != 0) return gain * (zz.x + zz.y);
     return gain * (MODE == 0 ? atan2_poly(zz.y, zz.x) : fmc_atan2(zz.y, zz.x));
 }
 template <int MODE>
@@ -214,7 +256,10 @@ __device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int
         }
         i += stride; pu += inc; pl += inc; o += stride;
     }
-    for (; i < nv; i += stride, pu += inc, pl += inc, o += stride) *o = poly_angle<MODE>(*pl, *pu, a.gain);
+    for (; i < nv; i += stride, pu += inc, pl += inc, o += stride) {
+        const float y = poly_angle<MODE>(*pl, *pu, a.gain);
+        if constexpr ((RR_POLY_ABLATE & 4) != 0) { if (y == 1234.5678f) *o = y; } else { *o = y; }
+    }
     if (left <= Sa) {                                                    // (wave-uniform) last tile: carry r[r_hi - 1]
         if (nv - 1 >= lane0 && ((nv - 1 - lane0) % stride) == 0) last_r_out[0] = from_reg(ldsR[lds_pad(a.Ls + nv - 1)]);
     }
