@@ -47,7 +47,7 @@ _PATHS = {"auto": PATH_AUTO, "direct": PATH_DIRECT, "fft": PATH_FFT}
 @contextlib.contextmanager
 def build_options(**kw):
     """fir_path='direct'|'fft', fir_prune=+-1, fir_half=-1, fir_cfg=0..7, fft_log2f=10..14, fft_no_split=1,
-    fftfloat_complex=1, fm_full=1, fm_poly=-1, dstream_no_vmm=1, host_sync_copies=1"""
+    fftfloat_complex=1, fm_full=1, fm_poly=-1, dstream_no_vmm=1, host_sync_copies=1, fir_poly=+-1"""
     global _build_opts
     prev = _build_opts
     _build_opts = dict(prev, **kw)

@@ -98,6 +98,24 @@ template <class TapT> static void build_poly(const std::vector<TapT>& rev, int d
 
 static void compute_hpos(const rr_c32* taps, size_t ntaps, int log2f, std::vector<cf>& hpos);
 
+// decimating FirFilter<Complex>: where the decimate-first tiles beat the block's other kernels (MI355X, tools/fir_poly_probe.py,
+// ms per 1e8 samples, poly / best other, real-valued taps — Complex taps only slow the direct form down):
+//   /3: 31 taps 0.264 / 0.410, 127 0.264 / 0.278, 401 0.281 / 0.346, 1000 0.346 / 0.427      /4: 401 0.260 / 0.261, 1000 0.292 / 0.413
+//   /5: 127 0.251 / 0.320, 1000 0.276 / 0.417     /6: 127 0.248 / 0.259, 401 0.256 / 0.316, 2467 0.321 / 0.575
+//   /7: 255 0.274 / 0.311, 2467 0.348 / 0.583     /8: 1000 0.321 / 0.306, 2467 0.355 / 0.593 (pruned inverse below that)
+//   /10: 31 0.317 / 0.355, 255 0.319 / 0.518, 2467 0.349 / 0.580      /12: 2467 0.519 / 0.579      /2, /16: never
+static bool fir_poly_wins(size_t ntaps, size_t deci) {
+    switch (deci) {
+    case 3: case 10: return ntaps >= 24;
+    case 4: return ntaps >= 400;
+    case 5: case 6: return ntaps >= 100;
+    case 7: return ntaps >= 200;
+    case 8: return ntaps >= 1500;
+    case 12: return ntaps >= 2000;
+    default: return false;
+    }
+}
+
 FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq, bool allow_fft)
     : Block("FirFilter<Complex>", 8, 8) {
     if (ntaps == 0) throw Error("FirFilter: empty taps");            // fir.rs:372
@@ -190,7 +208,22 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
         RR_HIP(hipStreamSynchronize(stream));
         half_ok = true;
     }
-    if (prune || half_ok) {
+    // decimations the last radix cannot prune (3, 5, 6, 7 ...): decimate-first tiles — deci phase transforms and ONE inverse
+    // per 1024 output positions (kernels_poly.hip; VERDICT r1 #3 "likewise for FirFilter decimations divisible by 3").
+    // Where they win is measured (tools/fir_poly_probe.py); fir_poly > 0 forces them wherever the kernel exists.
+    if (allow_fft && !force_direct && deci >= 2 && bo.fir_poly >= 0 &&
+        fm_poly_supported(1, (long)std::min<size_t>(deci, 1 << 20), (int)std::min<size_t>(ntaps, 1 << 24), false)) {
+        const bool poly_default = fir_poly_wins(ntaps, deci);
+        if (bo.fir_poly > 0 || poly_default) {
+            std::vector<rr_c32> ct(ntaps);
+            for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
+            poly.reset(new PolyTables());
+            if (!poly->build(ct.data(), 1, ntaps, deci, false, stream)) poly.reset();
+            RR_HIP(hipStreamSynchronize(stream));
+        }
+    }
+    if (poly) { prune.reset(); half_ok = false; }
+    if (poly || prune || half_ok) {
     } else if (allow_fft && fits && !force_direct && (force_fft || wins)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
@@ -212,7 +245,8 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     const size_t out_n = n / d;
     VSrc<cf> src{nullptr, 0, static_cast<const cf*>(in), (long)in_len};
     prof_begin(s);
-    if (half_ok) launch_fftfilt_half(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, d_htw.p, d_htw_half.p, d_hhpos.p, s);
+    if (poly) launch_fir_poly(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, poly->d_tw.p, poly->d_h.p, s);
+    else if (half_ok) launch_fftfilt_half(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, d_htw.p, d_htw_half.p, d_hhpos.p, s);
     else if (prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
     else if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s);
     else if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s);

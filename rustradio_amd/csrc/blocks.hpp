@@ -88,6 +88,8 @@ struct FirC32 : Block {
     std::unique_ptr<PruneTables> prune;           // deci 4 / 8 / 16: pruned inverse transform (k_fftfilt_prune)
     // other even decimations, <= 600 taps: 2048-point tiles with the half-size inverse (k_fftfilt_half)
     bool half_ok = false;
+    // decimations 3 / 5 / 6 / 7 ...: decimate-first tiles (k_fm_chain_poly with the samples stored, kernels_poly.hip)
+    std::unique_ptr<PolyTables> poly;
     DevBuf<cf> d_htw, d_htw_half, d_hhpos;
     DevBuf<unsigned char> d_tp, d_rev, d_tab;
     bool rot_on = false;

@@ -32,6 +32,7 @@ struct BuildOpts {
     int fm_poly = 0;           // 0 auto, < 0 off: polyphase (decimate-first) tiles of the fused chains
     int dstream_no_vmm = 0;
     int host_sync_copies = 0;  // host-window work(): the simple staged path (no pinned double buffering)
+    int fir_poly = 0;          // 0 auto, > 0 on wherever supported, < 0 off: decimating FirFilter<Complex> on decimate-first tiles
 };
 const BuildOpts& build_opts();
 void set_build_opts(const BuildOpts* o);   // nullptr = reset

@@ -129,6 +129,8 @@ void launch_fm_chain_poly(VSrc<cf> src, float* out, int L, const cf* tw, const c
                           cf* last_out, hipStream_t s);
 void launch_fm_chain_poly_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& a, const cf* last_in,
                               cf* last_out, hipStream_t s);
+// decimating FirFilter<Complex> (deci = D) on the decimate-first tiles: out[m] = sum_k t[k] x[m D + L - 1 - k]
+void launch_fir_poly(VSrc<cf> src, cf* out, long n_out, int L, int D, const cf* tw, const cf* hreg, hipStream_t s);
 void launch_fm_multi_poly(VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
                           const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 void launch_fm_multi_poly_iq8(VSrcIQ8 src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,

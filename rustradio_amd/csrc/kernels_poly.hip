@@ -265,6 +265,17 @@ __device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int
     }
 }
 
+// MODE 2 of the chain kernel (decimating FirFilter<Complex>): the tile's samples r[u0 + i] go out as they are
+__device__ __forceinline__ void poly_store_tile(const creg* ldsR, int lane0, int stride, long u0, int Sa, const PolyArgs& a,
+                                                creg* __restrict__ out) {
+    const long left = a.r_hi - u0;
+    const int nv = left < Sa ? (int)left : Sa;
+    creg* o = out + (u0 - a.o_base) + lane0;
+    const creg* pu = ldsR + lds_pad(a.Ls + lane0);
+    const int inc = stride + (stride >> 4);
+    for (int i = lane0; i < nv; i += stride, pu += inc, o += stride) *o = *pu;
+}
+
 template <int D, class SRC>
 __global__ __launch_bounds__(128, RR_POLY_WAVES)
 void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
@@ -320,7 +331,8 @@ void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __
         tile_sync<128>();
         PSTAMP(4);
         if (a.mode == 0) poly_demod_tile<0>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
-        else poly_demod_tile<1>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        else if (a.mode == 1) poly_demod_tile<1>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        else poly_store_tile(ldsR, w * PT + t, 2 * PT, u0, Sa, a, reinterpret_cast<creg*>(out));
         PSTAMP(5);
         // (the next tile rewrites exB / ldsR only after its first barrier, which both waves reach after these reads)
     }
@@ -456,6 +468,14 @@ void launch_fm_chain_poly(VSrc<cf> src, float* out, int L, const cf* tw, const c
 void launch_fm_chain_poly_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& a, const cf* last_in,
                               cf* last_out, hipStream_t s) {
     launch_chain_poly_t(src, out, L, tw, hreg, a, last_in, last_out, s);
+}
+// Decimating FirFilter<Complex> on the same tiles: out[m] = sum_k t[k] x[m D + L - 1 - k], m < n_out (Fir::filter_n, fir.rs:181-189;
+// "valid" mode: the window itself holds the L - 1 samples of history) = the chain's r[u] with the stream origin at V[L - 1]
+// and the samples stored instead of demodulated.
+void launch_fir_poly(VSrc<cf> src, cf* out, long n_out, int L, int D, const cf* tw, const cf* hreg, hipStream_t s) {
+    FmChainArgs h{};
+    h.A = 0; h.n_y = n_out * (long)D; h.r_lo = 0; h.r_hi = n_out; h.o_base = 0; h.I = 1; h.D = D; h.gain = 1.0f; h.mode = 2;
+    launch_chain_poly_t(src, reinterpret_cast<float*>(out), L, tw, hreg, h, nullptr, nullptr, s);
 }
 
 template <int D, class SRC>

@@ -92,7 +92,7 @@ def test_fir_nondecimating_both_paths(rr, monkeypatch, path, L, cplx):
     assert rr.fir_uses_fft_tiles(f) == (path == "fft" or (path == "auto" and L >= (28 if cplx else 40)))
 
 
-@pytest.mark.parametrize("path", ["direct", "fft", "auto", "prune", "half"])
+@pytest.mark.parametrize("path", ["direct", "fft", "auto", "prune", "half", "poly"])
 @pytest.mark.parametrize("L,deci,cplx", [(5, 4, True), (40, 4, False), (500, 4, True), (64, 8, False), (1020, 8, True), (3, 16, False), (2049, 16, True),
                                          (5, 2, False), (127, 2, False), (128, 2, True), (600, 2, False), (601, 2, True), (401, 6, True), (90, 10, False), (700, 14, True), (33, 4096, True), (64, 22, False), (127, 3, True), (255, 8, True), (401, 7, False),
                                          (1000, 16, True), (64, 100, False), (2000, 5, False), (3584, 4096, False), (5000, 3, True), (9000, 16, False),
@@ -106,11 +106,16 @@ def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
         knob(rr, monkeypatch, fir_path="fft")
         knob(rr, monkeypatch, fir_prune=-1)
         knob(rr, monkeypatch, fir_half=-1)
+        knob(rr, monkeypatch, fir_poly=-1)
     elif path == "prune":                             # deci 4 / 8 / 16: pruned inverse transform (else as "auto")
         knob(rr, monkeypatch, fir_prune=1)
+        knob(rr, monkeypatch, fir_poly=-1)
     elif path == "half":                              # even deci, <= 1025 taps: half-size inverse on 2048-point tiles
         knob(rr, monkeypatch, fir_path="fft")
         knob(rr, monkeypatch, fir_prune=-1)
+        knob(rr, monkeypatch, fir_poly=-1)
+    elif path == "poly":                              # decimate-first tiles wherever the kernel exists (deci 2..8, 10, 12, 16)
+        knob(rr, monkeypatch, fir_poly=1)
     if path == "direct" and L >= 5000:
         pytest.skip("direct-form fallback at thousands of taps: covered by test_fir_complex history, slow")
     x = rnd_c(120000, L * 3 + deci)
@@ -167,7 +172,7 @@ def test_fir_translate(rr, mode):
 @pytest.mark.parametrize("deci,f", [(1, 2.1e6), (2, -7e6), (4, 11e6), (8, -12.5e6), (16, 3e6), (6, 1e6)])
 def test_fir_translate_on_tiles(rr, deci, f):
     """.translate() (pre-rotated taps + output rotator, fir.rs:430-473) on the FFT-tile paths: 255 taps at deci 1 (plain
-    tiles), 2 / 6 (half-size inverse), 4 / 8 / 16 (pruned inverse)."""
+    tiles), 2 (half-size inverse), 6 (decimate-first tiles), 4 / 8 / 16 (pruned inverse)."""
     x = rnd_c(60000, 5 + deci)
     taps = orc.low_pass_complex(100e6, 5e6, 943e3)
     assert len(taps) == 255
