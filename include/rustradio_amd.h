@@ -314,7 +314,7 @@ int rr_block_work_streams(rr_block *b, rr_dstream *src, rr_dstream *dst, size_t 
 typedef struct rr_fanout rr_fanout;
 #define RR_FANOUT_ID_BYTES 128
 enum rr_fanout_flags {
-    RR_FANOUT_TIMING      = 1,  /* time every broadcast with HIP events on the communication stream (rr_fanout_stats) */
+    RR_FANOUT_TIMING      = 1,  /* time every 4th broadcast with HIP events on the communication stream (rr_fanout_stats) */
     RR_FANOUT_RCCL_ALWAYS = 2,  /* run a one-rank group through RCCL as well (tests of the RCCL path on a one-GPU machine) */
     RR_FANOUT_MESH        = 4   /* fan out by ncclScatter (1/world of the tile to each rank) + in-place ncclAllGather between the
                                    receivers instead of one ncclBroadcast: a broadcast is bounded by ONE of the owner's xGMI

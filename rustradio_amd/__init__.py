@@ -329,7 +329,7 @@ class Fanout:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:                            # (module globals are gone at interpreter shutdown)
             lib().rr_fanout_destroy(h)
 
     def produce_buf(self, t: int, stream: int = 0) -> int:

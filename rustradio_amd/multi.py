@@ -117,6 +117,7 @@ class TileFanout:
     """
 
     ALGOS = ("bcast", "scatter_allgather")
+    TIME_EVERY = 4          # every 4th fan-out is timed with HIP events on the communication stream
 
     def __init__(self, dist, rank, tile_elems, dtype, device, produce, src_rank=0, algo="bcast"):
         self.dist, self.rank, self.src, self.produce = dist, rank, src_rank, produce
@@ -210,12 +211,15 @@ class TileFanout:
             if self.rank == self.src:
                 self.produce(t, self.buf[h])
             if self.dist is not None:
-                b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                b.record(self.comm)
-                self._fan(h, self.algo)
-                e.record(self.comm)
-                self.t_beg.append(b)
-                self.t_end.append(e)
+                if t % self.TIME_EVERY == 0:                # a sample of the tiles is timed: two events and their
+                    b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # creation cost host time
+                    b.record(self.comm)
+                    self._fan(h, self.algo)
+                    e.record(self.comm)
+                    self.t_beg.append(b)
+                    self.t_end.append(e)
+                else:
+                    self._fan(h, self.algo)
             self.ready[h].record(self.comm)
         self.n_bcast += 1
 
@@ -256,14 +260,14 @@ class AbiFanout:
     torch.distributed group that launched the ranks; the double buffer, the communication stream, the events and the
     RCCL broadcasts are the library's.  `produce(t, out)` fills the torch alias of the half on the owning rank."""
 
-    def __init__(self, rr, dist, rank, tile_elems, dtype, device, produce, src_rank=0, rccl_always=False, mesh=False):
+    def __init__(self, rr, dist, rank, tile_elems, dtype, device, produce, src_rank=0, rccl_always=False, mesh=False, timing=True):
         self.rank, self.src, self.produce, self.dtype, self.device = rank, src_rank, produce, dtype, device
         self.bytes_per_tile = tile_elems * torch.empty(0, dtype=dtype).element_size()
         world = dist.get_world_size() if dist is not None else 1
         gid = [rr.fanout_unique_id() if (rank == src_rank and (world > 1 or rccl_always)) else None]
         if dist is not None and world > 1:
             dist.broadcast_object_list(gid, src=src_rank)
-        flags = rr.FANOUT_TIMING | (rr.FANOUT_RCCL_ALWAYS if rccl_always else 0) | (rr.FANOUT_MESH if mesh else 0)
+        flags = (rr.FANOUT_TIMING if timing else 0) | (rr.FANOUT_RCCL_ALWAYS if rccl_always else 0) | (rr.FANOUT_MESH if mesh else 0)
         self.algo = "scatter_allgather" if mesh else "bcast"
         self.calibration = None
         self.fan = rr.Fanout(gid[0], rank, world, self.bytes_per_tile, src_rank, flags)

@@ -58,7 +58,7 @@ def test_one_rank_fanout_through_rccl(rr, mesh):
     fan = rr.Fanout(gid, 0, 1, 4 * n, flags=rr.FANOUT_RCCL_ALWAYS | rr.FANOUT_TIMING | (rr.FANOUT_MESH if mesh else 0))
     _drive(rr, fan, 7, n, torch.cuda.current_stream(), True)
     ms, nb = fan.stats()
-    assert nb == 7 and ms > 0
+    assert nb == 2 and ms > 0                                    # tiles 0 and 4 of the 7: every 4th broadcast is timed
     assert fan.stats() == (0.0, 0)                               # drained
 
 
@@ -114,4 +114,4 @@ def test_abi_fanout_adapter_matches_tilefanout_interface(rr):
     torch.cuda.synchronize()
     assert torch.equal(out, store * 2.0)
     ms, nb = fan.broadcast_ms()
-    assert nb == ntiles - 1 and ms > 0 and fan.n_bcast == ntiles
+    assert nb == 1 and ms > 0 and fan.n_bcast == ntiles          # tile 4 (tile 0's timing was drained by reset_timing)

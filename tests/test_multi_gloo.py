@@ -259,5 +259,5 @@ def test_tile_fanout_on_a_one_rank_rccl_group():
     for t, v in enumerate(sums):
         lo = t * n
         assert v == float(n) * lo + n * (n - 1) / 2
-    assert backend == "nccl" and nb == 8 and ms > 0
+    assert backend == "nccl" and nb == 2 and ms > 0          # tiles 0 and 4 of the 8 (TileFanout.TIME_EVERY)
     assert (units, secs) == (3.0, 0.25)
