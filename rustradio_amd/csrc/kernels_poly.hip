@@ -24,6 +24,7 @@
 //   k_fm_multi_poly: N channels on one input (configs[3]).  A workgroup = 8 waves: waves 0 .. D-1 transform one phase
 //     each and park the D spectra in LDS (the forward work is shared by all channels, as in k_fm_multi); then every wave
 //     takes every 8th channel: sum_p H_{c,p} X_p from the parked spectra, inverse, demodulation.
+#include <algorithm>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -445,7 +446,12 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
     if (nr <= 0) return;
     const long ntiles = (nr + Sa - 1) / Sa;
     const size_t smem = sizeof(cf) * (3 * PLE + 64);
-    const long grid = grid_for_tiles(k_fm_chain_poly<D, SRC>, 128, smem, ntiles);
+    long grid = grid_for_tiles(k_fm_chain_poly<D, SRC>, 128, smem, ntiles);
+    // A few tiles per resident workgroup (configs[2]: 4228 tiles on 1024 slots = 4.1) end in a round where most of the
+    // chip waits for the workgroups with one tile more.  Launching 3x the resident workgroups lets the hardware dispatcher
+    // hand the tiles out as slots free up (tools/percu_sweep.sh: 0.0685 -> 0.063 ms; 1 tile per workgroup 0.0645; with 17
+    // tiles per slot, full_chain_fused, the persistent grid stays ahead: 0.319 vs 0.330).
+    if (ntiles > grid && ntiles < 12 * grid) grid = std::min(ntiles, 3 * grid);
     hipLaunchKernelGGL((k_fm_chain_poly<D, SRC>), dim3((unsigned)grid), dim3(128), smem, s, src, out, ntiles, tw, hreg, a, last_in, last_out,
                        fft_stamp_buffer());
     RR_HIP(hipGetLastError());
@@ -486,7 +492,8 @@ static void launch_multi_poly_d(SRC src, float* out, long out_stride, int L, con
     if (nr <= 0) return;
     const long ntiles = (nr + Sa - 1) / Sa;
     const size_t smem = sizeof(cf) * (8 * PLE + D * PF + 64);
-    const long grid = grid_for_tiles(k_fm_multi_poly<D, SRC>, 512, smem, ntiles);
+    long grid = grid_for_tiles(k_fm_multi_poly<D, SRC>, 512, smem, ntiles);
+    if (ntiles > grid && ntiles < 12 * grid) grid = std::min(ntiles, 3 * grid);      // (as launch_chain_poly_d: 0.093 -> 0.0905 ms)
     hipLaunchKernelGGL((k_fm_multi_poly<D, SRC>), dim3((unsigned)grid), dim3(512), smem, s, src, out, out_stride, ntiles, tw, hreg,
                        nchan, a, last_in, last_out, fft_stamp_buffer());
     RR_HIP(hipGetLastError());
