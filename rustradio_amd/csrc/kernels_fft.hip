@@ -22,7 +22,8 @@
 // Measurement builds (never shipped; make ABLATE=<bits> / TIMING=1 OUT=../lib_ablate):
 //   -DRR_FFT_ABLATE_BITS=<bits>  compile-time phase ablation: 1 no input loads, 2 no output stores,
 //        4 no LDS exchanges, 8 no butterflies, 16 inputs from an L2-resident window, 32 outputs to
-//        an L2-resident window.  (Compile-time so that the ablated kernel keeps the production
+//        an L2-resident window; in k_fftfilt_prune's real-stream path also 64 no second response, 128 no batched tail.
+//        (Compile-time so that the ablated kernel keeps the production
 //        register allocation; a runtime flag version spilled 208 B/lane and skewed every number.)
 //   -DRR_FFT_TIMING_BUILD  workgroup 0 / thread 0 stamps s_memtime at every phase boundary of its
 //        3rd tile (env RR_FFT_STAMPS=1, read back with rr_debug_fft_stamps).
@@ -527,7 +528,18 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             creg v[16];
             if constexpr (REAL2) {
                 const long va = 2 * tile * S, vb = va + S;
-                if (va >= rsrc.plen && vb - rsrc.plen + F <= rsrc.in_len) {
+                if (RR_ABLATE(256) && va >= rsrc.plen && vb - rsrc.plen + F <= rsrc.in_len) {   // measurement only: the tile's 16 KB as 8 dense 16-byte loads per lane (wrong data)
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    const f4* pa = reinterpret_cast<const f4*>(rsrc.in + ((va - rsrc.plen) & ~3L)) + t;
+#pragma unroll
+                    for (int n = 0; n < 4; n++) {
+                        const f4 qa = pa[n * T], qb = pa[(S & ~3L) / 4 + n * T];
+                        v[4 * n] = mk(qa.x, qb.x); v[4 * n + 1] = mk(qa.y, qb.y); v[4 * n + 2] = mk(qa.z, qb.z); v[4 * n + 3] = mk(qa.w, qb.w);
+                    }
+                } else if (RR_ABLATE(1)) {   // measurement only: no input traffic
+#pragma unroll
+                    for (int n = 0; n < 16; n++) v[n] = mk((float)(t + n) * 1e-3f, (float)(tile & 255) * 1e-3f);
+                } else if (va >= rsrc.plen && vb - rsrc.plen + F <= rsrc.in_len) {
                     const float* pa = rsrc.in + (va - rsrc.plen) + t;
 #pragma unroll
                     for (int n = 0; n < 16; n++) v[n] = mk(pa[n * T], pa[S + n * T]);
@@ -570,7 +582,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
                 for (int k = 1; k < D; k++) z = cadd(z, cmul(v[u * D + k], h1[u * D + k]));
                 park[lds_pad(256 * (TWO ? 2 * b : b) + t + T * u)] = z;
             }
-            if constexpr (TWO) {
+            if constexpr (TWO && !RR_ABLATE(64)) {
                 RR_PHASE();
                 load_h<LOG2F, Plan<LOG2F>::NP - 1>(hrB, t, hpos2b);   // the second response is re-read per tile (L1 / L2)
 #pragma unroll
@@ -618,7 +630,12 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             // samples of segment 2 tile + c (storing the parts with 4-byte strided stores costs 1.34x the write traffic).
             const int b2 = b >> 1, c = b & 1;
             creg p[16];
-            prune_tail<T>(p, park, t, twb);
+            if (RR_ABLATE(128)) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) p[k] = park[17 * t + k];
+            } else {
+                prune_tail<T>(p, park, t, twb);
+            }
             creg* stash = lds + 17 * t;
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) stash[n1] = p[n1];
@@ -631,7 +648,8 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
                 const creg q = other[n1];
-                if (16 * n1 >= lo && 16 * n1 < lim) po[16 * n1] = c ? mk(q.y, p[n1].y) : mk(p[n1].x, q.x);
+                if (RR_ABLATE(2)) { if (q.x == 1234.5678f) po[16 * n1] = q; }
+                else if (16 * n1 >= lo && 16 * n1 < lim) po[16 * n1] = c ? mk(q.y, p[n1].y) : mk(p[n1].x, q.x);
             }
         }
         tile_sync<T>();                                  // the next batch parks into the slots just read
