@@ -34,11 +34,11 @@ def _both(rr, make, x, stream_bytes, exact=False, scale=None):
         assert max_norm_err(yg, yo, scale) <= TOL
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(40))
 def test_fuzz_fir(rr, seed):
     rng = np.random.default_rng(1000 + seed)
-    L = int(rng.choice([1, 2, 3, 7, 8, 9, 31, 64, 65, 127, 200, 255, 256, 257, 511, 1000]))
-    d = int(rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 9, 16, 25, 64]))
+    L = int(rng.choice([1, 2, 3, 7, 8, 9, 31, 64, 65, 127, 200, 255, 256, 257, 401, 511, 1000, 2467]))
+    d = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 25, 64]))
     n = int(rng.integers(L + d, 120_000))
     cplx_taps = bool(rng.integers(0, 2))
     real_in = bool(rng.integers(0, 3) == 0)
@@ -171,19 +171,21 @@ def test_fuzz_device_rings(rr, seed):
     assert len(yh) == len(yd) and np.array_equal(yh, yd)
 
 
-_FIR_PATHS = [{}, {"fir_path": "direct"}, {"fir_path": "fft", "fir_prune": -1, "fir_half": -1},
-              {"fir_path": "fft", "fir_prune": -1}, {"fir_path": "fft", "fir_prune": 1}]
+_FIR_PATHS = [{}, {"fir_path": "direct"}, {"fir_path": "fft", "fir_prune": -1, "fir_half": -1, "fir_poly": -1},
+              {"fir_path": "fft", "fir_prune": -1, "fir_poly": -1}, {"fir_path": "fft", "fir_prune": 1, "fir_poly": -1},
+              {"fir_poly": 1}]
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(48))
 def test_fuzz_fir_every_path(rr, monkeypatch, seed):
     """Random FirFilter shapes (Complex and Float streams, real and Complex taps, decimations incl. 4 / 8 / 16 and
     other even ones) through every arithmetic path the block can take: automatic choice, direct form, overlap-save
-    tiles with a decimating store, half-size inverse, pruned inverse — identical protocol, outputs within 1e-5."""
+    tiles with a decimating store, half-size inverse, pruned inverse, decimate-first tiles — identical protocol, outputs
+    within 1e-5."""
     rng = np.random.default_rng(5000 + seed)
     knob(rr, monkeypatch, **_FIR_PATHS[seed % len(_FIR_PATHS)])
     L = int(rng.choice([1, 5, 16, 33, 64, 127, 200, 255, 401, 600, 601, 1000, 1025, 2049]))
-    d = int(rng.choice([1, 2, 2, 4, 4, 6, 8, 8, 10, 16, 16, 22, 3, 5]))
+    d = int(rng.choice([1, 2, 2, 4, 4, 6, 8, 8, 10, 16, 16, 22, 3, 5, 7, 12]))
     if seed % len(_FIR_PATHS) == 1 and L > 700:
         L = 257                                       # (the direct form's fallback for long decimating filters is slow)
     n = int(rng.integers(L + d, 200_000))

@@ -13,7 +13,12 @@ class MP:
     def __init__(self): self.saved = {}
     def setenv(self, k, v):
         self.saved.setdefault(k, os.environ.get(k)); os.environ[k] = v
+    def setattr(self, obj, name, value):
+        self.saved.setdefault(("attr", id(obj), name), (obj, name, getattr(obj, name))); setattr(obj, name, value)
     def undo(self):
+        for k, v in list(self.saved.items()):
+            if isinstance(k, tuple) and k[0] == "attr":
+                setattr(v[0], v[1], v[2]); del self.saved[k]
         for k, v in self.saved.items():
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
