@@ -166,6 +166,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     // (tools/fir_paths_probe.py on MI355X: 127 real taps 0.65 vs 0.32 ms, 127 Complex taps 1.09 vs 0.32 ms)
     const BuildOpts& bo = build_opts();
     const bool force_direct = bo.fir_path == RR_PATH_DIRECT, force_fft = bo.fir_path == RR_PATH_FFT;
+    window_aware = bo.fir_poly <= 0 && bo.fir_prune <= 0 && !force_fft;   // a forced path is used at every window size
     // d > 1: the same tiles with a decimating store (k_fftfilt_deci, k_fftfilt_split<.., true>).  The transform cost
     // per input sample does not shrink with d while the direct form's does, so the bar is on taps per output
     // phase; beyond ~320 taps the direct form's LDS tile no longer fits for most decimations and it collapses
@@ -223,8 +224,10 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
         }
     }
     if (poly) { prune.reset(); half_ok = false; }
-    if (poly || prune || half_ok) {
-    } else if (allow_fft && fits && !force_direct && (force_fft || wins)) {
+    // (the pruned / decimate-first kernels need a window of many tiles to fill the chip — work_dev picks per call; the tiles
+    //  with a decimating store stay available beside them as the small-window path of long filters)
+    if (half_ok) {
+    } else if (allow_fft && fits && !force_direct && (force_fft || wins || poly || prune)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
         fftk.reset(new FftFilter(ct.data(), ntaps));
@@ -245,9 +248,33 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     const size_t out_n = n / d;
     VSrc<cf> src{nullptr, 0, static_cast<const cf*>(in), (long)in_len};
     prof_begin(s);
-    if (poly) launch_fir_poly(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, poly->d_tw.p, poly->d_h.p, s);
+    // Window-size-aware choice (round 2, tools/call_overhead.py): the batched pruned inverse (D tiles per workgroup) and the
+    // decimate-first tiles (d x 1024 inputs per workgroup) only pay once a window holds more units than the chip has
+    // workgroup slots — at the reference's ring size (512,000 samples) they leave most CUs idle: 255 taps /8 pruned 34 us
+    // against 8.7 us direct, 401 taps /6 decimate-first 18.7 against 9.9 us.  FirFilter carries no state between calls
+    // (the window holds the history), so the choice is per call.
+    bool use_poly = poly != nullptr, use_prune = prune != nullptr;
+    if (window_aware && (use_poly || use_prune)) {
+        if (use_poly) {
+            const size_t Ls = (L + d - 1) / d, per_tile = 1024 - Ls;
+            use_poly = out_n >= 1000 * per_tile;                               // one tile per resident workgroup slot
+        } else {
+            const size_t F = (size_t)1 << prune->log2f, per_batch = (F - L + 1) / d * d * d;   // D tiles of F - L + 1 inputs
+            use_prune = n >= 1400 * per_batch;
+        }
+    }
+    bool small_direct = false;
+    if ((poly && !use_poly) || (prune && !use_prune)) {
+        // small window: direct form (5 us + 7.8e-8 us per tap-phase and sample, twice that for Complex taps) or the tiles
+        // with a decimating store (9 us + 3.1e-6 us per sample), whichever the fitted costs favour
+        const double t_direct = 5.0 + 7.8e-8 * (double)n * ((double)L / (double)d) * (pl.complex_taps ? 2.0 : 1.0);
+        const double t_tiles = 9.0 + 3.1e-6 * (double)n;
+        small_direct = !fftk || t_direct <= t_tiles;
+    }
+    if (use_poly) launch_fir_poly(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, poly->d_tw.p, poly->d_h.p, s);
+    else if (small_direct) launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
     else if (half_ok) launch_fftfilt_half(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, d_htw.p, d_htw_half.p, d_hhpos.p, s);
-    else if (prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
+    else if (use_prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
     else if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s);
     else if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s);
     else if (fftk) fftk->filter(src, static_cast<cf*>(out), (long)out_n, s);
@@ -333,7 +360,14 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     const size_t out_n = n / d;
     VSrc<float> src{hist[cur].p, (long)hn, static_cast<const float*>(in), (long)in_len};
     prof_begin(s);
-    if (prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s);
+    // (as FirC32::work_dev: a batch is D / 2 tiles of 2 (F - Lg + 1) real samples; below ~2100 batches — 30 M samples at
+    //  65 * 255 taps / 8 — the direct form is faster: 1 M samples 31.7 -> 10.1 us, 8 M 34.0 -> 22.7 us)
+    bool use_prune = prune != nullptr;
+    if (use_prune && fir->window_aware) {
+        const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - (size_t)plG.L + 1) * (d / 2);
+        use_prune = n >= 2100 * per_batch;
+    }
+    if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s);
     else launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s);
     prof_end(s);
     fir->rotate_output(static_cast<cf*>(out), out_n, s);
@@ -765,6 +799,7 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     // 0.065 / 0.087, 1:6 0.067 / 0.085, 1:7 0.083 / 0.095, 1:8 0.096 / 0.083; 2467 taps 1:6 0.086 / 0.157, 1:10 0.113 / 0.152,
     // 1:12 0.159 / 0.149 — every decimation up to 6 (7 phases and more run in two register batches per wave), and up to
     // 10 for filters long enough to push the other kernels onto 4096-point or split tiles.  fm_poly > 0 forces them.
+    window_aware = build_opts().fm_poly <= 0;
     const bool poly_wins = D <= 6 || (D <= 10 && f->L >= 800);
     if ((build_opts().fm_poly > 0 || (build_opts().fm_poly == 0 && poly_wins)) && !build_opts().fm_full && I == 1 && D >= 2) {
         std::vector<rr_c32> ct(f->L);
@@ -820,10 +855,19 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         FmChainArgs a;
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = gain; a.mode = mode;
+        // decimate-first tiles cover D x 946 inputs each: below one tile per resident workgroup slot (~6 M samples at 1:6)
+        // the 2048-point tiles keep more of the chip busy (tools/call_overhead.py, 463 taps 1:6, 512 k samples: 21.7 us
+        // decimate-first, 15.4-18.8 us on the 2048-point tiles; 8 M samples: 32.9 against 35.1).  All kernels share the
+        // carried state (prefix, pending samples, last r), so the choice is per call.
+        bool use_poly = poly != nullptr;
+        if (use_poly && window_aware) {
+            const uint64_t Ls = (f->L + (uint64_t)D - 1) / (uint64_t)D;
+            use_poly = (a.r_hi - a.r_lo) >= (long)(1000 * (1024 - Ls));
+        }
         prof_begin(s);
-        if (poly && packed)
+        if (use_poly && packed)
             launch_fm_chain_poly_iq8(src8, static_cast<float*>(out), (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
-        else if (poly)
+        else if (use_poly)
             launch_fm_chain_poly(src, static_cast<float*>(out), (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (f->nsub && packed)
             launch_fm_chain_split_iq8(f->nsub, src8, static_cast<float*>(out), (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,

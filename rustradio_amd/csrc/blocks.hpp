@@ -90,6 +90,7 @@ struct FirC32 : Block {
     bool half_ok = false;
     // decimations 3 / 5 / 6 / 7 ...: decimate-first tiles (k_fm_chain_poly with the samples stored, kernels_poly.hip)
     std::unique_ptr<PolyTables> poly;
+    bool window_aware = true;                     // per-call choice by window size (off when a path is forced: tests, probes)
     DevBuf<cf> d_htw, d_htw_half, d_hhpos;
     DevBuf<unsigned char> d_tp, d_rev, d_tab;
     bool rot_on = false;
@@ -192,6 +193,7 @@ struct FmChain : Block {
     DevBuf<cf> d_tw_half;             // w_(F/2)^k: half-size inverse (interp 1, even deci, 2048-point tiles; k_fm_chain_half)
     bool half_ok = false;
     std::unique_ptr<PolyTables> poly; // interp 1, integer deci: decimate-first tiles (k_fm_chain_poly)
+    bool window_aware = true;         // windows of too few tiles run on the 2048-point kernels (off when fm_poly is forced)
     FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false,
             int max_log2f = 14, const rr_c32* fir_taps = nullptr, size_t fir_ntaps = 0);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""GPU box: fixed cost of one work_dev() call per block type — 20 back-to-back calls on windows of 64k / 512k samples, events
+around the batch (GPU time per call) and host time per call."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import rustradio_amd as rr
+s = torch.cuda.current_stream().cuda_stream
+lp = rr.low_pass_complex
+blocks = [("FftFilter401", lambda: rr.FftFilter(lp(10e6, 1e6, 60e3)), 8, 8, 1),
+          ("Fir127", lambda: rr.FirFilter(lp(10e6, 1e6, 190e3)), 8, 8, 1),
+          ("Fir255/8", lambda: rr.FirFilter(lp(100e6, 5e6, 943e3), deci=8), 8, 8, 8),
+          ("Fir401/6 poly", lambda: rr.FirFilter(lp(10e6, 1e6, 60e3), deci=6), 8, 8, 6),
+          ("FmChain463 1:6", lambda: rr.FmChain(lp(2.4e6, 100e3, 12.5e3), 1, 6, 1.0), 8, 4, 6),
+          ("HilbertFir65*255/8", lambda: rr.HilbertFir(65, lp(100e6, 5e6, 943e3), 8), 4, 8, 8),
+          ("Fir255/8 no-prune", lambda: _opt(dict(fir_prune=-1), lambda: rr.FirFilter(lp(100e6, 5e6, 943e3), deci=8)), 8, 8, 8),
+          ("Fir255/8 direct", lambda: _opt(dict(fir_path="direct"), lambda: rr.FirFilter(lp(100e6, 5e6, 943e3), deci=8)), 8, 8, 8),
+          ("Fir401/6 no-poly", lambda: _opt(dict(fir_poly=-1), lambda: rr.FirFilter(lp(10e6, 1e6, 60e3), deci=6)), 8, 8, 6),
+          ("Fir401/6 direct", lambda: _opt(dict(fir_path="direct"), lambda: rr.FirFilter(lp(10e6, 1e6, 60e3), deci=6)), 8, 8, 6),
+          ("FmChain no-poly", lambda: _opt(dict(fm_poly=-1), lambda: rr.FmChain(lp(2.4e6, 100e3, 12.5e3), 1, 6, 1.0)), 8, 4, 6),
+          ("FmChain full", lambda: _opt(dict(fm_poly=-1, fm_full=1), lambda: rr.FmChain(lp(2.4e6, 100e3, 12.5e3), 1, 6, 1.0)), 8, 4, 6),
+          ("HilbertFir direct", lambda: _opt(dict(fir_path="direct"), lambda: rr.HilbertFir(65, lp(100e6, 5e6, 943e3), 8)), 4, 8, 8),
+          ("HilbertFir no-prune", lambda: _opt(dict(fir_prune=-1), lambda: rr.HilbertFir(65, lp(100e6, 5e6, 943e3), 8)), 4, 8, 8),
+          ("Resampler1:6", lambda: rr.RationalResampler(1, 6), 8, 8, 6),
+          ("QuadDemod", lambda: rr.QuadratureDemod(1.0), 8, 4, 1),
+          ("Hilbert65", lambda: rr.Hilbert(65), 4, 8, 1)]
+def _opt(o, f):
+    with rr.build_options(**o):
+        return f()
+
+
+for n in (512_000, 2_000_000, 8_000_000):
+    x = torch.rand(2 * n, device="cuda") * 2 - 1
+    y = torch.empty(2 * n + 4096, device="cuda")
+    print()
+    for name, mk, ies, oes, d in blocks:
+        b = mk(); cap = n // d + 16
+        for _ in range(5): b.work_dev(x.data_ptr(), n, y.data_ptr(), cap, s)
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); a.record()
+        for _ in range(20): b.work_dev(x.data_ptr(), n, y.data_ptr(), cap, s)
+        e.record(); host = (time.perf_counter() - t0) / 20 * 1e6
+        torch.cuda.synchronize()
+        print(f"n={n:7d} {name:20s} gpu {a.elapsed_time(e) / 20 * 1e3:6.1f} us/call  host {host:5.1f} us/call")
