@@ -82,8 +82,8 @@ struct FirC32 : Block {
     FirPlan pl;
     // Non-decimating filters beyond a few taps run as overlap-save FFT tiles (the FftFilter kernel on a window
     // with no history: y[m] = sum_k rev[k] x[m + k] is that kernel's output for an empty prefix): the direct form
-    // costs 2-4 multiply-adds per tap and sample, the tiles a constant ~0.3 ms per 1e8 samples.  RR_FIR_DIRECT=1
-    // forces the direct kernel, RR_FIR_FFT=1 the tiles for any length (both read at construction).
+    // costs 2-4 multiply-adds per tap and sample, the tiles a constant ~0.3 ms per 1e8 samples.  rr_build_opts.fir_path
+    // forces the direct kernel or the tiles for any length (read at construction).
     std::unique_ptr<FftFilter> fftk;
     std::unique_ptr<PruneTables> prune;           // deci 4 / 8 / 16: pruned inverse transform (k_fftfilt_prune)
     // other even decimations, <= 600 taps: 2048-point tiles with the half-size inverse (k_fftfilt_half)

@@ -14,11 +14,10 @@ for L, d in ((32, 2), (64, 2), (127, 2), (255, 2), (401, 2), (1000, 2), (127, 6)
         t = rng.uniform(-1, 1, L) + (1j * rng.uniform(-1, 1, L) if cplx else 0)
         t = (t / L).astype(np.complex64)
         row = []
-        for env in ({"RR_FIR_DIRECT": "1"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0", "RR_FIR_HALF": "0"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0"}, {}):
-            for k in ("RR_FIR_DIRECT", "RR_FIR_FFT", "RR_FIR_PRUNE", "RR_FIR_HALF"):
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            f = rr.FirFilter(t, deci=d)
+        for opts in ({"fir_path": "direct"}, {"fir_path": "fft", "fir_prune": -1, "fir_half": -1, "fir_poly": -1},
+                     {"fir_path": "fft", "fir_prune": -1, "fir_poly": -1}, {}):
+            with rr.build_options(**opts):
+                f = rr.FirFilter(t, deci=d)
             for _ in range(2):
                 f.work_dev(x.data_ptr(), n, y.data_ptr(), n)
             torch.cuda.synchronize()

@@ -22,23 +22,17 @@ def run(f, k=4):
 for L, d in ((65, 1), (127, 1), (463, 1), (463, 6), (64, 4), (255, 4), (127, 8), (255, 8), (1000, 8), (255, 16), (1000, 16)):
     t = (rng.uniform(-1, 1, L) / L).astype(np.float32)
     row = []
-    for env in ({"RR_FIR_DIRECT": "1"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0"}, {"RR_FIR_PRUNE": "1"}, {}):
-        for k in ("RR_FIR_DIRECT", "RR_FIR_FFT", "RR_FIR_PRUNE"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        row.append(run(rr.FirFilter(t, deci=d)))
+    for opts in ({"fir_path": "direct"}, {"fir_path": "fft", "fir_prune": -1}, {"fir_prune": 1}, {}):
+        with rr.build_options(**opts):
+            row.append(run(rr.FirFilter(t, deci=d)))
     print(f"FirFilter<Float> L={L:5d} d={d:3d}: direct {row[0]:.4f}  tiles {row[1]:.4f}  pruned {row[2]:.4f}  auto {row[3]:.4f} ms", flush=True)
-for k in ("RR_FIR_DIRECT", "RR_FIR_FFT", "RR_FIR_PRUNE"):
-    os.environ.pop(k, None)
 # FftFilterFloat: inner streams are 512,000 samples, so time whole-stream throughput over ring-sized windows
 m = 512_000
 for L in (127, 401, 2467):
     t = (rng.uniform(-1, 1, L) / L).astype(np.float32)
-    for env in (None, "RR_FFTFLOAT_COMPLEX"):
-        os.environ.pop("RR_FFTFLOAT_COMPLEX", None)
-        if env:
-            os.environ[env] = "1"
-        f = rr.FftFilterFloat(t)
+    for env in (None, "fftfloat_complex"):
+        with rr.build_options(**({env: 1} if env else {})):
+            f = rr.FftFilterFloat(t)
         tot = 0
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(100):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""GPU box: non-decimating FirFilter<Complex> at 1e8 samples through the direct-form kernel (RR_FIR_DIRECT=1)
-and through the overlap-save FFT tiles (RR_FIR_FFT=1), real and Complex taps, by filter length: where the
+"""GPU box: non-decimating FirFilter<Complex> at 1e8 samples through the direct-form kernel (fir_path="direct")
+and through the overlap-save FFT tiles (fir_path="fft"), real and Complex taps, by filter length: where the
 crossover lies (FirC32's min_taps) and what the automatic choice costs."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,12 +15,9 @@ for L in (2, 4, 8, 12, 16, 24, 32, 64, 127, 255, 1000):
         t = rng.uniform(-1, 1, L) + (1j * rng.uniform(-1, 1, L) if cplx else 0)
         t = (t / L).astype(np.complex64)
         row = []
-        for env in ("RR_FIR_DIRECT", "RR_FIR_FFT", None):
-            for k in ("RR_FIR_DIRECT", "RR_FIR_FFT"):
-                os.environ.pop(k, None)
-            if env:
-                os.environ[env] = "1"
-            f = rr.FirFilter(t)
+        for opts in ({"fir_path": "direct"}, {"fir_path": "fft"}, {}):
+            with rr.build_options(**opts):
+                f = rr.FirFilter(t)
             for _ in range(2):
                 f.work_dev(x.data_ptr(), n, y.data_ptr(), n)
             torch.cuda.synchronize()

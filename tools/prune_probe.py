@@ -10,9 +10,10 @@ n = 100_000_000
 x = torch.rand(2 * n, device="cuda") * 2 - 1
 y = torch.empty(2 * n, device="cuda")
 rng = np.random.default_rng(1)
-ENV = ("RR_FIR_DIRECT", "RR_FIR_FFT", "RR_FIR_PRUNE")
+OPTS = {}
 def run(make, nin):
-    f = make()
+    with rr.build_options(**OPTS):
+        f = make()
     for _ in range(2):
         f.work_dev(x.data_ptr(), nin, y.data_ptr(), n)
     torch.cuda.synchronize()
@@ -23,22 +24,20 @@ def run(make, nin):
     ms, k = f.profile()
     return ms / k
 def setenv(**kw):
-    for k in ENV:
-        os.environ.pop(k, None)
-    os.environ.update(kw)
+    OPTS.clear(); OPTS.update(kw)
 for L, d in ((32, 4), (64, 4), (127, 4), (401, 4), (64, 8), (127, 8), (255, 8), (401, 8), (1000, 8), (255, 16), (401, 16), (1000, 16), (2000, 16)):
     for cplx in (False, True):
         t = rng.uniform(-1, 1, L) + (1j * rng.uniform(-1, 1, L) if cplx else 0)
         t = (t / L).astype(np.complex64)
         row = []
-        for env in ({"RR_FIR_DIRECT": "1"}, {"RR_FIR_FFT": "1", "RR_FIR_PRUNE": "0"}, {"RR_FIR_PRUNE": "1"}, {}):
+        for env in ({"fir_path": "direct"}, {"fir_path": "fft", "fir_prune": -1, "fir_poly": -1}, {"fir_prune": 1}, {}):
             setenv(**env)
             row.append(run(lambda: rr.FirFilter(t, deci=d), n))
         print(f"FirFilter L={L:5d} d={d:3d} {'complex' if cplx else 'real   '} taps: direct {row[0]:.4f}  deci-store {row[1]:.4f}  pruned {row[2]:.4f}  auto {row[3]:.4f} ms", flush=True)
 taps = rr.low_pass_complex(100e6, 5e6, 943e3)
 for hn, tp, d in ((65, taps, 8), (65, taps, 16), (65, taps, 4), (129, rr.low_pass_complex(100e6, 2e6, 400e3), 16)):
     row = []
-    for env in ({"RR_FIR_PRUNE": "0"}, {"RR_FIR_PRUNE": "1"}):
+    for env in ({"fir_prune": -1}, {"fir_prune": 1}):
         setenv(**env)
         row.append(run(lambda: rr.HilbertFir(hn, tp, d), n))
     print(f"HilbertFir hn={hn} L={len(tp)} d={d}: direct {row[0]:.4f}  pruned {row[1]:.4f} ms per 1e8 real samples", flush=True)

@@ -1,23 +1,21 @@
 #!/usr/bin/env python3
-"""GPU box, measurement library (make ABLATE=1 OUT=../lib_ablate): per-phase cycle counts of one
-FftFilter tile (wave 0 of workgroup 0, its 3rd tile).  Usage: RR_FFT_STAMPS=1 python tools/stamps.py [log2f] [grid_limit]"""
-import ctypes as C, os, sys, shutil
+"""GPU box, timing library (make -C rustradio_amd/csrc TIMING=1 OUT=../lib_timing, loaded through RR_LIB_PATH — the product
+library is never overwritten): per-phase cycle counts of one FftFilter tile (wave 0 of workgroup 0, its 3rd tile).
+Usage: RR_FFT_STAMPS=1 RR_LIB_PATH=$PWD/rustradio_amd/lib_timing/librustradio_amd.so python tools/stamps.py [log2f] [samples]"""
+import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, "rustradio_amd", "lib", "librustradio_amd.so")
-abl = os.path.join(ROOT, "rustradio_amd", "lib_ablate", "librustradio_amd.so")
-shutil.copy(lib, "/tmp/rr_keep.so"); shutil.copy(abl, lib)
 try:
     os.environ["RR_FFT_STAMPS"] = "1"
-    if len(sys.argv) > 1:
-        os.environ["RR_FFT_LOG2F"] = sys.argv[1]
     import torch, numpy as np
     import rustradio_amd as rr
+    OPTS = {"fft_log2f": int(sys.argv[1])} if len(sys.argv) > 1 else {}
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
     taps = rr.low_pass_complex(10e6, 1e6, 60e3)
     x = torch.rand(2 * n, device="cuda") * 2 - 1
     y = torch.empty(2 * (n + 4096), device="cuda")
-    b = rr.FftFilter(taps)
+    with rr.build_options(**OPTS):
+        b = rr.FftFilter(taps)
     for _ in range(3):
         b.work_dev(x.data_ptr(), n, y.data_ptr(), n + 4096, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -30,4 +28,4 @@ try:
     for i, nm in enumerate(names):
         print(f"  {nm:28s} {s[i+1]-s[i]:7d}")
 finally:
-    shutil.copy("/tmp/rr_keep.so", lib)
+    pass
