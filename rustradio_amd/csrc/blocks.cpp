@@ -269,7 +269,8 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
         // with a decimating store (9 us + 3.1e-6 us per sample), whichever the fitted costs favour
         const double t_direct = 5.0 + 7.8e-8 * (double)n * ((double)L / (double)d) * (pl.complex_taps ? 2.0 : 1.0);
         const double t_tiles = 9.0 + 3.1e-6 * (double)n;
-        small_direct = !fftk || t_direct <= t_tiles;
+        // (beyond ~320 taps the direct form's LDS tile stops fitting and it collapses: never there)
+        small_direct = !fftk || (L <= 320 && t_direct <= t_tiles);
     }
     if (use_poly) launch_fir_poly(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, poly->d_tw.p, poly->d_h.p, s);
     else if (small_direct) launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);

@@ -21,6 +21,9 @@ blocks = [("FftFilter401", lambda: rr.FftFilter(lp(10e6, 1e6, 60e3)), 8, 8, 1),
           ("FmChain full", lambda: _opt(dict(fm_poly=-1, fm_full=1), lambda: rr.FmChain(lp(2.4e6, 100e3, 12.5e3), 1, 6, 1.0)), 8, 4, 6),
           ("HilbertFir direct", lambda: _opt(dict(fir_path="direct"), lambda: rr.HilbertFir(65, lp(100e6, 5e6, 943e3), 8)), 4, 8, 8),
           ("HilbertFir no-prune", lambda: _opt(dict(fir_prune=-1), lambda: rr.HilbertFir(65, lp(100e6, 5e6, 943e3), 8)), 4, 8, 8),
+          ("Fir1000/16", lambda: rr.FirFilter(lp(100e6, 2e6, 240e3)[:1000], deci=16), 8, 8, 16),
+          ("Fir2000/5", lambda: rr.FirFilter(np.concatenate([lp(100e6, 2e6, 240e3), lp(100e6, 2e6, 240e3)])[:2000], deci=5), 8, 8, 5),
+          ("Fir1000/4", lambda: rr.FirFilter(lp(100e6, 2e6, 240e3)[:1000], deci=4), 8, 8, 4),
           ("Resampler1:6", lambda: rr.RationalResampler(1, 6), 8, 8, 6),
           ("QuadDemod", lambda: rr.QuadratureDemod(1.0), 8, 4, 1),
           ("Hilbert65", lambda: rr.Hilbert(65), 4, 8, 1)]
