@@ -296,3 +296,36 @@ def test_fuzz_fftstream_float_filters_and_multi(rr, seed):
             dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
             dd = np.minimum(dd, 2 * np.pi - dd)
             assert np.all(dd <= bound[:len(dd)])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_any_size_transforms(rr, seed):
+    """FftStream beyond one tile — four-step powers of two, Bluestein for everything else, up to the stream capacity —
+    against numpy's f64 FFT with the reference's work() arithmetic (fft_stream.rs:71-117: whole frames of min(in, out)), and
+    now and then an FftFilter beyond 16383 taps (overlap-save frames through the same engine) against the oracle."""
+    rng = np.random.default_rng(11000 + seed)
+    kind = seed % 4
+    if kind == 0:
+        size = 1 << int(rng.integers(15, 19))
+    elif kind == 1:
+        size = int(rng.integers(2049, 20_000))
+    elif kind == 2:
+        size = int(rng.integers(20_000, 200_000))
+    else:
+        size = int(rng.choice([16385, 32767, 65537, 99_991, 131_071, 262_145, 400_000, 511_999]))
+    nfr = int(rng.integers(1, max(2, 512_000 // size + 1)))
+    x = _c(rng, nfr * size + int(rng.integers(0, size)))
+    cap = int(rng.choice([512_000, size + int(rng.integers(0, 512_000 - size + 1))]))
+    b = rr.FftStream(size)
+    st, c, p, need, out = b.work(x, cap)
+    n = min(len(x), cap)
+    n -= n % size
+    assert (st, c, p) == (0, n, n)                                   # RR_AGAIN, whole frames only
+    ref = np.fft.fft(x[:n].astype(np.complex128).reshape(-1, size), axis=1).reshape(-1)
+    assert np.max(np.abs(out - ref)) <= TOL * np.max(np.abs(ref))
+    assert b.work(x[:size - 1], cap)[:4] == (1, 0, 0, size)          # WAIT_SRC(size)
+    if seed % 4 == 3:
+        L = int(rng.integers(16_384, 30_000))
+        taps = _c(rng, L) / (L // 8)
+        xs = _c(rng, int(rng.integers(60_000, 200_000)))
+        _both(rr, lambda m: [m.FftFilter(taps)], xs, int(rng.choice([4_096_000, 8 * (65_536 - L + int(rng.integers(1, 9000)))])))
