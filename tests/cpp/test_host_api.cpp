@@ -239,6 +239,53 @@ static void fft_message_block() {
     CHECK(threw);
 }
 
+// rr_fanout_* from compiled code, as a Rust graph would drive it (one-rank group: the double buffer without a communicator).
+// The "source block" and the consumer are rr blocks working on device pointers; device memory comes from rr_dstream rings.
+static void fanout_from_c_abi() {
+    const size_t n = 100000, tiles = 5;
+    std::vector<float> host(n * tiles);
+    for (size_t i = 0; i < host.size(); i++) host[i] = (float)(i % 1000) * 0.25f;
+    rr_dstream* src = rr_dstream_create(4, 4 * host.size());
+    rr_dstream* dst = rr_dstream_create(4, 4 * host.size());
+    CHECK(src && dst);
+    CHECK(rr_dstream_copy_in(src, 0, host.data(), host.size(), nullptr) == 0 && rr_dstream_produce(src, host.size()) == 0);
+    const void* dsrc = nullptr; void* ddst = nullptr;
+    CHECK(rr_dstream_read_buf(src, &dsrc) == host.size());
+    CHECK(rr_dstream_write_buf(dst, &ddst, nullptr) >= host.size());
+    rr_fanout* f = rr_fanout_create(nullptr, 0, 1, 0, 4 * n, 0);
+    CHECK(f != nullptr);
+    rr_block* producer = rr_multiply_const_f32_create(1.0f);
+    rr_block* consumer = rr_multiply_const_f32_create(3.0f);
+    size_t c = 0, p = 0, need = 0;
+    auto produce = [&](unsigned long long t) {
+        void* buf = rr_fanout_produce_buf(f, t, nullptr);
+        CHECK(buf != nullptr);
+        rr_block_work_dev(producer, static_cast<const float*>(dsrc) + t * n, n, buf, n, &c, &p, &need, nullptr);
+        CHECK(c == n && p == n);
+        CHECK(rr_fanout_submit(f, t, nullptr) == 0);
+    };
+    produce(0);
+    for (unsigned long long t = 0; t < tiles; t++) {
+        if (t + 1 < tiles) produce(t + 1);                       // tile t + 1 travels while tile t is consumed
+        const void* x = rr_fanout_acquire(f, t, nullptr);
+        CHECK(x != nullptr);
+        rr_block_work_dev(consumer, x, n, static_cast<float*>(ddst) + t * n, n, &c, &p, &need, nullptr);
+        CHECK(c == n && p == n);
+        CHECK(rr_fanout_release(f, t, nullptr) == 0);
+    }
+    CHECK(rr_fanout_produce_buf(f, tiles + 1, nullptr) == nullptr);   // out of order: an error, not a race
+    CHECK(rr_dstream_produce(dst, host.size()) == 0);
+    std::vector<float> back(host.size());
+    CHECK(rr_dstream_copy_out(dst, 0, back.data(), back.size(), nullptr) == 0);
+    bool same = true;
+    for (size_t i = 0; i < host.size(); i++) same = same && back[i] == host[i] * 3.0f;
+    CHECK(same);
+    double ms = -1; size_t nb = 99;
+    CHECK(rr_fanout_stats(f, &ms, &nb) == 0 && nb == 0);           // no communicator: nothing to time
+    rr_block_destroy(producer); rr_block_destroy(consumer);
+    rr_fanout_destroy(f); rr_dstream_destroy(src); rr_dstream_destroy(dst);
+}
+
 static void fused_blocks_equal_their_chains() {
     const size_t n = 300000;
     std::vector<Complex> x(n);
@@ -562,7 +609,7 @@ static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
     fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
-    device_resident_graph(); fused_blocks_equal_their_chains(); fft_message_block(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests(); handles_on_concurrent_threads();
+    device_resident_graph(); fused_blocks_equal_their_chains(); fanout_from_c_abi(); fft_message_block(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests(); handles_on_concurrent_threads();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }
