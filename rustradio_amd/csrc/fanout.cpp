@@ -191,16 +191,17 @@ struct Fanout {
     void stats(double* ms, size_t* n) {
         RR_HIP(hipSetDevice(device));
         RR_HIP(hipStreamSynchronize(cs));
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> done;
+        done.swap(spans);                                              // the list is drained whatever happens below
         double sum = 0;
-        for (auto& e : spans) {
+        size_t ok = 0;
+        for (auto& e : done) {
             float x = 0;
-            RR_HIP(hipEventElapsedTime(&x, e.first, e.second));
-            sum += x;
+            if (hipEventElapsedTime(&x, e.first, e.second) == hipSuccess) { sum += x; ok++; }
             (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
         }
         if (ms) *ms = sum;
-        if (n) *n = spans.size();
-        spans.clear();
+        if (n) *n = ok;
     }
 };
 }  // namespace rr
