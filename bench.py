@@ -677,7 +677,8 @@ def _sources_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rustradio_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
+        # kernels, their headers and the block logic that picks between them (not the ABI / fan-out / ring plumbing)
+        if f.endswith((".hip", ".hpp")) or f == "blocks.cpp":
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
