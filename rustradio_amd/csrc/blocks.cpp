@@ -800,7 +800,7 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     // 0.065 / 0.087, 1:6 0.067 / 0.085, 1:7 0.083 / 0.095, 1:8 0.096 / 0.083; 2467 taps 1:6 0.086 / 0.157, 1:10 0.113 / 0.152,
     // 1:12 0.159 / 0.149 — every decimation up to 6 (7 phases and more run in two register batches per wave), and up to
     // 10 for filters long enough to push the other kernels onto 4096-point or split tiles.  fm_poly > 0 forces them.
-    window_aware = build_opts().fm_poly <= 0;
+    window_aware = build_opts().fm_poly == 0;          // any forced choice is used at every window size
     const bool poly_wins = D <= 6 || (D <= 10 && f->L >= 800);
     if ((build_opts().fm_poly > 0 || (build_opts().fm_poly == 0 && poly_wins)) && !build_opts().fm_full && I == 1 && D >= 2) {
         std::vector<rr_c32> ct(f->L);
@@ -865,6 +865,9 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
             const uint64_t Ls = (f->L + (uint64_t)D - 1) / (uint64_t)D;
             use_poly = (a.r_hi - a.r_lo) >= (long)(1000 * (1024 - Ls));
         }
+        // (and below ~1.2 M samples the plain 2048-point tiles — more, smaller workgroups — beat the half-size inverse,
+        //  which finishes two tiles per workgroup: 512 k samples 15.4 against 18.8 us)
+        const bool use_half = half_ok && (!window_aware || n_y >= 1200000);
         prof_begin(s);
         if (use_poly && packed)
             launch_fm_chain_poly_iq8(src8, static_cast<float*>(out), (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
@@ -876,10 +879,10 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         else if (f->nsub)
             launch_fm_chain_split(f->nsub, src, static_cast<float*>(out), (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
                                   last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
-        else if (half_ok && packed)
+        else if (use_half && packed)
             launch_fm_chain_half_iq8(src8, static_cast<float*>(out), (int)f->L, f->d_tw.p, d_tw_half.p, f->d_hpos.p, a,
                                      last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
-        else if (half_ok)
+        else if (use_half)
             launch_fm_chain_half(src, static_cast<float*>(out), (int)f->L, f->d_tw.p, d_tw_half.p, f->d_hpos.p, a,
                                  last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (packed)
