@@ -405,7 +405,9 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
         prune.reset(new PruneTables());
         if (!prune->build(td, deci, false, stream)) prune.reset();
     }
-    if (!prune && fits && !force_direct && (force_fft || wins)) {
+    window_aware = bo.fir_prune <= 0 && !force_fft;
+    // (with the pruned inverse the tiles stay beside it as the small-window path of long filters, see work_dev)
+    if (fits && !force_direct && (force_fft || wins || prune)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {taps[i], 0.0f};
         fftk.reset(new FftFilter(ct.data(), ntaps, false, 12, true));
@@ -422,7 +424,16 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     n = std::min(n, out_cap * d);
     VSrc<float> src{nullptr, 0, static_cast<const float*>(in), (long)in_len};
     prof_begin(s);
-    if (prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
+    // as FirC32::work_dev: a batch of the pruned inverse is D tiles of two real segments; below ~1600 batches (46 M samples at
+    // 255 taps / 8) the direct form or the plain tiles finish a call sooner (1 M samples: 33.9 -> 6.7 us, 8 M: 38.5 -> 14.6)
+    bool use_prune = prune != nullptr;
+    if (use_prune && window_aware) {
+        const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - L + 1) * d;
+        use_prune = n >= 1600 * per_batch;
+    }
+    const bool small_direct = prune && !use_prune && (!fftk || L <= 320);
+    if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
+    else if (small_direct) launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
     else if (fftk) fftk->filter_real(src, static_cast<float*>(out), (long)(n / d), (int)d, s);
     else launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
     prof_end(s);

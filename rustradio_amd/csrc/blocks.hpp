@@ -130,6 +130,7 @@ struct FirF32 : Block {
     DevBuf<float> d_tp, d_rev;
     std::unique_ptr<FftFilter> fftk;   // long filters: overlap-save tiles on the real stream (see FirC32::fftk)
     std::unique_ptr<PruneTables> prune; // deci 4 / 8 / 16: pruned inverse (k_fftfilt_prune, real stream x real taps)
+    bool window_aware = true;           // per-call choice by window size (off when a path is forced)
     ~FirF32() override;
     FirF32(const float* taps, size_t ntaps, size_t deci);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;

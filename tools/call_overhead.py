@@ -24,6 +24,11 @@ blocks = [("FftFilter401", lambda: rr.FftFilter(lp(10e6, 1e6, 60e3)), 8, 8, 1),
           ("Fir1000/16", lambda: rr.FirFilter(lp(100e6, 2e6, 240e3)[:1000], deci=16), 8, 8, 16),
           ("Fir2000/5", lambda: rr.FirFilter(np.concatenate([lp(100e6, 2e6, 240e3), lp(100e6, 2e6, 240e3)])[:2000], deci=5), 8, 8, 5),
           ("Fir1000/4", lambda: rr.FirFilter(lp(100e6, 2e6, 240e3)[:1000], deci=4), 8, 8, 4),
+          ("FirFloat255/8", lambda: rr.FirFilter(lp(100e6, 5e6, 943e3).real.astype(np.float32), deci=8), 4, 4, 8),
+          ("FirFloat255/8 direct", lambda: _opt(dict(fir_path="direct"), lambda: rr.FirFilter(lp(100e6, 5e6, 943e3).real.astype(np.float32), deci=8)), 4, 4, 8),
+          ("FirFloat255/8 no-prune", lambda: _opt(dict(fir_prune=-1), lambda: rr.FirFilter(lp(100e6, 5e6, 943e3).real.astype(np.float32), deci=8)), 4, 4, 8),
+          ("FirFloat1000/4", lambda: rr.FirFilter(lp(100e6, 2e6, 240e3)[:1000].real.astype(np.float32), deci=4), 4, 4, 4),
+          ("FirFloat1000/4 no-prune", lambda: _opt(dict(fir_prune=-1), lambda: rr.FirFilter(lp(100e6, 2e6, 240e3)[:1000].real.astype(np.float32), deci=4)), 4, 4, 4),
           ("Resampler1:6", lambda: rr.RationalResampler(1, 6), 8, 8, 6),
           ("QuadDemod", lambda: rr.QuadratureDemod(1.0), 8, 4, 1),
           ("Hilbert65", lambda: rr.Hilbert(65), 4, 8, 1)]
