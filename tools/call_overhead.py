@@ -29,6 +29,11 @@ blocks = [("FftFilter401", lambda: rr.FftFilter(lp(10e6, 1e6, 60e3)), 8, 8, 1),
           ("FirFloat255/8 no-prune", lambda: _opt(dict(fir_prune=-1), lambda: rr.FirFilter(lp(100e6, 5e6, 943e3).real.astype(np.float32), deci=8)), 4, 4, 8),
           ("FirFloat1000/4", lambda: rr.FirFilter(lp(100e6, 2e6, 240e3)[:1000].real.astype(np.float32), deci=4), 4, 4, 4),
           ("FirFloat1000/4 no-prune", lambda: _opt(dict(fir_prune=-1), lambda: rr.FirFilter(lp(100e6, 2e6, 240e3)[:1000].real.astype(np.float32), deci=4)), 4, 4, 4),
+          ("FftFilterFloat963", lambda: rr.FftFilterFloat(rr.low_pass(200e3, 15e3, 5e3)), 4, 4, 1),
+          ("AudioChain963 6:25", lambda: rr.AudioChain(rr.low_pass(200e3, 15e3, 5e3), 6, 25, 0.5), 4, 4, 4),
+          ("FftStream1024", lambda: rr.FftStream(1024), 8, 8, 1),
+          ("FftStream3000", lambda: rr.FftStream(3000), 8, 8, 1),
+          ("FftStream65536", lambda: rr.FftStream(65536), 8, 8, 1),
           ("Resampler1:6", lambda: rr.RationalResampler(1, 6), 8, 8, 6),
           ("QuadDemod", lambda: rr.QuadratureDemod(1.0), 8, 4, 1),
           ("Hilbert65", lambda: rr.Hilbert(65), 4, 8, 1)]
