@@ -509,13 +509,19 @@ def run_timed(w, steps, warmup, dist, stream, fan=None, src_ptr=None):
     cs = stream.cuda_stream
     t = 0
 
+    k = getattr(fan, "tile_steps", 1)           # steps of source per fanned-out tile
+    step_bytes = getattr(fan, "step_bytes", 0)
+
     def one(t):
         if fan is None:
             return w.step(cs, src_ptr)           # (src_ptr: a tile already resident on this rank instead of bufs[0])
-        fan.prefetch(t + 1)                      # tile t+1 travels while tile t is computed
-        x = fan.acquire(t, stream)
-        u = w.step(cs, x.data_ptr())
-        fan.release(t, stream)
+        T, sub = divmod(t, k)
+        if sub == 0:
+            fan.prefetch(T + 1)                  # tile T+1 travels while the k steps of tile T are computed
+        x = fan.acquire(T, stream)               # (idempotent; the compute stream waits for the tile's fan-out)
+        u = w.step(cs, x.data_ptr() + sub * step_bytes)
+        if sub == k - 1:
+            fan.release(T, stream)
         return u
 
     if fan is not None:
@@ -820,6 +826,9 @@ def main():
     ap.add_argument("--fanout-algo", choices=("auto", "bcast", "scatter_allgather"), default="auto",
                     help="N > 1, --fanout torch: one broadcast per tile, scatter + all-gather over the xGMI mesh, or (default) "
                          "whichever is faster on this job's fabric, timed before the run")
+    ap.add_argument("--tile-steps", type=int, default=4,
+                    help="N > 1: steps of source per fanned-out tile (the fan-out of a tile costs the host ~0.1 ms through "
+                         "torch.distributed, as much as one 0.09 ms step: tools/fanout_overhead.py)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="rr_build_opts override for every block built (e.g. fft_log2f=11, fir_path=direct)")
     args = ap.parse_args()
@@ -865,7 +874,7 @@ def main():
     with rr.build_options(**opts):
         w = WORKLOADS[wname](dev, rank, world, shared_src)
     def make_fan(wl):
-        """the streaming fan-out of wl's shared source (resident on rank 0): one tile = one step's input"""
+        """the streaming fan-out of wl's shared source (resident on rank 0): one tile = --tile-steps steps of input"""
         if world == 1:
             return None
         store = wl.bufs[0]
@@ -873,32 +882,43 @@ def main():
         dist.broadcast(meta, src=0)
         sdtype = torch.uint8 if wl.in_mult == 2 else torch.float32
 
-        def produce(t, out):                  # rank 0: the source block writes tile t into the ring half
-            out.copy_(store, non_blocking=True)
+        k = max(1, args.tile_steps)
+        step_elems = int(meta.item())
+
+        def produce(t, out):                  # rank 0: the source block writes the k steps of tile t into the ring half
+            out.view(k, step_elems).copy_(store.unsqueeze(0).expand(k, step_elems), non_blocking=True)
+
+        def tag(f):
+            f.tile_steps, f.step_bytes = k, step_elems * (1 if sdtype == torch.uint8 else 4)
+            if k >= 2:
+                f.TIME_EVERY = 1              # a fan-out every k steps: timing each one costs the stream little
+            return f
         if args.fanout == "abi":
             if backend != "nccl":
                 raise SystemExit("bench.py --fanout abi: rr_fanout_* binds RCCL, which needs one GPU per rank")
-            return multi.AbiFanout(rr, dist, rank, int(meta.item()), sdtype, dev, produce,
-                                   mesh=args.fanout_algo == "scatter_allgather")
+            return tag(multi.AbiFanout(rr, dist, rank, k * step_elems, sdtype, dev, produce,
+                                       mesh=args.fanout_algo == "scatter_allgather"))
         try:
-            return multi.TileFanout(dist, rank, int(meta.item()), sdtype, dev, produce, algo=args.fanout_algo)
+            return tag(multi.TileFanout(dist, rank, k * step_elems, sdtype, dev, produce, algo=args.fanout_algo))
         except RuntimeError as e:             # a backend without scatter / all-gather on device tensors: the broadcast always works
             if rank == 0:
                 print(f"bench.py: fan-out algorithm {args.fanout_algo!r} unavailable ({e}); using bcast", file=sys.stderr)
-            return multi.TileFanout(dist, rank, int(meta.item()), sdtype, dev, produce, algo="bcast")
+            return tag(multi.TileFanout(dist, rank, k * step_elems, sdtype, dev, produce, algo="bcast"))
 
     def collective_report(fan_, kms_, steps_, wall_ms):
         bms_sum, bn = fan_.broadcast_ms()
         bms = bms_sum / max(bn, 1)
         kstep = kms_ / max(steps_, 1)
+        ks = getattr(fan_, "tile_steps", 1)
+        bstep = bms / ks                         # fan-out time per step of source
         return {"backend": "rccl" if backend == "nccl" else backend, "fanout": args.fanout,
                 "algorithm": getattr(fan_, "algo", "bcast"), "calibration_ms_per_tile": getattr(fan_, "calibration", None),
                 "ranks": dist.get_world_size(),
-                "devices_visible": ndev, "tile_bytes": fan_.bytes_per_tile, "broadcasts_timed": bn,
-                "broadcast_ms_per_tile": round(bms, 4),
+                "devices_visible": ndev, "tile_bytes": fan_.bytes_per_tile, "tile_steps": ks, "broadcasts_timed": bn,
+                "broadcast_ms_per_tile": round(bms, 4), "broadcast_ms_per_step": round(bstep, 4),
                 "source_broadcast_gbs": round(fan_.bytes_per_tile / (bms * 1e-3) / 1e9, 1) if bms > 0 else None,
                 "kernel_ms_per_step": round(kstep, 4),
-                "overlap": round(max(0.0, min(1.0, (bms + kstep - wall_ms) / max(min(bms, kstep), 1e-9))), 3)}
+                "overlap": round(max(0.0, min(1.0, (bstep + kstep - wall_ms) / max(min(bstep, kstep), 1e-9))), 3)}
 
     fan = make_fan(w)
     units, dt, kms, launches, dom_units, step_ms = run_timed(w, args.steps, args.warmup, dist, stream, fan)
@@ -912,7 +932,7 @@ def main():
     resident = None
     if fan is not None:
         torch.cuda.synchronize()
-        tile = fan.buf[0] if hasattr(fan, "buf") else fan.acquire(fan.issued, stream)
+        tile = fan.buf[0] if hasattr(fan, "buf") else fan.acquire(fan.issued, stream)      # (its first step's worth is read)
         u1, t1, _, _, _, sm1 = run_timed(w, args.steps, 2, dist, stream, None, tile.data_ptr())
         u1a, t1a = multi.aggregate(dist, u1, t1, dev)
         resident = {"value": round(u1a / t1a / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(t1a / args.steps * 1e3, 4),

@@ -43,7 +43,7 @@ def test_two_rank_line():
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "configs[3]" in d["config"]["workload"]
     c = d["collective"]
-    assert c["ranks"] == 2 and c["tile_bytes"] == 19_200_000 and c["broadcasts_timed"] >= 1
+    assert c["ranks"] == 2 and c["tile_steps"] == 4 and c["tile_bytes"] == 4 * 19_200_000 and c["broadcasts_timed"] >= 1
     assert c["algorithm"] in ("bcast", "scatter_allgather")
     res = d["resident_source"]
     assert res["value"] > 0 and d["value"] > 0

@@ -20,17 +20,19 @@ out = torch.empty(32 * cap, device=dev)
 stream = torch.cuda.current_stream()
 
 
-def loop(fan, steps=60):
+def loop(fan, steps=60, k=1):
     t = 0
     if fan: fan.prefetch(0)
     def one(t):
         if fan:
-            fan.prefetch(t + 1); x = fan.acquire(t, stream); p = x.data_ptr()
+            T, sub = divmod(t, k)
+            if sub == 0: fan.prefetch(T + 1)
+            x = fan.acquire(T, stream); p = x.data_ptr() + sub * 8 * n
         else:
             p = store.data_ptr()
         blk.work_dev(p, n, out.data_ptr(), cap, stream.cuda_stream)
-        if fan: fan.release(t, stream)
-    for _ in range(5): one(t); t += 1
+        if fan and t % k == k - 1: fan.release(t // k, stream)
+    for _ in range(8): one(t); t += 1
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): one(t); t += 1
     host = time.perf_counter() - t0
@@ -46,6 +48,13 @@ for algo in ("bcast", "scatter_allgather"):
     if algo != "bcast":
         fan.can_scatter, fan.algo = True, algo          # one rank: force the two-collective form for its host cost
     print("%-24s host %.3f ms/step, wall %.3f" % (algo, *loop(fan)))
+for k in (2, 4):
+    def producek(t, o): o.view(k, 2 * n).copy_(store.unsqueeze(0).expand(k, 2 * n), non_blocking=True)
+    for algo in ("bcast", "scatter_allgather"):
+        fan = multi.TileFanout(dist, 0, 2 * n * k, torch.float32, dev, producek, algo="bcast")
+        if algo != "bcast":
+            fan.can_scatter, fan.algo = True, algo
+        print("%-24s host %.3f ms/step, wall %.3f" % (f"{algo} tile={k} steps", *loop(fan, 60, k)))
 for mesh, timing, rccl in ((False, True, True), (True, True, True), (False, False, True), (False, False, False)):
     fan = multi.AbiFanout(rr, None, 0, 2 * n, torch.float32, dev, produce, rccl_always=rccl, mesh=mesh, timing=timing)
     print("%-24s host %.3f ms/step, wall %.3f" % ("abi " + ("mesh" if mesh else "bcast") + ("" if timing else " untimed") + ("" if rccl else " no-rccl"), *loop(fan)))
