@@ -493,7 +493,7 @@ WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_c
 
 
 # ---- measurement ------------------------------------------------------------------------------
-def run_timed(w, steps, warmup, dist, stream, fan=None, src_ptr=None):
+def run_timed(w, steps, warmup, dist, stream, fan=None, src_ptr=None, settle_ms=0.0):
     """W untimed warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize on both sides.
     With `fan` (multi.TileFanout) every step's input is the tile rank 0 produced and broadcast during the previous
     step.  -> units, wall seconds, dominant-kernel ms, launches, dominant units, per-step times (ms, HIP events)
@@ -526,6 +526,29 @@ def run_timed(w, steps, warmup, dist, stream, fan=None, src_ptr=None):
 
     if fan is not None:
         fan.prefetch(0)
+    # Settle (untimed, before the W warm-up steps): the same step back to back for ~settle_ms of GPU time.  From idle the
+    # first few passes run at boost clocks, the power controller then clamps hard and relaxes to its equilibrium over the
+    # next ~40 ms (tools/step_series.py, FftFilter, ms per step: 0.33 0.33 0.34 | 0.40 0.42 0.45 0.47 ... | 0.38 by step 30,
+    # 0.357 by step 50, 0.342 from step 100 on for as long as the load lasts).  A streaming graph runs for hours: the
+    # sustained rate is the one to report, and W = 5 warm-up steps end in the middle of the dip.
+    n_settle = 0
+    if settle_ms > 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(4):
+            one(t); t += 1
+        e1.record(stream)
+        torch.cuda.synchronize()
+        est = max(e0.elapsed_time(e1) / 4, 1e-3)
+        n_settle = int(min(4000, max(40, settle_ms / est)))
+        if dist is not None:                     # every rank runs the same number of steps (the fan-out is collective)
+            ns = torch.tensor([n_settle], dtype=torch.int64, device=stream.device)
+            dist.all_reduce(ns, op=dist.ReduceOp.MAX)
+            n_settle = int(ns.item())
+        for _ in range(n_settle):
+            one(t); t += 1
+        n_settle += 4
+    w.settle_steps = n_settle
     for _ in range(warmup):
         one(t); t += 1
     torch.cuda.synchronize()
@@ -826,6 +849,9 @@ def main():
     ap.add_argument("--fanout-algo", choices=("auto", "bcast", "scatter_allgather"), default="auto",
                     help="N > 1, --fanout torch: one broadcast per tile, scatter + all-gather over the xGMI mesh, or (default) "
                          "whichever is faster on this job's fabric, timed before the run")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed passes of the workload before the warm-up steps, until the power controller's start-up "
+                         "transient is over (tools/step_series.py); 0 = none")
     ap.add_argument("--tile-steps", type=int, default=4,
                     help="N > 1: steps of source per fanned-out tile (the fan-out of a tile costs the host ~0.1 ms through "
                          "torch.distributed, as much as one 0.09 ms step: tools/fanout_overhead.py)")
@@ -921,7 +947,8 @@ def main():
                 "overlap": round(max(0.0, min(1.0, (bstep + kstep - wall_ms) / max(min(bstep, kstep), 1e-9))), 3)}
 
     fan = make_fan(w)
-    units, dt, kms, launches, dom_units, step_ms = run_timed(w, args.steps, args.warmup, dist, stream, fan)
+    units, dt, kms, launches, dom_units, step_ms = run_timed(w, args.steps, args.warmup, dist, stream, fan, settle_ms=args.settle_ms)
+    settle_main = getattr(w, "settle_steps", 0)
 
     # max over ranks of the wall time, sum over ranks of the units
     units_all, dt = multi.aggregate(dist, units, dt, dev)
@@ -933,7 +960,7 @@ def main():
     if fan is not None:
         torch.cuda.synchronize()
         tile = fan.buf[0] if hasattr(fan, "buf") else fan.acquire(fan.issued, stream)      # (its first step's worth is read)
-        u1, t1, _, _, _, sm1 = run_timed(w, args.steps, 2, dist, stream, None, tile.data_ptr())
+        u1, t1, _, _, _, sm1 = run_timed(w, args.steps, 2, dist, stream, None, tile.data_ptr(), settle_ms=args.settle_ms / 2)
         u1a, t1a = multi.aggregate(dist, u1, t1, dev)
         resident = {"value": round(u1a / t1a / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(t1a / args.steps * 1e3, 4),
                     "ms_per_step_median": round(statistics.median(sm1), 4),
@@ -948,7 +975,7 @@ def main():
                 wo = WORKLOADS[name](dev, rank, world, shared_src if streamed else (lambda gen, numel, dtype: gen()))
             k = max(3, min(args.steps, 10)) if name != "fir" else 200
             fo = make_fan(wo) if streamed else None
-            u, t, km, ln, du, sm = run_timed(wo, k, 2, dist, stream, fo)
+            u, t, km, ln, du, sm = run_timed(wo, k, 2, dist, stream, fo, settle_ms=args.settle_ms / 2)
             ua, ta = multi.aggregate(dist, u, t, dev)
             avg_s = km / max(ln, 1) * 1e-3
             ach = (wo.dominant_bytes_per_unit * du / max(ln, 1)) / avg_s / 1e9 if km > 0 else None
@@ -995,7 +1022,7 @@ def main():
                f"tile by tile on a communication stream, double-buffered against the compute stream, inside the timed region")
         line = {
             "metric": METRIC, "value": round(value, 2), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_main,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "ms_per_step_median": round(statistics.median(step_ms), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
