@@ -532,6 +532,17 @@ def run_timed(w, steps, warmup, dist, stream, fan=None, src_ptr=None, settle_ms=
     # 0.357 by step 50, 0.342 from step 100 on for as long as the load lasts).  A streaming graph runs for hours: the
     # sustained rate is the one to report, and W = 5 warm-up steps end in the middle of the dip.
     n_settle = 0
+    w.cold_ms_per_step = None
+    if settle_ms > 0 and fan is None and dist is None and getattr(w, "report_cold", False):
+        # for the record: the same W + K steps straight from idle, i.e. what the line would say without the settle phase
+        for _ in range(warmup):
+            one(t); t += 1
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(steps):
+            one(t); t += 1
+        torch.cuda.synchronize()
+        w.cold_ms_per_step = (time.perf_counter() - c0) / max(steps, 1) * 1e3
     if settle_ms > 0:
         for _ in range(2):                       # (the very first launch of a kernel pays its one-time set-up)
             one(t); t += 1
@@ -949,6 +960,7 @@ def main():
                 "overlap": round(max(0.0, min(1.0, (bstep + kstep - wall_ms) / max(min(bstep, kstep), 1e-9))), 3)}
 
     fan = make_fan(w)
+    w.report_cold = True
     units, dt, kms, launches, dom_units, step_ms = run_timed(w, args.steps, args.warmup, dist, stream, fan, settle_ms=args.settle_ms)
     settle_main = getattr(w, "settle_steps", 0)
 
@@ -1025,6 +1037,7 @@ def main():
         line = {
             "metric": METRIC, "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_main,
+            "ms_per_step_from_idle": None if getattr(w, "cold_ms_per_step", None) is None else round(w.cold_ms_per_step, 4),
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "ms_per_step_median": round(statistics.median(step_ms), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
