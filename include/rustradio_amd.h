@@ -112,8 +112,10 @@ int    rr_hilbert_taps(const float *window, size_t ntaps, float *out);
 /* FirFilter::<Complex>::builder(taps).deci(deci)[.translate(samp_rate, freq)].build(src)
  * (src/fir.rs:303-386, 476-486).  translate != 0 requests frequency translation
  * (freq == 0 disables it, fir.rs:438-440).  NULL on invalid args (the reference asserts).
- * Arithmetic: Fir::filter_n (fir.rs:166-197) either in direct form or — longer filters — on overlap-save FFT
- * tiles, whichever is cheaper for (ntaps, deci); both within 1e-5 of the reference (rr_fir_fft_tile tells). */
+ * Arithmetic: Fir::filter_n (fir.rs:166-197) in direct form or on overlap-save FFT tiles (plain, decimating store,
+ * half-size / pruned inverse, decimate-first), whichever is cheaper for (ntaps, deci) AND the window of the call — the
+ * block carries no arithmetic state between calls, so a 512,000-sample ring and a 1e8-sample batch may take different
+ * kernels; all within 1e-5 of the reference (rr_fir_fft_tile tells the large-window choice; rr_build_opts forces one). */
 rr_block *rr_fir_c32_create(const rr_c32 *taps, size_t ntaps, size_t deci,
                             int translate, float samp_rate, float freq);
 /* FirFilter::<Float> (same generic block, src/fir.rs:343-386; long filters on real-stream overlap-save tiles). */
