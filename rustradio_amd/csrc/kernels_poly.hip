@@ -344,7 +344,7 @@ template <int D, class SRC>
 __global__ __launch_bounds__(512, 1)
 void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long ntiles, const cf* __restrict__ tw,
                      const cf* __restrict__ hreg, int nchan, PolyArgs a, const cf* __restrict__ last_r_in,
-                     cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg) {
+                     cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg, int groups) {
     static_assert(D <= 8, "one phase per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     creg* lds = reinterpret_cast<creg*>(smem_raw);
@@ -359,15 +359,20 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
     const int Sa = PF - a.Ls;
     const creg* hr = reinterpret_cast<const creg*>(hreg);
 
+    // A unit of work = (tile, channel group): with fewer tiles than CUs (ring-sized windows) the channels of a tile are split
+    // over `groups` workgroups — each repeats the shared forward transforms (~1/11 of a 32-channel tile) and takes every
+    // groups-th block of 8 channels; groups == 1 for windows that fill the chip.
     int iter = 0;
-    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step, iter++) {
+    for (TileIter it(ntiles * groups); it.tile < it.end; it.tile += it.step, iter++) {
 #ifdef RR_FFT_TIMING_BUILD
         unsigned long long* stamps = (dbg && blockIdx.x == 0 && t == 0 && iter == 1 && w < 2) ? dbg + 16 * w : nullptr;
 #else
         (void)dbg; (void)iter;
 #endif
         PSTAMP(0);
-        const long u0 = a.r_lo + it.tile * Sa;
+        const long tile_ = it.tile / groups;
+        const int grp = (int)(it.tile - tile_ * groups);
+        const long u0 = a.r_lo + tile_ * Sa;
         const long vbase = (u0 - a.Ls) * D + a.off;
         const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
         if (w < D) {
@@ -381,7 +386,7 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
         tile_sync<512>();
         PSTAMP(2);
 #pragma unroll 1
-        for (int c = w; c < nchan; c += 8) {
+        for (int c = 8 * grp + w; c < nchan; c += 8 * groups) {
             const creg* hc = hr + (long)c * D * 16 * PT + t;
             creg z[16], h[2][16];
 #pragma unroll
@@ -399,16 +404,16 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
                 for (int j = 0; j < 16; j++) z[j] = cmac(z[j], park[(p * 16 + j) * PT + t], h[p & 1][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (c == w) PSTAMP(3);
+            if (c == 8 * grp + w) PSTAMP(3);
             poly_inverse(z, t, ex, tw0, tab1);
             lds_store<PLG, 0>(z, t, ex);                 // natural order in the wave's own area
             wave_fence();
-            if (c == w) PSTAMP(4);
+            if (c == 8 * grp + w) PSTAMP(4);
             float* oc = out + (long)c * out_stride;
             if (a.mode == 0) poly_demod_tile<0>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
             else poly_demod_tile<1>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
             wave_fence();
-            if (c == w) PSTAMP(5);
+            if (c == 8 * grp + w) PSTAMP(5);
         }
         PSTAMP(6);
         tile_sync<512>();                                // every wave is done with the parked spectra
@@ -492,10 +497,16 @@ static void launch_multi_poly_d(SRC src, float* out, long out_stride, int L, con
     if (nr <= 0) return;
     const long ntiles = (nr + Sa - 1) / Sa;
     const size_t smem = sizeof(cf) * (8 * PLE + D * PF + 64);
-    long grid = grid_for_tiles(k_fm_multi_poly<D, SRC>, 512, smem, ntiles);
-    if (ntiles > grid && ntiles < 12 * grid) grid = std::min(ntiles, 3 * grid);      // (as launch_chain_poly_d: 0.093 -> 0.0905 ms)
+    // fewer tiles than CUs (a 512,000-sample ring holds 90 at 1:6): split each tile's channels over several workgroups
+    // (tools/multi_small.py: 32 channels, 512 k samples 76 -> 45 us per call)
+    const long cus = device_cu_count();
+    const int max_groups = std::max(1, (nchan + 7) / 8);
+    const int groups = ntiles >= cus ? 1 : (int)std::min<long>(max_groups, cus / ntiles);
+    const long units = ntiles * groups;
+    long grid = grid_for_tiles(k_fm_multi_poly<D, SRC>, 512, smem, units);
+    if (units > grid && units < 12 * grid) grid = std::min(units, 3 * grid);         // (as launch_chain_poly_d: 0.093 -> 0.0905 ms)
     hipLaunchKernelGGL((k_fm_multi_poly<D, SRC>), dim3((unsigned)grid), dim3(512), smem, s, src, out, out_stride, ntiles, tw, hreg,
-                       nchan, a, last_in, last_out, fft_stamp_buffer());
+                       nchan, a, last_in, last_out, fft_stamp_buffer(), groups);
     RR_HIP(hipGetLastError());
 }
 template <class SRC>
