@@ -34,6 +34,10 @@ blocks = [("FftFilter401", lambda: rr.FftFilter(lp(10e6, 1e6, 60e3)), 8, 8, 1),
           ("FftStream1024", lambda: rr.FftStream(1024), 8, 8, 1),
           ("FftStream3000", lambda: rr.FftStream(3000), 8, 8, 1),
           ("FftStream65536", lambda: rr.FftStream(65536), 8, 8, 1),
+          ("FftFilter2467", lambda: rr.FftFilter(lp(1.024e6, 100e3, 1e3)), 8, 8, 1),
+          ("FftFilter2467 F=4096", lambda: _opt(dict(fft_log2f=12), lambda: rr.FftFilter(lp(1.024e6, 100e3, 1e3))), 8, 8, 1),
+          ("FftFilter2467 F=16384", lambda: _opt(dict(fft_log2f=14), lambda: rr.FftFilter(lp(1.024e6, 100e3, 1e3))), 8, 8, 1),
+          ("FmChain2467 25:128", lambda: rr.FmChain(lp(1.024e6, 100e3, 1e3), 200000, 1024000, 1.0), 8, 4, 5),
           ("Resampler1:6", lambda: rr.RationalResampler(1, 6), 8, 8, 6),
           ("QuadDemod", lambda: rr.QuadratureDemod(1.0), 8, 4, 1),
           ("Hilbert65", lambda: rr.Hilbert(65), 4, 8, 1)]
