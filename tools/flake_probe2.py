@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+"""GPU box: as flake_probe.py, tile by tile — which tiles (if any) differ between two runs of FftFilter on the same input."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
