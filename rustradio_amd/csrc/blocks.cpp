@@ -675,6 +675,22 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
         d_hs.upload(hs.data(), hs.size(), stream);
         d_wk.upload(wk.data(), wk.size(), stream);
         d_tw4096.upload(tw4.data(), tw4.size(), stream);
+        // Small windows: a split tile is one workgroup of 512 threads per 8192 / 16384 points, two per CU — a ring-sized
+        // window (512,000 samples = 90 tiles at 2467 taps) leaves most of the chip idle.  The plain 4096-point tile is less
+        // efficient per sample but four to ten times as many workgroups (tools/call_overhead.py, 2467 taps: 512 k samples
+        // 26.2 -> 16.8 us, 2 M 30.3 -> 25.3, 8 M 57.4 -> 64.3): kept beside the split tables, chosen per call (results do
+        // not depend on the tile beyond f32 rounding, the carried state is tile-independent).
+        if (!real && L + 512 <= 4096 && build_opts().fft_log2f == 0) {
+            std::vector<cf> hp, twa(4096);
+            compute_hpos(taps, ntaps, 12, hp);
+            for (size_t k = 0; k < 4096; k++) {
+                const double a = -2.0 * 3.14159265358979323846 * (double)k / 4096.0;
+                twa[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+            }
+            d_hpos_alt.upload(hp.data(), 4096, stream);
+            d_tw_alt.upload(twa.data(), 4096, stream);
+            alt_log2f = 12;
+        }
     }
     // prefix = [L-1 history samples][pending < nsamples]; zero history at stream start (A.4)
     const size_t pcap = hist + nsamples + 1;
@@ -703,7 +719,8 @@ void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s) {
         }
         return;
     }
-    if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s);
+    if (nsub && alt_log2f && n_out < small_window_outputs()) launch_fftfilt_os(alt_log2f, src, out, n_out, (int)L, d_tw_alt.p, d_hpos_alt.p, s);
+    else if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s);
     else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s);
 }
 
@@ -879,11 +896,19 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         // (and below ~1.2 M samples the plain 2048-point tiles — more, smaller workgroups — beat the half-size inverse,
         //  which finishes two tiles per workgroup: 512 k samples 15.4 against 18.8 us)
         const bool use_half = half_ok && (!window_aware || n_y >= 1200000);
+        const bool use_alt = f->nsub && f->alt_log2f && window_aware && (long)n_y < f->small_window_outputs() &&
+                             (int64_t)((D + I - 1) / I) < (int64_t)(((size_t)1 << f->alt_log2f) - f->L + 1);
         prof_begin(s);
         if (use_poly && packed)
             launch_fm_chain_poly_iq8(src8, static_cast<float*>(out), (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (use_poly)
             launch_fm_chain_poly(src, static_cast<float*>(out), (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (use_alt && packed)        // long filter, window of too few split tiles: the plain 4096-point chain tile (see FftFilter)
+            launch_fm_chain_iq8(f->alt_log2f, src8, static_cast<float*>(out), (int)f->L, f->d_tw_alt.p, f->d_hpos_alt.p, a,
+                                last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+        else if (use_alt)
+            launch_fm_chain(f->alt_log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw_alt.p, f->d_hpos_alt.p, a,
+                            last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (f->nsub && packed)
             launch_fm_chain_split_iq8(f->nsub, src8, static_cast<float*>(out), (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
                                       last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);

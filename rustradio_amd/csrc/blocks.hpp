@@ -143,6 +143,11 @@ struct FftFilter : Block {
     // >= 8192-point tiles as nsub interleaved 4096-point sub-transforms (kernels_fft.hip k_fftfilt_split)
     int nsub = 0;
     DevBuf<cf> d_tw4096, d_hs, d_wk;
+    // plain 4096-point tile beside the split tables, for windows of too few split tiles to fill the chip
+    int alt_log2f = 0;
+    DevBuf<cf> d_tw_alt, d_hpos_alt;
+    // below ~520 split tiles (two resident workgroups per CU) the alternate tile wins
+    long small_window_outputs() const { return 520L * (long)(((size_t)1 << log2f) - L + 1); }
     // more than 16383 taps: overlap-save frames of M = 2^m >= 2 L points through the any-size transform (AnyFft)
     std::unique_ptr<AnyFft> big;
     size_t bigM = 0;

@@ -197,6 +197,33 @@ def test_fftfilter(rr, L):
     assert (f_ref, s_ref) == orc.fftfilter_dims(orc.FftFilter(taps))
 
 
+@pytest.mark.parametrize("L", [2467, 3300])
+@pytest.mark.parametrize("forced", [13, 14, 0])
+def test_long_filter_split_and_alternate_tiles(rr, monkeypatch, L, forced):
+    """Filters of 2500-3500 taps run on 8192-point split tiles for large windows and on plain 4096-point tiles for windows of
+    too few split tiles to fill the chip (chosen per call).  forced = 13 / 14: the split tiles on these small inputs too
+    (rr_build_opts.fft_log2f); 0: the block's own choice (the alternate tile here).  FftFilter and the fused chains, c32 and u8."""
+    if forced:
+        knob(rr, monkeypatch, fft_log2f=forced)
+    taps = rnd_c(L, 17 + L) / (L // 4)
+    x = rnd_c(300_000, L)
+    both(rr, lambda m: [m.FftFilter(taps)], x)
+    both(rr, lambda m: [m.FftFilter(taps)], x[:120_000], stream_bytes=8 * (8192 - L + 3000))
+    z = fm_signal(200_000, 1.024e6, 0.0, L)
+    for I, D in ((25, 128), (1, 5)):
+        knob(rr, monkeypatch, fm_poly=-1)                  # (1:5 would otherwise take the decimate-first tiles)
+        yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D), orc.QuadratureDemod(1.0)], z)
+        ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D)], z)
+        yg = run_chain([rr.FmChain(taps, I, D, 1.0)], z)
+        _demod_close(yg, yo, ro)
+    b = np.empty(2 * len(z), np.uint8)
+    b[0::2] = np.clip(np.round(z.real / 0.008 + 127), 0, 255)
+    b[1::2] = np.clip(np.round(z.imag / 0.008 + 127), 0, 255)
+    yo = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(25, 128), orc.QuadratureDemod(1.0)], b)
+    ro = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(25, 128)], b)
+    _demod_close(run_chain([rr.FmChainU8(taps, 25, 128, 1.0)], b), yo, ro)
+
+
 def test_fftfilter_chunked_and_small_outputs(rr):
     taps = orc.low_pass_complex(10e6, 1e6, 60e3)
     x = rnd_c(150_000, 77)
