@@ -122,7 +122,8 @@ rr_block *rr_fir_c32_create(const rr_c32 *taps, size_t ntaps, size_t deci,
 rr_block *rr_fir_f32_create(const float *taps, size_t ntaps, size_t deci);
 /* FftFilter::new(src, taps) (src/fft_filter.rs:242-279).  Up to 16383 taps run on LDS-resident overlap-save tiles; longer
  * filters (up to 524,288 taps; the reference has no limit) as overlap-save frames of 2^m >= 2 ntaps points through the
- * any-size transform (plain HBM-streaming passes). */
+ * any-size transform (plain HBM-streaming passes).  The tile size is internal (rr_fftfilter_dims reports it) and, for long
+ * filters, depends on the window of the call; outputs do not depend on it beyond f32 rounding. */
 rr_block *rr_fftfilter_create(const rr_c32 *taps, size_t ntaps);
 /* FftFilterFloat::new(src, taps) (src/fft_filter.rs:391-426). */
 rr_block *rr_fftfilter_float_create(const float *taps, size_t ntaps);
