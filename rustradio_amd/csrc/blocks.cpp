@@ -260,7 +260,9 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
             use_poly = out_n >= 1000 * per_tile;                               // one tile per resident workgroup slot
         } else {
             const size_t F = (size_t)1 << prune->log2f, per_batch = (F - L + 1) / d * d * d;   // D tiles of F - L + 1 inputs
-            use_prune = n >= 1400 * per_batch;
+            // (crossover in batches, tools/prune_window_probe.py: ~1.0-1.5x the resident workgroup slots of the tile —
+            //  64-thread tiles at /4: 2000, 128-thread at /8: 1500, 256-thread at /16: 550)
+            use_prune = n >= (d == 4 ? 2000 : d == 8 ? 1500 : 550) * per_batch;
         }
     }
     bool small_direct = false;
@@ -366,7 +368,7 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     bool use_prune = prune != nullptr;
     if (use_prune && fir->window_aware) {
         const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - (size_t)plG.L + 1) * (d / 2);
-        use_prune = n >= 2100 * per_batch;
+        use_prune = n >= (d == 4 ? 2800 : d == 8 ? 2100 : 800) * per_batch;
     }
     if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s);
     else launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s);
@@ -429,7 +431,7 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     bool use_prune = prune != nullptr;
     if (use_prune && window_aware) {
         const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - L + 1) * d;
-        use_prune = n >= 1600 * per_batch;
+        use_prune = n >= (d == 4 ? 2200 : d == 8 ? 1600 : 600) * per_batch;
     }
     const bool small_direct = prune && !use_prune && (!fftk || L <= 320);
     if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
