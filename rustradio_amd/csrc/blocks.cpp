@@ -335,7 +335,8 @@ HilbertFir::HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c3
     // deci 4 / 8 / 16: real-stream tiles with the pruned inverse; taps in caller order t[k] = G[Lg - 1 - k]
     // (tools/prune_probe.py: 65 (*) 255 taps /8 0.219 -> 0.191 ms per 1e8 real samples, /4 0.37 -> 0.23, /16 a tie)
     const size_t g_per_phase = G.size() / std::max<size_t>(deci, 1);
-    const bool prune_default = deci == 4 ? g_per_phase >= 8 : deci == 8 ? g_per_phase >= 24 : g_per_phase >= 24;
+    // (/16: 65 * 255 taps at 1.28e8 samples 202 us pruned against 376 us direct, tools/prune_window_probe2.py)
+    const bool prune_default = deci == 4 ? g_per_phase >= 8 : deci == 8 ? g_per_phase >= 24 : g_per_phase >= 8;
     if (build_opts().fir_path != RR_PATH_DIRECT && (build_opts().fir_prune ? build_opts().fir_prune > 0 : prune_default) &&
         prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
         std::vector<std::complex<double>> td(G.size());
@@ -368,7 +369,7 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     bool use_prune = prune != nullptr;
     if (use_prune && fir->window_aware) {
         const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - (size_t)plG.L + 1) * (d / 2);
-        use_prune = n >= (d == 4 ? 2800 : d == 8 ? 2100 : 800) * per_batch;
+        use_prune = n >= (d == 4 ? 1500 : d == 8 ? 1500 : 350) * per_batch;   // (tools/prune_window_probe2.py)
     }
     if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s);
     else launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s);
@@ -431,7 +432,7 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     bool use_prune = prune != nullptr;
     if (use_prune && window_aware) {
         const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - L + 1) * d;
-        use_prune = n >= (d == 4 ? 2200 : d == 8 ? 1600 : 600) * per_batch;
+        use_prune = n >= (d == 4 ? 2000 : d == 8 ? 1700 : 370) * per_batch;   // (tools/prune_window_probe2.py)
     }
     const bool small_direct = prune && !use_prune && (!fftk || L <= 320);
     if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
