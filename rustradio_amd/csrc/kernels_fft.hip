@@ -101,8 +101,12 @@ template <int LOG2F, int VAR> struct TileXform {
         }
     }
     // forward half: on exit v holds the spectrum in the (digit-reversed) pass-(NP-1) layout
+    // (s_setprio 2 around the transform halves: waves in their arithmetic / LDS phases issue ahead of waves that are only
+    //  queueing memory operations — same-box A/B at the sustained clocks: FftFilter 0.3337 -> 0.3310 ms, FirFilter 127
+    //  taps 0.3202 -> 0.3135; priority 3 is the same)
     __device__ __forceinline__ void forward(creg* v, creg* lds, unsigned long long* stamps = nullptr) const {
         (void)stamps;
+        __builtin_amdgcn_s_setprio(2);
         if constexpr (!REG) asm volatile("" ::: "memory");   // keep per-tile table loads inside the tile loop
         creg twl[15];
         const bool do_lds = !RR_ABLATE(4), do_math = !RR_ABLATE(8);
@@ -138,10 +142,12 @@ template <int LOG2F, int VAR> struct TileXform {
 #undef lds_store
 #undef lds_load
 #undef fwd_pass
+        __builtin_amdgcn_s_setprio(0);
     }
     // inverse half (the mirror): spectrum (already multiplied by H) -> v[n] = y[n*T + t]
     __device__ __forceinline__ void inverse(creg* v, creg* lds, unsigned long long* stamps = nullptr) const {
         (void)stamps;
+        __builtin_amdgcn_s_setprio(2);
         creg twl[15];
         const bool do_lds = !RR_ABLATE(4), do_math = !RR_ABLATE(8);
 #define lds_store if (do_lds) lds_store
@@ -177,6 +183,7 @@ template <int LOG2F, int VAR> struct TileXform {
 #undef lds_store
 #undef lds_load
 #undef inv_pass
+        __builtin_amdgcn_s_setprio(0);
     }
     __device__ __forceinline__ void run(creg* v, creg* lds, int ablate, unsigned long long* stamps = nullptr) const {
         (void)ablate;
@@ -553,7 +560,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             }
             RR_PHASE();
             if constexpr (REAL2) {                       // TileXform::forward with the pass-1 twiddles from the LDS table
-                creg twl[15];
+                creg twl[15];                            // (no s_setprio here: it costs this kernel 4 %)
                 fwd_pass<LOG2F, 0>(v, tw0p);
                 RR_PHASE();
                 lds_store<LOG2F, 0>(v, t, lds);
