@@ -51,6 +51,9 @@ struct PolyArgs {
 #ifndef RR_POLY_WAVES
 #define RR_POLY_WAVES 2
 #endif
+#ifndef RR_POLY_OVERSUB
+#define RR_POLY_OVERSUB 3
+#endif
 #ifndef RR_POLY_WIDE
 #define RR_POLY_WIDE 1
 #endif
@@ -456,7 +459,7 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
     // chip waits for the workgroups with one tile more.  Launching 3x the resident workgroups lets the hardware dispatcher
     // hand the tiles out as slots free up (tools/percu_sweep.sh: 0.0685 -> 0.063 ms; 1 tile per workgroup 0.0645; with 17
     // tiles per slot, full_chain_fused, the persistent grid stays ahead: 0.319 vs 0.330).
-    if (ntiles > grid && ntiles < 12 * grid) grid = std::min(ntiles, 3 * grid);
+    if (ntiles > grid && ntiles < 12 * grid) grid = std::min(ntiles, (long)RR_POLY_OVERSUB * grid);
     hipLaunchKernelGGL((k_fm_chain_poly<D, SRC>), dim3((unsigned)grid), dim3(128), smem, s, src, out, ntiles, tw, hreg, a, last_in, last_out,
                        fft_stamp_buffer());
     RR_HIP(hipGetLastError());
