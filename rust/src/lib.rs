@@ -518,8 +518,9 @@ impl GpuFused<Complex, Complex> {
     }
 }
 impl GpuFused<Float, Complex> {
-    /// `translate` = `Some((samp_rate, freq))` for `.translate()`; `replay_rotator` selects the bit-faithful f32 rotator
-    /// recurrence (RR_ROT_REPLAY) instead of the closed-form model.
+    /// `translate` = `Some((samp_rate, freq))` for `.translate()`; `replay_rotator` = true keeps the library default, the
+    /// reference's own f32 rotator recurrence replayed bit for bit (RR_ROT_REPLAY, generated ahead on a side stream);
+    /// false opts into the parallel closed-form model (RR_ROT_MODEL), which is outside 1e-5 parity beyond ~1e5 outputs.
     pub fn hilbert_fir(src: ReadStream<Float>, hilbert_ntaps: usize, window_type: &WindowType, taps: &[Complex], deci: usize,
                        translate: Option<(Float, Float)>, replay_rotator: bool) -> Result<(Self, ReadStream<Complex>)> {
         let (w, parm) = window_code(window_type);

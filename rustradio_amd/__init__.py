@@ -360,7 +360,7 @@ class Fanout:
         return ms.value, n.value
 
 
-def FirFilter(taps, deci: int = 1, translate=None, rotator: int = ROT_MODEL) -> Block:
+def FirFilter(taps, deci: int = 1, translate=None, rotator: int = ROT_REPLAY) -> Block:
     """FirFilter::builder(taps).deci(deci).translate(samp_rate, freq).build(src)."""
     if np.iscomplexobj(np.asarray(taps)):
         t = np.ascontiguousarray(taps, np.complex64)
@@ -491,7 +491,7 @@ def FmChainU8(taps, interp: int, deci: int, gain: float = 1.0, mode: int = ATAN2
 
 
 def HilbertFir(hilbert_ntaps: int, taps, deci: int = 1, translate=None, wtype: int = WIN_HAMMING, parm: float = 0.0,
-               rotator: int = ROT_MODEL) -> Block:
+               rotator: int = ROT_REPLAY) -> Block:
     """Hilbert(hilbert_ntaps, wtype) -> FirFilter<Complex>(taps, deci[, translate]) fused into one composite
     decimating FIR on the real input (examples/ax25-1200-rx.rs:238-247 wiring); f32 in, Complex out."""
     t = np.ascontiguousarray(taps, np.complex64)

@@ -234,7 +234,15 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
         if (deci > 1 && fftk->log2f >= 13 && !fftk->nsub) fftk.reset();   // (RR_FFT_NO_SPLIT measurement runs)
     }
 }
-FirC32::~FirC32() = default;
+FirC32::~FirC32() {
+    (void)hipSetDevice(device);
+    if (rot_stream) {
+        (void)hipStreamSynchronize(rot_stream);
+        (void)hipStreamDestroy(rot_stream);
+        (void)hipEventDestroy(ev_gen);
+        (void)hipEventDestroy(ev_used);
+    }
+}
 
 int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                      size_t* produced, size_t* need, hipStream_t s) {
@@ -288,25 +296,60 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     return RR_AGAIN;                                                 // fir.rs:549
 }
 
+// The reference's rotator (fir.rs:464-473): out[m] *= phase; phase *= step, in f32, never renormalised.
+//   RR_ROT_REPLAY (default): that recurrence, bit for bit, for any stream length.  It is inherently serial (~5 ns per
+//     output on one lane) but data-independent, so it is generated AHEAD: after every call the side stream walks the chain
+//     on into a ring of phases for the next window while this window's filter kernels (and whatever the graph runs next)
+//     execute; a call waits only for the part of its range the chain has not reached.  Sustained back-to-back calls are
+//     bounded by the chain (~200 M outputs/s); a graph paced by its source (100 Msps / 8 = 12.5 M outputs/s in
+//     BASELINE configs[4]) never waits.
+//   RR_ROT_MODEL (opt-in): phase0 * step^m in f64, parallel; NOT within 1e-5 of the reference beyond ~1e5 outputs
+//     (it does not reproduce the recurrence's accumulated rounding; tests/test_gpu_edges_fullsize.py).
+void FirC32::rotor_generate(size_t upto) {
+    if (upto <= rot_gen) return;
+    // the slots of [rot_gen, upto) still hold phases [rot_gen - cap, upto - cap): every rotate kernel that reads them has been
+    // enqueued before the last ev_used record (callers keep upto - consumed <= cap)
+    if (used_pending) { RR_HIP(hipStreamWaitEvent(rot_stream, ev_used, 0)); used_pending = false; }
+    launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, (long)rot_gen, (long)(ring_cap - 1), 0, (long)(upto - rot_gen), rot_stream);
+    RR_HIP(hipEventRecord(ev_gen, rot_stream));
+    rot_gen = upto;
+}
+
 void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
-    if (rot_on) {                                                    // fir.rs:464-473
-        if (rot_mode == RR_ROT_REPLAY) {
-            // the reference's f32 recurrence replayed ON THE DEVICE from the carried phase: no host loop, no upload, no
-            // synchronisation (a device-resident chain stays asynchronous)
-            if (!d_phase.p) {
-                d_phase.reserve(1);
-                const cf p0 = mkcf(ph0x, ph0y);
-                RR_HIP(hipMemcpyAsync(d_phase.p, &p0, sizeof(cf), hipMemcpyHostToDevice, s));
-                RR_HIP(hipStreamSynchronize(s));                     // (p0 is a stack variable; once per block)
-            }
-            d_tab.reserve(out_n * sizeof(cf));
-            launch_rotor_replay(d_phase.p, stx, sty, reinterpret_cast<cf*>(d_tab.p), (long)out_n, s);
-            launch_rotate_table(static_cast<cf*>(out), (long)out_n, reinterpret_cast<const cf*>(d_tab.p), s);
-        } else {
-            launch_rotate_model(static_cast<cf*>(out), (long)out_n, ph0x, ph0y, stx, sty, (long)n_rot, s);
-        }
+    if (!rot_on || out_n == 0) return;
+    if (rot_mode != RR_ROT_REPLAY) {
+        launch_rotate_model(out, (long)out_n, ph0x, ph0y, stx, sty, (long)n_rot, s);
         n_rot += out_n;
+        return;
     }
+    if (!rot_stream) {
+        RR_HIP(hipStreamCreateWithFlags(&rot_stream, hipStreamNonBlocking));
+        RR_HIP(hipEventCreateWithFlags(&ev_gen, hipEventDisableTiming));
+        RR_HIP(hipEventCreateWithFlags(&ev_used, hipEventDisableTiming));
+        // ring: four windows of the first call's size, 2^16 .. 2^22 phases (0.5 .. 32 MB); larger calls go through in halves
+        ring_cap = (size_t)1 << 16;
+        while (ring_cap < 4 * out_n && ring_cap < ((size_t)1 << 22)) ring_cap <<= 1;
+        d_ring.reserve(ring_cap);
+        d_phase.reserve(1);
+        const cf p0 = mkcf(ph0x, ph0y);
+        RR_HIP(hipMemcpyAsync(d_phase.p, &p0, sizeof(cf), hipMemcpyHostToDevice, rot_stream));
+        RR_HIP(hipStreamSynchronize(rot_stream));                    // (p0 is a stack variable; once per block)
+        // (mode switched to REPLAY after outputs were already rotated: walk the chain up to here without storing)
+        if (n_rot) launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, 0, (long)(ring_cap - 1), (long)n_rot, 0, rot_stream);
+        rot_gen = n_rot;
+    }
+    const size_t half = ring_cap / 2;
+    for (size_t done = 0; done < out_n;) {
+        const size_t chunk = std::min(out_n - done, half);
+        rotor_generate(n_rot + done + chunk);                        // (no-op when the look-ahead already covers it)
+        RR_HIP(hipStreamWaitEvent(s, ev_gen, 0));
+        launch_rotate_table(out + done, (long)chunk, d_ring.p, (long)((n_rot + done) & (ring_cap - 1)), (long)(ring_cap - 1), s);
+        RR_HIP(hipEventRecord(ev_used, s));
+        used_pending = true;
+        done += chunk;
+    }
+    n_rot += out_n;
+    rotor_generate(n_rot + std::min(out_n, half));                   // look-ahead: the next window of the same size
 }
 
 // ---- Hilbert -> FirFilter<Complex> as one composite decimating FIR ------------------------------------------
@@ -371,11 +414,13 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
         const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - (size_t)plG.L + 1) * (d / 2);
         use_prune = n >= (d == 4 ? 1500 : d == 8 ? 1500 : 350) * per_batch;   // (tools/prune_window_probe2.py)
     }
-    if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s);
+    // (the hn samples before the new window become the next call's history: written by the tile kernel itself)
+    const CarryOut carry{hist[cur ^ 1].p, (long)n, (long)hn};
+    if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s, carry);
     else launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s);
     prof_end(s);
     fir->rotate_output(static_cast<cf*>(out), out_n, s);
-    launch_vcopy_f32(src, (long)n, hist[cur ^ 1].p, (long)hn, s);              // the hn samples before the new window
+    if (!use_prune) launch_carry(src, carry, s);
     cur ^= 1;
     *consumed = n; *produced = out_n;
     return RR_AGAIN;
@@ -704,7 +749,7 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
     RR_HIP(hipStreamSynchronize(stream));
 }
 
-void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s) {
+void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOut carry) {
     if (big) {
         // y = conj(FFT_M(conj(FFT_M(frame) H))) per overlap-save frame, in chunks of <= 2^24 elements of work space
         const long M = (long)bigM, S = M - (long)L + 1;
@@ -720,15 +765,16 @@ void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s) {
             big->forward(bspec.p, bframes.p, nf, s);
             launch_ols_scatter(bframes.p, out, S, M, (long)L, f0, nf, n_out, s);
         }
+        launch_carry(src, carry, s);
         return;
     }
-    if (nsub && alt_log2f && n_out < small_window_outputs()) launch_fftfilt_os(alt_log2f, src, out, n_out, (int)L, d_tw_alt.p, d_hpos_alt.p, s);
-    else if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s);
-    else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s);
+    if (nsub && alt_log2f && n_out < small_window_outputs()) launch_fftfilt_os(alt_log2f, src, out, n_out, (int)L, d_tw_alt.p, d_hpos_alt.p, s, carry);
+    else if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s, carry);
+    else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s, carry);
 }
 
-void FftFilter::filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s) {
-    launch_fftfilt_real(log2f, src, out, n_out, (int)L, d, d_tw.p, d_hpos.p, s);
+void FftFilter::filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s, CarryOut carry) {
+    launch_fftfilt_real(log2f, src, out, n_out, (int)L, d, d_tw.p, d_hpos.p, s, carry);
 }
 
 int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
@@ -753,13 +799,18 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     const long plen = (long)(hist + pend_len);
     if (real_stream) {
         VSrc<float> rsrc{reinterpret_cast<const float*>(prefix[cur].p), plen, static_cast<const float*>(in), (long)in_len};
+        // new carry = last `hist` samples before the first unprocessed one, then the unprocessed tail: written by the
+        // filter kernel itself (any workgroup: it reads this call's stream and writes the OTHER prefix buffer)
+        CarryOut carry;
+        if (*consumed) carry = CarryOut{prefix[cur ^ 1].p, (long)n_out, (long)(hist + new_pend)};
         if (k) {
             prof_begin(s);
-            filter_real(rsrc, static_cast<float*>(out), (long)n_out, 1, s);
+            filter_real(rsrc, static_cast<float*>(out), (long)n_out, 1, s, carry);
             prof_end(s);
+        } else {
+            launch_carry(rsrc, carry, s);
         }
         if (*consumed) {
-            launch_vcopy_f32(rsrc, (long)n_out, reinterpret_cast<float*>(prefix[cur ^ 1].p), (long)(hist + new_pend), s);
             cur ^= 1;
             pend_len = new_pend;
         }
@@ -767,9 +818,11 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
         return st;
     }
     VSrc<cf> src{prefix[cur].p, plen, static_cast<const cf*>(in), (long)in_len};
+    CarryOut carry;      // (as above)
+    if (*consumed) carry = CarryOut{prefix[cur ^ 1].p, (long)n_out, (long)(hist + new_pend)};
     if (k) {
         prof_begin(s);
-        filter(src, static_cast<cf*>(out), (long)n_out, s);
+        filter(src, static_cast<cf*>(out), (long)n_out, s, carry);
         prof_end(s);
         if (front && emitted == 0) {   // head fix: FftFilter's zero history under the first L2 - 1 outputs (n_out >= S > L2 - 1)
             const long L2 = (long)(L - front);
@@ -778,10 +831,10 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
             launch_head_y(d_zhead.p, d_t2.p, (int)L2, static_cast<cf*>(out), L2 - 1, s);
         }
         emitted += n_out;
+    } else {
+        launch_carry(src, carry, s);
     }
     if (*consumed) {
-        // new carry = last `hist` samples before the first unprocessed one, then the unprocessed tail
-        launch_vcopy_c32(src, (long)n_out, prefix[cur ^ 1].p, (long)(hist + new_pend), s);
         cur ^= 1;
         pend_len = new_pend;
     }
@@ -887,6 +940,7 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         FmChainArgs a;
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = gain; a.mode = mode;
+        if (*consumed) a.carry = CarryOut{f->prefix[f->cur ^ 1].p, (long)n_y, (long)(f->hist + new_pend)};   // (see FftFilter::work_dev)
         // decimate-first tiles cover D x 946 inputs each: below one tile per resident workgroup slot (~6 M samples at 1:6)
         // the 2048-point tiles keep more of the chip busy (tools/call_overhead.py, 463 taps 1:6, 512 k samples: 21.7 us
         // decimate-first, 15.4-18.8 us on the 2048-point tiles; 8 M samples: 32.9 against 35.1).  All kernels share the
@@ -942,10 +996,11 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
                               last_r[cur_lr ^ 1].p, s);
         }
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
-    }
-    if (*consumed) {
+    } else if (*consumed) {                        // nothing to filter yet: the window only joins the pending samples
         if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);
         else launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);
+    }
+    if (*consumed) {
         f->cur ^= 1;
         f->pend_len = new_pend;
     }
@@ -1000,13 +1055,15 @@ int AudioChain::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     VSrc<float> src{reinterpret_cast<const float*>(f->prefix[f->cur].p), (long)(f->hist + f->pend_len),
                     static_cast<const float*>(in), (long)in_len};
     if (k) {
-        AudioChainArgs a{(long)n1, (long)n_y, (long)o_old, (long)N2(n1 + n_y), I, D, scale};
+        AudioChainArgs a{(long)n1, (long)n_y, (long)o_old, (long)N2(n1 + n_y), I, D, scale, {}};
+        if (*consumed) a.carry = CarryOut{f->prefix[f->cur ^ 1].p, (long)n_y, (long)(f->hist + new_pend)};
         prof_begin(s);
         launch_audio_chain(f->log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a, s);
         prof_end(s);
+    } else if (*consumed) {
+        launch_vcopy_f32(src, (long)n_y, reinterpret_cast<float*>(f->prefix[f->cur ^ 1].p), (long)(f->hist + new_pend), s);
     }
     if (*consumed) {
-        launch_vcopy_f32(src, (long)n_y, reinterpret_cast<float*>(f->prefix[f->cur ^ 1].p), (long)(f->hist + new_pend), s);
         f->cur ^= 1;
         f->pend_len = new_pend;
     }
@@ -1089,6 +1146,7 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         FmChainArgs a;
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = ch.gain; a.mode = ch.mode;
+        if (*consumed) a.carry = CarryOut{f->prefix[f->cur ^ 1].p, (long)n_y, (long)(f->hist + new_pend)};
         prof_begin(s);
         if (poly && packed)
             launch_fm_multi_poly_iq8(src8, static_cast<float*>(out), (long)out_cap, (int)f->L, poly->d_tw.p, poly->d_h.p, (int)C, a,
@@ -1110,10 +1168,11 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
                             (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         prof_end(s);
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
-    }
-    if (*consumed) {
+    } else if (*consumed) {
         if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);
         else launch_vcopy_c32(src, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);
+    }
+    if (*consumed) {
         f->cur ^= 1;
         f->pend_len = new_pend;
     }

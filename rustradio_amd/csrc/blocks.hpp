@@ -92,12 +92,22 @@ struct FirC32 : Block {
     std::unique_ptr<PolyTables> poly;
     bool window_aware = true;                     // per-call choice by window size (off when a path is forced: tests, probes)
     DevBuf<cf> d_htw, d_htw_half, d_hhpos;
-    DevBuf<unsigned char> d_tp, d_rev, d_tab;
+    DevBuf<unsigned char> d_tp, d_rev;
     bool rot_on = false;
-    int rot_mode = RR_ROT_MODEL;
+    int rot_mode = RR_ROT_REPLAY;                 // the reference's own recurrence is the default (fir.rs:464-473)
     float ph0x = 1, ph0y = 0, stx = 1, sty = 0;   // f32-rounded phase0 / step (fir.rs:453-461)
-    DevBuf<cf> d_phase;                           // REPLAY state: the carried f32 phase, on the device
     size_t n_rot = 0;                             // outputs rotated so far
+    // RR_ROT_REPLAY: the phase chain is data-independent, so it is generated AHEAD of the filter — one lane on a side
+    // stream walks the f32 recurrence into a ring of phases while the filter kernels of the current window run; a call
+    // only waits for the part of its range the chain has not reached yet.
+    DevBuf<cf> d_phase;                           // the carried f32 phase (the next one to generate), on the device
+    DevBuf<cf> d_ring;                            // ring of generated phases: entry i at slot i & (ring_cap - 1)
+    size_t ring_cap = 0;                          // power of two
+    size_t rot_gen = 0;                           // phases generated (enqueued) so far
+    hipStream_t rot_stream = nullptr;
+    hipEvent_t ev_gen = nullptr, ev_used = nullptr;
+    bool used_pending = false;
+    void rotor_generate(size_t upto);             // enqueue the chain up to phase index `upto` (exclusive) on rot_stream
     std::vector<std::complex<float>> h_taps;      // caller-order taps after the translate pre-rotation
     // allow_fft = false: bookkeeping / direct form only (HilbertFir's inner object)
     FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq, bool allow_fft = true);
@@ -177,8 +187,9 @@ struct FftFilter : Block {
     size_t avail(size_t in_len) const { return front ? (in_len > front ? in_len - front : 0) : in_len; }
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
     // out[n] = sum_k t[k] src[n + L - 1 - k], n < n_out (the tile kernel of the chosen size)
-    void filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s);
-    void filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s);   // out[m] = y[m d]
+    // (carry: the caller's carry-state update, written by the same launch — common.hpp CarryOut)
+    void filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOut carry = {});
+    void filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s, CarryOut carry = {});   // out[m] = y[m d]
 };
 
 // Fused FftFilter -> RationalResampler(interp:deci) -> QuadratureDemod (one kernel per call).

@@ -87,6 +87,21 @@ template <class T> struct VSrc {
 #endif
 };
 
+// Carry-state update folded into the main kernel of a work() call: dst[i] = src.load(v0 + i), i < n (n == 0: nothing).
+// The carry only READS this call's virtual stream (prefix[cur] ++ window) and writes the OTHER prefix buffer, which no
+// workgroup of the launch reads, so any workgroup may do it at any time: every thread of the grid moves at most one
+// element (round 2 spent a separate k_vcopy launch per call on it: 5-8 % of the GPU time of the fused chains).
+struct CarryOut {
+    void* dst = nullptr;
+    long v0 = 0, n = 0;
+};
+#if defined(__HIPCC__)
+template <class T, class SRC> __device__ __forceinline__ void carry_store(const SRC& src, const CarryOut& c) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += (long)gridDim.x * blockDim.x)
+        static_cast<T*>(c.dst)[i] = src.load(c.v0 + i);
+}
+#endif
+
 #if defined(__HIPCC__)
 // Exactly-rounded single operations that the optimiser cannot fuse.  The kernels are compiled with
 // -ffp-contract=fast and HIP's __fmul_rn/__fadd_rn/__fsub_rn are plain operators — which it DOES

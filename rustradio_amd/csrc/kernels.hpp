@@ -12,8 +12,10 @@ namespace rr {
 //   hpos       : device table of H (scaled by 1/F) in digit-reversed position order
 bool fftfilt_supported(int log2f);
 int fft_read_stamps(unsigned long long* host16);   // measurement builds only (else returns 0)
+// (carry: the caller's carry-state update, done by this launch — every launcher below that takes one falls back to a
+//  separate copy kernel when it has nothing to launch)
 void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw,
-                       const cf* hpos, hipStream_t s);
+                       const cf* hpos, hipStream_t s, CarryOut carry = {});
 
 // The same filter keeping every d-th output: out[m] = y[m d], m < n_out (tiles of 1024..4096 points, d <= 4096) —
 // the decimating FirFilter (fir.rs:181-189) on overlap-save tiles.
@@ -23,13 +25,14 @@ void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, in
 // Real stream, real taps (hpos from Complex(t, 0)): out[m] = y[m d], y[n] = sum_k t[k] xx[n + L - 1 - k]; two
 // overlap-save segments ride in the real / imaginary lanes of one Complex tile (tiles of 1024..4096 points).
 void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
-                         hipStream_t s);
+                         hipStream_t s, CarryOut carry = {});
 
 // FftFilterFloat -> RationalResampler(I:D) -> MultiplyConst fused on the real-stream tiles: out[m - r_lo] = scale *
 // y[floor(m D / I)] for the resampled samples m in [r_lo, r_hi) whose source lies in this call's y[A .. A + n_y).
 struct AudioChainArgs {
     long A, n_y, r_lo, r_hi, I, D;
     float scale;
+    CarryOut carry;    // the block's carry-state update, written by this launch (common.hpp)
 };
 void launch_audio_chain(int log2f, VSrc<float> src, float* out, int L, const cf* tw, const cf* hpos, const AudioChainArgs& a,
                         hipStream_t s);
@@ -45,7 +48,7 @@ void launch_fftfilt_prune_f32(int log2f, VSrc<float> src, float* out, long n_out
                               const cf* twb, hipStream_t s);
 // real stream, Complex taps t = Gr + i Gi: hpos2r / hpos2i from the real tap sets Gr / Gi; Complex output
 void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
-                               const cf* hpos2i, const cf* twb, hipStream_t s);
+                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry = {});
 
 // Even decimations on 2048-point tiles with the half-size inverse (k_fftfilt_half): out[m] = y[m d], m < n_out.
 // tw = w_2048^k, tw_half = w_1024^k, hpos = H / F in the 2048-point position order.
@@ -57,7 +60,7 @@ void launch_fftfilt_half(VSrc<cf> src, cf* out, long n_out, int L, int d, const 
 // (k_fftfilt_split).  tw4096: w_4096^k;  wk[t] = w_F^t, t < 256;  hs[r][p] = H[nsub bin(p) + r] / F with
 // bin(p) = fftfilt_split_bin(p), the bin at position p of the 4096-point spectrum layout.
 void launch_fftfilt_split(int nsub, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw4096, const cf* hs, const cf* wk,
-                          hipStream_t s);
+                          hipStream_t s, CarryOut carry = {});
 void launch_fftfilt_split_deci(int nsub, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw4096, const cf* hs,
                                const cf* wk, hipStream_t s);   // out[m] = y[m d], m < n_out
 int fftfilt_split_bin(int p);
@@ -81,6 +84,7 @@ struct FmChainArgs {
     long I, D;         // reduced interp / deci
     float gain;
     int mode;          // RR_ATAN2_*
+    CarryOut carry;    // the block's carry-state update (new prefix), written by this launch (common.hpp)
 };
 // out[(u-1) - o_base] = gain * atan2(conj(r[u-1]) r[u]) for u in [max(r_lo,1), r_hi); r[r_lo-1] is
 // *last_in (previous call), r[r_hi-1] is written to *last_out.
@@ -161,10 +165,11 @@ bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src
 // y[m] *= phase0 * step^(m0 + m) evaluated in f64 (RR_ROT_MODEL)
 void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, double sy, long m0,
                          hipStream_t s);
-// table[i] = phase_i, phase_{i+1} = phase_i * step in f32 (the reference's recurrence), phase_0 = *state; *state <- phase_n
-void launch_rotor_replay(cf* state, float stx, float sty, cf* table, long n, hipStream_t s);
-// y[m] *= table[m]
-void launch_rotate_table(cf* y, long n, const cf* table, hipStream_t s);
+// RR_ROT_REPLAY: phase_{i+1} = phase_i * step in f32 (the reference's recurrence) from *state: nskip steps without a store,
+// then ring[(pos0 + i) & mask] = phase_i for i < n (mask = ring capacity - 1, a power of two); *state <- the phase after them
+void launch_rotor_replay(cf* state, float stx, float sty, cf* ring, long pos0, long mask, long nskip, long n, hipStream_t s);
+// y[m] *= ring[(pos0 + m) & mask]
+void launch_rotate_table(cf* y, long n, const cf* ring, long pos0, long mask, hipStream_t s);
 
 // ---- kernels_misc.hip --------------------------------------------------------------
 // out[r + m] = in[floor((m*D - c0) / I)], m < n_gather; out[0..r) = *pending
@@ -182,6 +187,10 @@ void launch_rtlsdr_decode(const unsigned char* in, cf* out, long n_out, hipStrea
 void launch_vcopy_c32(VSrc<cf> src, long v0, cf* dst, long n, hipStream_t s);
 void launch_vcopy_iq8(VSrcIQ8 src, long v0, cf* dst, long n, hipStream_t s);   // decoding copy
 void launch_vcopy_f32(VSrc<float> src, long v0, float* dst, long n, hipStream_t s);
+// a CarryOut as its own launch (calls without a main kernel; launchers with nothing to launch)
+void launch_carry(VSrc<cf> src, const CarryOut& c, hipStream_t s);
+void launch_carry(VSrcIQ8 src, const CarryOut& c, hipStream_t s);
+void launch_carry(VSrc<float> src, const CarryOut& c, hipStream_t s);
 void launch_f32_to_c32(const float* in, cf* out, long n, hipStream_t s);
 void launch_c32_re(const cf* in, float* out, long n, hipStream_t s);
 

@@ -272,7 +272,8 @@ template <int LOG2F, int VAR>
 __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
 void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles,
                   const cf* __restrict__ tw, const cf* __restrict__ hpos, int ablate,
-                  unsigned long long* __restrict__ dbg, long tile_base) {
+                  unsigned long long* __restrict__ dbg, long tile_base, CarryOut carry) {
+    carry_store<cf>(src, carry);
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -395,7 +396,8 @@ __device__ __attribute__((noinline)) void stage_pair_slow(creg* lds, VSrc<float>
 template <int LOG2F, bool DECI>
 __global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
 void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L, int d, long ntiles,
-                    const cf* __restrict__ tw, const cf* __restrict__ hpos) {
+                    const cf* __restrict__ tw, const cf* __restrict__ hpos, CarryOut carry) {
+    carry_store<float>(src, carry);
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -492,7 +494,8 @@ template <int LOG2F, int MODE>
 __global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
 void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long n_out, int L, long S, long ntiles,
                      const cf* __restrict__ tw, const cf* __restrict__ hpos2, const cf* __restrict__ hpos2b,
-                     const cf* __restrict__ twb_tab) {
+                     const cf* __restrict__ twb_tab, CarryOut carry) {
+    if constexpr (MODE == 0) carry_store<cf>(csrc, carry); else carry_store<float>(rsrc, carry);
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     constexpr int D = F / 256;
@@ -700,7 +703,8 @@ __device__ __forceinline__ creg window_at(const VSrcIQ8& src, long i) {
 template <int NSUB, bool DECI>
 __global__ __launch_bounds__(256, 2)
 void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d, long ntiles, const cf* __restrict__ tw,
-                     const cf* __restrict__ hs, const cf* __restrict__ wk) {
+                     const cf* __restrict__ hs, const cf* __restrict__ wk, CarryOut carry) {
+    carry_store<cf>(src, carry);
     constexpr int LOG2M = 12, M = 1 << LOG2M, T = M / 16, F = NSUB * M;
     constexpr int NP = Plan<LOG2M>::NP;
     constexpr int LE = lds_elems(M);
@@ -820,21 +824,22 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int 
 int fftfilt_split_bin(int p) { return bin_of_pos<12>(p); }
 
 template <int NSUB, bool DECI>
-static void launch_split_one(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hs, const cf* wk, hipStream_t s) {
+static void launch_split_one(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hs, const cf* wk, hipStream_t s,
+                             CarryOut carry = {}) {
     constexpr int M = 4096, F = NSUB * M;
     const long S = F - L + 1;
-    if (n_out <= 0) return;
+    if (n_out <= 0) { launch_carry(src, carry, s); return; }
     const long n_full = DECI ? (n_out - 1) * (long)d + 1 : n_out;
     const long ntiles = (n_full + S - 1) / S;
     const size_t smem = sizeof(cf) * lds_elems(M) * NSUB;
     const long grid = grid_for_tiles(k_fftfilt_split<NSUB, DECI>, 256, smem, ntiles);
-    hipLaunchKernelGGL((k_fftfilt_split<NSUB, DECI>), dim3((unsigned)grid), dim3(256), smem, s, src, out, n_out, L, d, ntiles, tw, hs, wk);
+    hipLaunchKernelGGL((k_fftfilt_split<NSUB, DECI>), dim3((unsigned)grid), dim3(256), smem, s, src, out, n_out, L, d, ntiles, tw, hs, wk, carry);
     RR_HIP(hipGetLastError());
 }
 void launch_fftfilt_split(int nsub, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw4096, const cf* hs, const cf* wk,
-                          hipStream_t s) {
-    if (nsub == 2) launch_split_one<2, false>(src, out, n_out, L, 1, tw4096, hs, wk, s);
-    else if (nsub == 4) launch_split_one<4, false>(src, out, n_out, L, 1, tw4096, hs, wk, s);
+                          hipStream_t s, CarryOut carry) {
+    if (nsub == 2) launch_split_one<2, false>(src, out, n_out, L, 1, tw4096, hs, wk, s, carry);
+    else if (nsub == 4) launch_split_one<4, false>(src, out, n_out, L, 1, tw4096, hs, wk, s, carry);
     else throw Error("fftfilt_split: 2 or 4 sub-transforms");
 }
 void launch_fftfilt_split_deci(int nsub, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw4096, const cf* hs,
@@ -1086,6 +1091,7 @@ struct FmArgs {
     int G;           // max distance between the sources of r[m] and r[m+1]
     float gain;
     int mode;        // RR_ATAN2_*
+    CarryOut carry;  // the block's new carry prefix, written by this launch (common.hpp)
 };
 
 // Tile advance of the fused chains.  For interp 1 a tile owns exactly Sp / D demodulated samples when D | Sp; rounding
@@ -1126,11 +1132,13 @@ struct AudioArgs {
     long r_lo, r_hi;   // resampled samples whose source lies in this call
     long I, D;         // reduced interp / deci
     float scale;
+    CarryOut carry;    // the block's new carry prefix, written by this launch
 };
 template <int LOG2F>
 __global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
 void k_audio_chain(VSrc<float> src, float* __restrict__ out, int L, long ntiles, const cf* __restrict__ tw,
                    const cf* __restrict__ hpos, AudioArgs a) {
+    carry_store<float>(src, a.carry);
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1180,9 +1188,9 @@ template <int LOG2F>
 static void launch_audio_one(VSrc<float> src, float* out, int L, const cf* tw, const cf* hpos, const AudioChainArgs& h, hipStream_t s) {
     constexpr int F = 1 << LOG2F, T = F / 16;
     const long S = F - L + 1;
-    if (h.n_y <= 0) return;
+    if (h.n_y <= 0) { launch_carry(src, h.carry, s); return; }
     const long ntiles = (h.n_y + 2 * S - 1) / (2 * S);
-    AudioArgs a{h.A, h.n_y, h.r_lo, h.r_hi, h.I, h.D, h.scale};
+    AudioArgs a{h.A, h.n_y, h.r_lo, h.r_hi, h.I, h.D, h.scale, h.carry};
     const size_t smem = sizeof(cf) * lds_elems(F);
     const long grid = grid_for_tiles(k_audio_chain<LOG2F>, T, smem, ntiles);
     hipLaunchKernelGGL((k_audio_chain<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, L, ntiles, tw, hpos, a);
@@ -1206,6 +1214,7 @@ __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER
 void k_fm_chain(SRC src, float* __restrict__ out, int L, long ntiles, const cf* __restrict__ tw,
                 const cf* __restrict__ hpos, FmArgs a, const cf* __restrict__ last_r_in,
                 cf* __restrict__ last_r_out) {
+    carry_store<cf>(src, a.carry);
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1270,6 +1279,7 @@ __global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
 void k_fm_multi(SRC src, float* __restrict__ out, long out_stride, int L, long ntiles,
                 const cf* __restrict__ tw, const cf* __restrict__ hpos_all, int nchan, FmArgs a,
                 const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    carry_store<cf>(src, a.carry);
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     constexpr int NP = Plan<LOG2F>::NP;
@@ -1350,6 +1360,7 @@ __global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
 void k_fm_multi_half(SRC src, float* __restrict__ out, long out_stride, int L, long ntiles, long Sp,
                      const cf* __restrict__ tw, const cf* __restrict__ tw_half, const cf* __restrict__ hpos_all,
                      int nchan, FmArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    carry_store<cf>(src, a.carry);
     constexpr int F = 1 << LOG2F, T = F / 16, LH = LOG2F - 1, FH = F / 2, TH = T / 2;
     constexpr int NP = Plan<LOG2F>::NP;
     constexpr int D3 = F / 256, DH = D3 / 2;             // last radix of the full / the half plan
@@ -1479,6 +1490,7 @@ __global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
 void k_fm_chain_half(SRC src, float* __restrict__ out, int L, long ntiles, long Sp, const cf* __restrict__ tw,
                      const cf* __restrict__ tw_half, const cf* __restrict__ hpos, FmArgs a,
                      const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    carry_store<cf>(src, a.carry);
     constexpr int F = 1 << LOG2F, T = F / 16, LH = LOG2F - 1, FH = F / 2, TH = T / 2;
     constexpr int NP = Plan<LOG2F>::NP;
     constexpr int D3 = F / 256, DH = D3 / 2, U = 16 / D3;
@@ -1768,29 +1780,29 @@ int device_cu_count() {
 
 
 template <int LOG2F, int VAR>
-static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s, long tile_lo = 0, long tile_hi = -1) {
+static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s, CarryOut carry, long tile_lo = 0, long tile_hi = -1) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     const long S = F - L + 1;
     if (tile_hi < 0) tile_hi = (n_out + S - 1) / S;     // all tiles
     const long ntiles = tile_hi - tile_lo;
-    if (ntiles <= 0) return;
+    if (ntiles <= 0) { launch_carry(src, carry, s); return; }
     const size_t smem = sizeof(cf) * lds_elems(F);
     const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR>, T, smem, ntiles);
     const int ablate = 0;
     hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L,
-                       ntiles, tw, hpos, ablate, fft_stamp_buffer(), tile_lo);
+                       ntiles, tw, hpos, ablate, fft_stamp_buffer(), tile_lo, carry);
     RR_HIP(hipGetLastError());
 }
 
 void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw,
-                       const cf* hpos, hipStream_t s) {
+                       const cf* hpos, hipStream_t s, CarryOut carry) {
     switch (log2f) {
-    case 10: launch_one<10, 0>(src, out, n_out, L, tw, hpos, s); break;
-    case 11: launch_one<11, 0>(src, out, n_out, L, tw, hpos, s); break;
-    case 12: launch_one<12, 0>(src, out, n_out, L, tw, hpos, s); break;
-    case 13: launch_one<13, 3>(src, out, n_out, L, tw, hpos, s); break;
-    case 14: launch_one<14, 3>(src, out, n_out, L, tw, hpos, s); break;
+    case 10: launch_one<10, 0>(src, out, n_out, L, tw, hpos, s, carry); break;
+    case 11: launch_one<11, 0>(src, out, n_out, L, tw, hpos, s, carry); break;
+    case 12: launch_one<12, 0>(src, out, n_out, L, tw, hpos, s, carry); break;
+    case 13: launch_one<13, 3>(src, out, n_out, L, tw, hpos, s, carry); break;
+    case 14: launch_one<14, 3>(src, out, n_out, L, tw, hpos, s, carry); break;
     default: throw Error("fftfilt: unsupported tile size");
     }
 }
@@ -1822,42 +1834,42 @@ void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, in
 }
 
 template <int LOG2F, bool DECI>
-static void launch_real_one(VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos, hipStream_t s) {
+static void launch_real_one(VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos, hipStream_t s, CarryOut carry) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     const long S = F - L + 1;
-    if (n_out <= 0) return;
+    if (n_out <= 0) { launch_carry(src, carry, s); return; }
     const long n_full = DECI ? (n_out - 1) * (long)d + 1 : n_out;
     const long nseg = (n_full + S - 1) / S;
     const long ntiles = (nseg + 1) / 2;
     const size_t smem = sizeof(cf) * lds_elems(F);
     const long grid = grid_for_tiles(k_fftfilt_real<LOG2F, DECI>, T, smem, ntiles);
     hipLaunchKernelGGL((k_fftfilt_real<LOG2F, DECI>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L, d,
-                       ntiles, tw, hpos);
+                       ntiles, tw, hpos, carry);
     RR_HIP(hipGetLastError());
 }
 void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
-                         hipStream_t s) {
+                         hipStream_t s, CarryOut carry) {
     if (d < 1 || d > 4096) throw Error("fftfilt_real: decimation out of range");
     if (2L * ((1L << log2f) - L + 1) <= 0) throw Error("fftfilt_real: tile too small");
     switch (log2f * 2 + (d > 1)) {
-    case 20: launch_real_one<10, false>(src, out, n_out, L, d, tw, hpos, s); break;
-    case 21: launch_real_one<10, true>(src, out, n_out, L, d, tw, hpos, s); break;
-    case 22: launch_real_one<11, false>(src, out, n_out, L, d, tw, hpos, s); break;
-    case 23: launch_real_one<11, true>(src, out, n_out, L, d, tw, hpos, s); break;
-    case 24: launch_real_one<12, false>(src, out, n_out, L, d, tw, hpos, s); break;
-    case 25: launch_real_one<12, true>(src, out, n_out, L, d, tw, hpos, s); break;
+    case 20: launch_real_one<10, false>(src, out, n_out, L, d, tw, hpos, s, carry); break;
+    case 21: launch_real_one<10, true>(src, out, n_out, L, d, tw, hpos, s, carry); break;
+    case 22: launch_real_one<11, false>(src, out, n_out, L, d, tw, hpos, s, carry); break;
+    case 23: launch_real_one<11, true>(src, out, n_out, L, d, tw, hpos, s, carry); break;
+    case 24: launch_real_one<12, false>(src, out, n_out, L, d, tw, hpos, s, carry); break;
+    case 25: launch_real_one<12, true>(src, out, n_out, L, d, tw, hpos, s, carry); break;
     default: throw Error("fftfilt_real: unsupported tile size");
     }
 }
 
 template <int LOG2F, int MODE>
 static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                             const cf* hpos2b, const cf* twb, hipStream_t s) {
+                             const cf* hpos2b, const cf* twb, hipStream_t s, CarryOut carry = {}) {
     constexpr int F = 1 << LOG2F, T = F / 16, D = F / 256;
     const long S = (F - L + 1) / D * D;                  // tiles advance by a multiple of D: one phase c for all tiles
     if (S <= 0) throw Error("fftfilt_prune: filter too long for the tile");
-    if (n_out <= 0) return;
+    if (n_out <= 0) { if (MODE == 0) launch_carry(csrc, carry, s); else launch_carry(rsrc, carry, s); return; }
     const long Sd = S / D;
     const long nseg = (n_out + Sd - 1) / Sd;
     const long ntiles = MODE ? (nseg + 1) / 2 : nseg;
@@ -1865,7 +1877,7 @@ static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_ou
     constexpr int BT = MODE == 1 ? D / 2 : D;             // tiles per batch (MODE 1: two responses per tile)
     const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, MODE>, T, smem, (ntiles + BT - 1) / BT);
     hipLaunchKernelGGL((k_fftfilt_prune<LOG2F, MODE>), dim3((unsigned)grid), dim3(T), smem, s, csrc, rsrc, out, n_out, L, S,
-                       ntiles, tw, hpos2, hpos2b, twb);
+                       ntiles, tw, hpos2, hpos2b, twb, carry);
     RR_HIP(hipGetLastError());
 }
 int prune_log2f_for_deci(int d) { return d == 4 ? 10 : d == 8 ? 11 : d == 16 ? 12 : 0; }
@@ -1891,12 +1903,12 @@ void launch_fftfilt_prune_f32(int log2f, VSrc<float> src, float* out, long n_out
     }
 }
 void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
-                               const cf* hpos2i, const cf* twb, hipStream_t s) {
+                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry) {
     VSrc<cf> none{nullptr, 0, nullptr, 0};
     switch (log2f) {
-    case 10: launch_prune_one<10, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
-    case 11: launch_prune_one<11, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
-    case 12: launch_prune_one<12, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s); break;
+    case 10: launch_prune_one<10, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, carry); break;
+    case 11: launch_prune_one<11, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, carry); break;
+    case 12: launch_prune_one<12, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, carry); break;
     default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }
@@ -1908,11 +1920,11 @@ static void launch_fm_one(SRC src, float* out, int L, const cf* tw, const cf* hp
     constexpr int T = F / 16;
     FmArgs a;
     a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
-    a.I = h.I; a.D = h.D; a.G = (int)((h.D + h.I - 1) / h.I); a.gain = h.gain; a.mode = h.mode;
+    a.I = h.I; a.D = h.D; a.G = (int)((h.D + h.I - 1) / h.I); a.gain = h.gain; a.mode = h.mode; a.carry = h.carry;
     const long Sp = fm_advance((F - L + 1) - a.G, a.I, a.D, T);
     if (Sp <= 0) throw Error("fm_chain: decimation too large for the tile");
     const long ntiles = (h.n_y + Sp - 1) / Sp;
-    if (ntiles <= 0) return;
+    if (ntiles <= 0) { launch_carry(src, h.carry, s); return; }
     const size_t smem = sizeof(cf) * lds_elems(F);
     const long grid = grid_for_tiles(k_fm_chain<LOG2F, VAR, SRC>, T, smem, ntiles);
     hipLaunchKernelGGL((k_fm_chain<LOG2F, VAR, SRC>), dim3((unsigned)grid), dim3(T), smem, s, src, out, L, ntiles, tw,
@@ -1951,6 +1963,7 @@ __global__ __launch_bounds__(256, 2)
 void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, const cf* __restrict__ tw,
                       const cf* __restrict__ hs, const cf* __restrict__ wk, FmArgs a,
                       const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    carry_store<cf>(src, a.carry);
     constexpr int LOG2M = 12, M = 1 << LOG2M, T = M / 16, F = NSUB * M;
     constexpr int NP = Plan<LOG2M>::NP;
     constexpr int LE = lds_elems(M);
@@ -2070,11 +2083,11 @@ static void launch_fm_split_one(SRC src, float* out, int L, const cf* tw, const 
     constexpr int F = NSUB * 4096;
     FmArgs a;
     a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
-    a.I = h.I; a.D = h.D; a.G = (int)((h.D + h.I - 1) / h.I); a.gain = h.gain; a.mode = h.mode;
+    a.I = h.I; a.D = h.D; a.G = (int)((h.D + h.I - 1) / h.I); a.gain = h.gain; a.mode = h.mode; a.carry = h.carry;
     const long Sp = fm_advance((F - L + 1) - a.G, a.I, a.D, 256);
     if (Sp <= 0) throw Error("fm_chain: decimation too large for the tile");
     const long ntiles = (h.n_y + Sp - 1) / Sp;
-    if (ntiles <= 0) return;
+    if (ntiles <= 0) { launch_carry(src, h.carry, s); return; }
     const size_t smem = sizeof(cf) * lds_elems(4096) * NSUB;
     const long grid = grid_for_tiles(k_fm_chain_split<NSUB, SRC>, 256, smem, ntiles);
     hipLaunchKernelGGL((k_fm_chain_split<NSUB, SRC>), dim3((unsigned)grid), dim3(256), smem, s, src, out, L, ntiles, tw, hs, wk,
@@ -2099,11 +2112,11 @@ static void launch_fm_multi_one(SRC src, float* out, long out_stride, int L, con
     constexpr int T = F / 16;
     FmArgs a;
     a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
-    a.I = h.I; a.D = h.D; a.G = (int)((h.D + h.I - 1) / h.I); a.gain = h.gain; a.mode = h.mode;
+    a.I = h.I; a.D = h.D; a.G = (int)((h.D + h.I - 1) / h.I); a.gain = h.gain; a.mode = h.mode; a.carry = h.carry;
     const long Sp = fm_advance((F - L + 1) - a.G, a.I, a.D, T);
     if (Sp <= 0) throw Error("fm_multi: decimation too large for the tile");
     const long ntiles = (h.n_y + Sp - 1) / Sp;
-    if (ntiles <= 0) return;
+    if (ntiles <= 0) { launch_carry(src, h.carry, s); return; }
     const size_t smem = 2 * sizeof(cf) * lds_elems(F);
     const long grid = grid_for_tiles(k_fm_multi<LOG2F, SRC>, T, smem, ntiles);
     hipLaunchKernelGGL((k_fm_multi<LOG2F, SRC>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles,
@@ -2122,11 +2135,11 @@ static void launch_fm_multi_half_t(int log2f, SRC src, float* out, long out_stri
     if (!fm_multi_half_supported(log2f, h.I, h.D, L)) throw Error("fm_multi_half: unsupported shape");
     FmArgs a;
     a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
-    a.I = h.I; a.D = h.D; a.G = (int)h.D; a.gain = h.gain; a.mode = h.mode;
+    a.I = h.I; a.D = h.D; a.G = (int)h.D; a.gain = h.gain; a.mode = h.mode; a.carry = h.carry;
     // even advance: one parity shift per call; room for the shift (a multiple of 64 D is even)
     const long Sp = fm_advance(((F - L + 1) - a.G - 1) & ~1L, 1, a.D, 64);
     const long ntiles = (h.n_y + Sp - 1) / Sp;
-    if (ntiles <= 0) return;
+    if (ntiles <= 0) { launch_carry(src, h.carry, s); return; }
     const size_t smem = sizeof(cf) * (2 * lds_elems(F) + 64);
     const long grid = grid_for_tiles(k_fm_multi_half<LOG2F, SRC>, T, smem, ntiles);
     hipLaunchKernelGGL((k_fm_multi_half<LOG2F, SRC>), dim3((unsigned)grid), dim3(T), smem, s, src, out, out_stride, L, ntiles, Sp,
@@ -2148,10 +2161,10 @@ static void launch_fm_chain_half_t(SRC src, float* out, int L, const cf* tw, con
     constexpr int LOG2F = 11, F = 1 << LOG2F, T = F / 16;
     FmArgs a;
     a.A = h.A; a.n_y = h.n_y; a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
-    a.I = h.I; a.D = h.D; a.G = (int)h.D; a.gain = h.gain; a.mode = h.mode;
+    a.I = h.I; a.D = h.D; a.G = (int)h.D; a.gain = h.gain; a.mode = h.mode; a.carry = h.carry;
     const long Sp = fm_advance(((F - L + 1) - a.G - 1) & ~1L, 1, a.D, 64);
     const long ntiles = (h.n_y + Sp - 1) / Sp;
-    if (ntiles <= 0) return;
+    if (ntiles <= 0) { launch_carry(src, h.carry, s); return; }
     const size_t smem = sizeof(cf) * (lds_elems(F) + 2 * lds_elems(F / 2) + 128 + 64);
     const long grid = grid_for_tiles(k_fm_chain_half<LOG2F, SRC>, T, smem, (ntiles + 1) / 2);
     hipLaunchKernelGGL((k_fm_chain_half<LOG2F, SRC>), dim3((unsigned)grid), dim3(T), smem, s, src, out, L, ntiles, Sp, tw,

@@ -588,9 +588,10 @@ __global__ __launch_bounds__(256) void k_rotate_model(cf* __restrict__ y, long n
         zmul(rx, ry, gx, gy);
     }
 }
-__global__ __launch_bounds__(256) void k_rotate_table(cf* __restrict__ y, long n, const cf* __restrict__ tab) {
+// y[i] *= ring[(pos0 + i) & mask]: the phases the replay kernel left in its ring (mask = capacity - 1, a power of two)
+__global__ __launch_bounds__(256) void k_rotate_table(cf* __restrict__ y, long n, const cf* __restrict__ tab, long pos0, long mask) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const cf v = y[i], p = tab[i];
+        const cf v = y[i], p = tab[(pos0 + i) & mask];
         // sample * phase, un-contracted num-complex order (fir.rs:469)
         y[i] = mkcf(sub_rn(mul_rn(v.x, p.x), mul_rn(v.y, p.y)),
                   add_rn(mul_rn(v.x, p.y), mul_rn(v.y, p.x)));
@@ -613,28 +614,68 @@ void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, doubl
     RR_HIP(hipGetLastError());
 }
 // The reference's rotator (fir.rs:464-473) is a sequential f32 recurrence, phase <- phase * step once per output and
-// never renormalised; replaying it bit for bit is inherently serial (every step rounds).  One lane walks the chain for
-// the outputs of this window from the phase carried in *state (device memory, so a chain of device-resident blocks never
-// synchronises with the host) and leaves the table for k_rotate_table: ~5 ns per output.
-__global__ void k_rotor_replay(cf* __restrict__ state, float stx, float sty, cf* __restrict__ tab, long n) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float x = state->x, y = state->y;
-    for (long i = 0; i < n; i++) {
-        tab[i] = mkcf(x, y);
-        const float nx = sub_rn(mul_rn(x, stx), mul_rn(y, sty));      // num-complex order, un-contracted
-        const float ny = add_rn(mul_rn(x, sty), mul_rn(y, stx));
-        x = nx; y = ny;
-    }
-    state->x = x; state->y = y;
+// never renormalised; replaying it bit for bit is inherently serial (every one of the six operations of a step rounds, and
+// the rounding errors of step m feed step m + 1: no closed form, no parallel prefix).  ONE LANE walks the chain from the
+// phase carried in *state (device memory: a chain of device-resident blocks never synchronises with the host), skips
+// `nskip` steps without storing and leaves the next n phases in the ring tab[(pos0 + i) & mask] for k_rotate_table.
+// A step is three packed instructions — (x sx, x sy), (y sy, y sx), and their sum with the low half negated: exactly the
+// four rounded products and the two rounded sums of num-complex's `phase * step`, a - b being a + (-b) bit for bit — with
+// the step in a scalar register pair; the stores are fire-and-forget.  The chain is data-independent, so the block runs it
+// AHEAD of the filter on a side stream (blocks.cpp FirC32::rotate_output).
+__device__ __forceinline__ creg rotor_step(creg z, creg st) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    creg p, q, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p) : "v"(z), "s"(st));   // (x sx, x sy)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(z), "s"(st));   // (y sy, y sx)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));                    // (x sx - y sy, x sy + y sx)
+    return r;
+#else
+    return mk(z.x * st.x - z.y * st.y, z.x * st.y + z.y * st.x);
+#endif
 }
-void launch_rotor_replay(cf* state, float stx, float sty, cf* table, long n, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_rotor_replay, dim3(1), dim3(64), 0, s, state, stx, sty, table, n);
+// A lone wave gets one issue slot every 4 clocks whatever the instruction (the CU's arbiter visits each SIMD in turn), so
+// the cost of a step is its INSTRUCTION COUNT x 4 clocks, not its latency: the first version of this loop — three packed
+// operations, one 8-byte store and seven scalar instructions of ring-index arithmetic per phase — ran at 24.5 ns per
+// output (tools/replay_rate.py).  Here a block of 16 phases is 48 packed operations, 8 sixteen-byte stores at immediate
+// offsets from one scalar pointer and 5 scalar instructions: 3.8 instructions per phase.  The ring wrap is taken out of
+// the loop (two contiguous segments).
+__device__ __forceinline__ void rotor_run(creg& z, const creg st, creg* __restrict__ p, long n) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef f4 f4u __attribute__((aligned(8)));
+    long i = 0;
+    for (; i + 16 <= n; i += 16, p += 16) {
+        creg o[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { o[k] = z; z = rotor_step(z, st); }
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            f4 w; w.x = o[k].x; w.y = o[k].y; w.z = o[k + 1].x; w.w = o[k + 1].y;
+            *reinterpret_cast<f4u*>(p + k) = w;
+        }
+    }
+    for (; i < n; i++, p++) { *p = z; z = rotor_step(z, st); }
+}
+__global__ void k_rotor_replay(cf* __restrict__ state, float stx, float sty, cf* __restrict__ tab, long pos0, long mask,
+                               long nskip, long n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const creg st = mk(stx, sty);
+    creg z = to_reg(*state);
+    for (long i = 0; i < nskip; i++) z = rotor_step(z, st);
+    creg* ring = reinterpret_cast<creg*>(tab);
+    const long start = pos0 & mask, cap = mask + 1;
+    const long n0 = n < cap - start ? n : cap - start;              // up to the end of the ring, then from its start
+    rotor_run(z, st, ring + start, n0);
+    rotor_run(z, st, ring, n - n0);
+    *state = from_reg(z);
+}
+void launch_rotor_replay(cf* state, float stx, float sty, cf* ring, long pos0, long mask, long nskip, long n, hipStream_t s) {
+    if (n <= 0 && nskip <= 0) return;
+    hipLaunchKernelGGL(k_rotor_replay, dim3(1), dim3(64), 0, s, state, stx, sty, ring, pos0, mask, nskip, n);
     RR_HIP(hipGetLastError());
 }
-void launch_rotate_table(cf* y, long n, const cf* table, hipStream_t s) {
+void launch_rotate_table(cf* y, long n, const cf* ring, long pos0, long mask, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_rotate_table, dim3(rot_grid(n)), dim3(256), 0, s, y, n, table);
+    hipLaunchKernelGGL(k_rotate_table, dim3(rot_grid(n)), dim3(256), 0, s, y, n, ring, pos0, mask);
     RR_HIP(hipGetLastError());
 }
 

@@ -191,6 +191,15 @@ void launch_vcopy_f32(VSrc<float> src, long v0, float* dst, long n, hipStream_t 
     hipLaunchKernelGGL(k_vcopy<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, v0, dst, n);
     RR_HIP(hipGetLastError());
 }
+void launch_carry(VSrc<cf> src, const CarryOut& c, hipStream_t s) {
+    if (c.n > 0) launch_vcopy_c32(src, c.v0, static_cast<cf*>(c.dst), c.n, s);
+}
+void launch_carry(VSrcIQ8 src, const CarryOut& c, hipStream_t s) {
+    if (c.n > 0) launch_vcopy_iq8(src, c.v0, static_cast<cf*>(c.dst), c.n, s);
+}
+void launch_carry(VSrc<float> src, const CarryOut& c, hipStream_t s) {
+    if (c.n > 0) launch_vcopy_f32(src, c.v0, static_cast<float*>(c.dst), c.n, s);
+}
 
 __global__ __launch_bounds__(256) void k_f32_to_c32(const float* __restrict__ in, cf* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)

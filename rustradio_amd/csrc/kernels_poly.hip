@@ -42,6 +42,7 @@ struct PolyArgs {
     int Ls;              // taps per phase, ceil(L / D)
     float gain;
     int mode;            // RR_ATAN2_*
+    CarryOut carry;      // the block's new carry prefix, written by this launch (common.hpp)
 };
 
 // tuning: phases loaded per batch and waves per SIMD of the single-chain kernel (measured on MI355X)
@@ -229,8 +230,17 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
     }
 }
 
-// Demodulation of one tile: tile position Ls + i holds r[u0 + i]; this lane takes i = lane0, lane0 + stride, ...
-// (stride a multiple of 16, so the padded LDS address advances by a constant).  The loop body is two LDS reads, the
+// The finished tile in natural order, UNPADDED (position p in slot p): the demodulation below reads 64 consecutive slots from
+// an arbitrary start (Ls + i), and 32 lanes x 8 B from ANY 8-byte-aligned start cover the 64 banks exactly once, while the
+// padded exchange layout puts two or three pad slots inside such a run and made every one of these reads a 2-way conflict
+// (round 2 counters: SQ_LDS_BANK_CONFLICT 7.8e5 per fm_multi launch = 406 k demodulation reads x 2 extra cycles).
+__device__ __forceinline__ void nat_store(const creg* z, int t, creg* area) {
+#pragma unroll
+    for (int n = 0; n < 16; n++) area[n * PT + t] = z[n];
+}
+
+// Demodulation of one tile: tile position Ls + i (natural order, nat_store) holds r[u0 + i]; this lane takes i = lane0,
+// lane0 + stride, ...  The loop body is two LDS reads, the
 // conj-multiply as one packed multiply + one packed FMA, atan2 and one store; the special samples — r[0] has no partner,
 // the first pair of a call takes its lower sample from the previous call, the last r of a call is carried — sit in the
 // first / last tile of a call only and are handled under wave-uniform tests outside the steady-state loop.
@@ -248,9 +258,9 @@ __device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int
     const long left = a.r_hi - u0;
     const int nv = left < Sa ? (int)left : Sa;                          // valid samples of this tile
     float* o = out + ((u0 - 1) - a.o_base) + lane0;                      // o[i] = demodulated pair (r[u0 + i - 1], r[u0 + i])
-    const creg* pu = ldsR + lds_pad(a.Ls + lane0);
-    const creg* pl = ldsR + lds_pad(a.Ls + lane0 - 1);
-    const int inc = stride + (stride >> 4);
+    const creg* pu = ldsR + a.Ls + lane0;
+    const creg* pl = pu - 1;
+    const int inc = stride;
     int i = lane0;
     if (u0 == a.r_lo) {                                                  // (wave-uniform) first tile of the call
         if (i < nv) {
@@ -265,7 +275,7 @@ __device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int
         if constexpr ((RR_POLY_ABLATE & 4) != 0) { if (y == 1234.5678f) *o = y; } else { *o = y; }
     }
     if (left <= Sa) {                                                    // (wave-uniform) last tile: carry r[r_hi - 1]
-        if (nv - 1 >= lane0 && ((nv - 1 - lane0) % stride) == 0) last_r_out[0] = from_reg(ldsR[lds_pad(a.Ls + nv - 1)]);
+        if (nv - 1 >= lane0 && ((nv - 1 - lane0) % stride) == 0) last_r_out[0] = from_reg(ldsR[a.Ls + nv - 1]);
     }
 }
 
@@ -275,15 +285,15 @@ __device__ __forceinline__ void poly_store_tile(const creg* ldsR, int lane0, int
     const long left = a.r_hi - u0;
     const int nv = left < Sa ? (int)left : Sa;
     creg* o = out + (u0 - a.o_base) + lane0;
-    const creg* pu = ldsR + lds_pad(a.Ls + lane0);
-    const int inc = stride + (stride >> 4);
-    for (int i = lane0; i < nv; i += stride, pu += inc, o += stride) *o = *pu;
+    const creg* pu = ldsR + a.Ls + lane0;
+    for (int i = lane0; i < nv; i += stride, pu += stride, o += stride) *o = *pu;
 }
 
 template <int D, class SRC>
 __global__ __launch_bounds__(128, RR_POLY_WAVES)
 void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
                      PolyArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg) {
+    carry_store<cf>(src, a.carry);
     constexpr int PHA = (D + 1) / 2, PHB = D - PHA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     creg* lds = reinterpret_cast<creg*>(smem_raw);
@@ -329,7 +339,7 @@ void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __
 #pragma unroll
             for (int j = 0; j < 16; j++) z[j] = cadd(z[j], exB[j * PT + t]);
             poly_inverse(z, t, ex, tw0, tab1);
-            lds_store<PLG, 0>(z, t, ldsR);
+            nat_store(z, t, ldsR);
         }
         PSTAMP(3);
         tile_sync<128>();
@@ -348,6 +358,7 @@ __global__ __launch_bounds__(512, 1)
 void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long ntiles, const cf* __restrict__ tw,
                      const cf* __restrict__ hreg, int nchan, PolyArgs a, const cf* __restrict__ last_r_in,
                      cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg, int groups) {
+    carry_store<cf>(src, a.carry);
     static_assert(D <= 8, "one phase per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     creg* lds = reinterpret_cast<creg*>(smem_raw);
@@ -409,7 +420,8 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
             }
             if (c == 8 * grp + w) PSTAMP(3);
             poly_inverse(z, t, ex, tw0, tab1);
-            lds_store<PLG, 0>(z, t, ex);                 // natural order in the wave's own area
+            wave_fence();
+            nat_store(z, t, ex);                         // natural order in the wave's own area
             wave_fence();
             if (c == 8 * grp + w) PSTAMP(4);
             float* oc = out + (long)c * out_stride;
@@ -442,7 +454,7 @@ static PolyArgs poly_args(const FmChainArgs& h, int L) {
     a.off = (long)(L - 1) - h.A;
     a.r_lo = h.r_lo; a.r_hi = h.r_hi; a.o_base = h.o_base;
     a.Ls = (int)((L + h.D - 1) / h.D);
-    a.gain = h.gain; a.mode = h.mode;
+    a.gain = h.gain; a.mode = h.mode; a.carry = h.carry;
     return a;
 }
 
@@ -451,7 +463,7 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
                                 cf* last_out, hipStream_t s) {
     const PolyArgs a = poly_args(h, L);
     const long Sa = PF - a.Ls, nr = a.r_hi - a.r_lo;
-    if (nr <= 0) return;
+    if (nr <= 0) { launch_carry(src, h.carry, s); return; }
     const long ntiles = (nr + Sa - 1) / Sa;
     const size_t smem = sizeof(cf) * (3 * PLE + 64);
     long grid = grid_for_tiles(k_fm_chain_poly<D, SRC>, 128, smem, ntiles);
@@ -497,7 +509,7 @@ static void launch_multi_poly_d(SRC src, float* out, long out_stride, int L, con
                                 const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
     const PolyArgs a = poly_args(h, L);
     const long Sa = PF - a.Ls, nr = a.r_hi - a.r_lo;
-    if (nr <= 0) return;
+    if (nr <= 0) { launch_carry(src, h.carry, s); return; }
     const long ntiles = (nr + Sa - 1) / Sa;
     const size_t smem = sizeof(cf) * (8 * PLE + D * PF + 64);
     // fewer tiles than CUs (a 512,000-sample ring holds 90 at 1:6): split each tile's channels over several workgroups

@@ -216,12 +216,62 @@ def test_windows_beyond_2_31_elements(rr):
     assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
 
 
+def test_translate_default_mode_is_the_reference_recurrence_for_1e7_outputs(rr):
+    """the DEFAULT `.translate()` (no rotator argument = RR_ROT_REPLAY) against the oracle over more than
+    1e7 outputs, bit for bit.  A 1-tap (1 + 0j) filter makes the FIR exact (x * 1 - y * 0, x * 0 + y * 1), so every output
+    bit is the rotator's: out[m] = x[m] * phase_m, phase_{m+1} = phase_m * step in f32 (fir.rs:464-473).  Driven (a) through
+    reference-sized host windows — many calls, the look-ahead ring wraps 40 times — and (b) as ONE device-resident call of
+    1.2e7 outputs, which goes through the 2^22-entry ring in halves."""
+    import torch
+    fs, f = 1.0e6, 123_456.7
+    one = np.ones(1, np.complex64)
+    n = 12_000_000
+    x = rnd_c(n, 77)
+    yo = run_chain([orc.FirFilter(one, translate=(fs, f))], x)
+    assert len(yo) == n
+    yg = run_chain([rr.FirFilter(one, translate=(fs, f))], x)               # (a) default arguments
+    assert len(yg) == n
+    assert np.array_equal(yg.view(np.uint32), yo.view(np.uint32)), int(np.flatnonzero(yg != yo)[0])
+    blk = rr.FirFilter(one, translate=(fs, f))                               # (b) one call
+    dx = torch.from_numpy(x.view(np.float32)).cuda()
+    dy = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+    st, c, p, need = blk.work_dev(dx.data_ptr(), n, dy.data_ptr(), n)
+    blk.sync()
+    torch.cuda.synchronize()
+    assert (st, c, p) == (AGAIN, n, n)
+    yb = dy.cpu().numpy().view(np.complex64)
+    assert np.array_equal(yb.view(np.uint32), yo.view(np.uint32)), int(np.flatnonzero(yb != yo)[0])
+    # a second call continues the chain where the first one stopped (the look-ahead generated past it)
+    st, c, p, need = blk.work_dev(dx.data_ptr(), 1000, dy.data_ptr(), 1000)
+    blk.sync()
+    torch.cuda.synchronize()
+    o2 = orc.FirFilter(one, translate=(fs, f))
+    y2 = run_chain([o2], np.concatenate([x, x[:1000]]))
+    assert np.array_equal(dy[:2000].cpu().numpy().view(np.complex64).view(np.uint32), y2[n:].view(np.uint32))
+
+
+def test_translate_default_mode_long_decimating_stream(rr):
+    """The default rotator behind a REAL filter: 1.1e7 outputs of a 16-tap /2 translate filter stay within 1e-5 of the
+    oracle to the end of the stream (the f64 model is 0.16 away by then, test_rotator_drift_vs_length's 1.5e-8 * n)."""
+    fs, f, d = 10e6, -1.234e6, 2
+    taps = orc.low_pass_complex(fs, 2e6, 1.6e6)
+    assert 9 <= len(taps) <= 17
+    x = rnd_c(22_000_100, 78)
+    yo = run_chain([orc.FirFilter(taps, deci=d, translate=(fs, f))], x)
+    yg = run_chain([rr.FirFilter(taps, deci=d, translate=(fs, f))], x)
+    assert len(yo) == len(yg) >= 11_000_000
+    assert max_norm_err(yg, yo) <= TOL
+    assert max_norm_err(yg[-100_000:], yo[-100_000:]) <= TOL
+    ym = run_chain([rr.FirFilter(taps, deci=d, translate=(fs, f), rotator=rr.ROT_MODEL)], x)
+    print("opt-in RR_ROT_MODEL after 1.1e7 outputs: max-normalised error", max_norm_err(ym[-100_000:], yo[-100_000:]))
+
+
 def test_rotator_drift_vs_length(rr):
-    """FirFilter::translate's rotator (fir.rs:464-473) is an un-renormalised f32 recurrence.  The default RR_ROT_MODEL
+    """FirFilter::translate's rotator (fir.rs:464-473) is an un-renormalised f32 recurrence.  The opt-in RR_ROT_MODEL
     evaluates phase0 * step^m in f64 from the same f32-rounded phase0 / step: it reproduces the recurrence's systematic
     drift (|step| != 1 after rounding) but not its accumulated rounding noise.  This pins the bound the header states:
     |model - replay| <= 1e-7 * n after n outputs (measured ~3e-8 * n), so MODEL is inside the 1e-5 parity bar for about
-    1e2 outputs in the worst case and REPLAY (bit-faithful, on the device) is there for long streams."""
+    1e2 outputs in the worst case and REPLAY (the default: bit-faithful, on the device) is there for long streams."""
     fs, f = 1.0e6, 123_456.7
     one = np.ones(1, np.complex64)                                # a 1-tap filter: the output IS the rotator (times x)
     n = 1_000_000

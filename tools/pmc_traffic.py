@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the PMC passes of tools/pmc_run.sh.
-HBM bytes per launch = FETCH_SIZE[KB]*1024*2 + WRITE_SIZE[KB]*1024: FETCH_SIZE on gfx950 counts a
-coalesced streaming read at half its bytes (MI355X_MICROARCH.md §HBM); WRITE_SIZE matched the
-known output size exactly (800,000,xxx B for 1e8 complex samples)."""
+"""profiles/traffic.json from the PMC passes of tools/pmc_run.sh / tools/traffic_all.sh.
+HBM bytes per launch = FETCH_SIZE[KB] * 1024 * f_read + WRITE_SIZE[KB] * 1024 * f_write with the factors CALIBRATED on this
+part for the tile kernels' own access shapes (profiles/fetch_calibration.json, tools/fetchcal.sh: known byte counts read
+2 / 4 / 8 / 16 B per lane, lane-consecutive and tile-strided -> f_read = 2.000 for every width, f_write = 1.000; the
+guide's x2, MI355X_MICROARCH.md §HBM, was stated for 16 B/lane only)."""
 import hashlib
 import json
 import os
@@ -22,7 +23,14 @@ def sources_hash():
     return h.hexdigest()[:16]
 
 
+def factors():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cal = json.load(open(os.path.join(root, "profiles", "fetch_calibration.json")))
+    return cal["rd_tiles<float2,64>"]["factor"], cal["wr_tiles<float2,128>"]["factor"]
+
+
 summary, workload, kernel = sys.argv[1], sys.argv[2], sys.argv[3]
+f_read, f_write = factors()
 vals, cur = {}, None
 for line in open(summary):
     if line.startswith("=="):
@@ -35,9 +43,10 @@ try:
     d = json.load(open(out_path))
 except Exception:
     d = {}
-d[workload] = {"hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
+d[workload] = {"hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * f_read + vals["WRITE_SIZE"] * 1024 * f_write,
+               "fetch_factor": f_read, "write_factor": f_write,
                "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"],
                "kernel": kernel, "sources_sha16": sources_hash(),
-               "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes"}
+               "note": "factors calibrated on known byte counts in the kernels' access shapes (profiles/fetch_calibration.json); separate --pmc passes"}
 json.dump(d, open(out_path, "w"), indent=1)
 print(d[workload])
