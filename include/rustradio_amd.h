@@ -314,6 +314,9 @@ int rr_block_work_streams(rr_block *b, rr_dstream *src, rr_dstream *dst, size_t 
  *         rr_fanout_submit(f, t, s_src)                      -- collective: broadcast of tile t on the communication stream
  *         x = rr_fanout_acquire(f, t, s_blk);  rr_block_work_dev(b, x, …, s_blk) …;  rr_fanout_release(f, t, s_blk)
  *     submit(t + 1) may (and for overlap should) be called before acquire(t); tile t + 2 needs release(t) first.
+ *     release(t) is called ONCE per tile, on the one stream that has (transitively) waited for every reader of the tile:
+ *     blocks reading a tile on several streams join them into one (hipStreamWaitEvent) before the release — a second
+ *     release of the same tile, or one of a tile that has left the double buffer, is an error.
  * A one-rank fan-out (world 1) needs neither an id nor RCCL and keeps the same calls, so a graph is written once.
  * RCCL is bound at run time (dlopen), the library itself does not depend on it.  Like a block, a handle is driven by one
  * thread at a time; calls made out of protocol order (a tile skipped, a half not yet released) fail with RR_ERR / NULL and

@@ -39,7 +39,10 @@ def lib():
     if _lib is not None:
         return _lib
     build()
-    L = C.CDLL(_LIB_PATH)
+    # bench.py's cpu_baseline leg times a build of the same source made for its host (-O3 -march=native) and
+    # names it here; tests and smoke() never set this and always check against the portable build
+    path = os.environ.get("RR_ORACLE_LIB") or _LIB_PATH
+    L = C.CDLL(path)
     sz, f32, vp, i32 = C.c_size_t, C.c_float, C.c_void_p, C.c_int
     L.orc_make_window.argtypes = [i32, f32, sz, vp]; L.orc_make_window.restype = i32
     L.orc_compute_ntaps.argtypes = [f32, f32, i32]; L.orc_compute_ntaps.restype = sz

@@ -24,6 +24,7 @@ import ctypes as C
 import numpy as np
 
 import contextlib
+import threading
 
 from ._lib import BuildOpts, lib as _raw_lib, last_error, LIB_PATH  # noqa: F401
 
@@ -40,21 +41,29 @@ DEFAULT_STREAM_SIZE = 4_096_000  # bytes, src/stream.rs:105
 # `build_options(...)` is a context manager: every block / DeviceStream created inside it is built with these
 # overrides (each create call gets its own rr_next_create_options; nothing is read from the environment).
 PATH_AUTO, PATH_DIRECT, PATH_FFT = 0, 1, 2
-_build_opts: dict = {}
+_build_opts: dict = {}                 # process-wide defaults (tests patch this through harness.knob)
+_tls = threading.local()               # build_options() is per THREAD, like the C side's pending overrides
 _PATHS = {"auto": PATH_AUTO, "direct": PATH_DIRECT, "fft": PATH_FFT}
+# the create calls that CONSUME rr_next_create_options (abi.cpp OptsScope): every block constructor and rr_dstream_create.
+# rr_fanout_create does not — handing it the overrides would leave them pending for the thread's next block
+_NO_OPTS_CREATES = ("rr_fanout_create",)
+
+
+def _effective_opts() -> dict:
+    o = getattr(_tls, "opts", None)
+    return _build_opts if o is None else o
 
 
 @contextlib.contextmanager
 def build_options(**kw):
     """fir_path='direct'|'fft', fir_prune=+-1, fir_half=-1, fir_cfg=0..7, fft_log2f=10..14, fft_no_split=1,
     fftfloat_complex=1, fm_full=1, fm_poly=-1, dstream_no_vmm=1, host_sync_copies=1, fir_poly=+-1"""
-    global _build_opts
-    prev = _build_opts
-    _build_opts = dict(prev, **kw)
+    prev = getattr(_tls, "opts", None)
+    _tls.opts = dict(_effective_opts(), **kw)
     try:
         yield
     finally:
-        _build_opts = prev
+        _tls.opts = prev
 
 
 class _CreateProxy:
@@ -62,12 +71,13 @@ class _CreateProxy:
 
     def __getattr__(self, name):
         f = getattr(_raw_lib(), name)
-        if not (name.endswith("_create") and _build_opts):
+        opts = _effective_opts()
+        if not (name.endswith("_create") and name not in _NO_OPTS_CREATES and opts):
             return f
 
         def create(*a):
             o = BuildOpts()
-            for k, v in _build_opts.items():
+            for k, v in opts.items():
                 if k == "fir_path":
                     v = _PATHS.get(v, v)
                 if k == "fir_cfg":

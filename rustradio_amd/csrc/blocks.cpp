@@ -15,6 +15,14 @@
 
 namespace rr {
 
+// The per-call kernel choices below compare a window's tiles / batches with the chip's resident workgroup slots.  The
+// crossovers were measured on one MI355X (256 CUs; tools/call_overhead.py, tools/prune_window_probe*.py) and are kept as
+// multiples of THAT chip's slots: on a partitioned (CPX) or smaller device they scale with its CU count.
+static size_t chip_units(size_t measured_on_256_cus) {
+    const size_t cus = (size_t)std::max(1, device_cu_count());
+    return std::max<size_t>(1, (measured_on_256_cus * cus + 128) / 256);
+}
+
 static thread_local int g_device = 0;
 void set_thread_device(int d) { g_device = d; }
 int thread_device() { return g_device; }
@@ -265,12 +273,12 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     if (window_aware && (use_poly || use_prune)) {
         if (use_poly) {
             const size_t Ls = (L + d - 1) / d, per_tile = 1024 - Ls;
-            use_poly = out_n >= 1000 * per_tile;                               // one tile per resident workgroup slot
+            use_poly = out_n >= chip_units(1000) * per_tile;                   // one tile per resident workgroup slot
         } else {
             const size_t F = (size_t)1 << prune->log2f, per_batch = (F - L + 1) / d * d * d;   // D tiles of F - L + 1 inputs
             // (crossover in batches, tools/prune_window_probe.py: ~1.0-1.5x the resident workgroup slots of the tile —
             //  64-thread tiles at /4: 2000, 128-thread at /8: 1500, 256-thread at /16: 550)
-            use_prune = n >= (d == 4 ? 2000 : d == 8 ? 1500 : 550) * per_batch;
+            use_prune = n >= chip_units(d == 4 ? 2000 : d == 8 ? 1500 : 550) * per_batch;
         }
     }
     bool small_direct = false;
@@ -412,7 +420,7 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     bool use_prune = prune != nullptr;
     if (use_prune && fir->window_aware) {
         const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - (size_t)plG.L + 1) * (d / 2);
-        use_prune = n >= (d == 4 ? 1500 : d == 8 ? 1500 : 350) * per_batch;   // (tools/prune_window_probe2.py)
+        use_prune = n >= chip_units(d == 4 ? 1500 : d == 8 ? 1500 : 350) * per_batch;   // (tools/prune_window_probe2.py)
     }
     // (the hn samples before the new window become the next call's history: written by the tile kernel itself)
     const CarryOut carry{hist[cur ^ 1].p, (long)n, (long)hn};
@@ -477,7 +485,7 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     bool use_prune = prune != nullptr;
     if (use_prune && window_aware) {
         const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - L + 1) * d;
-        use_prune = n >= (d == 4 ? 2000 : d == 8 ? 1700 : 370) * per_batch;   // (tools/prune_window_probe2.py)
+        use_prune = n >= chip_units(d == 4 ? 2000 : d == 8 ? 1700 : 370) * per_batch;   // (tools/prune_window_probe2.py)
     }
     const bool small_direct = prune && !use_prune && (!fftk || L <= 320);
     if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
@@ -948,11 +956,11 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         bool use_poly = poly != nullptr;
         if (use_poly && window_aware) {
             const uint64_t Ls = (f->L + (uint64_t)D - 1) / (uint64_t)D;
-            use_poly = (a.r_hi - a.r_lo) >= (long)(1000 * (1024 - Ls));
+            use_poly = (a.r_hi - a.r_lo) >= (long)(chip_units(1000) * (1024 - Ls));
         }
         // (and below ~1.2 M samples the plain 2048-point tiles — more, smaller workgroups — beat the half-size inverse,
         //  which finishes two tiles per workgroup: 512 k samples 15.4 against 18.8 us)
-        const bool use_half = half_ok && (!window_aware || n_y >= 1200000);
+        const bool use_half = half_ok && (!window_aware || n_y >= chip_units(1200000));
         const bool use_alt = f->nsub && f->alt_log2f && window_aware && (long)n_y < f->small_window_outputs() &&
                              (int64_t)((D + I - 1) / I) < (int64_t)(((size_t)1 << f->alt_log2f) - f->L + 1);
         prof_begin(s);

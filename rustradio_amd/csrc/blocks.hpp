@@ -157,7 +157,9 @@ struct FftFilter : Block {
     int alt_log2f = 0;
     DevBuf<cf> d_tw_alt, d_hpos_alt;
     // below ~520 split tiles (two resident workgroups per CU) the alternate tile wins
-    long small_window_outputs() const { return 520L * (long)(((size_t)1 << log2f) - L + 1); }
+    long small_window_outputs() const {
+        return (520L * (long)device_cu_count() + 128) / 256 * (long)(((size_t)1 << log2f) - L + 1);   // (520 on the 256 CUs it was measured on)
+    }
     // more than 16383 taps: overlap-save frames of M = 2^m >= 2 L points through the any-size transform (AnyFft)
     std::unique_ptr<AnyFft> big;
     size_t bigM = 0;

@@ -185,6 +185,10 @@ struct Fanout {
         const int h = (int)(t & 1);
         RR_HIP(hipSetDevice(device));
         if ((long long)t > issued) throw Error("rr_fanout_release: tile was never submitted");
+        if ((long long)t + 2 <= issued) throw Error("rr_fanout_release: tile is no longer in the double buffer");
+        // ONE release per tile (the header's protocol): a second record on another stream would replace this event and the
+        // next broadcast into the half would wait for that stream only
+        if (rel[h] == (long long)t) throw Error("rr_fanout_release: tile already released (one compute stream per fan-out: join the readers' streams first)");
         RR_HIP(hipEventRecord(freed[h], compute));
         rel[h] = (long long)t;
     }

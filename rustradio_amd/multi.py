@@ -54,6 +54,36 @@ def cfg5_translate_hz(rank: int, world: int, fs: float = 100e6) -> float:
     return (rank + 0.5) * fs / (2.0 * world)       # the analytic signal occupies (0, fs/2): one slice per GPU
 
 
+XGMI_LINK_GBS = 153.0          # /opt/skills/guides/MI355X_MICROARCH.md: 7 point-to-point links x ~153 GB/s per GPU
+COLLECTIVE_LATENCY_MS = 0.02   # launch + protocol latency of one RCCL collective on a communication stream (assumed)
+
+
+def predict_fanout(world: int, tile_bytes: int, compute_ms_per_tile: float):
+    """PREDICTED cost of fanning one tile of the shared source out to `world` GPUs of one xGMI mesh, per algorithm, and
+    the weak-scaling efficiency that follows when the fan-out of tile t+1 overlaps the compute on tile t:
+    efficiency = compute / max(compute, fan-out).  Written down BEFORE any multi-GPU run (no node with more than one
+    GPU has ever run this code: VERDICT r2 #5) so that the first measured curve can be checked against it.
+
+      bcast              every byte of the tile leaves the owner over ONE link (ring / tree edge): tile / link
+      scatter_allgather  the owner's world-1 links carry tile / world each, then every rank gathers world-1 pieces of
+                         tile / world over its own links to the other receivers: 2 tile / (world link)
+    (two GPUs share one link, so at world = 2 both are tile / link.)"""
+    link = XGMI_LINK_GBS * 1e9
+    out = {}
+    for algo, ncoll in (("bcast", 1), ("scatter_allgather", 2)):
+        if world <= 1:
+            t = 0.0
+        elif algo == "bcast":
+            t = tile_bytes / link * 1e3 + ncoll * COLLECTIVE_LATENCY_MS
+        else:
+            t = 2.0 * tile_bytes / (world * link) * 1e3 + ncoll * COLLECTIVE_LATENCY_MS
+        out[algo] = {"fanout_ms_per_tile": round(t, 4),
+                     "per_link_gbs_needed_to_hide": None if compute_ms_per_tile <= 0 else round(
+                         (tile_bytes if algo == "bcast" else 2.0 * tile_bytes / max(world, 1)) / (compute_ms_per_tile * 1e-3) / 1e9, 1),
+                     "efficiency": round(compute_ms_per_tile / max(compute_ms_per_tile, t), 3) if compute_ms_per_tile > 0 else None}
+    return out
+
+
 def broadcast_source(dist, rank: int, make, device, src_rank: int = 0):
     """Fan-out of the shared IQ source.  `make()` builds the float32 tensor on the owning
     rank only; every rank returns an identical tensor on `device`.  -> (tensor, GB/s)."""

@@ -38,6 +38,24 @@ def max_norm_err(got, ref, scale=None) -> float:
     return float(np.max(np.abs(got.astype(np.complex128) - ref.astype(np.complex128)))) / den
 
 
+def angle_parity(yg, yo, ro, tol=1e-5, skip=0):
+    """Chain-level check of a demodulated stream against the oracle's (say how much of the allowance is
+    used).  atan2 amplifies a 1e-5 error of the resampled stream `ro` by 1 / |r|, so the bound per sample is the stage
+    bound propagated through it, tol pi + eps / |r[m]| + eps / |r[m+1]| with eps = tol max|r|.  Returns
+      used        = max over samples of |d angle| / bound          (must be <= 1)
+      above_plain = fraction of samples (after `skip`) whose error exceeds the PLAIN tol pi
+      max_err_pi  = the largest error in units of pi"""
+    yg = np.asarray(yg, np.float64); yo = np.asarray(yo, np.float64)
+    assert yg.shape == yo.shape and len(yg) > 0, (yg.shape, yo.shape)
+    mag = np.abs(np.asarray(ro).astype(np.complex128))
+    eps = tol * float(np.max(mag))
+    bound = (tol * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30))[:len(yg)]
+    d = np.abs(yg - yo)
+    d = np.minimum(d, 2 * np.pi - d)                              # +-pi wrap
+    return {"used": float(np.max(d / bound)), "above_plain": float(np.mean(d[skip:] > tol * np.pi)) if len(d) > skip else 0.0,
+            "max_err_pi": float(np.max(d) / np.pi)}
+
+
 class Ring:
     """A stream as the blocks see it: `buf` = readable window, `free()` = writable window."""
 

@@ -34,7 +34,9 @@ def test_single_gpu_line():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["launches"] == 3 and 0 < r["frac"] < 1 and r["peak"] == 8000.0
+    assert "ALGORITHMIC bytes" in r["frac_counts"]
     assert "configs[1]" in d["config"]["workload"]
+    assert d["config"]["settle_steps"] >= 40 and d["ms_per_step_from_idle"] > 0 and d["value_from_idle"] > 0
 
 
 def test_two_rank_line():
@@ -52,6 +54,23 @@ def test_two_rank_line():
         assert res["value"] > d["value"]
     # both shards ran: 2 ranks x 32 channels x 2.4e6 samples x 3 steps in the timed region
     assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * 3 - 2 * 32 * 2_400_000 * 3) / (2 * 32 * 2_400_000 * 3) < 0.01
-    for name in ("fm_multi_u8", "channelizer"):
+    for name in ("fm_multi_u8", "channelizer", "channelizer_model"):
         assert d["others"][name]["msamples_per_s"] > 0
     assert "translate" in d["others"]["channelizer"]["workload"]  # configs[4], N > 1: one channel offset per rank
+    # ... measured on the ON-PARITY rotator by default, named in the workload string; the opt-in model beside it, labelled
+    assert d["others"]["channelizer"]["rotator"] == "replay" and "rotator=replay" in d["others"]["channelizer"]["workload"]
+    assert d["others"]["channelizer_model"]["rotator"] == "model" and "OFF parity" in d["others"]["channelizer_model"]["workload"]
+    # the line anchors its own scaling curve: the same workload on one rank, source resident
+    a = d["scale_anchor"]
+    assert a["workload_key"] == d["config"]["workload_key"] == "fm_multi" and a["n1_value"] > 0
+    assert abs(d["scaling_efficiency_vs_anchor"] - d["value"] / (2 * a["n1_value"])) < 1e-3
+    # ... and carries the fan-out PREDICTION (no run on more than one GPU has happened yet) for bcast and mesh at 2 / 4 / 8
+    pr = c["predicted"]
+    assert set(pr["at_2_4_8_gpus"]) == {"2", "4", "8"}
+    for n in ("2", "4", "8"):
+        for algo in ("bcast", "scatter_allgather"):
+            e = pr["at_2_4_8_gpus"][n][algo]
+            assert e["fanout_ms_per_tile"] > 0 and 0 < e["efficiency"] <= 1
+    assert pr["assumptions"]["xgmi_link_gbs"] == 153.0
+    # the library's own fan-out (rr_fanout_*) is the measured one whenever every rank has a GPU
+    assert c["fanout"] == ("abi" if c["backend"] == "rccl" else "torch")

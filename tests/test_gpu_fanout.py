@@ -2,6 +2,13 @@
 reference's in-process Tee tree, src/tee.rs:10-24).  The box has one GPU, so the group has one rank: once without a
 communicator (the plain double buffer) and once through RCCL (RR_FANOUT_RCCL_ALWAYS: ncclCommInitRank + ncclBroadcast on
 the communication stream).  The "source block" and the consumer are real blocks driven on device pointers."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -115,3 +122,40 @@ def test_abi_fanout_adapter_matches_tilefanout_interface(rr):
     assert torch.equal(out, store * 2.0)
     ms, nb = fan.broadcast_ms()
     assert nb == 1 and ms > 0 and fan.n_bcast == ntiles          # tile 4 (tile 0's timing was drained by reset_timing)
+
+
+def _run_ranks(rr, world, flags, nbytes, ntiles=6):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fanout_rank import tile_bytes_of
+    want = [zlib.crc32(tile_bytes_of(t, nbytes).tobytes()) for t in range(ntiles)]
+    with tempfile.TemporaryDirectory() as xdir:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fanout_rank.py"),
+                                   str(r), str(world), xdir, str(flags), str(nbytes), str(ntiles)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+        outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (r, e[-2000:])
+        d = json.loads([l for l in o.strip().split("\n") if l.startswith("{")][-1])
+        assert d["rank"] == r and d["crcs"] == want, (r, d["crcs"], want)
+        assert d["timed"] >= 1 and d["fanout_ms"] > 0
+
+
+def test_fanout_rank_processes_one_rank(rr):
+    """the rank script of the multi-GPU test below on a one-rank RCCL group (what this box can run): child process, group id
+    through a file, tiles produced one ahead, CRC32 of every tile as acquired"""
+    _run_ranks(rr, 1, rr.FANOUT_RCCL_ALWAYS | rr.FANOUT_MESH, (1 << 20) + 13)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the multi-rank RCCL paths of rr_fanout_* "
+                    "(ncclBroadcast with world > 1, in-place ncclScatter + ncclAllGather, cross-rank event ordering) have never "
+                    "run on hardware — the development box has one GPU (ADVICE r2)")
+@pytest.mark.parametrize("mesh", [False, True])
+@pytest.mark.parametrize("nbytes", [4 << 20, (4 << 20) + 13])
+def test_fanout_across_gpus(rr, mesh, nbytes):
+    """rr_fanout_* on one rank PER GPU (2 ranks, or 4 when the node has them): rank processes are started before any of
+    them touches a GPU, the group id travels through a file, every rank reports the CRC32 of every tile it acquired — all
+    must equal the owner's content, for the broadcast and for the mesh algorithm, also when the tile does not divide by the
+    number of ranks."""
+    world = 4 if torch.cuda.device_count() >= 4 else 2
+    _run_ranks(rr, world, rr.FANOUT_MESH if mesh else 0, nbytes)
