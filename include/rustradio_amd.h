@@ -48,7 +48,11 @@ enum rr_window { RR_WIN_HAMMING = 0, RR_WIN_BLACKMAN = 1, RR_WIN_BLACKMAN_HARRIS
 /* QuadratureDemod atan2 flavour: RR_ATAN2_EXACT = `f32::atan2`
  * (--no-default-features build, src/quadrature_demod.rs:96-109);
  * RR_ATAN2_FAST = `fast_math::atan2` (default Cargo feature, :77-81). */
-enum rr_atan2 { RR_ATAN2_EXACT = 0, RR_ATAN2_FAST = 1 };
+enum rr_atan2 { RR_ATAN2_EXACT = 0, RR_ATAN2_FAST = 1,
+                /* fused-chain constructors only (rr_fm_chain*_create, rr_fm_multi*_create): the chain's demodulator is the
+                 * FastFM block (src/quadrature_demod.rs:144-165: one output per resampled sample, two samples of history,
+                 * `gain` unused) instead of QuadratureDemod */
+                RR_DEMOD_FASTFM = 2 };
 
 /* Rotator evaluation for FirFilter::translate (src/fir.rs:464-473: `sample *= phase; phase *= step` in f32, never
  * renormalised):
@@ -169,7 +173,12 @@ rr_block *rr_hilbert_create(size_t ntaps, int window, float window_parm);
  * The output stream must be able to hold one filter block's worth of demodulated samples,
  * ceil(nsamples * interp / deci) (the three separate blocks need only `nsamples` Complex slots in THEIR rings):
  * with the reference's 4,096,000-byte streams that is any ratio up to interp/deci ~ 60 at 16384-point blocks; a
- * smaller output window returns WAIT_DST(n) forever — use the three blocks there. */
+ * smaller output window returns WAIT_DST(n) forever — use the three blocks there.
+ * No tap-count limit (the reference has none, src/fft_filter.rs:36-42): up to 16383 taps the chain is one kernel per call;
+ * beyond that — or for a decimation larger than a tile — the SAME constructor returns the unfused composition of the three
+ * GPU blocks behind the one handle (device-resident intermediates, one work() call, same whole-stream output).
+ * atan2_mode = RR_DEMOD_FASTFM puts FastFM (src/quadrature_demod.rs:144-165) in the demodulator's place: one output per
+ * resampled sample, bit-exact against FftFilter -> RationalResampler -> FastFM (composition; `gain` unused). */
 rr_block *rr_fm_chain_create(const rr_c32 *taps, size_t ntaps, size_t interp, size_t deci,
                              float gain, int atan2_mode);
 
@@ -201,7 +210,8 @@ rr_block *rr_fm_chain_u8_create(const rr_c32 *taps, size_t ntaps, size_t interp,
  * (src/fft_filter.rs:365-491, src/rational_resampler.rs:125-206, src/multiply_const.rs:6-23) as ONE real-valued kernel:
  * f32 in, f32 out; whole-stream output equals the three blocks in sequence.  work() like rr_fm_chain_create: WAIT_DST(n)
  * when the next filter block's resampled samples do not fit, else consumes like FftFilter (whole pending block) and
- * WAIT_SRC(nsamples - pending).  ntaps <= 3584 (NULL beyond: use the three blocks). */
+ * WAIT_SRC(nsamples - pending).  Up to 3584 taps one kernel per call; longer filters run as the unfused composition of
+ * the three GPU blocks behind the same handle (no tap-count limit, as in the reference). */
 rr_block *rr_audio_chain_create(const float *taps, size_t ntaps, size_t interp, size_t deci, float scale);
 
 /* Graph-level fusion of Hilbert::new(src, hilbert_ntaps, &window) (src/hilbert.rs:38-61) ->
@@ -219,7 +229,8 @@ rr_block *rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_p
  * tile's forward FFT is computed once for all channels.  The block has nchan OUTPUT windows:
  * rr_block_work[_dev] takes `out` as nchan consecutive windows of out_cap elements (channel c at
  * out + c*out_cap) and reports the per-channel consumed/produced (identical for all channels).
- * ntaps <= 4094. */
+ * Up to 4094 taps the channels share every tile's forward transform in one kernel; longer filters (the reference has no
+ * limit) run as one rr_fm_chain per channel on the shared window behind the same handle.  atan2_mode as rr_fm_chain_create. */
 rr_block *rr_fm_multi_create(const rr_c32 *taps, size_t nchan, size_t ntaps, size_t interp, size_t deci,
                              float gain, int atan2_mode);
 /* The same fed by the RTL-SDR byte stream: RtlSdrDecode (src/rtlsdr_decode.rs:9-47) fused in front of the Tee, as in

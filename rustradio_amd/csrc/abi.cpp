@@ -130,7 +130,7 @@ rr_block* rr_resampler_create(size_t interp, size_t deci, size_t elem_size) {
 }
 rr_block* rr_fm_chain_u8_create(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain,
                                 int atan2_mode) {
-    return make_block([&] { return new rr::FmChain(taps, ntaps, interp, deci, gain, atan2_mode, true); });
+    return make_block([&] { return rr::make_fm_chain(taps, ntaps, interp, deci, gain, atan2_mode, true, nullptr, 0); });
 }
 rr_block* rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_parm, const rr_c32* taps, size_t ntaps,
                                 size_t deci, int translate, float samp_rate, float freq) {
@@ -171,7 +171,7 @@ rr_block* rr_hilbert_create(size_t ntaps, int window, float window_parm) {
     return make_block([&] { return new rr::Hilbert(ntaps, window, window_parm); });
 }
 rr_block* rr_fm_chain_create(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int atan2_mode) {
-    return make_block([&] { return new rr::FmChain(taps, ntaps, interp, deci, gain, atan2_mode); });
+    return make_block([&] { return rr::make_fm_chain(taps, ntaps, interp, deci, gain, atan2_mode, false, nullptr, 0); });
 }
 rr_block* rr_fir_fftfilter_create(const rr_c32* fir_taps, size_t fir_ntaps, const rr_c32* fft_taps, size_t fft_ntaps) {
     return make_block([&] {
@@ -185,19 +185,19 @@ rr_block* rr_fir_fm_chain_create(const rr_c32* fir_taps, size_t fir_ntaps, const
                                  size_t interp, size_t deci, float gain, int atan2_mode) {
     return make_block([&] {
         if (!fir_taps || fir_ntaps == 0) throw rr::Error("FirFilter: empty taps");
-        return new rr::FmChain(fft_taps, fft_ntaps, interp, deci, gain, atan2_mode, false, 14, fir_taps, fir_ntaps);
+        return rr::make_fm_chain(fft_taps, fft_ntaps, interp, deci, gain, atan2_mode, false, fir_taps, fir_ntaps);
     });
 }
 rr_block* rr_audio_chain_create(const float* taps, size_t ntaps, size_t interp, size_t deci, float scale) {
-    return make_block([&] { return new rr::AudioChain(taps, ntaps, interp, deci, scale); });
+    return make_block([&] { return rr::make_audio_chain(taps, ntaps, interp, deci, scale); });
 }
 rr_block* rr_fm_multi_create(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain,
                              int atan2_mode) {
-    return make_block([&] { return new rr::FmMulti(taps, nchan, ntaps, interp, deci, gain, atan2_mode); });
+    return make_block([&] { return rr::make_fm_multi(taps, nchan, ntaps, interp, deci, gain, atan2_mode, false); });
 }
 rr_block* rr_fm_multi_u8_create(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain,
                                 int atan2_mode) {
-    return make_block([&] { return new rr::FmMulti(taps, nchan, ntaps, interp, deci, gain, atan2_mode, true); });
+    return make_block([&] { return rr::make_fm_multi(taps, nchan, ntaps, interp, deci, gain, atan2_mode, true); });
 }
 size_t rr_block_out_windows(const rr_block* b) { return b ? b->b->out_windows() : 0; }
 void rr_block_destroy(rr_block* b) { delete b; }

@@ -309,6 +309,38 @@ struct RtlSdrDecode : Block {
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 
+// ---- compositions inside the library (compose.cpp) --------------------------------------------------------------------
+// Blocks in series behind ONE handle: inner blocks chained through device-resident buffers of the reference's stream
+// capacity, one Graph::run-style round loop per work() call.  What the fused kernels do not cover runs as this.
+struct Series : Block {
+    std::vector<std::unique_ptr<Block>> b;
+    struct Link {
+        DevBuf<unsigned char> buf[2];     // linear window; consume() moves the rest to the front of the other buffer
+        int cur = 0;
+        size_t len = 0, cap = 0, es = 0;
+    };
+    std::unique_ptr<Link[]> link;         // link[i] between b[i] and b[i + 1]
+    Series(const char* name, std::vector<std::unique_ptr<Block>> blocks);
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+    bool eof(bool src_eof) override;
+};
+// N blocks of one shape on ONE shared input window, N output windows (the reference's Tee fan-out + N chains).
+struct Parallel : Block {
+    std::vector<std::unique_ptr<Block>> ch;
+    Parallel(const char* name, std::vector<std::unique_ptr<Block>> channels);
+    size_t out_windows() const override { return ch.size(); }
+    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+    int work_host(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*) override;
+    bool eof(bool src_eof) override;
+};
+// What rr_fm_chain*_create / rr_fm_multi*_create / rr_audio_chain_create build: the fused block where its kernels reach, the
+// unfused composition (same protocol, same output) for every other shape the separate blocks take — no constructor cliffs.
+// mode: RR_ATAN2_EXACT / RR_ATAN2_FAST (QuadratureDemod) or RR_DEMOD_FASTFM (FastFM, quadrature_demod.rs:144-165).
+Block* make_fm_chain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool u8,
+                     const rr_c32* fir_taps, size_t fir_ntaps);
+Block* make_fm_multi(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool u8);
+Block* make_audio_chain(const float* taps, size_t ntaps, size_t interp, size_t deci, float scale);
+
 struct Hilbert : Block {
     FirPlan pl;
     DevBuf<float> d_tp, d_rev;

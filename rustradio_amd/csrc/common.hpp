@@ -103,6 +103,21 @@ template <class T, class SRC> __device__ __forceinline__ void carry_store(const 
 #endif
 
 #if defined(__HIPCC__)
+// Window pointers as GLOBAL-address-space pointers.  The windows reach the kernels inside by-value structs (VSrc); whether
+// the compiler then proves them global (global_load, vmcnt only) or leaves them generic (flat_load: also counted on
+// lgkmcnt, and ordered with the LDS exchanges of the tile) turned out to depend on unrelated code of the same translation
+// unit — round 3: rewriting k_fm_chain's epilogue turned the 16 tile loads of EVERY load_tile16 kernel, the headline's
+// included, into flat loads and made two kernels spill.  The hot loads therefore say it themselves.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> using gptr = const T __attribute__((address_space(1)))*;
+template <class T> __device__ __forceinline__ gptr<T> as_global(const T* p) { return (gptr<T>)p; }
+#else           // (host pass of the same translation unit: plain pointers)
+template <class T> using gptr = const T*;
+template <class T> __host__ __device__ inline gptr<T> as_global(const T* p) { return p; }
+#endif
+#endif
+
+#if defined(__HIPCC__)
 // Exactly-rounded single operations that the optimiser cannot fuse.  The kernels are compiled with
 // -ffp-contract=fast and HIP's __fmul_rn/__fadd_rn/__fsub_rn are plain operators — which it DOES
 // contract into FMAs (found by the bit-exact MultiplyConst<Complex> test).  Used wherever the

@@ -22,7 +22,8 @@
 // Measurement builds (never shipped; make ABLATE=<bits> / TIMING=1 OUT=../lib_ablate):
 //   -DRR_FFT_ABLATE_BITS=<bits>  compile-time phase ablation: 1 no input loads, 2 no output stores,
 //        4 no LDS exchanges, 8 no butterflies, 16 inputs from an L2-resident window, 32 outputs to
-//        an L2-resident window; in k_fftfilt_prune's real-stream path also 64 no second response, 128 no batched tail.
+//        an L2-resident window; in k_fftfilt_prune's real-stream path also 64 no second response, 128 no batched tail;
+//        in k_fm_chain_split 512 no inverse transforms / output butterfly, 1024 no demodulation.
 //        (Compile-time so that the ablated kernel keeps the production
 //        register allocation; a runtime flag version spilled 208 B/lane and skewed every number.)
 //   -DRR_FFT_TIMING_BUILD  workgroup 0 / thread 0 stamps s_memtime at every phase boundary of its
@@ -221,7 +222,7 @@ __device__ __attribute__((noinline)) void stage_tile_slow(creg* lds, const cf* p
 template <int LOG2F> __device__ __forceinline__ void load_tile16(creg* v, const VSrc<cf>& src, long v0, int t, creg* lds) {
     constexpr int T = 1 << (LOG2F - 4);
     if (v0 >= src.plen && v0 - src.plen + 16 * T <= src.in_len) {
-        const creg* p = reinterpret_cast<const creg*>(src.in) + (v0 - src.plen) + t;
+        const gptr<creg> p = as_global(reinterpret_cast<const creg*>(src.in) + (v0 - src.plen) + t);
 #pragma unroll
         for (int n = 0; n < 16; n++) v[n] = p[n * T];
     } else {
@@ -245,7 +246,7 @@ __device__ __attribute__((noinline)) void stage_tile_slow_iq8(creg* lds, VSrcIQ8
 template <int LOG2F> __device__ __forceinline__ void load_tile16(creg* v, const VSrcIQ8& src, long v0, int t, creg* lds) {
     constexpr int T = 1 << (LOG2F - 4);
     if (v0 >= src.plen && v0 - src.plen + 16 * T <= src.in_len) {
-        const unsigned short* p = reinterpret_cast<const unsigned short*>(src.in) + (v0 - src.plen) + t;
+        const gptr<unsigned short> p = as_global(reinterpret_cast<const unsigned short*>(src.in) + (v0 - src.plen) + t);
         unsigned short w[16];
 #pragma unroll
         for (int n = 0; n < 16; n++) w[n] = p[n * T];
@@ -693,9 +694,9 @@ __device__ __attribute__((noinline)) void stage_tile_slow_at(creg* lds, SRC src,
     }
 }
 // sample i of the caller's window (interior tiles only)
-__device__ __forceinline__ creg window_at(const VSrc<cf>& src, long i) { return reinterpret_cast<const creg*>(src.in)[i]; }
+__device__ __forceinline__ creg window_at(const VSrc<cf>& src, long i) { return as_global(reinterpret_cast<const creg*>(src.in))[i]; }
 __device__ __forceinline__ creg window_at(const VSrcIQ8& src, long i) {
-    return to_reg(VSrcIQ8::decode(reinterpret_cast<const unsigned short*>(src.in)[i]));
+    return to_reg(VSrcIQ8::decode(as_global(reinterpret_cast<const unsigned short*>(src.in))[i]));
 }
 
 // DECI: keep every d-th filtered sample (out[m] = y[m d], n_out counts kept samples) — the index arithmetic of
@@ -1121,6 +1122,79 @@ struct SrcWalk {
     }
 };
 
+// Resample + demodulate the part of one filtered tile (natural order in LDS, `at(p)` = tile position p) that the tile owns:
+// the resampled samples u = u_lo + t, u_lo + t + T, ... < u_hi whose source lies in the tile's own Sp outputs
+// (rational_resampler.rs:183-198, quadrature_demod.rs:65-109).  Round 3: everything per OUTPUT is 32-bit and tile-local —
+// positions pu / pl of r[u] / r[u - 1] advance by (qs, rs) with one conditional carry, the lower partner's start follows
+// from the upper one's ((u - 1) D = u D - D: no second division), the three special samples of a call (r[0] has no
+// partner, the first pair takes its lower sample from the previous call, the last r is carried) are tested on k == 0 /
+// k == n - 1 only.  The first version walked 64-bit stream indices with two 64-bit divisions per thread and tile and cost
+// ~150 instructions per output on the 8192-point tiles (4.4 outputs per thread and tile at 25:128): 19 % of the rtl_fm
+// front end (tools/rtl_fm_ablate.sh: 0.142 ms with, 0.115 ms without it).
+template <int T> struct TileWalk {
+    int n = 0;                       // outputs of this thread in the tile
+    int pu, pl, qs;                  // tile positions of r[u] / r[u - 1]; step of T outputs
+    unsigned ru, rl, rs, I32;        // u D mod I, (u - 1) D mod I; remainder step
+    bool first_here, carry_here, no_partner;
+    long o_off;                      // index of this thread's first output in the call's output window
+    __device__ __forceinline__ void init(long tile, long Sp, long ys, int first, const FmArgs& a, int t) {
+        const long y_lo = tile * Sp, y_hi = min((tile + 1) * Sp, a.n_y);
+        long u_lo = ((a.A + y_lo) * a.I + a.D - 1) / a.D;             // u >= ceil((A + y) I / D): wave-uniform
+        long u_hi = ((a.A + y_hi) * a.I + a.D - 1) / a.D;
+        if (u_lo < a.r_lo) u_lo = a.r_lo;
+        if (u_hi > a.r_hi) u_hi = a.r_hi;
+        const long u0 = u_lo + t;
+        n = u0 < u_hi ? (int)((u_hi - u0 + T - 1) / T) : 0;           // (T is a power of two)
+        if (n == 0) return;
+        SrcWalk wu;
+        wu.init(u0, a.I, a.D);
+        I32 = (unsigned)a.I;                                          // (I <= 2^31: FmChain's constructor)
+        const int qd = (int)(a.D / a.I);
+        const unsigned rd = (unsigned)(a.D % a.I);
+        qs = (int)(((long)T * a.D) / a.I);
+        rs = (unsigned)(((long)T * a.D) % a.I);
+        pu = (int)(wu.q - a.A - ys) + first;
+        ru = (unsigned)wu.r;
+        pl = pu - qd - (ru < rd ? 1 : 0);
+        rl = ru < rd ? ru + (I32 - rd) : ru - rd;
+        first_here = u0 == a.r_lo;                                    // this thread starts on the call's first sample
+        no_partner = first_here && u0 == 0;                           // ... which is r[0] of the stream
+        carry_here = u0 + (long)(n - 1) * T == a.r_hi - 1;            // ... ends on the call's last one
+        o_off = (u0 - 1) - a.o_base;
+    }
+    template <class AT>
+    __device__ __forceinline__ void run(AT at, const FmArgs& a, float* __restrict__ out, const cf* __restrict__ last_in,
+                                        cf* __restrict__ last_out) const {
+        int pu_ = pu, pl_ = pl;
+        unsigned ru_ = ru, rl_ = rl;
+        float* o = out + o_off;
+        for (int k = 0; k < n; k++, o += T) {
+            const creg xu = at(pu_);
+            if (carry_here && k == n - 1) last_out[0] = from_reg(xu); // carry for the next call
+            if (!(no_partner && k == 0)) {                            // r[0] has no lower partner
+                const creg xl = (first_here && k == 0) ? to_reg(last_in[0]) : at(pl_);   // lower sample from the previous call
+                // conj(xl) * xu in num-complex order, un-contracted (quadrature_demod.rs:72)
+                const float na = -xl.y;
+                const float re = sub_rn(mul_rn(xl.x, xu.x), mul_rn(na, xu.y));
+                const float im = add_rn(mul_rn(xl.x, xu.y), mul_rn(na, xu.x));
+                const float ang = a.mode == 0 ? atan2_poly(im, re) : fmc_atan2(im, re);
+                *o = mul_rn(a.gain, ang);
+            }
+            pu_ += qs; ru_ += rs;
+            if (ru_ >= I32) { ru_ -= I32; pu_++; }
+            pl_ += qs; rl_ += rs;
+            if (rl_ >= I32) { rl_ -= I32; pl_++; }
+        }
+    }
+};
+template <int T, class AT>
+__device__ __forceinline__ void fm_epilogue(AT at, long tile, long Sp, long ys, int first, const FmArgs& a, int t,
+                                            float* __restrict__ out, const cf* __restrict__ last_in, cf* __restrict__ last_out) {
+    TileWalk<T> w;
+    w.init(tile, Sp, ys, first, a, t);
+    w.run(at, a, out, last_in, last_out);
+}
+
 // ---- FftFilterFloat -> RationalResampler -> MultiplyConst fused (the rtl_fm audio stage, examples/rtl_fm.rs:398-418) ----
 // The real-stream tile above (two overlap-save segments per Complex tile); instead of storing the filtered segments
 // the tile parks them in LDS in stream order and every thread picks resampled samples out[m] = scale * y[floor(m D / I)]
@@ -1222,7 +1296,6 @@ void k_fm_chain(SRC src, float* __restrict__ out, int L, long ntiles, const cf* 
     const int t = threadIdx.x;
     const int first = L - 1;
     const long Sp = fm_advance((F - L + 1) - a.G, a.I, a.D, T);
-    const long qs = ((long)T * a.D) / a.I, rs = ((long)T * a.D) % a.I;      // SrcWalk step of T outputs
     TileXform<LOG2F, VAR> X;
     X.init(t, tw, hpos);
 
@@ -1239,31 +1312,7 @@ void k_fm_chain(SRC src, float* __restrict__ out, int L, long ntiles, const cf* 
         tile_sync<T>();
 
         // upper samples u with source in [tile*Sp, min((tile+1)*Sp, n_y))  (relative to A)
-        const long y_lo = tile * Sp, y_hi = min((tile + 1) * Sp, a.n_y);
-        // u >= ceil((A + y) * I / D)
-        long u_lo = ((a.A + y_lo) * a.I + a.D - 1) / a.D;
-        long u_hi = ((a.A + y_hi) * a.I + a.D - 1) / a.D;
-        if (u_lo < a.r_lo) u_lo = a.r_lo;
-        if (u_hi > a.r_hi) u_hi = a.r_hi;
-        SrcWalk wu, wl;
-        wu.init(u_lo + t, a.I, a.D);
-        wl.init(u_lo + t - 1, a.I, a.D);
-        for (long u = u_lo + t; u < u_hi; u += T, wu.step(qs, rs, a.I), wl.step(qs, rs, a.I)) {
-            const long gu = wu.q - a.A;                            // source of r[u], relative to A
-            const creg ru = lds[lds_pad((int)(gu - ys) + first)];
-            if (u == a.r_hi - 1) last_r_out[0] = from_reg(ru);     // carry for the next call
-            if (u != 0) {                                           // r[0] has no lower partner
-                creg rl;
-                if (u == a.r_lo) rl = to_reg(last_r_in[0]);         // lower sample from the previous call
-                else rl = lds[lds_pad((int)(wl.q - a.A - ys) + first)];
-                // conj(rl) * ru in num-complex order, un-contracted (quadrature_demod.rs:72)
-                const float na = -rl.y;
-                const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
-                const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
-                const float ang = a.mode == 0 ? atan2_poly(im, re) : fmc_atan2(im, re);
-                out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
-            }
-        }
+        fm_epilogue<T>([&](int p) -> creg { return lds[lds_pad(p)]; }, tile, Sp, ys, first, a, t, out, last_r_in, last_r_out);
         tile_sync<T>();        // epilogue reads done before the next tile's first exchange
     }
 }
@@ -1972,11 +2021,9 @@ void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, cons
     const int t = threadIdx.x;
     const int first = L - 1;
     const long Sp = fm_advance((F - L + 1) - a.G, a.I, a.D, 256);
-    const long qs = ((long)T * a.D) / a.I, rs = ((long)T * a.D) % a.I;
     TileXform<LOG2M, 0> X;
     X.init_no_h(t, tw);
     const creg wbase = to_reg(wk[t]);                   // w_F^t
-    auto at = [&](long p) -> creg { return area[(p / M) * LE + lds_pad((int)(p % M))]; };
 
     for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
         const long tile = it.tile;
@@ -2028,12 +2075,12 @@ void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, cons
             lds_load<LOG2M, 0>(v, t, lds);
             X.forward(v, lds);
             apply_h(v, h);
-            X.inverse(v, lds);
-            lds_store<LOG2M, 0>(v, t, lds);
+            if (!RR_ABLATE(512)) X.inverse(v, lds);      // (measurement builds: 512 = no inverse transforms / output butterfly —
+            lds_store<LOG2M, 0>(v, t, lds);              //  the most ANY pruning of the inverse side could save)
         }
         // output butterfly: y[n + s M] into the own natural slots of area s
 #pragma unroll 1
-        for (int n0 = 0; n0 < 16; n0 += 8) {
+        for (int n0 = RR_ABLATE(512) ? 16 : 0; n0 < 16; n0 += 8) {
             creg wko[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) wko[k] = cmul(wbase, split_step<NSUB>(n0 + k));
@@ -2053,26 +2100,9 @@ void k_fm_chain_split(SRC src, float* __restrict__ out, int L, long ntiles, cons
         }
         tile_sync<T>();
         // resample + demodulate (as k_fm_chain)
-        const long y_lo = tile * Sp, y_hi = min((tile + 1) * Sp, a.n_y);
-        long u_lo = ((a.A + y_lo) * a.I + a.D - 1) / a.D;
-        long u_hi = ((a.A + y_hi) * a.I + a.D - 1) / a.D;
-        if (u_lo < a.r_lo) u_lo = a.r_lo;
-        if (u_hi > a.r_hi) u_hi = a.r_hi;
-        SrcWalk wu, wl;
-        wu.init(u_lo + t, a.I, a.D);
-        wl.init(u_lo + t - 1, a.I, a.D);
-        for (long u = u_lo + t; u < u_hi; u += T, wu.step(qs, rs, a.I), wl.step(qs, rs, a.I)) {
-            const creg ru = at(wu.q - a.A - ys + first);
-            if (u == a.r_hi - 1) last_r_out[0] = from_reg(ru);
-            if (u != 0) {
-                const creg rl = u == a.r_lo ? to_reg(last_r_in[0]) : at(wl.q - a.A - ys + first);
-                const float na = -rl.y;
-                const float re = sub_rn(mul_rn(rl.x, ru.x), mul_rn(na, ru.y));
-                const float im = add_rn(mul_rn(rl.x, ru.y), mul_rn(na, ru.x));
-                const float ang = a.mode == 0 ? atan2_poly(im, re) : fmc_atan2(im, re);
-                out[(u - 1) - a.o_base] = mul_rn(a.gain, ang);
-            }
-        }
+        if (!RR_ABLATE(1024))                            // (measurement builds: 1024 = no demodulation)
+            fm_epilogue<T>([&](int p) -> creg { return area[(p >> LOG2M) * LE + lds_pad(p & (M - 1))]; }, tile, Sp, ys, first, a, t,
+                           out, last_r_in, last_r_out);
         tile_sync<T>();        // epilogue reads done before the next tile rewrites the areas
     }
 }

@@ -84,9 +84,9 @@ __device__ __forceinline__ creg cmac(creg acc, creg a, creg w) {
 #endif
 }
 
-__device__ __forceinline__ creg poly_elem(const VSrc<cf>& s, long i) { return reinterpret_cast<const creg*>(s.in)[i]; }
+__device__ __forceinline__ creg poly_elem(const VSrc<cf>& s, long i) { return as_global(reinterpret_cast<const creg*>(s.in))[i]; }
 __device__ __forceinline__ creg poly_elem(const VSrcIQ8& s, long i) {
-    return to_reg(VSrcIQ8::decode(reinterpret_cast<const unsigned short*>(s.in)[i]));
+    return to_reg(VSrcIQ8::decode(as_global(reinterpret_cast<const unsigned short*>(s.in))[i]));
 }
 
 // Boundary tiles (touching the carry prefix, the start of the stream or the end of the window) are staged through
@@ -171,15 +171,15 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
                 // the batch's phases are NBV ADJACENT samples per lane: fetched as 16-byte pairs (+ one 8-byte rest) — every
                 // load instruction of a 48-byte lane stride looks up the same 24 cache lines whatever its width, so two
                 // loads per position instead of three are a third fewer L1 look-ups
-                const creg* base = reinterpret_cast<const creg*>(src.in) + i0;
+                const gptr<creg> base = as_global(reinterpret_cast<const creg*>(src.in) + i0);
 #pragma unroll
                 for (int n = 0; n < 16; n++) {
-                    const creg* q = base + (long)D * PT * n;
+                    const gptr<creg> q = base + (long)D * PT * n;
 #pragma unroll
                     for (int k = 0; k < (NB + 1) / 2; k++) {
                         const int i = nbv - 1 - 2 * k;
                         if (i >= 1) {
-                            const creg2u w = *reinterpret_cast<const creg2u*>(q - i);
+                            const creg2u w = *reinterpret_cast<gptr<creg2u>>(q - i);
                             v[i][n] = mk(w.x, w.y);
                             v[i - 1][n] = mk(w.z, w.w);
                         } else if (i == 0) {

@@ -243,8 +243,13 @@ def test_fftfilter_rejects_too_many_taps(rr):
         rr.FftFilter(np.ones((1 << 19) + 1, np.complex64))  # frames of 2^m >= 2 L points beyond the any-size transform's 2^20
     with pytest.raises(ValueError):
         rr.FftFilter(np.ones(0, np.complex64))
-    with pytest.raises(ValueError):                          # the fused chains run on LDS tiles only
-        rr.FmChain(np.ones(16384, np.complex64), 1, 6, 1.0)
+    # (the fused chains have no limit of their own any more: beyond their tiles the constructor composes the three blocks —
+    #  test_no_constructor_cliffs_*; what is left is FftFilter's own 2^19 taps and the reference's argument errors)
+    assert rr.FmChain(np.ones(16384, np.complex64), 1, 6, 1.0) is not None
+    with pytest.raises(ValueError):
+        rr.FmChain(np.ones((1 << 19) + 1, np.complex64), 1, 6, 1.0)
+    with pytest.raises(ValueError):
+        rr.FmChain(np.ones(100, np.complex64), 1, 0, 1.0)     # "RationalResampler created using deci 0"
 
 
 @pytest.mark.parametrize("inner", ["real", "complex"])
@@ -697,8 +702,7 @@ def test_fm_chain_fused_protocol(rr):
     assert st == WAIT_DST and p <= 100 and c == 561 - 512
     with pytest.raises(ValueError):
         rr.FmChain(taps, 0, 6)
-    with pytest.raises(ValueError):
-        rr.FmChain(taps, 1, 100000)
+    assert rr.FmChain(taps, 1, 100000) is not None              # beyond any tile: composed (test_no_constructor_cliffs_*)
 
 
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 30_000])
@@ -817,7 +821,7 @@ def test_fm_multi_u8_shared_source(rr, D, odd):
 
 
 def test_fm_multi_long_filters(rr):
-    """FmMulti with the rtl_fm-sized filter (2467 taps -> 4096-point tiles); more than 4094 taps is refused"""
+    """FmMulti with the rtl_fm-sized filter (2467 taps -> 4096-point tiles); beyond 4094 taps: test_no_constructor_cliffs"""
     fs, n = 1.024e6, 250_000
     proto = orc.low_pass_complex(fs, 100e3, 1e3)
     assert len(proto) == 2467
@@ -830,8 +834,6 @@ def test_fm_multi_long_filters(rr):
         ro = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(25, 128)], x)       # fresh blocks: they carry state
         assert p == len(yo)
         _demod_close(out[ch], yo, ro)
-    with pytest.raises(Exception):
-        rr.FmMulti(np.ones((2, 4095), np.complex64), 1, 6, 1.0)
 
 
 # ---- device-resident streams (rr_dstream) --------------------------------------------
@@ -993,9 +995,107 @@ def test_audio_chain_protocol(rr):
     st, c, p, need, out = b.work(x[100:3000], 1000)             # 3000 = 2 blocks + 830
     assert (st, c, p, need) == (WAIT_SRC, 2900, 521, 1085 - 830)
     with pytest.raises(ValueError):
-        rr.AudioChain(taps, 0, 5)
+        rr.AudioChain(taps, 0, 5)                               # the reference's own argument error, fused or not
     with pytest.raises(ValueError):
-        rr.AudioChain(np.ones(4000, np.float32), 1, 5)
+        rr.AudioChain(np.zeros(0, np.float32), 1, 5)
+
+
+# ---- no constructor cliffs: the fused constructors take every shape the separate blocks take ------------
+@pytest.mark.parametrize("L", [5000, 20000])
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 70_000])
+def test_no_constructor_cliffs_fm_chain(rr, L, stream_bytes):
+    """rr.FmChain / FmChainU8 at 5000 taps (fused: split tiles) and 20000 taps (beyond the 16384-point tiles: the SAME
+    constructor returns the unfused composition FftFilter -> RationalResampler -> QuadratureDemod behind one handle) against
+    the oracle's three blocks; the reference sizes its transform from any tap count (fft_filter.rs:36-42)."""
+    fs, n = 2.4e6, 300_000
+    x = fm_signal(n, fs, 0.0, 7 + L)
+    taps = (rnd_c(L, L) / (L // 4)).astype(np.complex64)
+    yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(1, 6), orc.QuadratureDemod(0.7)], x, stream_bytes=stream_bytes)
+    ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(1, 6)], x, stream_bytes=stream_bytes)
+    yg = run_chain([rr.FmChain(taps, 1, 6, 0.7)], x, stream_bytes=stream_bytes)
+    assert len(yo) > 0
+    _demod_close(yg / 0.7, yo / 0.7, ro)
+    if stream_bytes == 4_096_000:                               # ... and from the RTL-SDR byte stream
+        b = np.empty(2 * n, np.uint8)
+        b[0::2] = np.clip(np.round(x.real / 0.008 + 127), 0, 255)
+        b[1::2] = np.clip(np.round(x.imag / 0.008 + 127), 0, 255)
+        front = [orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(1, 6)]
+        yo8 = run_chain(front + [orc.QuadratureDemod(0.7)], b)
+        ro8 = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(1, 6)], b)
+        yg8 = run_chain([rr.FmChainU8(taps, 1, 6, 0.7)], b)
+        _demod_close(yg8 / 0.7, yo8 / 0.7, ro8)
+
+
+def test_no_constructor_cliffs_fm_chain_beyond_the_tile(rr):
+    """a decimation larger than any tile (1:20000 on a 65-tap filter) is a shape the three blocks take: so does rr.FmChain"""
+    x = fm_signal(400_000, 2.4e6, 0.0, 3)
+    taps = orc.low_pass_complex(2.4e6, 100e3, 80e3)
+    yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(1, 20000), orc.QuadratureDemod(1.0)], x)
+    yg = run_chain([rr.FmChain(taps, 1, 20000, 1.0)], x)
+    ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(1, 20000)], x)
+    assert len(yo) == len(yg) > 5
+    _demod_close(yg, yo, ro)
+
+
+@pytest.mark.parametrize("L", [5000, 20000])
+def test_no_constructor_cliffs_fm_multi(rr, L):
+    """rr.FmMulti beyond 4094 taps: one chain per channel on the shared window behind the same handle (each still fused
+    up to 16383 taps), every channel against its own oracle chain"""
+    fs, n = 2.4e6, 260_000
+    x = fm_signal(n, fs, 0.0, 11 + L)
+    proto = (rnd_c(L, L + 1) / (L // 4)).astype(np.complex64)
+    k = np.arange(L, dtype=np.float64)
+    taps = np.stack([(proto.astype(np.complex128) * np.exp(2j * np.pi * c * 30e3 * k / fs)).astype(np.complex64) for c in range(3)])
+    blk = rr.FmMulti(taps, 1, 6, 1.0)
+    outs = [[] for _ in range(3)]
+    ring, pos = np.zeros(0, np.complex64), 0
+    while True:
+        take = min(512_000 - len(ring), n - pos)
+        ring = np.concatenate([ring, x[pos:pos + take]]); pos += take
+        st, c, p, need, out = blk.work(ring, 100_000)
+        ring = ring[c:]
+        for ch in range(3):
+            outs[ch].append(out.reshape(3, -1)[ch])
+        if take == 0 and c == 0 and p == 0:
+            break
+    for ch in range(3):
+        yo = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(1, 6), orc.QuadratureDemod(1.0)], x)
+        ro = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(1, 6)], x)
+        _demod_close(np.concatenate(outs[ch]), yo, ro)
+
+
+@pytest.mark.parametrize("L", [3585, 5000, 20000])
+def test_no_constructor_cliffs_audio_chain(rr, L):
+    """rr.AudioChain beyond 3584 taps: FftFilterFloat -> RationalResampler -> MultiplyConst unfused behind the same handle"""
+    taps = rnd_f(L, L) / (L // 8)
+    x = rnd_f(300_000, L + 1)
+    yo = run_chain([orc.FftFilterFloat(taps), orc.RationalResampler(6, 25, np.float32), orc.MultiplyConst(0.35)], x)
+    yg = run_chain([rr.AudioChain(taps, 6, 25, 0.35)], x)
+    assert len(yo) == len(yg) > 0
+    assert max_norm_err(yg, yo) <= TOL
+
+
+@pytest.mark.parametrize("L,I,D", [(463, 1, 6), (127, 25, 128), (2467, 1, 5)])
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 20_000])
+def test_fm_chain_with_fastfm_demodulator(rr, L, I, D, stream_bytes):
+    """SURVEY §8 f3 / VERDICT r2 #5: FastFM (quadrature_demod.rs:144-165) as the chain's demodulator through the fused
+    constructors (atan2_mode = RR_DEMOD_FASTFM): FftFilter -> RationalResampler -> FastFM.  FastFM multiplies differences of
+    samples, so the bound is the filter stage's 1e-5 propagated through it: |d out| <= 8 eps max|r|, eps = 1e-5 max|r| (two
+    products of a difference of two samples, within 2 eps and up to 2 max|r|, with a sample, within eps and up to max|r|)."""
+    fs = 2.4e6
+    x = fm_signal(300_000, fs, 0.0, 31 + L)
+    taps = orc.low_pass_complex(fs, 100e3, 12.5e3) if L == 463 else (rnd_c(L, L) / max(1, L // 4)).astype(np.complex64)
+    yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D), orc.FastFM()], x, stream_bytes=stream_bytes)
+    ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D)], x, stream_bytes=stream_bytes)
+    yg = run_chain([rr.FmChain(taps, I, D, 1.0, rr.DEMOD_FASTFM)], x, stream_bytes=stream_bytes)
+    assert len(yo) == len(yg) == len(ro) > 0
+    rmax = float(np.max(np.abs(ro)))
+    assert np.max(np.abs(yg.astype(np.float64) - yo.astype(np.float64))) <= 8 * TOL * rmax * rmax
+    # ... and for N channels on one window
+    taps2 = np.stack([taps, np.conj(taps)])
+    st, c, p, need, out = rr.FmMulti(taps2, I, D, 1.0, rr.DEMOD_FASTFM).work(x, 4_096_000 // 4)
+    yo2 = run_chain([orc.FftFilter(taps2[1]), orc.RationalResampler(I, D), orc.FastFM()], x)
+    assert p == len(yo2) and np.max(np.abs(out.reshape(2, -1)[1][:p].astype(np.float64) - yo2)) <= 8 * TOL * rmax * rmax
 
 
 # ---- .translate(): the exact rotator replay on the device, and the model's drift against it --------------------------

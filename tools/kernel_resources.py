@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--extra", default="", help="extra compiler flags, e.g. -DRR_POLY_NB=2")
     ap.add_argument("files", nargs="*")
     a = ap.parse_args()
-    files = a.files or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("kernels_") and f.endswith(".hip"))
+    files = [os.path.abspath(f) for f in a.files] or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("kernels_") and f.endswith(".hip"))
     build(files, a.build, a.extra.split())
     bad = 0
     for f in files:
