@@ -307,6 +307,9 @@ int         rr_dstream_produce(rr_dstream *s, size_t n);                        
 int         rr_dstream_copy_in(rr_dstream *s, size_t offset, const void *host, size_t n, void *hip_stream);
 /* copy `n` elements at `offset` of the read window to HOST memory; waits for the stream (data valid on return) */
 int         rr_dstream_copy_out(rr_dstream *s, size_t offset, void *host, size_t n, void *hip_stream);
+/* `n` elements at `src_offset` of src's READ window -> dst's WRITE window at `dst_offset` (not yet produced), device to
+ * device on `hip_stream`, no host involvement: what Tee (src/tee.rs:10-24) and a ring-to-ring copy need between two HBM rings */
+int         rr_dstream_copy(rr_dstream *dst, size_t dst_offset, rr_dstream *src, size_t src_offset, size_t n, void *hip_stream);
 /* One Block::work() between two device streams: rr_block_work_dev over their windows + consume/produce. */
 int rr_block_work_streams(rr_block *b, rr_dstream *src, rr_dstream *dst, size_t *consumed, size_t *produced,
                           size_t *need, void *hip_stream);

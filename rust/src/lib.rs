@@ -86,6 +86,7 @@ unsafe extern "C" {
     fn rr_dstream_produce(s: *mut RrDStream, n: usize) -> c_int;
     fn rr_dstream_copy_in(s: *mut RrDStream, offset: usize, host: *const c_void, n: usize, hip_stream: *mut c_void) -> c_int;
     fn rr_dstream_copy_out(s: *mut RrDStream, offset: usize, host: *mut c_void, n: usize, hip_stream: *mut c_void) -> c_int;
+    fn rr_dstream_copy(dst: *mut RrDStream, dst_offset: usize, src: *mut RrDStream, src_offset: usize, n: usize, hip_stream: *mut c_void) -> c_int;
     fn rr_block_work_streams(b: *mut RrBlock, src: *mut RrDStream, dst: *mut RrDStream, consumed: *mut usize,
                              produced: *mut usize, need: *mut usize, hip_stream: *mut c_void) -> c_int;
 }

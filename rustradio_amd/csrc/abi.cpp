@@ -351,6 +351,22 @@ int rr_dstream_copy_out(rr_dstream* s, size_t offset, void* host, size_t n, void
         RR_HIP(hipStreamSynchronize(st));           // the host may read `host` on return
     });
 }
+int rr_dstream_copy(rr_dstream* dst, size_t dst_offset, rr_dstream* src, size_t src_offset, size_t n, void* hip_stream) {
+    if (!dst || !src) { rr::set_last_error("null dstream"); return RR_ERR; }
+    return guarded([&] {
+        rr::DStream& d = *dst->s;
+        rr::DStream& r = *src->s;
+        auto st = static_cast<hipStream_t>(hip_stream);
+        if (d.es != r.es) throw rr::Error("dstream copy: element sizes differ");
+        if (d.device != r.device) throw rr::Error("dstream copy: rings on different devices");
+        if (src_offset + n > r.used()) throw rr::Error("dstream copy: beyond the read window");
+        RR_HIP(hipSetDevice(d.device));
+        unsigned char* w = static_cast<unsigned char*>(d.write_ptr(st));
+        if (dst_offset + n > d.free()) throw rr::Error("dstream copy: beyond the write window");
+        if (n) RR_HIP(hipMemcpyAsync(w + dst_offset * d.es, static_cast<const unsigned char*>(r.read_ptr()) + src_offset * r.es, n * d.es,
+                                     hipMemcpyDeviceToDevice, st));
+    });
+}
 int rr_block_work_streams(rr_block* b, rr_dstream* src, rr_dstream* dst, size_t* consumed, size_t* produced,
                           size_t* need, void* hip_stream) {
     size_t c = 0, p = 0, nd = 0;

@@ -128,6 +128,7 @@ public:
     const T* begin() const { host_only(); return slice(); }
     const T* end() const { host_only(); return slice() + len(); }
     // first n samples of the window into host memory (any placement)
+    rr_dstream* dstream() const { return s_->ds; }
     void copy_to(T* host, size_t n) const {
         if (n > len()) throw Error("copy_to: n > readable");
         if (!s_->ds) { if (n) std::memcpy(host, slice(), n * sizeof(T)); return; }
@@ -179,6 +180,12 @@ public:
     T* slice() { return s_->ds ? dptr_ : s_->buf.data() + base_; }     // host or DEVICE pointer
     size_t len() const { return s_->ds ? dlen_ : s_->cap - base_; }
     bool is_empty() const { return len() == 0; }
+    // n samples of a DEVICE-resident read window into this DEVICE-resident write window: no host hop (rr_dstream_copy)
+    void fill_from_device(const BufferReader<T>& src, size_t n) {
+        if (n > len()) throw Error("fill_from_device: n > free");
+        if (!s_->ds || !src.dstream()) throw Error("fill_from_device: both streams must be device-resident");
+        if (rr_dstream_copy(s_->ds, 0, src.dstream(), 0, n, nullptr) != 0) throw Error(rr_last_error());
+    }
     void fill_from_slice(const T* src, size_t n) {                      // src = host memory
         if (n > len()) throw Error("fill_from_slice: n > free");
         if (!s_->ds) { std::memcpy(slice(), src, n * sizeof(T)); return; }
@@ -902,7 +909,7 @@ public:
         for (auto& t : tags) if (t.pos() < n) keep.push_back(t);
         if (!input.device()) out.fill_from_slice(input.slice(), n);
         else if (!out.device()) input.copy_to(out.slice(), n);
-        else { bounce_.resize(n); input.copy_to(bounce_.data(), n); out.fill_from_slice(bounce_.data(), n); }
+        else out.fill_from_device(input, n);                              // HBM ring to HBM ring: device-to-device
         input.consume(n);
         out.produce(n, keep);
         return BlockRet::again();
@@ -935,11 +942,19 @@ public:
         }
         std::vector<Tag> keep;
         for (auto& t : tags) if (t.pos() < n) keep.push_back(t);
+        // every output takes the samples the cheapest way its placement allows: device rings straight from a device input
+        // (rr_dstream_copy, no host hop), everything else through host memory (one download at most)
         const T* hp = nullptr;
-        if (input.device()) { bounce_.resize(n); input.copy_to(bounce_.data(), n); hp = bounce_.data(); }
-        else hp = input.slice();
-        o1.fill_from_slice(hp, n);
-        o2.fill_from_slice(hp, n);
+        auto feed = [&](BufferWriter<T>& o) {
+            if (input.device() && o.device()) { o.fill_from_device(input, n); return; }
+            if (!hp) {
+                if (input.device()) { bounce_.resize(n); input.copy_to(bounce_.data(), n); hp = bounce_.data(); }
+                else hp = input.slice();
+            }
+            o.fill_from_slice(hp, n);
+        };
+        feed(o1);
+        feed(o2);
         input.consume(n);
         o1.produce(n, keep);
         o2.produce(n, keep);

@@ -606,10 +606,35 @@ static void tee_and_signal_source() {            // src/tee.rs:10-24, src/signal
     for (size_t i = 0; i < 10; i++) CHECK(ra.slice()[i] == rb.slice()[i]);
 }
 
+// Tee and MemCopy between HBM rings stay on the device (rr_dstream_copy; round 2 bounced them through host memory):
+// VectorSource(host) -> MemCopy -> device ring -> Tee -> two device rings -> MemCopy each -> host sinks, tags included.
+static void tee_and_memcopy_between_device_rings() {
+    std::vector<Complex> x(300000);
+    for (size_t i = 0; i < x.size(); i++) x[i] = Complex((float)i, -(float)(i % 977));
+    auto [src, s0] = VectorSource<Complex>::new_(x);
+    auto [up, s1] = MemCopy<Complex>::new_(std::move(s0), Memory::Device);
+    auto [tee, a, b] = with_memory(Memory::Device, [&, s = std::move(s1)]() mutable { return Tee<Complex>::new_(std::move(s)); });
+    auto [mid, a2] = MemCopy<Complex>::new_(std::move(a), Memory::Device);          // device ring to device ring
+    auto [da, ha] = MemCopy<Complex>::new_(std::move(a2), Memory::Host);
+    auto [db, hb] = MemCopy<Complex>::new_(std::move(b), Memory::Host);
+    auto ka = std::make_unique<VectorSink<Complex>>(std::move(ha));
+    auto kb = std::make_unique<VectorSink<Complex>>(std::move(hb));
+    auto oa = ka->hook();
+    auto ob = kb->hook();
+    auto ta = ka->tag_hook();
+    Graph g;
+    g.add(std::move(src)); g.add(std::move(up)); g.add(std::move(tee)); g.add(std::move(mid)); g.add(std::move(da)); g.add(std::move(db));
+    g.add(std::move(ka)); g.add(std::move(kb));
+    g.run();
+    CHECK(oa->size() == x.size() && ob->size() == x.size());
+    CHECK(*oa == x && *ob == x);
+    CHECK(!ta->empty() && (*ta)[0].pos() == 0);       // VectorSource::start travels through every copy
+}
+
 int main() {
     test_complex(); test_identity(); moving_avg(); translate_matches_mixed_input(); test_filter_generator();
     fft_tag_propagation(); resampler_examples(); quad_known(); rtlsdr_decode_tests(); hilbert_rejects_even(); graph_fm_chain();
-    device_resident_graph(); fused_blocks_equal_their_chains(); fanout_from_c_abi(); fft_message_block(); tee_and_signal_source(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests(); handles_on_concurrent_threads();
+    device_resident_graph(); fused_blocks_equal_their_chains(); fanout_from_c_abi(); fft_message_block(); tee_and_signal_source(); tee_and_memcopy_between_device_rings(); sync_blocks(); fftstream_adds_frame_tags(); file_source_tests(); handles_on_concurrent_threads();
     printf(g_fail ? "FAILED (%d)\n" : "OK\n", g_fail);
     return g_fail ? 1 : 0;
 }
