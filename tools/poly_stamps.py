@@ -6,7 +6,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import rustradio_amd as rr
-n = 24_000_000
+n = 96_000_000       # (workgroup 0 must reach its third tile under the 3x oversubscribed grid)
 taps = rr.low_pass_complex(2.4e6, 100e3, 12.5e3)
 x = torch.rand(2 * n, device="cuda") * 2 - 1
 y = torch.empty(n // 6 + 1024, device="cuda")

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import rustradio_amd as rr
 from rustradio_amd import multi
-n = 2_400_000
+n = 9_600_000        # (4 steps worth: workgroup 0 must reach its second tile under the 3x oversubscribed grid)
 taps = multi.cfg4_taps(rr.low_pass_complex(2.4e6, 100e3, 12.5e3), range(32))
 x = torch.rand(2 * n, device="cuda") * 2 - 1
 cap = n // 6 + 1024
