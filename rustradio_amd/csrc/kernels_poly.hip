@@ -65,6 +65,10 @@ struct PolyArgs {
 #endif
 typedef float creg2 __attribute__((ext_vector_type(4)));
 typedef creg2 creg2u __attribute__((aligned(8)));                        // two adjacent Complex samples, 8-byte aligned
+#ifndef RR_STAMP_WAVE_A
+#define RR_STAMP_WAVE_A 0
+#define RR_STAMP_WAVE_B 1
+#endif
 #ifdef RR_FFT_TIMING_BUILD
 #define PSTAMP(i) do { if (stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
@@ -388,7 +392,9 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
     int iter = 0;
     for (TileIter it(ntiles * groups); it.tile < it.end; it.tile += it.step, iter++) {
 #ifdef RR_FFT_TIMING_BUILD
-        unsigned long long* stamps = (dbg && blockIdx.x == 0 && t == 0 && iter == 1 && w < 2) ? dbg + 16 * w : nullptr;
+        // (timing builds: two waves of workgroup 0 are stamped — RR_STAMP_WAVE_A / _B, default 0 and 1)
+        unsigned long long* stamps = (dbg && blockIdx.x == 0 && t == 0 && iter == 1 && (w == RR_STAMP_WAVE_A || w == RR_STAMP_WAVE_B))
+                                         ? dbg + 16 * (w == RR_STAMP_WAVE_A ? 0 : 1) : nullptr;
 #else
         (void)dbg; (void)iter;
 #endif
@@ -408,6 +414,12 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
         PSTAMP(1);
         tile_sync<512>();
         PSTAMP(2);
+        // (round 3, tools/poly_stamps_multi.py on every wave pair: the two waves of a SIMD do not share it evenly — the older
+        //  one, waves 0-3, issues first and runs a channel in 14.7 k clocks, the younger one, waves 4-7, takes 25 k for its
+        //  first channel and ~16 k for the others — so waves 0-3 wait 17 k of a tile's 79 k clocks at the final barrier.
+        //  Handing the channels out dynamically (a queue in LDS, one ds_add_rtn per channel: the fast waves take more) evens
+        //  the waves out and changes nothing: 0.0795 against 0.0786 ms — the SIMD's issue slots are the limit, whichever
+        //  wave uses them.  Removed.)
 #pragma unroll 1
         for (int c = 8 * grp + w; c < nchan; c += 8 * groups) {
             const creg* hc = hr + (long)c * D * 16 * PT + t;
