@@ -623,8 +623,7 @@ bool PolyTables::build(const rr_c32* taps, size_t C, size_t L, size_t D, bool mu
             for (int j = 0; j < 16; j++)
                 for (int lane = 0; lane < 64; lane++) {
                     const auto v = H[(size_t)fm_poly_bin(j, lane)] / (double)F;
-                    // multi-channel kernel: a lane's registers j, j + 1 adjacent (16-byte loads); single chain: register-major
-                    dst[multi ? ((j >> 1) * 64 + lane) * 2 + (j & 1) : j * 64 + lane] = mkcf((float)v.real(), (float)v.imag());
+                    dst[j * 64 + lane] = mkcf((float)v.real(), (float)v.imag());
                 }
         }
     for (size_t k = 0; k < F; k++) {

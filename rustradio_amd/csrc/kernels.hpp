@@ -126,9 +126,7 @@ void launch_fm_chain_half_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, cons
 
 // ---- kernels_poly.hip: fused FM chains with an integer decimation on decimate-first (polyphase) tiles ----------------
 // tw = w_1024^k; hreg = per channel and phase p the response FFT_1024(t[D j + p]) / 1024, register-major:
-// hreg[((c D + p) 16 + j) 64 + lane] = H_{c,p}[fm_poly_bin(j, lane)] for the single-chain kernels; for k_fm_multi_poly
-// hreg[(((c D + p) 8 + j / 2) 64 + lane) 2 + j % 2]: a lane's registers j, j + 1 adjacent, one 16-byte load brings both (the
-// same loads in the single-chain kernel cost it 12 spilled registers).  a.I must be 1.
+// hreg[((c D + p) 16 + j) 64 + lane] = H_{c,p}[fm_poly_bin(j, lane)].  a.I must be 1.
 bool fm_poly_supported(long I, long D, int L, bool multi);
 int fm_poly_bin(int j, int lane);
 void launch_fm_chain_poly(VSrc<cf> src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& a, const cf* last_in,

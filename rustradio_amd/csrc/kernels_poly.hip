@@ -222,7 +222,7 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 creg h[16];
-                const gptr<creg> hp = as_global(hreg + (long)(P0 + pb + i) * 16 * PT + t);
+                const creg* hp = hreg + (long)(P0 + pb + i) * 16 * PT + t;
 #pragma unroll
                 for (int j = 0; j < 16; j++) h[j] = (RR_POLY_ABLATE & 8) ? mk(1.0f + j, (float)t) : hp[j * PT];
                 fwd_pass<PLG, 2>(v[i], nullptr);         // (P == 1: no twiddles)
@@ -422,13 +422,12 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
         //  wave uses them.  Removed.)
 #pragma unroll 1
         for (int c = 8 * grp + w; c < nchan; c += 8 * groups) {
-            // (16-byte loads of the register pairs j, j + 1: half the VMEM instructions of the response stream)
-            const gptr<creg2> hc2 = as_global(reinterpret_cast<const creg2*>(hr + (long)c * D * 16 * PT) + t);
+            const creg* hc = hr + (long)c * D * 16 * PT + t;
             creg z[16], h[2][16];
 #pragma unroll
             for (int j = 0; j < 16; j++) z[j] = mk(0.0f, 0.0f);
 #pragma unroll
-            for (int j = 0; j < 16; j += 2) { const creg2 w2 = hc2[(j >> 1) * PT]; h[0][j] = mk(w2.x, w2.y); h[0][j + 1] = mk(w2.z, w2.w); }
+            for (int j = 0; j < 16; j++) h[0][j] = hc[j * PT];
             // (round 3: two phases in flight / the prefetch running on into the next channel's first phases during the inverse
             //  transform and the demodulation — three response buffers, 256 VGPRs with 6 spilled, or two without spills —
             //  measured 0.0838 / 0.0830 ms against 0.0806 ms for this form, same box: the response stream from L2 is not what
@@ -437,10 +436,7 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
             for (int p = 0; p < D; p++) {                    // phase p + 1's response is in flight while phase p is multiplied
                 if (p + 1 < D) {
 #pragma unroll
-                    for (int j = 0; j < 16; j += 2) {
-                        const creg2 w2 = hc2[((p + 1) * 8 + (j >> 1)) * PT];
-                        h[(p + 1) & 1][j] = mk(w2.x, w2.y); h[(p + 1) & 1][j + 1] = mk(w2.z, w2.w);
-                    }
+                    for (int j = 0; j < 16; j++) h[(p + 1) & 1][j] = hc[((p + 1) * 16 + j) * PT];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
