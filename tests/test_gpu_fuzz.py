@@ -135,7 +135,7 @@ def test_fuzz_translate_and_u8_chain(rr, seed):
     x = _c(rng, n)
     taps = _c(rng, L) / max(1, L // 8)
     ring = int(rng.choice([4_096_000, 8 * (L + d + int(rng.integers(8, 3000)))]))
-    _both(rr, lambda m: [m.FirFilter(taps, deci=d, translate=(fs, f), **({"rotator": rr.ROT_REPLAY} if m is rr else {}))], x, ring)
+    _both(rr, lambda m: [m.FirFilter(taps, deci=d, translate=(fs, f))], x, ring)      # the DEFAULT rotator: the reference's recurrence
     # RTL-SDR bytes -> fused chain vs the four oracle blocks
     b = rng.integers(0, 256, 2 * int(rng.integers(2000, 80_000)) + int(rng.integers(0, 2)), dtype=np.uint8)
     I, D = int(rng.integers(1, 5)), int(rng.integers(1, 12))
@@ -329,3 +329,71 @@ def test_fuzz_any_size_transforms(rr, seed):
         taps = _c(rng, L) / (L // 8)
         xs = _c(rng, int(rng.integers(60_000, 200_000)))
         _both(rr, lambda m: [m.FftFilter(taps)], xs, int(rng.choice([4_096_000, 8 * (65_536 - L + int(rng.integers(1, 9000)))])))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_compositions_and_fastfm(rr, seed):
+    """Round 3: the fused-chain constructors beyond their tiles (the unfused composition behind the same handle: FmChain /
+    FmChainU8 / AudioChain / FmMulti with random tap counts on both sides of every limit, random ratios and ring sizes) and
+    FastFM as the chain's demodulator, against the oracle's separate blocks."""
+    rng = np.random.default_rng(13000 + seed)
+    L = int(rng.choice([300, 3584, 3585, 4094, 4095, 9000, 16383, 16384, 17000]))
+    I, D = int(rng.integers(1, 4)), int(rng.integers(1, 9))
+    n = int(rng.integers(3 * L, 3 * L + 200_000))
+    x = _c(rng, n)
+    taps = _c(rng, L) / max(1, L // 4)
+    ring = int(rng.choice([4_096_000, 8 * (2 * L + int(rng.integers(100, 40_000)))]))
+    kind = seed % 4
+    if kind == 0:                                    # QuadratureDemod chain
+        yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D), orc.QuadratureDemod(0.8)], x, stream_bytes=max(ring, 8 * 140_000))
+        ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D)], x, stream_bytes=max(ring, 8 * 140_000))
+        yg = run_chain([rr.FmChain(taps, I, D, 0.8)], x, stream_bytes=max(ring, 8 * 140_000))
+        assert len(yg) == len(yo)
+        if len(yo):
+            eps = TOL * float(np.max(np.abs(ro)))
+            mag = np.abs(ro.astype(np.complex128))
+            bound = 0.8 * (TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30))
+            dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
+            dd = np.minimum(dd, 0.8 * 2 * np.pi - dd)
+            assert np.all(dd <= bound[:len(dd)])
+    elif kind == 1:                                  # FastFM as the demodulator
+        yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D), orc.FastFM()], x, stream_bytes=max(ring, 8 * 140_000))
+        ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D)], x, stream_bytes=max(ring, 8 * 140_000))
+        yg = run_chain([rr.FmChain(taps, I, D, 1.0, rr.DEMOD_FASTFM)], x, stream_bytes=max(ring, 8 * 140_000))
+        assert len(yg) == len(yo)
+        if len(yo):
+            rmax = float(np.max(np.abs(ro)))
+            assert np.max(np.abs(yg.astype(np.float64) - yo.astype(np.float64))) <= 8 * TOL * rmax * rmax
+    elif kind == 2:                                  # the audio stage
+        xf = rng.uniform(-1, 1, n).astype(np.float32)
+        tf = (rng.uniform(-1, 1, L) / max(1, L // 8)).astype(np.float32)
+        yo = run_chain([orc.FftFilterFloat(tf), orc.RationalResampler(I, D, np.float32), orc.MultiplyConst(0.5)], xf)
+        yg = run_chain([rr.AudioChain(tf, I, D, 0.5)], xf)
+        assert len(yg) == len(yo)
+        if len(yo):
+            assert max_norm_err(yg, yo) <= TOL
+    else:                                            # two channels on one window
+        t2 = np.stack([taps, np.conj(taps)])
+        blk = rr.FmMulti(t2, I, D, 1.0)
+        outs, ringbuf, pos = [[], []], np.zeros(0, np.complex64), 0
+        while True:
+            take = min(512_000 - len(ringbuf), n - pos)
+            ringbuf = np.concatenate([ringbuf, x[pos:pos + take]]); pos += take
+            st, c, p, need, out = blk.work(ringbuf, 1_024_000)
+            ringbuf = ringbuf[c:]
+            for ch in range(2):
+                outs[ch].append(out.reshape(2, -1)[ch])
+            if take == 0 and c == 0 and p == 0:
+                break
+        for ch in range(2):
+            yo = run_chain([orc.FftFilter(t2[ch]), orc.RationalResampler(I, D), orc.QuadratureDemod(1.0)], x)
+            ro = run_chain([orc.FftFilter(t2[ch]), orc.RationalResampler(I, D)], x)
+            yg = np.concatenate(outs[ch])
+            assert len(yg) == len(yo)
+            if len(yo):
+                eps = TOL * float(np.max(np.abs(ro)))
+                mag = np.abs(ro.astype(np.complex128))
+                bound = TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30)
+                dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
+                dd = np.minimum(dd, 2 * np.pi - dd)
+                assert np.all(dd <= bound[:len(dd)])
