@@ -982,6 +982,8 @@ def main():
     stream = torch.cuda.current_stream()
     with rr.build_options(**opts):
         w = WORKLOADS[wname](dev, rank, world, shared_src)
+    abi_check = {}
+
     def make_fan(wl):
         """the streaming fan-out of wl's shared source (resident on rank 0): one tile = --tile-steps steps of input"""
         if world == 1:
@@ -1005,8 +1007,15 @@ def main():
         if args.fanout == "abi":
             if backend != "nccl":
                 raise SystemExit("bench.py --fanout abi: rr_fanout_* binds RCCL, which needs one GPU per rank")
-            return tag(multi.AbiFanout(rr, dist, rank, k * step_elems, sdtype, dev, produce,
-                                       mesh=args.fanout_algo == "scatter_allgather"))
+            if "ok" not in abi_check:            # once per job: known tiles through both algorithms, checksums on every rank
+                abi_check["ok"], abi_check["why"] = multi.verify_abi_fanout(rr, dist, rank, dev)
+                if not abi_check["ok"] and rank == 0:
+                    print(f"bench.py: rr_fanout_* failed its self-check on this group ({abi_check['why']}); "
+                          "the fan-out runs through torch.distributed instead", file=sys.stderr)
+            if abi_check["ok"]:
+                return tag(multi.AbiFanout(rr, dist, rank, k * step_elems, sdtype, dev, produce,
+                                           mesh=args.fanout_algo == "scatter_allgather"))
+            args.fanout = "torch"
         try:
             return tag(multi.TileFanout(dist, rank, k * step_elems, sdtype, dev, produce, algo=args.fanout_algo))
         except RuntimeError as e:             # a backend without scatter / all-gather on device tensors: the broadcast always works
@@ -1021,6 +1030,9 @@ def main():
         ks = getattr(fan_, "tile_steps", 1)
         bstep = bms / ks                         # fan-out time per step of source
         return {"backend": "rccl" if backend == "nccl" else backend, "fanout": args.fanout,
+                "fanout_self_check": (None if "ok" not in abi_check else
+                                      "rr_fanout_* verified on this group (known tiles, both algorithms, checksums on every rank)"
+                                      if abi_check["ok"] else f"rr_fanout_* FAILED its self-check ({abi_check['why']}): torch.distributed fan-out used"),
                 "algorithm": getattr(fan_, "algo", "bcast"), "calibration_ms_per_tile": getattr(fan_, "calibration", None),
                 "ranks": dist.get_world_size(),
                 "devices_visible": ndev, "tile_bytes": fan_.bytes_per_tile, "tile_steps": ks, "broadcasts_timed": bn,

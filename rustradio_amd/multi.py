@@ -338,3 +338,38 @@ class AbiFanout:
 
     def broadcast_ms(self):
         return self.fan.stats()
+
+
+def verify_abi_fanout(rr, dist, rank, device, nbytes=(1 << 20) + 13, ntiles=3):
+    """First contact of `rr_fanout_*` with a group of more than one GPU (it has only ever run on one rank: DESIGN §6):
+    before a measurement relies on it, fan a few small tiles of known content out with both algorithms and compare a
+    checksum of what every rank acquired with the owner's.  -> (ok on EVERY rank, reason).  A mismatch or an error makes
+    bench.py fall back to the torch.distributed fan-out and say so in its line; only a hang inside RCCL cannot be caught."""
+    ok, why = True, ""
+    try:
+        idx = torch.arange(nbytes, device=device, dtype=torch.int64)
+        stream = torch.cuda.current_stream()
+        for mesh in (False, True):
+            def produce(t, out, _idx=idx):
+                out.copy_(((_idx * (t + 3)) % 251).to(torch.uint8), non_blocking=True)
+            fan = AbiFanout(rr, dist, rank, nbytes, torch.uint8, device, produce, mesh=mesh, timing=False)
+            fan.prefetch(0)
+            for t in range(ntiles):
+                if t + 1 < ntiles:
+                    fan.prefetch(t + 1)
+                x = fan.acquire(t, stream)
+                got = int(x.to(torch.int64).sum().item())
+                fan.release(t, stream)
+                want = int(((idx * (t + 3)) % 251).sum().item())
+                if got != want:
+                    ok, why = False, f"tile {t} ({'mesh' if mesh else 'bcast'}): checksum {got} != {want} on rank {rank}"
+            torch.cuda.synchronize()
+            del fan
+    except Exception as e:                      # noqa: BLE001 — anything the C ABI reports
+        ok, why = False, f"rank {rank}: {e}"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    all_ok = bool(flag.item())
+    if not all_ok and not why:
+        why = "another rank reported a mismatch"
+    return all_ok, why

@@ -249,6 +249,28 @@ def _rccl_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _abi_check_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import rustradio_amd as rr
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ok, why = multi.verify_abi_fanout(rr, dist, rank, dev)
+    q.put((rank, ok, why))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_abi_fanout_self_check_on_a_one_rank_rccl_group():
+    """the self-check bench.py runs before it relies on rr_fanout_* (multi.verify_abi_fanout: known tiles through both
+    algorithms, checksums, all-reduced verdict), on the group this box can form"""
+    (rank, ok, why), = _run(1, _abi_check_worker)
+    assert ok and why == ""
+
+
 @pytest.mark.gpu
 def test_tile_fanout_on_a_one_rank_rccl_group():
     """bench.py's N > 1 path runs over RCCL, which wants one GPU per rank; on the one-GPU box this drives the same calls
