@@ -486,10 +486,17 @@ impl<I: Sample, O: Sample> GpuFused<I, O> {
     }
 }
 impl GpuFused<Complex, Float> {
+    /// `FftFilter -> RationalResampler -> QuadratureDemod` behind one handle: one kernel per call up to 16383 taps, the unfused
+    /// composition of the three GPU blocks beyond (no tap-count limit, like src/fft_filter.rs:36-42).
     pub fn fm_chain(src: ReadStream<Complex>, taps: &[Complex], interp: usize, deci: usize, gain: Float, fast_math: bool)
         -> Result<(Self, ReadStream<Float>)> {
         // SAFETY: taps is a live slice of repr(C) Complex<f32>.
         Self::wrap(unsafe { rr_fm_chain_create(taps.as_ptr(), taps.len(), interp, deci, gain, fast_math as c_int) }, "GpuFmChain", src)
+    }
+    /// `FftFilter -> RationalResampler -> FastFM` (src/quadrature_demod.rs:144-165) behind one handle: RR_DEMOD_FASTFM = 2
+    pub fn fm_chain_fastfm(src: ReadStream<Complex>, taps: &[Complex], interp: usize, deci: usize) -> Result<(Self, ReadStream<Float>)> {
+        // SAFETY: taps is a live slice of repr(C) Complex<f32>.
+        Self::wrap(unsafe { rr_fm_chain_create(taps.as_ptr(), taps.len(), interp, deci, 1.0, 2) }, "GpuFmChainFastFM", src)
     }
     pub fn fir_fm_chain(src: ReadStream<Complex>, fir_taps: &[Complex], fft_taps: &[Complex], interp: usize, deci: usize,
                         gain: Float, fast_math: bool) -> Result<(Self, ReadStream<Float>)> {
