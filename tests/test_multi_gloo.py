@@ -283,3 +283,19 @@ def test_tile_fanout_on_a_one_rank_rccl_group():
         assert v == float(n) * lo + n * (n - 1) / 2
     assert backend == "nccl" and nb == 2 and ms > 0          # tiles 0 and 4 of the 8 (TileFanout.TIME_EVERY)
     assert (units, secs) == (3.0, 0.25)
+
+
+def test_fanout_prediction_table():
+    """multi.predict_fanout: the numbers DESIGN §6 writes down before any multi-GPU run (76.8 MB Complex<f32> tile of four
+    0.0806 ms steps over ~153 GB/s point-to-point links): one broadcast is single-link-bound at every N, the mesh form hides
+    behind the compute from 4 GPUs on, two GPUs share one link whatever the algorithm."""
+    tile, comp = 4 * 19_200_000, 4 * 0.0806
+    p2, p4, p8 = (multi.predict_fanout(n, tile, comp) for n in (2, 4, 8))
+    assert p2["bcast"]["fanout_ms_per_tile"] == p4["bcast"]["fanout_ms_per_tile"] == p8["bcast"]["fanout_ms_per_tile"]
+    assert abs(p8["bcast"]["fanout_ms_per_tile"] - (tile / 153e9 * 1e3 + 0.02)) < 1e-3
+    assert 0.6 < p8["bcast"]["efficiency"] < 0.65
+    assert p2["scatter_allgather"]["efficiency"] < 0.65 and p4["scatter_allgather"]["efficiency"] == 1.0 == p8["scatter_allgather"]["efficiency"]
+    assert abs(p8["scatter_allgather"]["fanout_ms_per_tile"] - (2 * tile / (8 * 153e9) * 1e3 + 0.04)) < 1e-3
+    u8 = multi.predict_fanout(8, tile // 4, comp)            # the RTL-SDR wire format: 2 B per sample
+    assert u8["bcast"]["efficiency"] == 1.0
+    assert multi.predict_fanout(1, tile, comp)["bcast"]["fanout_ms_per_tile"] == 0.0
