@@ -303,6 +303,11 @@ size_t      rr_dstream_read_buf(rr_dstream *s, const void **dev_ptr);
 size_t      rr_dstream_write_buf(rr_dstream *s, void **dev_ptr, void *hip_stream);
 int         rr_dstream_consume(rr_dstream *s, size_t n);                         /* BufferReader::consume */
 int         rr_dstream_produce(rr_dstream *s, size_t n);                         /* BufferWriter::produce */
+/* Streams: every call that takes a ring and a `hip_stream` may use its own stream — a source pushing window k + 1 on a copy
+ * stream while the blocks of window k run on a compute stream.  The ring orders them (an event from the last writer, and
+ * from every stream that read since, before a write; from the last writer before a read); with one stream driving a ring it
+ * costs nothing.  rr_dstream_read_buf hands out a raw window without a stream: callers that launch their own work on it are
+ * ordered like a block if they go through rr_block_work_streams, and on their own otherwise. */
 /* BufferWriter::fill_from_slice from HOST memory into the write window at `offset` (not yet produced) */
 int         rr_dstream_copy_in(rr_dstream *s, size_t offset, const void *host, size_t n, void *hip_stream);
 /* copy `n` elements at `offset` of the read window to HOST memory; waits for the stream (data valid on return) */

@@ -312,6 +312,7 @@ size_t rr_dstream_write_buf(rr_dstream* s, void** dev_ptr, void* hip_stream) {
     if (!s) return 0;
     try {
         RR_HIP(hipSetDevice(s->s->device));        // write_ptr may enqueue the fallback ring's move
+        s->s->will_write(static_cast<hipStream_t>(hip_stream));   // the caller writes the window on this stream
         void* p = s->s->write_ptr(static_cast<hipStream_t>(hip_stream));
         if (dev_ptr) *dev_ptr = p;
         return s->s->free();
@@ -334,6 +335,7 @@ int rr_dstream_copy_in(rr_dstream* s, size_t offset, const void* host, size_t n,
         rr::DStream& d = *s->s;
         auto st = static_cast<hipStream_t>(hip_stream);
         RR_HIP(hipSetDevice(d.device));
+        d.will_write(st);
         unsigned char* w = static_cast<unsigned char*>(d.write_ptr(st));
         if (offset + n > d.free()) throw rr::Error("dstream copy_in: beyond the write window");
         if (n) RR_HIP(hipMemcpyAsync(w + offset * d.es, host, n * d.es, hipMemcpyHostToDevice, st));
@@ -346,6 +348,7 @@ int rr_dstream_copy_out(rr_dstream* s, size_t offset, void* host, size_t n, void
         auto st = static_cast<hipStream_t>(hip_stream);
         if (offset + n > d.used()) throw rr::Error("dstream copy_out: beyond the read window");
         RR_HIP(hipSetDevice(d.device));
+        d.will_read(st);
         if (n) RR_HIP(hipMemcpyAsync(host, static_cast<const unsigned char*>(d.read_ptr()) + offset * d.es, n * d.es,
                                      hipMemcpyDeviceToHost, st));
         RR_HIP(hipStreamSynchronize(st));           // the host may read `host` on return
@@ -361,6 +364,8 @@ int rr_dstream_copy(rr_dstream* dst, size_t dst_offset, rr_dstream* src, size_t 
         if (d.device != r.device) throw rr::Error("dstream copy: rings on different devices");
         if (src_offset + n > r.used()) throw rr::Error("dstream copy: beyond the read window");
         RR_HIP(hipSetDevice(d.device));
+        r.will_read(st);
+        d.will_write(st);
         unsigned char* w = static_cast<unsigned char*>(d.write_ptr(st));
         if (dst_offset + n > d.free()) throw rr::Error("dstream copy: beyond the write window");
         if (n) RR_HIP(hipMemcpyAsync(w + dst_offset * d.es, static_cast<const unsigned char*>(r.read_ptr()) + src_offset * r.es, n * d.es,
@@ -380,6 +385,8 @@ int rr_block_work_streams(rr_block* b, rr_dstream* src, rr_dstream* dst, size_t*
     const int rc = guarded([&] {
         auto hs = static_cast<hipStream_t>(hip_stream);
         RR_HIP(hipSetDevice(dst->s->device));
+        src->s->will_read(hs);
+        dst->s->will_write(hs);
         void* out = dst->s->write_ptr(hs);
         st = rr_block_work_dev(b, src->s->read_ptr(), src->s->used(), out, dst->s->free(), &c, &p, &nd, hip_stream);
         if (st == RR_ERR) return;

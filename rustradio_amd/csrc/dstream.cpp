@@ -50,6 +50,7 @@ DStream::DStream(size_t elem_size, size_t capacity_bytes) : es(elem_size), cap(0
 }
 
 DStream::~DStream() {
+    if (ev_) (void)hipEventDestroy(ev_);
     if (vmm) {
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();            // nothing may still be running on the mapping
@@ -58,6 +59,25 @@ DStream::~DStream() {
         (void)hipMemAddressFree(va, 2 * phys);
         (void)hipMemRelease(handle);
     }
+}
+
+void DStream::order_after(hipStream_t later, hipStream_t earlier) {
+    if (later == earlier) return;
+    if (!ev_) RR_HIP(hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
+    RR_HIP(hipEventRecord(ev_, earlier));            // everything enqueued on `earlier` so far, the access in question included
+    RR_HIP(hipStreamWaitEvent(later, ev_, 0));
+}
+void DStream::will_read(hipStream_t s) {
+    if (has_writer_) order_after(s, last_writer_);
+    for (hipStream_t r : readers_) if (r == s) return;
+    readers_.push_back(s);
+}
+void DStream::will_write(hipStream_t s) {
+    if (has_writer_) order_after(s, last_writer_);
+    for (hipStream_t r : readers_) order_after(s, r);
+    readers_.clear();
+    last_writer_ = s;
+    has_writer_ = true;
 }
 
 void* DStream::write_ptr(hipStream_t s) {

@@ -14,6 +14,8 @@
 // All bookkeeping is on the host (counts never depend on data); device work is enqueued on the caller's
 // HIP stream.
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 
 namespace rr {
@@ -40,7 +42,23 @@ struct DStream {
     void* write_ptr(hipStream_t s);          // makes the free space contiguous (fallback: may enqueue the move on s)
     void consume(size_t n);
     void produce(size_t n);
+
+    // Streams (round 3).  Every entry point that touches the ring on a HIP stream declares it here first:
+    //   will_read(s)  — work on `s` is about to READ the read window   (a block's kernels, copy_out, the source side of a copy)
+    //   will_write(s) — work on `s` is about to WRITE the write window (copy_in, a block's output, the destination of a copy)
+    // As long as one stream drives the ring (the common case) this costs two pointer compares.  When a different stream
+    // shows up — a source pushing window k + 1 on a copy stream while the blocks of window k run on the compute stream —
+    // it is made to wait for the other side first: an event is recorded on the earlier stream NOW (which covers everything
+    // enqueued on it so far, the earlier access included) and the new stream waits for it.  Reads wait for the last
+    // writer; writes wait for the last writer and for every stream that has read since.
+    void will_read(hipStream_t s);
+    void will_write(hipStream_t s);
 private:
+    hipStream_t last_writer_ = nullptr;
+    bool has_writer_ = false;
+    std::vector<hipStream_t> readers_;       // streams that read since the last write
+    hipEvent_t ev_ = nullptr;
+    void order_after(hipStream_t later, hipStream_t earlier);
     bool try_vmm();
 };
 

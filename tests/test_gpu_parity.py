@@ -837,22 +837,24 @@ def test_fm_multi_long_filters(rr):
 
 
 # ---- device-resident streams (rr_dstream) --------------------------------------------
-def run_chain_device(rr, blocks, x, stream_bytes=4_096_000):
+def run_chain_device(rr, blocks, x, stream_bytes=4_096_000, streams=None):
     """the same stream graph as harness.run_chain, but every ring lives in HBM and blocks run through
-    rr_block_work_streams; only the source push and the sink pop touch the host"""
+    rr_block_work_streams; only the source push and the sink pop touch the host.  streams = (source, per block ..., sink) raw
+    HIP stream handles: every stage on its OWN stream (the rings order them: rr_dstream will_read / will_write)."""
     rings = [rr.DeviceStream(blocks[0].in_dtype, stream_bytes)] + [rr.DeviceStream(b.out_dtype, stream_bytes) for b in blocks]
     x = np.asarray(x, blocks[0].in_dtype)
+    streams = streams or [0] * (len(blocks) + 2)
     pos, outs = 0, []
     for _ in range(1_000_000):
-        moved = rings[0].push(x[pos:])
+        moved = rings[0].push(x[pos:], streams[0])
         pos += moved
         for i, b in enumerate(blocks):
             while True:
-                st, c, p, need = b.work_streams(rings[i], rings[i + 1])
+                st, c, p, need = b.work_streams(rings[i], rings[i + 1], streams[1 + i])
                 moved += c + p
                 if st != AGAIN or (c == 0 and p == 0):
                     break
-        y = rings[-1].pop()
+        y = rings[-1].pop(stream=streams[-1])
         moved += len(y)
         if len(y):
             outs.append(y)
@@ -883,6 +885,39 @@ def test_device_streams_equal_host_windows(rr, monkeypatch, stream_bytes, no_vmm
     b = np.random.default_rng(1).integers(0, 256, 100_001, dtype=np.uint8)
     mk3 = lambda: [rr.RtlSdrDecode(), rr.RationalResampler(5, 3, np.complex64)]
     assert np.array_equal(run_chain(mk3(), b, stream_bytes=stream_bytes), run_chain_device(rr, mk3(), b, stream_bytes=stream_bytes))
+
+
+@pytest.mark.parametrize("no_vmm", [False, True])
+def test_device_rings_order_their_streams(rr, monkeypatch, no_vmm):
+    """Round 3: every stage of a device-resident graph on its OWN HIP stream — the source's pushes, each block's kernels, the
+    sink's downloads — with small rings (so that a push of window k + 1 lands in the slots the blocks of window k are still
+    reading): the rings order the streams themselves and the output stays bit-identical to the one-stream run."""
+    import torch
+    if no_vmm:
+        knob(rr, monkeypatch, dstream_no_vmm=1)
+    fs = 2.4e6
+    x = fm_signal(300_000, fs, 0.0, 15)
+    taps = orc.low_pass_complex(fs, 100e3, 12.5e3 * 4)
+    mk = lambda: [rr.FftFilter(taps), rr.RationalResampler(3, 7, np.complex64), rr.QuadratureDemod(0.5)]
+    for stream_bytes in (8 * 9_000, 4_096_000):
+        y1 = run_chain_device(rr, mk(), x, stream_bytes=stream_bytes)
+        ss = [torch.cuda.Stream() for _ in range(5)]
+        yn = run_chain_device(rr, mk(), x, stream_bytes=stream_bytes, streams=[s.cuda_stream for s in ss])
+        torch.cuda.synchronize()
+        assert len(y1) == len(yn) > 0 and np.array_equal(y1, yn)
+    # ... and a ring-to-ring copy on a third stream between a writer and a reader on two others
+    a, b = rr.DeviceStream(np.float32, 4 * 50_000), rr.DeviceStream(np.float32, 4 * 50_000)
+    s0, s1, s2 = (torch.cuda.Stream() for _ in range(3))
+    v = np.arange(200_000, dtype=np.float32)
+    got, pos = [], 0
+    while pos < len(v) or a.readable() or b.readable():
+        pos += a.push(v[pos:], s0.cuda_stream)
+        n = min(a.readable(), b.free(s1.cuda_stream))
+        if n:
+            assert rr.lib().rr_dstream_copy(b._h, 0, a._h, 0, n, rr.C.c_void_p(s1.cuda_stream)) == 0
+            assert rr.lib().rr_dstream_produce(b._h, n) == 0 and rr.lib().rr_dstream_consume(a._h, n) == 0
+        got.append(b.pop(stream=s2.cuda_stream))
+    assert np.array_equal(np.concatenate(got), v)
 
 
 @pytest.mark.parametrize("no_vmm", [False, True])
