@@ -787,7 +787,7 @@ def _sources_hash():
     d = os.path.join(ROOT, "rustradio_amd", "csrc")
     for f in sorted(os.listdir(d)):
         # kernels, their headers and the block logic that picks between them (not the ABI / fan-out / ring plumbing)
-        if f.endswith((".hip", ".hpp")) or f == "blocks.cpp":
+        if (f.endswith((".hip", ".hpp")) and f != "dstream.hpp") or f == "blocks.cpp":
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
