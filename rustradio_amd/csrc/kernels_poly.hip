@@ -25,6 +25,9 @@
 //     each and park the D spectra in LDS (the forward work is shared by all channels, as in k_fm_multi); then every wave
 //     takes every 8th channel: sum_p H_{c,p} X_p from the parked spectra, inverse, demodulation.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -43,6 +46,14 @@ struct PolyArgs {
     float gain;
     int mode;            // RR_ATAN2_*
     CarryOut carry;      // the block's new carry prefix, written by this launch (common.hpp)
+};
+
+// The multi-channel kernel's work split, passed by value (kernel-argument segment: no table in HBM, nothing to upload or to keep
+// alive): workgroup b runs the channel rounds [start[b], start[b + 1]) of the launch.
+constexpr int POLY_PART_MAX = 320;
+struct PolyPart {
+    int rounds;                          // channel rounds per tile, ceil(nchan / 8)
+    int start[POLY_PART_MAX + 1];
 };
 
 // tuning: phases loaded per batch and waves per SIMD of the single-chain kernel (measured on MI355X)
@@ -279,6 +290,10 @@ __device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int
     // through VCC: 6 of the 45 issue slots of a round were s_nop) and the loop bookkeeping is paid once per pair
     for (; i + stride < nv; i += 2 * stride, pu += 2 * inc, pl += 2 * inc, o += 2 * stride) {
         const creg l0 = pl[0], u0v = pu[0], l1 = pl[inc], u1v = pu[inc];
+        // (round 3: the two angles' reductions, polynomials and gains as packed FP32 — 62 instead of 77 instructions per pair —
+        //  measured 0.0770 against 0.0765 ms: a v_pk_fma_f32 holds the SIMD 4.5 clocks against 2.6 for a v_fma_f32
+        //  (tools/micro/valubench.hip), so packing two independent scalar chains buys 13 % of their issue time and the
+        //  dependent packed chain pays it back in wait states.  Removed.)
         const float y0 = poly_angle<MODE>(l0, u0v, a.gain);
         const float y1 = poly_angle<MODE>(l1, u1v, a.gain);
         if constexpr ((RR_POLY_ABLATE & 4) != 0) { if (y0 == 1234.5678f) { o[0] = y0; o[stride] = y1; } } else { o[0] = y0; o[stride] = y1; }
@@ -370,7 +385,7 @@ template <int D, class SRC>
 __global__ __launch_bounds__(512, 1)
 void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long ntiles, const cf* __restrict__ tw,
                      const cf* __restrict__ hreg, int nchan, PolyArgs a, const cf* __restrict__ last_r_in,
-                     cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg, int groups) {
+                     cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg, PolyPart part) {
     carry_store<cf>(src, a.carry);
     static_assert(D <= 8, "one phase per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -386,11 +401,13 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
     const int Sa = PF - a.Ls;
     const creg* hr = reinterpret_cast<const creg*>(hreg);
 
-    // A unit of work = (tile, channel group): with fewer tiles than CUs (ring-sized windows) the channels of a tile are split
-    // over `groups` workgroups — each repeats the shared forward transforms (~1/11 of a 32-channel tile) and takes every
-    // groups-th block of 8 channels; groups == 1 for windows that fill the chip.
+    // A unit of work = a channel round: 8 channels of one tile, one per wave.  Workgroup b takes the rounds
+    // [part.start[b], part.start[b + 1]) of the launch's ntiles * R (R = ceil(nchan / 8), tile-major) and transforms a tile's
+    // input once per run of rounds it holds of that tile (launch_multi_poly_d balances rounds + transforms over the CUs).
+    (void)ntiles;
+    const int R = part.rounds;
     int iter = 0;
-    for (TileIter it(ntiles * groups); it.tile < it.end; it.tile += it.step, iter++) {
+    for (long cr = part.start[blockIdx.x], cr_end = part.start[blockIdx.x + 1]; cr < cr_end; iter++) {
 #ifdef RR_FFT_TIMING_BUILD
         // (timing builds: two waves of workgroup 0 are stamped — RR_STAMP_WAVE_A / _B, default 0 and 1)
         unsigned long long* stamps = (dbg && blockIdx.x == 0 && t == 0 && iter == 1 && (w == RR_STAMP_WAVE_A || w == RR_STAMP_WAVE_B))
@@ -399,8 +416,10 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
         (void)dbg; (void)iter;
 #endif
         PSTAMP(0);
-        const long tile_ = it.tile / groups;
-        const int grp = (int)(it.tile - tile_ * groups);
+        const long tile_ = cr / R;
+        const int r0 = (int)(cr - tile_ * R);
+        const int r1 = (int)(cr_end - cr < (long)(R - r0) ? r0 + (cr_end - cr) : R);
+        cr += r1 - r0;
         const long u0 = a.r_lo + tile_ * Sa;
         const long vbase = (u0 - a.Ls) * D + a.off;
         const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
@@ -421,13 +440,15 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
         //  the waves out and changes nothing: 0.0795 against 0.0786 ms — the SIMD's issue slots are the limit, whichever
         //  wave uses them.  Removed.)
 #pragma unroll 1
-        for (int c = 8 * grp + w; c < nchan; c += 8 * groups) {
+        for (int c = 8 * r0 + w; c < nchan && c < 8 * r1; c += 8) {
             const creg* hc = hr + (long)c * D * 16 * PT + t;
-            creg z[16], h[2][16];
+            creg z[16], h[2][16], x[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) z[j] = mk(0.0f, 0.0f);
 #pragma unroll
             for (int j = 0; j < 16; j++) h[0][j] = hc[j * PT];
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = park[j * PT + t];
             // (round 3: two phases in flight / the prefetch running on into the next channel's first phases during the inverse
             //  transform and the demodulation — three response buffers, 256 VGPRs with 6 spilled, or two without spills —
             //  measured 0.0838 / 0.0830 ms against 0.0806 ms for this form, same box: the response stream from L2 is not what
@@ -438,22 +459,30 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
 #pragma unroll
                     for (int j = 0; j < 16; j++) h[(p + 1) & 1][j] = hc[((p + 1) * 16 + j) * PT];
                 }
+                // All 16 parked values of the phase are requested before its first product: left to itself the compiler
+                // keeps two ds_read2st64_b64 in flight and waits for each pair (0.0778 -> 0.0765 ms, same box; requesting
+                // phase p + 1's values too — a second buffer of 32 VGPRs — spills 18 and measures 0.0833; rolling the 16 registers,
+                // half a phase ahead, 0.0786).
+                if (p > 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) x[j] = park[(p * 16 + j) * PT + t];
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 16; j++) z[j] = cmac(z[j], park[(p * 16 + j) * PT + t], h[p & 1][j]);
+                for (int j = 0; j < 16; j++) z[j] = cmac(z[j], x[j], h[p & 1][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (c == 8 * grp + w) PSTAMP(3);
+            if (c == 8 * r0 + w) PSTAMP(3);
             poly_inverse(z, t, ex, tw0, tab1);
             wave_fence();
             nat_store(z, t, ex);                         // natural order in the wave's own area
             wave_fence();
-            if (c == 8 * grp + w) PSTAMP(4);
+            if (c == 8 * r0 + w) PSTAMP(4);
             float* oc = out + (long)c * out_stride;
             if (a.mode == 0) poly_demod_tile<0>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
             else poly_demod_tile<1>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
             wave_fence();
-            if (c == 8 * grp + w) PSTAMP(5);
+            if (c == 8 * r0 + w) PSTAMP(5);
         }
         PSTAMP(6);
         tile_sync<512>();                                // every wave is done with the parked spectra
@@ -529,6 +558,55 @@ void launch_fir_poly(VSrc<cf> src, cf* out, long n_out, int L, int D, const cf* 
     launch_chain_poly_t(src, reinterpret_cast<float*>(out), L, tw, hreg, h, nullptr, nullptr, s);
 }
 
+// One workgroup per CU (the kernel's shared memory allows no more), each with a CONTIGUOUS run of channel rounds: a run costs
+// wC per round + wF per tile it touches (that tile's input is loaded and transformed again).  Whole tiles handed out one by
+// one leave most of the chip idle in the last wave of tiles — configs[3]'s 423 tiles on 256 CUs take two tile times, 2 x 78.5 k
+// clocks, for 1.65 tiles' worth of work per CU — so the runs are cut where the LARGEST cost is smallest: binary search on the
+// bound, greedy fill under it (optimal for contiguous runs; never worse than whole tiles; for fewer tiles than CUs it is the
+// split of a tile's channels over several workgroups that ring-sized windows need: 90 tiles -> 180 runs of two rounds).
+static PolyPart poly_partition(long ntiles, int R, int G, int wC, int wF) {
+    static std::mutex mu;
+    static std::map<std::tuple<long, int, int, int, int>, PolyPart> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_tuple(ntiles, R, G, wC, wF);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    if (cache.size() >= 64) cache.clear();
+    const long total = ntiles * R;
+    const long tile_cost = wF + (long)R * wC;
+    // fills workgroups greedily under the bound T; returns the rounds placed (== total when T is feasible)
+    auto fill = [&](long T, int* start) {
+        long cr = 0;
+        for (int b = 0; b < G; b++) {
+            if (start) start[b] = (int)cr;
+            long left = T;
+            while (cr < total) {
+                const long o = cr % R;
+                if (o == 0 && left >= tile_cost) {             // whole tiles
+                    const long m = std::min(left / tile_cost, (total - cr) / R);
+                    if (m > 0) { cr += m * R; left -= m * tile_cost; continue; }
+                }
+                const long k = std::min<long>(std::min<long>(R - o, total - cr), (left - wF) / wC);
+                if (k <= 0) break;
+                cr += k; left -= wF + k * wC;
+            }
+        }
+        if (start) start[G] = (int)cr;
+        return cr;
+    };
+    const long m = (total + G - 1) / G;
+    long lo = wF + wC, hi = m * wC + ((m + R - 2) / R + 1) * wF;   // hi: every window of m rounds fits, so the fill succeeds
+    while (lo < hi) {
+        const long mid = (lo + hi) / 2;
+        if (fill(mid, nullptr) >= total) hi = mid; else lo = mid + 1;
+    }
+    PolyPart p{};
+    p.rounds = R;
+    if (fill(hi, p.start) != total) throw Error("fm_multi_poly: internal error (work partition)");
+    for (int b = G + 1; b <= POLY_PART_MAX; b++) p.start[b] = (int)total;
+    return cache.emplace(key, p).first->second;
+}
+
 template <int D, class SRC>
 static void launch_multi_poly_d(SRC src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
                                 const FmChainArgs& h, const cf* last_in, cf* last_out, hipStream_t s) {
@@ -537,16 +615,18 @@ static void launch_multi_poly_d(SRC src, float* out, long out_stride, int L, con
     if (nr <= 0) { launch_carry(src, h.carry, s); return; }
     const long ntiles = (nr + Sa - 1) / Sa;
     const size_t smem = sizeof(cf) * (8 * PLE + D * PF + 64);
-    // fewer tiles than CUs (a 512,000-sample ring holds 90 at 1:6): split each tile's channels over several workgroups
-    // (tools/multi_small.py: 32 channels, 512 k samples 76 -> 45 us per call)
-    const long cus = device_cu_count();
-    const int max_groups = std::max(1, (nchan + 7) / 8);
-    const int groups = ntiles >= cus ? 1 : (int)std::min<long>(max_groups, cus / ntiles);
-    const long units = ntiles * groups;
-    long grid = grid_for_tiles(k_fm_multi_poly<D, SRC>, 512, smem, units);
-    if (units > grid && units < 12 * grid) grid = std::min(units, 3 * grid);         // (as launch_chain_poly_d: 0.093 -> 0.0905 ms)
-    hipLaunchKernelGGL((k_fm_multi_poly<D, SRC>), dim3((unsigned)grid), dim3(512), smem, s, src, out, out_stride, ntiles, tw, hreg,
-                       nchan, a, last_in, last_out, fft_stamp_buffer(), groups);
+    const int R = std::max(1, (nchan + 7) / 8);
+    if (ntiles * R > 0x7fffffffL) throw Error("fm_multi_poly: window too long");
+    const long G = std::min<long>(std::min<long>(device_cu_count(), POLY_PART_MAX), ntiles * R);
+    int wC = 16 + 5 * D / 2, wF = 14;
+#ifdef RR_MEASURE_KNOBS
+    if (const char* e = getenv("RR_POLY_WF")) wF = atoi(e);                          // measurement builds only
+    if (const char* e = getenv("RR_POLY_WC")) wC = atoi(e);
+#endif
+    const PolyPart part = poly_partition(ntiles, R, (int)G, wC, wF);
+    (void)grid_for_tiles(k_fm_multi_poly<D, SRC>, 512, smem, G);                     // (sets the shared-memory attribute once)
+    hipLaunchKernelGGL((k_fm_multi_poly<D, SRC>), dim3((unsigned)G), dim3(512), smem, s, src, out, out_stride, ntiles, tw, hreg,
+                       nchan, a, last_in, last_out, fft_stamp_buffer(), part);
     RR_HIP(hipGetLastError());
 }
 template <class SRC>

@@ -132,3 +132,16 @@ def test_cfg4_256_channels_sharded_over_8_ranks(rr):
         check_channels(yg, taps, x, 4_096_000)
         seen += chans
     assert seen == list(range(256))
+
+
+@pytest.mark.parametrize("nch,n", [(32, 2_400_000), (9, 3_100_000), (17, 1_460_000)])
+def test_cfg4_windows_of_more_tiles_than_cus(rr, nch, n):
+    """bench.py's fm_multi step itself — ONE window of 2,400,000 samples = 423 tiles on 256 CUs — and two more shapes: there
+    the launch hands every workgroup a contiguous run of channel rounds (8 channels of a tile each; launch_multi_poly_d)
+    that starts and ends INSIDE tiles, so a tile's channels are computed by up to two workgroups; 9 and 17 channels leave a
+    partial last round.  Every channel against its own oracle chain, as for the ring-sized windows above."""
+    proto = orc.low_pass_complex(FS, 100e3, 12.5e3)
+    taps = multi.cfg4_taps(proto, list(range(nch)))
+    x = stations(n, 59 + nch, [-1000e3, -960e3, -900e3, 0.0])
+    yg = drive_multi(rr.FmMulti(taps, 1, 6, 1.0), x, nch, n, n // 6 + 1024)
+    check_channels(yg, taps, x, 4_096_000)
