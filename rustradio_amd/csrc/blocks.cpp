@@ -623,7 +623,8 @@ bool PolyTables::build(const rr_c32* taps, size_t C, size_t L, size_t D, bool mu
             for (int j = 0; j < 16; j++)
                 for (int lane = 0; lane < 64; lane++) {
                     const auto v = H[(size_t)fm_poly_bin(j, lane)] / (double)F;
-                    dst[j * 64 + lane] = mkcf((float)v.real(), (float)v.imag());
+                    // a lane's registers 2 jj, 2 jj + 1 side by side (one 16-byte load per pair)
+                    dst[((j / 2) * 64 + lane) * 2 + (j & 1)] = mkcf((float)v.real(), (float)v.imag());
                 }
         }
     for (size_t k = 0; k < F; k++) {

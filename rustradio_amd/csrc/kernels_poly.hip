@@ -71,6 +71,12 @@ struct PolyPart {
 #endif
 // measurement builds only (make EXTRA=-DRR_POLY_ABLATE=<bits>, wrong results): 1 no input loads, 2 no atan2, 4 no output
 // stores, 8 no H loads, 16 no LDS exchanges inside the transforms
+#ifndef RR_POLY_H16
+#define RR_POLY_H16 1
+#endif
+#ifndef RR_POLY_CHAIN_TWLDS
+#define RR_POLY_CHAIN_TWLDS 1
+#endif
 #ifndef RR_POLY_ABLATE
 #define RR_POLY_ABLATE 0
 #endif
@@ -160,6 +166,24 @@ __device__ __forceinline__ void poly_inverse(creg* v, int t, creg* ex, const cre
     inv_pass<PLG, 0>(v, tw0);
 }
 
+// the same with the pass-0 twiddles read from an LDS table [15][64] right before the last pass
+__device__ __forceinline__ void poly_inverse_tab(creg* v, int t, creg* ex, const creg* tw0tab, const creg* tab1) {
+    creg twl[15];
+    inv_pass<PLG, 2>(v, twl);
+    lds_store<PLG, 2>(v, t, ex);
+    wave_fence();
+    lds_load<PLG, 1>(v, t, ex);
+#pragma unroll
+    for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<PLG, 1>::lo(t)];
+    inv_pass<PLG, 1>(v, twl);
+    lds_store<PLG, 1>(v, t, ex);
+    wave_fence();
+    lds_load<PLG, 0>(v, t, ex);
+#pragma unroll
+    for (int k = 0; k < 15; k++) twl[k] = tw0tab[k * PT + t];
+    inv_pass<PLG, 0>(v, twl);
+}
+
 // Phases [P0, P0 + NPH) of one tile on this wave: z += sum_p H_p X_p.  Loaded in batches of up to 3 phases — the lines
 // a batch shares are then touched by back-to-back loads (one fetch per line and wave) and there is one memory latency
 // per batch; hreg = this channel's responses, register-major [p][16][64].  Register budget (256 at 2 waves / SIMD): a
@@ -220,7 +244,13 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     creg twl[15];
+#if RR_POLY_CHAIN_TWLDS
+#pragma unroll
+                    for (int k = 0; k < 15; k++) twl[k] = tw0[k * PT + t];          // (tw0 = the LDS table [15][64])
+                    fwd_pass<PLG, 0>(v[i], twl);
+#else
                     fwd_pass<PLG, 0>(v[i], tw0);
+#endif
                     if constexpr (!(RR_POLY_ABLATE & 16)) lds_store<PLG, 0>(v[i], t, ex);
                     wave_fence();
                     if constexpr (!(RR_POLY_ABLATE & 16)) lds_load<PLG, 1>(v[i], t, ex);
@@ -233,9 +263,19 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 creg h[16];
+#if RR_POLY_H16
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const gptr<f32x4> hq = as_global(reinterpret_cast<const f32x4*>(hreg + (long)(P0 + pb + i) * 16 * PT) + t);
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    if constexpr ((RR_POLY_ABLATE & 8) != 0) { h[2 * jj] = mk(1.0f + jj, (float)t); h[2 * jj + 1] = mk(2.0f + jj, (float)t); }
+                    else { const f32x4 q = hq[jj * PT]; h[2 * jj] = mk(q.x, q.y); h[2 * jj + 1] = mk(q.z, q.w); }
+                }
+#else
                 const creg* hp = hreg + (long)(P0 + pb + i) * 16 * PT + t;
 #pragma unroll
                 for (int j = 0; j < 16; j++) h[j] = (RR_POLY_ABLATE & 8) ? mk(1.0f + j, (float)t) : hp[j * PT];
+#endif
                 fwd_pass<PLG, 2>(v[i], nullptr);         // (P == 1: no twiddles)
 #pragma unroll
                 for (int j = 0; j < 16; j++) z[j] = cmac(z[j], v[i][j], h[j]);
@@ -330,8 +370,20 @@ void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __
     creg* tab1 = lds + 3 * PLE;                          // w_64^j
     const int w = threadIdx.x >> 6, t_ = threadIdx.x & 63;
     creg* ex = lds + w * PLE;
+#if RR_POLY_CHAIN_TWLDS
+    // pass-0 twiddles of lane t in an LDS table [15][64] (read right before the passes that use them) instead of 30 VGPRs
+    // held for the whole kernel: the registers go to the 16-byte response loads
+    creg* tw0 = tab1 + 64;
+    if (w == 0) {
+        creg twr[15];
+        load_twiddles<PLG, 0>(twr, t_, tw);
+#pragma unroll
+        for (int k = 0; k < 15; k++) tw0[k * PT + t_] = twr[k];
+    }
+#else
     creg tw0[15];
     load_twiddles<PLG, 0>(tw0, t_, tw);
+#endif
     if (w == 0) tab1[t_] = to_reg(tw[t_ * (PF / 64)]);
     tile_sync<128>();
     const int Sa = PF - a.Ls;                            // demodulated samples per tile
@@ -366,7 +418,11 @@ void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __
         if (w == 0) {
 #pragma unroll
             for (int j = 0; j < 16; j++) z[j] = cadd(z[j], exB[j * PT + t]);
+#if RR_POLY_CHAIN_TWLDS
+            poly_inverse_tab(z, t, ex, tw0, tab1);
+#else
             poly_inverse(z, t, ex, tw0, tab1);
+#endif
             nat_store(z, t, ldsR);
         }
         PSTAMP(3);
@@ -437,28 +493,41 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
         //  one, waves 0-3, issues first and runs a channel in 14.7 k clocks, the younger one, waves 4-7, takes 25 k for its
         //  first channel and ~16 k for the others — so waves 0-3 wait 17 k of a tile's 79 k clocks at the final barrier.
         //  Handing the channels out dynamically (a queue in LDS, one ds_add_rtn per channel: the fast waves take more) evens
-        //  the waves out and changes nothing: 0.0795 against 0.0786 ms — the SIMD's issue slots are the limit, whichever
-        //  wave uses them.  Removed.)
+        //  the waves out and changes nothing: 0.0795 against 0.0786 ms.  Removed.  Starting waves 4-7 2 k / 4 k / 8 k clocks
+        //  late (s_sleep) so that the waves' response streams do not coincide costs exactly the delay: +3 / +5.5 / +10 %.)
 #pragma unroll 1
         for (int c = 8 * r0 + w; c < nchan && c < 8 * r1; c += 8) {
-            const creg* hc = hr + (long)c * D * 16 * PT + t;
-            creg z[16], h[2][16], x[16];
+            const int hsel = (RR_POLY_ABLATE & 32) ? (c & ~4) : (RR_POLY_ABLATE & 64) ? (c & ~7) : c;   // (32 / 64: timing only, waves share a response)
+            // Two response buffers: phase p + 1 in flight during phase p.  (Round 3: three and four buffers — with the pass-0
+            // twiddles moved from 30 persistent VGPRs to an LDS table, 218 / 250 VGPRs, no spills — measured 0.0638 / worse
+            // against 0.0618 ms: the stream is bound by bytes per clock through the vector-memory path, not by its latency.)
+            constexpr int NB = 2;
+            creg z[16], h[NB][16], x[16];
+            // 16 bytes per lane and load: registers 2 jj, 2 jj + 1 of a lane sit side by side in the multi-channel table
+            // (PolyTables::build) — the CU's vector-memory path moves 64 lanes x 8 B in the 16 clocks it needs for
+            // 64 lanes x 16 B (tools/micro/l1bench.hip: 74 against 135-145 B/ns per CU from an L2-resident table)
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const gptr<f32x4> hq = as_global(reinterpret_cast<const f32x4*>(hr + (long)hsel * D * 16 * PT) + t);
+            auto load_h = [&](creg* dst, int p, int seed) {
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    if constexpr ((RR_POLY_ABLATE & 8) != 0) {
+                        dst[2 * jj] = mk(1.0f + jj + seed, (float)(t + c)); dst[2 * jj + 1] = mk(2.0f + jj, (float)(t - c));
+                    } else {
+                        const f32x4 q = hq[(p * 8 + jj) * PT];
+                        dst[2 * jj] = mk(q.x, q.y); dst[2 * jj + 1] = mk(q.z, q.w);
+                    }
+                }
+            };
 #pragma unroll
             for (int j = 0; j < 16; j++) z[j] = mk(0.0f, 0.0f);
 #pragma unroll
-            for (int j = 0; j < 16; j++) h[0][j] = hc[j * PT];
+            for (int q = 0; q < NB - 1 && q < D; q++) load_h(h[q], q, 0);
 #pragma unroll
             for (int j = 0; j < 16; j++) x[j] = park[j * PT + t];
-            // (round 3: two phases in flight / the prefetch running on into the next channel's first phases during the inverse
-            //  transform and the demodulation — three response buffers, 256 VGPRs with 6 spilled, or two without spills —
-            //  measured 0.0838 / 0.0830 ms against 0.0806 ms for this form, same box: the response stream from L2 is not what
-            //  the multiply-accumulate phase waits for)
 #pragma unroll
-            for (int p = 0; p < D; p++) {                    // phase p + 1's response is in flight while phase p is multiplied
-                if (p + 1 < D) {
-#pragma unroll
-                    for (int j = 0; j < 16; j++) h[(p + 1) & 1][j] = hc[((p + 1) * 16 + j) * PT];
-                }
+            for (int p = 0; p < D; p++) {
+                if (p + NB - 1 < D) load_h(h[(p + NB - 1) % NB], p + NB - 1, p);
                 // All 16 parked values of the phase are requested before its first product: left to itself the compiler
                 // keeps two ds_read2st64_b64 in flight and waits for each pair (0.0778 -> 0.0765 ms, same box; requesting
                 // phase p + 1's values too — a second buffer of 32 VGPRs — spills 18 and measures 0.0833; rolling the 16 registers,
@@ -469,7 +538,7 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 16; j++) z[j] = cmac(z[j], x[j], h[p & 1][j]);
+                for (int j = 0; j < 16; j++) z[j] = cmac(z[j], x[j], h[p % NB][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (c == 8 * r0 + w) PSTAMP(3);
@@ -519,7 +588,7 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
     const long Sa = PF - a.Ls, nr = a.r_hi - a.r_lo;
     if (nr <= 0) { launch_carry(src, h.carry, s); return; }
     const long ntiles = (nr + Sa - 1) / Sa;
-    const size_t smem = sizeof(cf) * (3 * PLE + 64);
+    const size_t smem = sizeof(cf) * (3 * PLE + 64 + (RR_POLY_CHAIN_TWLDS ? 15 * PT : 0));
     long grid = grid_for_tiles(k_fm_chain_poly<D, SRC>, 128, smem, ntiles);
     // A few tiles per resident workgroup (configs[2]: 4228 tiles on 1024 slots = 4.1) end in a round where most of the
     // chip waits for the workgroups with one tile more.  Launching 3x the resident workgroups lets the hardware dispatcher
