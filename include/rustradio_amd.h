@@ -90,7 +90,8 @@ typedef struct {
     int fft_no_split;       /* tiles of 8192 / 16384 points as ONE workgroup instead of 2 / 4 sub-transforms */
     int fftfloat_complex;   /* FftFilterFloat: the reference's f32 -> Complex -> FftFilter -> .re inner path */
     int fm_full;            /* fused FM chains: full-size inverse transforms for 1:even ratios too */
-    int fm_poly;            /* fused FM chains: decimate-first (polyphase) tiles, > 0 wherever supported, < 0 never */
+    int fm_poly;            /* fused FM chains: decimate-first (polyphase) tiles, > 0 wherever supported, < 0 never;
+                               8 / 12: also fixes the multi-channel kernel's waves per workgroup (0 / 1: by predicted cost) */
     int dstream_no_vmm;     /* rr_dstream_create: the copying fallback ring instead of the double mapping */
     int host_sync_copies;   /* rr_block_work: plain staged copies instead of the pinned, overlapped pipeline */
     int fir_poly;           /* decimating FirFilter<Complex>: decimate-first (polyphase) tiles, > 0 wherever supported, < 0 never */

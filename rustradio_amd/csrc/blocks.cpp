@@ -1108,6 +1108,7 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
     if (build_opts().fm_poly >= 0 && !build_opts().fm_full && chain->I == 1) {
         poly.reset(new PolyTables());
         if (!poly->build(taps, C, ntaps, (size_t)chain->D, true, stream)) poly.reset();
+        if (build_opts().fm_poly == 8 || build_opts().fm_poly == 12) poly_waves = build_opts().fm_poly;
     }
     for (auto& b : last_r) { b.reserve(C); RR_HIP(hipMemsetAsync(b.p, 0, C * sizeof(cf), stream)); }
     RR_HIP(hipStreamSynchronize(stream));
@@ -1156,6 +1157,7 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         a.A = (long)n1; a.n_y = (long)n_y; a.r_lo = (long)N2(n1); a.r_hi = (long)N2(n1 + n_y);
         a.o_base = (long)o_old; a.I = I; a.D = D; a.gain = ch.gain; a.mode = ch.mode;
         if (*consumed) a.carry = CarryOut{f->prefix[f->cur ^ 1].p, (long)n_y, (long)(f->hist + new_pend)};
+        a.multi_waves = poly_waves;
         prof_begin(s);
         if (poly && packed)
             launch_fm_multi_poly_iq8(src8, static_cast<float*>(out), (long)out_cap, (int)f->L, poly->d_tw.p, poly->d_h.p, (int)C, a,

@@ -240,6 +240,7 @@ struct FmMulti : Block {
     DevBuf<cf> d_tw_half;             // w_(F/2)^k: half-size inverse transforms (interp 1, even deci; k_fm_multi_half)
     bool half_ok = false;
     std::unique_ptr<PolyTables> poly; // interp 1, deci 2..8: decimate-first tiles (k_fm_multi_poly)
+    int poly_waves = 0;               // rr_build_opts.fm_poly = 8 / 12 forces that kernel variant (parity tests of both)
     DevBuf<cf> last_r[2];             // [C]
     int cur_lr = 0;
     // iq8: RTL-SDR byte input, RtlSdrDecode fused in front (windows, `consumed` and WAIT_SRC `need` count BYTES)

@@ -85,6 +85,7 @@ struct FmChainArgs {
     float gain;
     int mode;          // RR_ATAN2_*
     CarryOut carry;    // the block's carry-state update (new prefix), written by this launch (common.hpp)
+    int multi_waves = 0;   // multi-channel decimate-first kernel: 0 = by predicted cost, 8 / 12 = that many waves per workgroup
 };
 // out[(u-1) - o_base] = gain * atan2(conj(r[u-1]) r[u]) for u in [max(r_lo,1), r_hi); r[r_lo-1] is
 // *last_in (previous call), r[r_hi-1] is written to *last_out.

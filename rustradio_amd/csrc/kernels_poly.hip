@@ -52,7 +52,8 @@ struct PolyArgs {
 // alive): workgroup b runs the channel rounds [start[b], start[b + 1]) of the launch.
 constexpr int POLY_PART_MAX = 320;
 struct PolyPart {
-    int rounds;                          // channel rounds per tile, ceil(nchan / 8)
+    int rounds;                          // channel rounds per tile, ceil(nchan / waves per workgroup)
+    int cost;                            // (host) the largest run cost in the units of poly_partition's weights
     int start[POLY_PART_MAX + 1];
 };
 
@@ -166,6 +167,23 @@ __device__ __forceinline__ void poly_inverse(creg* v, int t, creg* ex, const cre
     inv_pass<PLG, 0>(v, tw0);
 }
 
+// forward transform with the pass-0 twiddles read from an LDS table [15][64] (see poly_inverse_tab)
+__device__ __forceinline__ void poly_forward_tab(creg* v, int t, creg* ex, const creg* tw0tab, const creg* tab1) {
+    creg twl[15];
+#pragma unroll
+    for (int k = 0; k < 15; k++) twl[k] = tw0tab[k * PT + t];
+    fwd_pass<PLG, 0>(v, twl);
+    lds_store<PLG, 0>(v, t, ex);
+    wave_fence();
+    lds_load<PLG, 1>(v, t, ex);
+#pragma unroll
+    for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<PLG, 1>::lo(t)];
+    fwd_pass<PLG, 1>(v, twl);
+    lds_store<PLG, 1>(v, t, ex);
+    wave_fence();
+    lds_load<PLG, 2>(v, t, ex);
+    fwd_pass<PLG, 2>(v, twl);
+}
 // the same with the pass-0 twiddles read from an LDS table [15][64] right before the last pass
 __device__ __forceinline__ void poly_inverse_tab(creg* v, int t, creg* ex, const creg* tw0tab, const creg* tab1) {
     creg twl[15];
@@ -559,6 +577,91 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
     }
 }
 
+// ---- the same with three waves per SIMD (decimations up to 6) -------------------------------------------------------
+// 12 waves per workgroup = 12 channels per round.  What pays for the third wave: the pass-0 twiddles in an LDS table instead
+// of 30 VGPRs, the responses and the parked spectra in HALF-phase buffers (8 registers each, the next half in flight), so
+// that the kernel fits 168 VGPRs; LDS: 12 exchange areas + D parked spectra + the tables = 161.8 KB at D = 6.
+constexpr int MW = 12;
+template <int D, class SRC>
+__global__ __launch_bounds__(64 * MW, 1)
+void k_fm_multi_poly12(SRC src, float* __restrict__ out, long out_stride, long ntiles, const cf* __restrict__ tw,
+                       const cf* __restrict__ hreg, int nchan, PolyArgs a, const cf* __restrict__ last_r_in,
+                       cf* __restrict__ last_r_out, PolyPart part) {
+    carry_store<cf>(src, a.carry);
+    static_assert(D <= 6, "LDS: 12 exchange areas + D parked spectra");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    creg* park = lds + MW * PLE;                         // D spectra, register-major [p][16][64]
+    creg* tab1 = park + D * PF;
+    creg* tw0tab = tab1 + 64;                            // pass-0 twiddles of lane t, [15][64]
+    const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
+    creg* ex = lds + w * PLE;
+    if (w == 0) {
+        creg twr[15];
+        load_twiddles<PLG, 0>(twr, t, tw);
+#pragma unroll
+        for (int k = 0; k < 15; k++) tw0tab[k * PT + t] = twr[k];
+        tab1[t] = to_reg(tw[t * (PF / 64)]);
+    }
+    tile_sync<64 * MW>();
+    const int Sa = PF - a.Ls;
+    const creg* hr = reinterpret_cast<const creg*>(hreg);
+    (void)ntiles;
+    const int R = part.rounds;
+    for (long cr = part.start[blockIdx.x], cr_end = part.start[blockIdx.x + 1]; cr < cr_end;) {
+        const long tile_ = cr / R;
+        const int r0 = (int)(cr - tile_ * R);
+        const int r1 = (int)(cr_end - cr < (long)(R - r0) ? r0 + (cr_end - cr) : R);
+        cr += r1 - r0;
+        const long u0 = a.r_lo + tile_ * Sa;
+        const long vbase = (u0 - a.Ls) * D + a.off;
+        const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
+        if (w < D) {
+            creg v[16];
+            poly_load<D>(v, src, vbase, w, t, interior, ex);
+            poly_forward_tab(v, t, ex, tw0tab, tab1);
+#pragma unroll
+            for (int j = 0; j < 16; j++) park[(w * 16 + j) * PT + t] = v[j];
+        }
+        tile_sync<64 * MW>();
+#pragma unroll 1
+        for (int c = MW * r0 + w; c < nchan && c < MW * r1; c += MW) {
+            creg z[16], h[2][8], x[8];
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const gptr<f32x4> hq = as_global(reinterpret_cast<const f32x4*>(hr + (long)c * D * 16 * PT) + t);
+            auto load_h = [&](creg* dst, int k) {              // half-phase k: registers 8 (k & 1) .. + 7 of phase k / 2
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const f32x4 q = hq[(k * 4 + jj) * PT];
+                    dst[2 * jj] = mk(q.x, q.y); dst[2 * jj + 1] = mk(q.z, q.w);
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < 16; j++) z[j] = mk(0.0f, 0.0f);
+            load_h(h[0], 0);
+#pragma unroll
+            for (int k = 0; k < 2 * D; k++) {
+                if (k + 1 < 2 * D) load_h(h[(k + 1) & 1], k + 1);
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[j] = park[(k * 8 + j) * PT + t];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; j++) z[8 * (k & 1) + j] = cmac(z[8 * (k & 1) + j], x[j], h[k & 1][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            poly_inverse_tab(z, t, ex, tw0tab, tab1);
+            wave_fence();
+            nat_store(z, t, ex);
+            wave_fence();
+            float* oc = out + (long)c * out_stride;
+            if (a.mode == 0) poly_demod_tile<0>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+            else poly_demod_tile<1>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+            wave_fence();
+        }
+        tile_sync<64 * MW>();                            // every wave is done with the parked spectra
+    }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------------------
 bool fm_poly_supported(long I, long D, int L, bool multi) {
     if (I != 1) return false;
@@ -671,6 +774,7 @@ static PolyPart poly_partition(long ntiles, int R, int G, int wC, int wF) {
     }
     PolyPart p{};
     p.rounds = R;
+    p.cost = (int)std::min<long>(hi, 0x7fffffffL);
     if (fill(hi, p.start) != total) throw Error("fm_multi_poly: internal error (work partition)");
     for (int b = G + 1; b <= POLY_PART_MAX; b++) p.start[b] = (int)total;
     return cache.emplace(key, p).first->second;
@@ -684,15 +788,34 @@ static void launch_multi_poly_d(SRC src, float* out, long out_stride, int L, con
     if (nr <= 0) { launch_carry(src, h.carry, s); return; }
     const long ntiles = (nr + Sa - 1) / Sa;
     const size_t smem = sizeof(cf) * (8 * PLE + D * PF + 64);
-    const int R = std::max(1, (nchan + 7) / 8);
-    if (ntiles * R > 0x7fffffffL) throw Error("fm_multi_poly: window too long");
-    const long G = std::min<long>(std::min<long>(device_cu_count(), POLY_PART_MAX), ntiles * R);
+    // Two kernels: 8 waves per workgroup (any decimation up to 8) and 12 (three per SIMD, decimations up to 6).  A round of
+    // 12 channels costs 1.28x a round of 8 (24 M samples, 32 channels: 567 against 589 us per call) and cuts a launch into
+    // coarser pieces — ring-sized windows run faster on 8 waves (512 k samples: 24.5 against 29.6 us), one-second windows on
+    // 12 (2.4 M: 0.0568 against 0.0622 ms).  The choice is the smaller predicted cost of the launch's largest run.
     int wC = 16 + 5 * D / 2, wF = 14;
 #ifdef RR_MEASURE_KNOBS
     if (const char* e = getenv("RR_POLY_WF")) wF = atoi(e);                          // measurement builds only
     if (const char* e = getenv("RR_POLY_WC")) wC = atoi(e);
 #endif
+    const int R = std::max(1, (nchan + 7) / 8);
+    if (ntiles * R > 0x7fffffffL) throw Error("fm_multi_poly: window too long");
+    const long G = std::min<long>(std::min<long>(device_cu_count(), POLY_PART_MAX), ntiles * R);
     const PolyPart part = poly_partition(ntiles, R, (int)G, wC, wF);
+    if constexpr (D <= 6) {
+        const int R12 = (nchan + MW - 1) / MW;
+        const long G12 = std::min<long>(std::min<long>(device_cu_count(), POLY_PART_MAX), ntiles * R12);
+        const int wC12 = (wC * 39 + 16) / 32;        // (1.22x: fitted to the per-call times of both kernels, 1 M ... 24 M samples)
+        const PolyPart part12 = poly_partition(ntiles, R12, (int)G12, wC12, wF);
+        const bool use12 = h.multi_waves == 12 || (h.multi_waves == 0 && nchan > 8 && part12.cost < part.cost);
+        if (use12) {
+            const size_t smem12 = sizeof(cf) * (MW * PLE + D * PF + 64 + 15 * PT);
+            (void)grid_for_tiles(k_fm_multi_poly12<D, SRC>, 64 * MW, smem12, G12);               // (sets the shared-memory attribute once)
+            hipLaunchKernelGGL((k_fm_multi_poly12<D, SRC>), dim3((unsigned)G12), dim3(64 * MW), smem12, s, src, out, out_stride, ntiles, tw,
+                               hreg, nchan, a, last_in, last_out, part12);
+            RR_HIP(hipGetLastError());
+            return;
+        }
+    }
     (void)grid_for_tiles(k_fm_multi_poly<D, SRC>, 512, smem, G);                     // (sets the shared-memory attribute once)
     hipLaunchKernelGGL((k_fm_multi_poly<D, SRC>), dim3((unsigned)G), dim3(512), smem, s, src, out, out_stride, ntiles, tw, hreg,
                        nchan, a, last_in, last_out, fft_stamp_buffer(), part);

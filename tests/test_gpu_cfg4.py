@@ -72,7 +72,7 @@ def check_channels(yg_all, taps, x, stream_bytes, centred=()):
     return worst
 
 
-@pytest.mark.parametrize("kernel", ["auto", "half", "full"])
+@pytest.mark.parametrize("kernel", ["auto", "w8", "w12", "half", "full"])
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 8 * 37_003])
 def test_cfg4_32_channels_per_gpu(rr, monkeypatch, kernel, stream_bytes):
     """bench.py's fm_multi block at N = 1: channels 0..31 of the 256-channel bank, 600,000 samples, reference-sized
@@ -82,6 +82,8 @@ def test_cfg4_32_channels_per_gpu(rr, monkeypatch, kernel, stream_bytes):
         knob(rr, monkeypatch, fm_full=1, fm_poly=-1)
     elif kernel == "half":
         knob(rr, monkeypatch, fm_poly=-1)
+    elif kernel in ("w8", "w12"):          # the decimate-first kernel with 8 / 12 waves per workgroup at every window size
+        knob(rr, monkeypatch, fm_poly=int(kernel[1:]))
     proto = orc.low_pass_complex(FS, 100e3, 12.5e3)
     assert len(proto) == 463
     chans = list(multi.shard_channels(32, 1, 0))
@@ -134,12 +136,16 @@ def test_cfg4_256_channels_sharded_over_8_ranks(rr):
     assert seen == list(range(256))
 
 
+@pytest.mark.parametrize("waves", [0, 8, 12])
 @pytest.mark.parametrize("nch,n", [(32, 2_400_000), (9, 3_100_000), (17, 1_460_000)])
-def test_cfg4_windows_of_more_tiles_than_cus(rr, nch, n):
+def test_cfg4_windows_of_more_tiles_than_cus(rr, monkeypatch, nch, n, waves):
     """bench.py's fm_multi step itself — ONE window of 2,400,000 samples = 423 tiles on 256 CUs — and two more shapes: there
     the launch hands every workgroup a contiguous run of channel rounds (8 channels of a tile each; launch_multi_poly_d)
     that starts and ends INSIDE tiles, so a tile's channels are computed by up to two workgroups; 9 and 17 channels leave a
-    partial last round.  Every channel against its own oracle chain, as for the ring-sized windows above."""
+    partial last round.  Every channel against its own oracle chain, as for the ring-sized windows above.  waves = 8 / 12
+    forces the kernel variant (rr_build_opts.fm_poly), 0 is the library's own choice by predicted cost."""
+    if waves:
+        knob(rr, monkeypatch, fm_poly=waves)
     proto = orc.low_pass_complex(FS, 100e3, 12.5e3)
     taps = multi.cfg4_taps(proto, list(range(nch)))
     x = stations(n, 59 + nch, [-1000e3, -960e3, -900e3, 0.0])
