@@ -72,6 +72,9 @@ struct PolyPart {
 #endif
 // measurement builds only (make EXTRA=-DRR_POLY_ABLATE=<bits>, wrong results): 1 no input loads, 2 no atan2, 4 no output
 // stores, 8 no H loads, 16 no LDS exchanges inside the transforms
+#ifndef RR_POLY_CHAIN_W3
+#define RR_POLY_CHAIN_W3 1
+#endif
 #ifndef RR_POLY_H16
 #define RR_POLY_H16 1
 #endif
@@ -206,9 +209,9 @@ __device__ __forceinline__ void poly_inverse_tab(creg* v, int t, creg* ex, const
 // a batch shares are then touched by back-to-back loads (one fetch per line and wave) and there is one memory latency
 // per batch; hreg = this channel's responses, register-major [p][16][64].  Register budget (256 at 2 waves / SIMD): a
 // batch 96 + z 32 + pass-0 twiddles 30 + one pass's temporaries; H is fetched during the last (twiddle-free) pass.
-template <int D, int P0, int NPH, class SRC>
+template <int D, int NPH, class SRC>
 __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase, bool interior, int t, creg* ex,
-                                            const creg* tw0, const creg* tab1, const creg* __restrict__ hreg) {
+                                            const creg* tw0, const creg* tab1, const creg* __restrict__ hreg, int P0) {
     constexpr int NB = RR_POLY_NB < NPH ? RR_POLY_NB : NPH;
 #pragma unroll
     for (int pb = 0; pb < NPH; pb += NB) {
@@ -424,9 +427,9 @@ void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __
         int t = t_;                                      // opaque per tile: keeps the tile body's LDS / table addresses from
         asm volatile("" : "+v"(t));                      // being hoisted out of the loop into persistent VGPRs
         if (w == 0) {
-            poly_phases<D, 0, PHA>(z, src, vbase, interior, t, ex, tw0, tab1, hr);
+            poly_phases<D, PHA>(z, src, vbase, interior, t, ex, tw0, tab1, hr, 0);
         } else {
-            if constexpr (PHB > 0) poly_phases<D, PHA, PHB>(z, src, vbase, interior, t, ex, tw0, tab1, hr);
+            if constexpr (PHB > 0) poly_phases<D, PHB>(z, src, vbase, interior, t, ex, tw0, tab1, hr, PHA);
 #pragma unroll
             for (int j = 0; j < 16; j++) exB[j * PT + t] = z[j];
         }
@@ -451,6 +454,66 @@ void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __
         else poly_store_tile(ldsR, w * PT + t, 2 * PT, u0, Sa, a, reinterpret_cast<creg*>(out));
         PSTAMP(5);
         // (the next tile rewrites exB / ldsR only after its first barrier, which both waves reach after these reads)
+    }
+}
+
+// ---- the same with three waves per SIMD: NW waves per workgroup, D / NW phases each ---------------------------------------
+// (1:6 -> 3 waves x 2 phases, 1:4 -> 2 x 2, 1:8 -> 4 x 2, 1:3 -> 3 x 1, 1:2 -> 2 x 1: at most two phases per wave, pass-0
+// twiddles in the LDS table, 16-byte response loads = 168 VGPRs.)  The natural-order tile shares wave 0's exchange area —
+// one more barrier per tile, 8.7 KB less per workgroup — so that 12 waves' workgroups fit the CU's LDS.
+template <int D, int NW, class SRC>
+__global__ __launch_bounds__(64 * NW, 3)
+void k_fm_chain_polyw(SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
+                      PolyArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
+    carry_store<cf>(src, a.carry);
+    static_assert(D % NW == 0 && D / NW <= 2, "at most two phases per wave");
+    constexpr int PPW = D / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    creg* lds = reinterpret_cast<creg*>(smem_raw);
+    creg* ldsR = lds;                                    // the tile's resampled samples, natural order (= wave 0's area)
+    creg* tab1 = lds + NW * PLE;                         // w_64^j
+    creg* tw0 = tab1 + 64;                               // pass-0 twiddles of lane t, [15][64]
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t_ = threadIdx.x & 63;
+    creg* ex = lds + w * PLE;
+    if (w == 0) {
+        creg twr[15];
+        load_twiddles<PLG, 0>(twr, t_, tw);
+#pragma unroll
+        for (int k = 0; k < 15; k++) tw0[k * PT + t_] = twr[k];
+        tab1[t_] = to_reg(tw[t_ * (PF / 64)]);
+    }
+    tile_sync<64 * NW>();
+    const int Sa = PF - a.Ls;
+    const creg* hr = reinterpret_cast<const creg*>(hreg);
+    for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
+        const long u0 = a.r_lo + it.tile * Sa;
+        const long vbase = (u0 - a.Ls) * D + a.off;
+        const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
+        creg z[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) z[j] = mk(0.0f, 0.0f);
+        int t = t_;
+        asm volatile("" : "+v"(t));
+        poly_phases<D, PPW>(z, src, vbase, interior, t, ex, tw0, tab1, hr, w * PPW);
+        if (w != 0) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) ex[j * PT + t] = z[j];      // partial sum, register-major, in the wave's own area
+        }
+        tile_sync<64 * NW>();
+        if (w == 0) {
+#pragma unroll
+            for (int k = 1; k < NW; k++) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) z[j] = cadd(z[j], lds[k * PLE + j * PT + t]);
+            }
+            poly_inverse_tab(z, t, ex, tw0, tab1);
+            nat_store(z, t, ldsR);
+        }
+        tile_sync<64 * NW>();
+        if (a.mode == 0) poly_demod_tile<0>(ldsR, w * PT + t, NW * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        else if (a.mode == 1) poly_demod_tile<1>(ldsR, w * PT + t, NW * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        else poly_store_tile(ldsR, w * PT + t, NW * PT, u0, Sa, a, reinterpret_cast<creg*>(out));
+        tile_sync<64 * NW>();                            // wave 0's next transforms rewrite the area the others read here
     }
 }
 
@@ -684,6 +747,7 @@ static PolyArgs poly_args(const FmChainArgs& h, int L) {
     return a;
 }
 
+template <int D> struct ChainWaves { static constexpr int NW = D == 6 ? 3 : D == 4 ? 2 : D == 8 ? 4 : D == 3 ? 3 : D == 2 ? 2 : 0; };
 template <int D, class SRC>
 static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& h, const cf* last_in,
                                 cf* last_out, hipStream_t s) {
@@ -691,6 +755,18 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
     const long Sa = PF - a.Ls, nr = a.r_hi - a.r_lo;
     if (nr <= 0) { launch_carry(src, h.carry, s); return; }
     const long ntiles = (nr + Sa - 1) / Sa;
+#if RR_POLY_CHAIN_W3
+    if constexpr (ChainWaves<D>::NW != 0) {
+        constexpr int NW = ChainWaves<D>::NW;
+        const size_t smemw = sizeof(cf) * (NW * PLE + 64 + 15 * PT);
+        long gridw = grid_for_tiles(k_fm_chain_polyw<D, NW, SRC>, 64 * NW, smemw, ntiles);
+        if (ntiles > gridw && ntiles < 12 * gridw) gridw = std::min(ntiles, (long)RR_POLY_OVERSUB * gridw);
+        hipLaunchKernelGGL((k_fm_chain_polyw<D, NW, SRC>), dim3((unsigned)gridw), dim3(64 * NW), smemw, s, src, out, ntiles, tw, hreg, a,
+                           last_in, last_out);
+        RR_HIP(hipGetLastError());
+        return;
+    }
+#endif
     const size_t smem = sizeof(cf) * (3 * PLE + 64 + (RR_POLY_CHAIN_TWLDS ? 15 * PT : 0));
     long grid = grid_for_tiles(k_fm_chain_poly<D, SRC>, 128, smem, ntiles);
     // A few tiles per resident workgroup (configs[2]: 4228 tiles on 1024 slots = 4.1) end in a round where most of the
