@@ -75,6 +75,12 @@ struct PolyPart {
 #ifndef RR_POLY_CHAIN_W3
 #define RR_POLY_CHAIN_W3 1
 #endif
+#ifndef RR_POLY_PIPE
+#define RR_POLY_PIPE 1
+#endif
+#ifndef RR_POLY_PIPE_SPLIT
+#define RR_POLY_PIPE_SPLIT 8
+#endif
 #ifndef RR_POLY_H16
 #define RR_POLY_H16 1
 #endif
@@ -231,10 +237,12 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
                 // the batch's phases are NBV ADJACENT samples per lane: fetched as 16-byte pairs (+ one 8-byte rest) — every
                 // load instruction of a 48-byte lane stride looks up the same 24 cache lines whatever its width, so two
                 // loads per position instead of three are a third fewer L1 look-ups
-                const gptr<creg> base = as_global(reinterpret_cast<const creg*>(src.in) + i0);
+                // (RR_POLY_ABLATE & 128, timing only, wrong data: the same bytes as lane-consecutive 16-byte chunks)
+                const gptr<creg> base = (RR_POLY_ABLATE & 128) ? as_global(reinterpret_cast<const creg*>(src.in) + (i0 - (long)D * t + 2 * t + 2))
+                                                               : as_global(reinterpret_cast<const creg*>(src.in) + i0);
 #pragma unroll
                 for (int n = 0; n < 16; n++) {
-                    const gptr<creg> q = base + (long)D * PT * n;
+                    const gptr<creg> q = base + ((RR_POLY_ABLATE & 128) ? 128L * (3 * n + (P0 >> 1)) : (long)D * PT * n);
 #pragma unroll
                     for (int k = 0; k < (NB + 1) / 2; k++) {
                         const int i = nbv - 1 - 2 * k;
@@ -304,6 +312,77 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
             }
         }
     }
+}
+
+// The two halves of poly_phases for kernels that issue a tile's loads ahead of its arithmetic (k_fm_chain_polyw; one batch of
+// NPH <= 2 phases per wave).  poly_issue: interior tiles only — the NPH phases of position t + 64 n are adjacent samples.
+template <int D, int NPH, int N0 = 0, int N1 = 16, class SRC>
+__device__ __forceinline__ void poly_issue(creg (*v)[16], const SRC& src, long vbase, int t, int P0) {
+    static_assert(NPH == 1 || NPH == 2, "one batch of at most two phases");
+    const long i0 = vbase - src.plen - P0 + (long)D * t;
+    if constexpr ((RR_POLY_ABLATE & 1) != 0) {
+#pragma unroll
+        for (int n = N0; n < N1; n++)
+#pragma unroll
+            for (int i = 0; i < NPH; i++) v[i][n] = mk((float)(t + n) * 1e-3f, (float)(i0 & 255) * 1e-3f);
+    } else if constexpr (std::is_same<SRC, VSrc<cf>>::value && NPH == 2) {
+        const gptr<creg> base = as_global(reinterpret_cast<const creg*>(src.in) + i0);
+#pragma unroll
+        for (int n = N0; n < N1; n++) {
+            const creg2u w = *reinterpret_cast<gptr<creg2u>>(base + (long)D * PT * n - 1);
+            v[1][n] = mk(w.x, w.y);
+            v[0][n] = mk(w.z, w.w);
+        }
+    } else {
+#pragma unroll
+        for (int n = N0; n < N1; n++)
+#pragma unroll
+            for (int i = 0; i < NPH; i++) v[i][n] = poly_elem(src, i0 - i + (long)D * PT * n);
+    }
+}
+// the same for NPH == 2 on Complex streams, rows [N0, N1), into RAW 16-byte registers (phase P0 + 1 in .xy, phase P0 in .zw):
+// nothing touches the loaded values until poly_unpack, so nothing waits for them where they are issued
+template <int D, int N0, int N1>
+__device__ __forceinline__ void poly_issue_raw(creg2* raw, const creg* lane_base, int t) {
+    const gptr<creg> base = as_global(lane_base);        // the sample of phase P0 + 1 at position t
+#pragma unroll
+    for (int n = N0; n < N1; n++) {
+        if constexpr ((RR_POLY_ABLATE & 1) != 0) raw[n] = creg2{(float)(t + n) * 1e-3f, 1e-3f, 1e-3f, 2e-3f};
+        else raw[n] = *reinterpret_cast<gptr<creg2u>>(base + (long)D * PT * n);
+    }
+}
+// forward transform of one phase (pass-0 twiddles from the LDS table tw0tab), z += H_phase X
+__device__ __forceinline__ void poly_xform_mac(creg* z, creg* vi, int t, creg* ex, const creg* tw0tab, const creg* tab1,
+                                               const creg* __restrict__ hreg, int phase) {
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        creg twl[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) twl[k] = tw0tab[k * PT + t];
+        fwd_pass<PLG, 0>(vi, twl);
+        if constexpr (!(RR_POLY_ABLATE & 16)) lds_store<PLG, 0>(vi, t, ex);
+        wave_fence();
+        if constexpr (!(RR_POLY_ABLATE & 16)) lds_load<PLG, 1>(vi, t, ex);
+#pragma unroll
+        for (int k = 1; k < 16; k++) twl[k - 1] = tab1[k * PassGeom<PLG, 1>::lo(t)];
+        fwd_pass<PLG, 1>(vi, twl);
+        if constexpr (!(RR_POLY_ABLATE & 16)) lds_store<PLG, 1>(vi, t, ex);
+        wave_fence();
+        if constexpr (!(RR_POLY_ABLATE & 16)) lds_load<PLG, 2>(vi, t, ex);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    creg h[16];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const gptr<f32x4> hq = as_global(reinterpret_cast<const f32x4*>(hreg + (long)phase * 16 * PT) + t);
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        if constexpr ((RR_POLY_ABLATE & 8) != 0) { h[2 * jj] = mk(1.0f + jj, (float)t); h[2 * jj + 1] = mk(2.0f + jj, (float)t); }
+        else { const f32x4 q = hq[jj * PT]; h[2 * jj] = mk(q.x, q.y); h[2 * jj + 1] = mk(q.z, q.w); }
+    }
+    fwd_pass<PLG, 2>(vi, nullptr);                   // (P == 1: no twiddles)
+#pragma unroll
+    for (int j = 0; j < 16; j++) z[j] = cmac(z[j], vi[j], h[j]);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // The finished tile in natural order, UNPADDED (position p in slot p): the demodulation below reads 64 consecutive slots from
@@ -485,16 +564,67 @@ void k_fm_chain_polyw(SRC src, float* __restrict__ out, long ntiles, const cf* _
     tile_sync<64 * NW>();
     const int Sa = PF - a.Ls;
     const creg* hr = reinterpret_cast<const creg*>(hreg);
+    // Software-pipelined over tiles: the NEXT tile's loads are issued right after this tile's last product — half of them
+    // before the inverse transform, half after it (all 16 before it spill) — and fly during the partial sums, the inverse and
+    // the demodulation, a quarter of a tile's time and about one memory latency, in the registers the transforms have just
+    // released.  (Steady state, tools/chain_ablate.sh: 14.5 ns per tile, 10.4 without the input loads, 14.0 with them
+    // lane-consecutive — what the loads cost is a wave standing still for their latency.  Pipelined: 12.9 ns per tile at
+    // 9.6e7 samples, the metric's fused chain 0.2455 -> 0.2325 ms per 1e8; no change where a workgroup gets one or two tiles.)
+    auto tile_geom = [&](long tile, long& u0, long& vbase, bool& interior) {
+        u0 = a.r_lo + tile * Sa;
+        vbase = (u0 - a.Ls) * D + a.off;
+        interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
+    };
+    // Pipelined for two-phase waves on Complex streams (the byte stream's samples are converted where they are loaded).  The
+    // prefetch is issued on EVERY iteration — for a boundary or missing next tile from the response table, 48 KB that are
+    // always there, and thrown away — so that the raw registers are dead between their unpacking and the next issue; a
+    // conditional definition would keep all 64 of them alive through the transforms.
+    constexpr bool PIPE = RR_POLY_PIPE && PPW == 2 && std::is_same<SRC, VSrc<cf>>::value;
+    creg2 raw[PIPE ? 16 : 1];
+    bool have = false;                                   // raw holds, or is receiving, the coming tile's samples
+    auto lane_base = [&](bool ok, long vb, int tt) -> const creg* {
+        const creg* p = hr;                              // (safe dummy: D * 1024 samples of response)
+        if constexpr (std::is_same<SRC, VSrc<cf>>::value) {
+            if (ok) p = reinterpret_cast<const creg*>(src.in) + (vb - src.plen - w * PPW - 1);
+        }
+        return p + (long)D * tt;
+    };
+    if constexpr (PIPE) {
+        TileIter it0(ntiles);
+        long u0, vbase = 0; bool interior = false;
+        if (it0.tile < it0.end) tile_geom(it0.tile, u0, vbase, interior);
+        poly_issue_raw<D, 0, 16>(raw, lane_base(interior, vbase, t_), t_);
+        have = interior;
+    }
     for (TileIter it(ntiles); it.tile < it.end; it.tile += it.step) {
-        const long u0 = a.r_lo + it.tile * Sa;
-        const long vbase = (u0 - a.Ls) * D + a.off;
-        const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
-        creg z[16];
+        long u0, vbase; bool interior;
+        tile_geom(it.tile, u0, vbase, interior);
+        creg z[16], v[PPW][16];
 #pragma unroll
         for (int j = 0; j < 16; j++) z[j] = mk(0.0f, 0.0f);
         int t = t_;
         asm volatile("" : "+v"(t));
-        poly_phases<D, PPW>(z, src, vbase, interior, t, ex, tw0, tab1, hr, w * PPW);
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int n = 0; n < 16; n++) { v[1][n] = mk(raw[n].x, raw[n].y); v[0][n] = mk(raw[n].z, raw[n].w); }
+        }
+        if (!have) {
+            if (interior) poly_issue<D, PPW>(v, src, vbase, t, w * PPW);
+            else {
+#pragma unroll
+                for (int i = 0; i < PPW; i++) poly_load<D>(v[i], src, vbase, w * PPW + i, t, false, ex);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PPW; i++) poly_xform_mac(z, v[i], t, ex, tw0, tab1, hr, w * PPW + i);
+        long vbn = 0; bool intn = false;
+        if constexpr (PIPE) {
+            if (it.tile + it.step < it.end) { long u0n; tile_geom(it.tile + it.step, u0n, vbn, intn); }
+            have = intn;
+        }
+        const creg* nb = lane_base(intn, vbn, t);
+        // (the next tile's rows [0, SPLIT) before the inverse transform, the rest after it)
+        if constexpr (PIPE) poly_issue_raw<D, 0, RR_POLY_PIPE_SPLIT>(raw, nb, t);
         if (w != 0) {
 #pragma unroll
             for (int j = 0; j < 16; j++) ex[j * PT + t] = z[j];      // partial sum, register-major, in the wave's own area
@@ -509,6 +639,7 @@ void k_fm_chain_polyw(SRC src, float* __restrict__ out, long ntiles, const cf* _
             poly_inverse_tab(z, t, ex, tw0, tab1);
             nat_store(z, t, ldsR);
         }
+        if constexpr (PIPE) poly_issue_raw<D, RR_POLY_PIPE_SPLIT, 16>(raw, nb, t);
         tile_sync<64 * NW>();
         if (a.mode == 0) poly_demod_tile<0>(ldsR, w * PT + t, NW * PT, u0, Sa, a, out, last_r_in, last_r_out);
         else if (a.mode == 1) poly_demod_tile<1>(ldsR, w * PT + t, NW * PT, u0, Sa, a, out, last_r_in, last_r_out);
