@@ -660,7 +660,7 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
     creg* lds = reinterpret_cast<creg*>(smem_raw);
     creg* park = lds + 8 * PLE;                          // D spectra, register-major [p][16][64]
     creg* tab1 = park + D * PF;
-    const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x & 63;
     creg* ex = lds + w * PLE;
     creg tw0[15];
     load_twiddles<PLG, 0>(tw0, t, tw);
@@ -788,7 +788,7 @@ void k_fm_multi_poly12(SRC src, float* __restrict__ out, long out_stride, long n
     creg* park = lds + MW * PLE;                         // D spectra, register-major [p][16][64]
     creg* tab1 = park + D * PF;
     creg* tw0tab = tab1 + 64;                            // pass-0 twiddles of lane t, [15][64]
-    const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x & 63;   // (w in an SGPR: wave-uniform index arithmetic)
     creg* ex = lds + w * PLE;
     if (w == 0) {
         creg twr[15];
@@ -810,6 +810,8 @@ void k_fm_multi_poly12(SRC src, float* __restrict__ out, long out_stride, long n
         const long u0 = a.r_lo + tile_ * Sa;
         const long vbase = (u0 - a.Ls) * D + a.off;
         const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
+        // (requesting the NEXT run's tile before the demodulation of a wave's last channel — the k_fm_chain_polyw scheme, two
+        //  instances of the channel body — puts the kernel over its 168 registers: 7-14 spilled, 0.0588 against 0.0562 ms)
         if (w < D) {
             creg v[16];
             poly_load<D>(v, src, vbase, w, t, interior, ex);
