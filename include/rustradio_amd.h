@@ -300,10 +300,25 @@ size_t      rr_dstream_capacity(const rr_dstream *s);                           
 int         rr_dstream_is_double_mapped(const rr_dstream *s);
 /* ReadStream::read_buf() (stream.rs:208-217): returns the readable element count, *dev_ptr = window */
 size_t      rr_dstream_read_buf(rr_dstream *s, const void **dev_ptr);
-/* WriteStream::write_buf() (stream.rs:301-310): returns the free element count, *dev_ptr = window */
+/* WriteStream::write_buf() (stream.rs:301-310): returns the free element count, *dev_ptr = window (NULL: the count only) */
 size_t      rr_dstream_write_buf(rr_dstream *s, void **dev_ptr, void *hip_stream);
 int         rr_dstream_consume(rr_dstream *s, size_t n);                         /* BufferReader::consume */
 int         rr_dstream_produce(rr_dstream *s, size_t n);                         /* BufferWriter::produce */
+/* The two ends of a stream, and how a graph ENDS (round 4).  The reference's ReadStream / WriteStream share one
+ * Arc'd buffer; an end is "closed" when the other end has been dropped (strong count 1: src/stream.rs:148-150,166-168),
+ * ReadStream::eof() = writer gone AND ring empty (:237-246), and StreamWait::wait(need) returns true when `need` can
+ * never be met (:222-224,311-313) — the three facts Graph::run (src/graph.rs:126-147) and MTGraph (src/mtgraph.rs:98-116)
+ * finish a block on.  A shim holds one rr_dstream behind a writer handle and a reader handle, calls rr_dstream_close(s, side)
+ * when it drops one of them, and destroys the ring with the last.  Every rr_dstream_* call and rr_block_work_streams
+ * takes the ring's own lock, so the two ends may live on different threads (one thread per end). */
+enum { RR_SIDE_WRITER = 0, RR_SIDE_READER = 1 };
+int         rr_dstream_close(rr_dstream *s, int side);                           /* Drop of that end */
+int         rr_dstream_closed(rr_dstream *s, int side);                          /* 1 once `side` has been dropped */
+/* StreamWait::wait(need) for the `side` end: blocks until `need` elements are readable (READER) / free (WRITER), the
+ * other end closes, or `timeout_ms` passes; returns the count it saw last and sets *never (may be NULL) to 1 when that is
+ * below `need` and the other end is closed, i.e. the block should go ahead and EOF. */
+size_t      rr_dstream_wait(rr_dstream *s, int side, size_t need, unsigned timeout_ms, int *never);
+size_t      rr_dstream_id(const rr_dstream *s);                                  /* StreamWait::id(), shared by both ends */
 /* Streams: every call that takes a ring and a `hip_stream` may use its own stream — a source pushing window k + 1 on a copy
  * stream while the blocks of window k run on a compute stream.  The ring orders them (an event from the last writer, and
  * from every stream that read since, before a write; from the last writer before a read); with one stream driving a ring it

@@ -7,10 +7,11 @@
 //! `extern "C"` block below and checks every declaration (name, arity, argument and return types)
 //! against the header — and the C++ mirror `rustradio_amd/host/rustradio.hpp` implements the same shim
 //! logic and IS tested (`tests/cpp/test_host_api.cpp`).
-use std::ffi::{c_int, c_void, CStr};
+use std::ffi::{c_int, c_uint, c_void, CStr};
+use std::sync::Arc;
 
 use rustradio::block::{Block, BlockEOF, BlockName, BlockRet};
-use rustradio::stream::{new_stream, ReadStream, Tag, TagValue, WriteStream};
+use rustradio::stream::{new_stream, ReadStream, StreamWait, Tag, TagValue, WriteStream};
 use rustradio::window::WindowType;
 use rustradio::{Complex, Error, Float, Result, Sample};
 
@@ -31,7 +32,11 @@ pub struct RrFanout {
 const RR_AGAIN: c_int = 0;
 const RR_WAIT_SRC: c_int = 1;
 const RR_WAIT_DST: c_int = 2;
+const RR_EOF: c_int = 3;
 const RR_ERR: c_int = -1;
+// enum { RR_SIDE_WRITER, RR_SIDE_READER }
+const RR_SIDE_WRITER: c_int = 0;
+const RR_SIDE_READER: c_int = 1;
 
 unsafe extern "C" {
     fn rr_last_error() -> *const libc::c_char;
@@ -84,6 +89,10 @@ unsafe extern "C" {
     fn rr_dstream_write_buf(s: *mut RrDStream, dev_ptr: *mut *mut c_void, hip_stream: *mut c_void) -> usize;
     fn rr_dstream_consume(s: *mut RrDStream, n: usize) -> c_int;
     fn rr_dstream_produce(s: *mut RrDStream, n: usize) -> c_int;
+    fn rr_dstream_close(s: *mut RrDStream, side: c_int) -> c_int;
+    fn rr_dstream_closed(s: *mut RrDStream, side: c_int) -> c_int;
+    fn rr_dstream_wait(s: *mut RrDStream, side: c_int, need: usize, timeout_ms: c_uint, never: *mut c_int) -> usize;
+    fn rr_dstream_id(s: *const RrDStream) -> usize;
     fn rr_dstream_copy_in(s: *mut RrDStream, offset: usize, host: *const c_void, n: usize, hip_stream: *mut c_void) -> c_int;
     fn rr_dstream_copy_out(s: *mut RrDStream, offset: usize, host: *mut c_void, n: usize, hip_stream: *mut c_void) -> c_int;
     fn rr_dstream_copy(dst: *mut RrDStream, dst_offset: usize, src: *mut RrDStream, src_offset: usize, n: usize, hip_stream: *mut c_void) -> c_int;
@@ -610,30 +619,86 @@ impl Block for GpuFmMulti {
 }
 
 // ---- device-resident streams (include/rustradio_amd.h rr_dstream_*) ---------------------------------------
-/// A stream ring in HBM with the reference's window contract (everything readable / all free space, contiguous).
-/// GPU blocks chained through `GpuStream`s never cross PCIe; `GpuUpload` / `GpuDownload` are the two ends.
-pub struct GpuStream<T: Sample> {
+// The reference's stream is ONE ring behind TWO handles, `WriteStream<T>` and `ReadStream<T>`, each an `Arc` of it
+// (src/stream.rs:187-190,256-258); an end is `closed()` when the other handle has been dropped (strong count 1,
+// :148-150,166-168), `ReadStream::eof()` = writer dropped AND ring empty (:237-246), and `wait(need)` is true when `need`
+// can never be met (:222-224,311-313).  `Graph::run` (src/graph.rs:126-147) and `MTGraph` (src/mtgraph.rs:98-116) end a
+// block on exactly those three facts, so the HBM rings carry them too: `new_gpu_stream()` returns the same two handles,
+// dropping one calls `rr_dstream_close(side)`, and both implement `StreamWait`.  The ring's counters live in the library
+// under the ring's own lock, so the two handles may sit in blocks on different threads (MTGraph).
+
+/// The ring both ends share (the reference's `Arc<Buffer<T>>`); destroyed with the last handle.
+struct GpuRing<T: Sample> {
     s: *mut RrDStream,
     _t: std::marker::PhantomData<T>,
 }
-// SAFETY: the ring has no thread affinity; it is driven by one block at a time like the reference's streams.
-unsafe impl<T: Sample> Send for GpuStream<T> {}
-impl<T: Sample> Drop for GpuStream<T> {
+// SAFETY: every rr_dstream_* entry point and rr_block_work_streams lock the ring inside the library.
+unsafe impl<T: Sample> Send for GpuRing<T> {}
+unsafe impl<T: Sample> Sync for GpuRing<T> {}
+impl<T: Sample> Drop for GpuRing<T> {
     fn drop(&mut self) {
-        // SAFETY: created by rr_dstream_create, destroyed once.
+        // SAFETY: created by rr_dstream_create, destroyed once (the Arc's last owner).
         unsafe { rr_dstream_destroy(self.s) }
     }
 }
-impl<T: Sample> GpuStream<T> {
-    /// `new_stream()` in HBM (src/stream.rs:336-339); `capacity_bytes` as `DEFAULT_STREAM_SIZE`.
-    pub fn new(capacity_bytes: usize) -> Result<Self> {
-        // SAFETY: plain values.
-        let s = unsafe { rr_dstream_create(std::mem::size_of::<T>(), capacity_bytes) };
-        if s.is_null() { Err(last_error()) } else { Ok(Self { s, _t: std::marker::PhantomData }) }
+/// How long one `StreamWait::wait` blocks at most before the runner's loop gets to look again.
+const WAIT_SLICE_MS: c_uint = 100;
+
+/// Writing end of an HBM ring (`WriteStream<T>`, src/stream.rs:256-313).
+pub struct GpuWriteStream<T: Sample> { ring: Arc<GpuRing<T>> }
+/// Reading end of an HBM ring (`ReadStream<T>`, src/stream.rs:187-246).
+pub struct GpuReadStream<T: Sample> { ring: Arc<GpuRing<T>> }
+
+/// `new_stream()` in HBM (src/stream.rs:336-339); `capacity_bytes` as `DEFAULT_STREAM_SIZE` (:105).
+pub fn new_gpu_stream<T: Sample>(capacity_bytes: usize) -> Result<(GpuWriteStream<T>, GpuReadStream<T>)> {
+    // SAFETY: plain values.
+    let s = unsafe { rr_dstream_create(std::mem::size_of::<T>(), capacity_bytes) };
+    if s.is_null() { return Err(last_error()); }
+    let ring = Arc::new(GpuRing { s, _t: std::marker::PhantomData });
+    Ok((GpuWriteStream { ring: ring.clone() }, GpuReadStream { ring }))
+}
+impl<T: Sample> Drop for GpuWriteStream<T> {
+    // SAFETY (both drops): the ring outlives the handle (Arc); the flag is what `closed()` / `eof()` / `wait()` of the other end read.
+    fn drop(&mut self) { unsafe { rr_dstream_close(self.ring.s, RR_SIDE_WRITER); } }
+}
+impl<T: Sample> Drop for GpuReadStream<T> {
+    fn drop(&mut self) { unsafe { rr_dstream_close(self.ring.s, RR_SIDE_READER); } }
+}
+impl<T: Sample> GpuWriteStream<T> {
+    #[must_use] pub fn capacity(&self) -> usize { unsafe { rr_dstream_capacity(self.ring.s) } }
+    /// `WriteStream::free()` (src/stream.rs:274-276).
+    #[must_use] pub fn free(&self) -> usize { unsafe { rr_dstream_write_buf(self.ring.s, std::ptr::null_mut(), std::ptr::null_mut()) } }
+}
+impl<T: Sample> GpuReadStream<T> {
+    #[must_use] pub fn capacity(&self) -> usize { unsafe { rr_dstream_capacity(self.ring.s) } }
+    #[must_use] pub fn readable(&self) -> usize { unsafe { rr_dstream_read_buf(self.ring.s, std::ptr::null_mut()) } }
+    /// `ReadStream::eof()` (src/stream.rs:237-246): the writer is gone and nothing is left to read.
+    #[must_use] pub fn eof(&self) -> bool {
+        // the flag first: once the writer is closed `readable()` can only fall
+        unsafe { rr_dstream_closed(self.ring.s, RR_SIDE_WRITER) != 0 } && self.readable() == 0
     }
-    #[must_use] pub fn capacity(&self) -> usize { unsafe { rr_dstream_capacity(self.s) } }
-    #[must_use] pub fn readable(&self) -> usize { unsafe { rr_dstream_read_buf(self.s, std::ptr::null_mut()) } }
-    #[must_use] pub fn free(&self) -> usize { unsafe { rr_dstream_write_buf(self.s, std::ptr::null_mut(), std::ptr::null_mut()) } }
+}
+fn ring_wait(s: *mut RrDStream, side: c_int, need: usize) -> bool {
+    let mut never: c_int = 0;
+    // SAFETY: valid ring; `never` is a live out-parameter.
+    unsafe { rr_dstream_wait(s, side, need, WAIT_SLICE_MS, &mut never) };
+    never != 0
+}
+#[cfg_attr(feature = "async", async_trait::async_trait)]
+impl<T: Sample + Sync + Send + 'static> StreamWait for GpuReadStream<T> {
+    fn id(&self) -> usize { unsafe { rr_dstream_id(self.ring.s) } }
+    fn wait(&self, need: usize) -> bool { ring_wait(self.ring.s, RR_SIDE_READER, need) }
+    fn closed(&self) -> bool { unsafe { rr_dstream_closed(self.ring.s, RR_SIDE_WRITER) != 0 } }
+    #[cfg(feature = "async")]
+    async fn wait_async(&self, need: usize) -> bool { self.wait(need) }
+}
+#[cfg_attr(feature = "async", async_trait::async_trait)]
+impl<T: Sample + Sync + Send + 'static> StreamWait for GpuWriteStream<T> {
+    fn id(&self) -> usize { unsafe { rr_dstream_id(self.ring.s) } }
+    fn wait(&self, need: usize) -> bool { ring_wait(self.ring.s, RR_SIDE_WRITER, need) }
+    fn closed(&self) -> bool { unsafe { rr_dstream_closed(self.ring.s, RR_SIDE_READER) != 0 } }
+    #[cfg(feature = "async")]
+    async fn wait_async(&self, need: usize) -> bool { self.wait(need) }
 }
 fn check(rc: c_int) -> Result<()> { if rc == RR_ERR { Err(last_error()) } else { Ok(()) } }
 
@@ -641,77 +706,101 @@ fn check(rc: c_int) -> Result<()> { if rc == RR_ERR { Err(last_error()) } else {
 /// `register_ring` (the reference's ring is one stable mapping) and the copies run as direct DMA.
 pub struct GpuUpload<T: Sample> {
     src: ReadStream<T>,
-    dst: std::sync::Arc<std::sync::Mutex<GpuStream<T>>>,
+    dst: GpuWriteStream<T>,
 }
 impl<T: Sample> GpuUpload<T> {
-    pub fn new(src: ReadStream<T>, dst: std::sync::Arc<std::sync::Mutex<GpuStream<T>>>) -> Self { Self { src, dst } }
+    /// `let (up, on_gpu) = GpuUpload::new(prev, 256 << 20)?;` — the block and the reading end of its HBM ring.
+    pub fn new(src: ReadStream<T>, capacity_bytes: usize) -> Result<(Self, GpuReadStream<T>)> {
+        let (dst, dr) = new_gpu_stream(capacity_bytes)?;
+        Ok((Self { src, dst }, dr))
+    }
 }
 impl<T: Sample> BlockName for GpuUpload<T> { fn block_name(&self) -> &str { "GpuUpload" } }
 impl<T: Sample> BlockEOF for GpuUpload<T> { fn eof(&mut self) -> bool { self.src.eof() } }
-impl<T: Sample> Block for GpuUpload<T> {
+impl<T: Sample + Sync + Send + 'static> Block for GpuUpload<T> {
     fn work(&mut self) -> Result<BlockRet<'_>> {
         let (input, _tags) = self.src.read_buf()?;
-        let d = self.dst.lock().map_err(|_| Error::msg("GpuUpload: poisoned stream lock"))?;
-        let n = input.slice().len().min(d.free());
-        if n == 0 { return Ok(BlockRet::WaitForStream(&self.src, 1)); }
-        // SAFETY: input is a live window of n elements; the ring has room for n.
-        check(unsafe { rr_dstream_copy_in(d.s, 0, input.slice().as_ptr().cast(), n, std::ptr::null_mut()) })?;
-        check(unsafe { rr_dstream_produce(d.s, n) })?;
+        let have = input.slice().len();
+        let n = have.min(self.dst.free());
+        if n == 0 {
+            // starved -> wait on the source; ring full -> wait on the ring (its reader dropping ends this block too)
+            return Ok(if have == 0 { BlockRet::WaitForStream(&self.src, 1) } else { BlockRet::WaitForStream(&self.dst, 1) });
+        }
+        // SAFETY: input is a live window of n elements; the ring has room for n (only this block writes it).
+        check(unsafe { rr_dstream_copy_in(self.dst.ring.s, 0, input.slice().as_ptr().cast(), n, std::ptr::null_mut()) })?;
+        check(unsafe { rr_dstream_produce(self.dst.ring.s, n) })?;
         input.consume(n);
         Ok(BlockRet::Again)
     }
 }
 /// HBM ring -> host ring (graph edge).
 pub struct GpuDownload<T: Sample> {
-    src: std::sync::Arc<std::sync::Mutex<GpuStream<T>>>,
+    src: GpuReadStream<T>,
     dst: WriteStream<T>,
 }
 impl<T: Sample> GpuDownload<T> {
-    pub fn new(src: std::sync::Arc<std::sync::Mutex<GpuStream<T>>>) -> (Self, ReadStream<T>) {
+    pub fn new(src: GpuReadStream<T>) -> (Self, ReadStream<T>) {
         let (dst, dr) = new_stream();
         (Self { src, dst }, dr)
     }
 }
 impl<T: Sample> BlockName for GpuDownload<T> { fn block_name(&self) -> &str { "GpuDownload" } }
-impl<T: Sample> BlockEOF for GpuDownload<T> { fn eof(&mut self) -> bool { false } }
-impl<T: Sample> Block for GpuDownload<T> {
+impl<T: Sample> BlockEOF for GpuDownload<T> { fn eof(&mut self) -> bool { self.src.eof() } }
+impl<T: Sample + Sync + Send + 'static> Block for GpuDownload<T> {
     fn work(&mut self) -> Result<BlockRet<'_>> {
         let mut out = self.dst.write_buf()?;
-        let s = self.src.lock().map_err(|_| Error::msg("GpuDownload: poisoned stream lock"))?;
-        let n = out.slice().len().min(s.readable());
-        if n == 0 { return Ok(BlockRet::WaitForStream(&self.dst, 1)); }
-        // SAFETY: out is a live window with room for n elements; the ring holds n readable elements.
-        check(unsafe { rr_dstream_copy_out(s.s, 0, out.slice().as_mut_ptr().cast(), n, std::ptr::null_mut()) })?;
-        check(unsafe { rr_dstream_consume(s.s, n) })?;
+        let have = self.src.readable();
+        let n = out.slice().len().min(have);
+        if n == 0 {
+            return Ok(if have == 0 { BlockRet::WaitForStream(&self.src, 1) } else { BlockRet::WaitForStream(&self.dst, 1) });
+        }
+        // SAFETY: out is a live window with room for n elements; the ring holds n readable elements (only this block reads it).
+        check(unsafe { rr_dstream_copy_out(self.src.ring.s, 0, out.slice().as_mut_ptr().cast(), n, std::ptr::null_mut()) })?;
+        check(unsafe { rr_dstream_consume(self.src.ring.s, n) })?;
         out.produce(n, &[]);
         Ok(BlockRet::Again)
     }
 }
-/// One GPU block between two HBM rings: `Block::work()` without a PCIe hop (rr_block_work_streams).
+/// One GPU block between two HBM rings: `Block::work()` without a PCIe hop (rr_block_work_streams).  The status is the
+/// block's own — `WaitForStream(src, need)` when starved, `WaitForStream(dst, need)` when the output ring is full — so
+/// both runners end it the reference's way: upstream dropped ∧ ring drained ∧ (resampler) no pending sample.
 pub struct GpuResident<I: Sample, O: Sample> {
     h: Handle,
     name: &'static str,
-    src: std::sync::Arc<std::sync::Mutex<GpuStream<I>>>,
-    dst: std::sync::Arc<std::sync::Mutex<GpuStream<O>>>,
+    src: GpuReadStream<I>,
+    dst: GpuWriteStream<O>,
 }
 impl<I: Sample, O: Sample> GpuResident<I, O> {
     /// `create` = any `rr_*_create` call, e.g. `|| unsafe { rr_fftfilter_create(taps.as_ptr(), taps.len()) }`.
-    pub fn new(create: impl FnOnce() -> *mut RrBlock, name: &'static str, src: std::sync::Arc<std::sync::Mutex<GpuStream<I>>>,
-               dst: std::sync::Arc<std::sync::Mutex<GpuStream<O>>>) -> Result<Self> {
-        Ok(Self { h: Handle::new(create())?, name, src, dst })
+    /// Returns the block and the reading end of its output ring (`out_capacity_bytes` in HBM).
+    pub fn new(create: impl FnOnce() -> *mut RrBlock, name: &'static str, src: GpuReadStream<I>,
+               out_capacity_bytes: usize) -> Result<(Self, GpuReadStream<O>)> {
+        let h = Handle::new(create())?;
+        let (dst, dr) = new_gpu_stream(out_capacity_bytes)?;
+        Ok((Self { h, name, src, dst }, dr))
     }
 }
 impl<I: Sample, O: Sample> BlockName for GpuResident<I, O> { fn block_name(&self) -> &str { self.name } }
-impl<I: Sample, O: Sample> BlockEOF for GpuResident<I, O> { fn eof(&mut self) -> bool { false } }
-impl<I: Sample, O: Sample> Block for GpuResident<I, O> {
+impl<I: Sample, O: Sample> BlockEOF for GpuResident<I, O> {
+    fn eof(&mut self) -> bool {
+        // SAFETY: valid handle.  rr_block_eof adds the block's own condition (src/rational_resampler.rs:209-213).
+        unsafe { rr_block_eof(self.h.0, self.src.eof() as c_int) != 0 }
+    }
+}
+impl<I: Sample + Sync + Send + 'static, O: Sample + Sync + Send + 'static> Block for GpuResident<I, O> {
     fn work(&mut self) -> Result<BlockRet<'_>> {
-        let s = self.src.lock().map_err(|_| Error::msg("GpuResident: poisoned stream lock"))?;
-        let d = self.dst.lock().map_err(|_| Error::msg("GpuResident: poisoned stream lock"))?;
         let (mut c, mut p, mut need) = (0usize, 0usize, 0usize);
         // SAFETY: valid handles; counts are final on return (they depend on lengths only), kernels run asynchronously.
-        let st = unsafe { rr_block_work_streams(self.h.0, s.s, d.s, &mut c, &mut p, &mut need, std::ptr::null_mut()) };
+        let st = unsafe {
+            rr_block_work_streams(self.h.0, self.src.ring.s, self.dst.ring.s, &mut c, &mut p, &mut need, std::ptr::null_mut())
+        };
         check(st)?;
-        Ok(if c > 0 || p > 0 || st == RR_AGAIN { BlockRet::Again } else { BlockRet::Pending })
+        Ok(match st {
+            RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need),
+            RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
+            RR_EOF => BlockRet::EOF,
+            _ => BlockRet::Again,
+        })
     }
 }
 

@@ -289,6 +289,22 @@ class DeviceStream:
     def free(self, stream: int = 0) -> int:
         return lib().rr_dstream_write_buf(self._h, None, C.c_void_p(stream))
 
+    SIDE_WRITER, SIDE_READER = 0, 1
+
+    def close(self, side: int) -> None:
+        """drop of the WriteStream / ReadStream end (rr_dstream_close): what the other end's closed() / eof() / wait() see"""
+        if lib().rr_dstream_close(self._h, side) != 0:
+            raise RuntimeError(last_error())
+
+    def closed(self, side: int) -> bool:
+        return bool(lib().rr_dstream_closed(self._h, side))
+
+    def wait(self, side: int, need: int, timeout_ms: int = 100):
+        """StreamWait::wait(need) of the `side` end (src/stream.rs:121-126) -> (count seen, never)"""
+        never = C.c_int(0)
+        n = lib().rr_dstream_wait(self._h, side, need, timeout_ms, C.byref(never))
+        return n, bool(never.value)
+
     def push(self, x: np.ndarray, stream: int = 0) -> int:
         """fill_from_slice + produce of as much of the host array `x` as fits -> elements taken"""
         x = np.ascontiguousarray(x, self.dtype)

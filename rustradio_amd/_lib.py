@@ -25,7 +25,7 @@ SYMBOLS = [
     "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps",
     "rr_host_register", "rr_host_unregister",
     "rr_dstream_create", "rr_dstream_destroy", "rr_dstream_capacity", "rr_dstream_is_double_mapped", "rr_dstream_read_buf", "rr_dstream_write_buf",
-    "rr_dstream_consume", "rr_dstream_produce", "rr_dstream_copy_in", "rr_dstream_copy_out", "rr_dstream_copy", "rr_block_work_streams",
+    "rr_dstream_consume", "rr_dstream_produce", "rr_dstream_close", "rr_dstream_closed", "rr_dstream_wait", "rr_dstream_id", "rr_dstream_copy_in", "rr_dstream_copy_out", "rr_dstream_copy", "rr_block_work_streams",
     "rr_fanout_unique_id", "rr_fanout_create", "rr_fanout_destroy", "rr_fanout_produce_buf", "rr_fanout_submit",
     "rr_fanout_acquire", "rr_fanout_release", "rr_fanout_stats",
 ]
@@ -116,6 +116,10 @@ def lib():
     L.rr_dstream_write_buf.argtypes = [vp, pvp, vp]; L.rr_dstream_write_buf.restype = sz
     L.rr_dstream_consume.argtypes = [vp, sz]; L.rr_dstream_consume.restype = i32
     L.rr_dstream_produce.argtypes = [vp, sz]; L.rr_dstream_produce.restype = i32
+    L.rr_dstream_close.argtypes = [vp, i32]; L.rr_dstream_close.restype = i32
+    L.rr_dstream_closed.argtypes = [vp, i32]; L.rr_dstream_closed.restype = i32
+    L.rr_dstream_wait.argtypes = [vp, i32, sz, C.c_uint, C.POINTER(C.c_int)]; L.rr_dstream_wait.restype = sz
+    L.rr_dstream_id.argtypes = [vp]; L.rr_dstream_id.restype = sz
     L.rr_dstream_copy_in.argtypes = [vp, sz, vp, sz, vp]; L.rr_dstream_copy_in.restype = i32
     L.rr_dstream_copy_out.argtypes = [vp, sz, vp, sz, vp]; L.rr_dstream_copy_out.restype = i32
     L.rr_dstream_copy.argtypes = [vp, sz, vp, sz, sz, vp]; L.rr_dstream_copy.restype = i32

@@ -1,6 +1,10 @@
 // abi.cpp — the extern "C" surface declared in include/rustradio_amd.h.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 
 #include "blocks.hpp"
@@ -10,8 +14,15 @@
 struct rr_block {
     std::unique_ptr<rr::Block> b;
 };
+// One ring + what makes it a two-ended stream between threads: every entry point takes `m` (two rings: both, deadlock-free),
+// produce / consume / close wake `cv`.  closed[side] is the reference's Arc strong count dropping to 1
+// (src/stream.rs:148-150,166-168): the shim sets it when it drops its WriteStream / ReadStream end.
 struct rr_dstream {
     std::unique_ptr<rr::DStream> s;
+    std::mutex m;
+    std::condition_variable cv;
+    bool closed[2] = {false, false};
+    size_t id = 0;
 };
 
 namespace rr {
@@ -291,9 +302,11 @@ int rr_host_unregister(void* ptr) {
 rr_dstream* rr_dstream_create(size_t elem_size, size_t capacity_bytes) {
     rr::OptsScope scope;
     try {
+        static std::atomic<size_t> next_id{1};
         std::unique_ptr<rr::DStream> d(new rr::DStream(elem_size, capacity_bytes));
         auto* h = new rr_dstream;
         h->s = std::move(d);
+        h->id = next_id++;
         return h;
     } catch (const std::exception& e) {
         rr::set_last_error(e.what());
@@ -303,18 +316,21 @@ rr_dstream* rr_dstream_create(size_t elem_size, size_t capacity_bytes) {
 void rr_dstream_destroy(rr_dstream* s) { delete s; }
 size_t rr_dstream_capacity(const rr_dstream* s) { return s ? s->s->cap : 0; }
 int rr_dstream_is_double_mapped(const rr_dstream* s) { return s && s->s->vmm ? 1 : 0; }
+size_t rr_dstream_id(const rr_dstream* s) { return s ? s->id : 0; }
 size_t rr_dstream_read_buf(rr_dstream* s, const void** dev_ptr) {
     if (!s) return 0;
+    std::lock_guard<std::mutex> g(s->m);
     if (dev_ptr) *dev_ptr = s->s->read_ptr();
     return s->s->used();
 }
 size_t rr_dstream_write_buf(rr_dstream* s, void** dev_ptr, void* hip_stream) {
     if (!s) return 0;
+    std::lock_guard<std::mutex> g(s->m);
     try {
+        if (!dev_ptr) return s->s->free();         // a count only: nothing is about to be written
         RR_HIP(hipSetDevice(s->s->device));        // write_ptr may enqueue the fallback ring's move
         s->s->will_write(static_cast<hipStream_t>(hip_stream));   // the caller writes the window on this stream
-        void* p = s->s->write_ptr(static_cast<hipStream_t>(hip_stream));
-        if (dev_ptr) *dev_ptr = p;
+        *dev_ptr = s->s->write_ptr(static_cast<hipStream_t>(hip_stream));
         return s->s->free();
     } catch (const std::exception& e) {
         rr::set_last_error(e.what());
@@ -323,14 +339,46 @@ size_t rr_dstream_write_buf(rr_dstream* s, void** dev_ptr, void* hip_stream) {
 }
 int rr_dstream_consume(rr_dstream* s, size_t n) {
     if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }
-    return guarded([&] { s->s->consume(n); });
+    std::lock_guard<std::mutex> g(s->m);
+    const int rc = guarded([&] { s->s->consume(n); });
+    if (n) s->cv.notify_all();
+    return rc;
 }
 int rr_dstream_produce(rr_dstream* s, size_t n) {
     if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }
-    return guarded([&] { s->s->produce(n); });
+    std::lock_guard<std::mutex> g(s->m);
+    const int rc = guarded([&] { s->s->produce(n); });
+    if (n) s->cv.notify_all();
+    return rc;
+}
+int rr_dstream_close(rr_dstream* s, int side) {
+    if (!s || (side != RR_SIDE_WRITER && side != RR_SIDE_READER)) { rr::set_last_error("rr_dstream_close: bad argument"); return RR_ERR; }
+    std::lock_guard<std::mutex> g(s->m);
+    s->closed[side] = true;
+    s->cv.notify_all();
+    return 0;
+}
+int rr_dstream_closed(rr_dstream* s, int side) {
+    if (!s || (side != RR_SIDE_WRITER && side != RR_SIDE_READER)) return 1;
+    std::lock_guard<std::mutex> g(s->m);
+    return s->closed[side] ? 1 : 0;
+}
+size_t rr_dstream_wait(rr_dstream* s, int side, size_t need, unsigned timeout_ms, int* never) {
+    if (never) *never = 1;
+    if (!s || (side != RR_SIDE_WRITER && side != RR_SIDE_READER)) return 0;
+    std::unique_lock<std::mutex> g(s->m);
+    // the READER waits for samples and gives up when the writer is gone; the WRITER waits for room and gives up when
+    // the reader is gone (ReadStream::wait_for_read / WriteStream::wait_for_write, src/stream.rs:222-224,311-313)
+    const int other = side == RR_SIDE_READER ? RR_SIDE_WRITER : RR_SIDE_READER;
+    auto have = [&] { return side == RR_SIDE_READER ? s->s->used() : s->s->free(); };
+    s->cv.wait_for(g, std::chrono::milliseconds(timeout_ms), [&] { return have() >= need || s->closed[other]; });
+    const size_t n = have();
+    if (never) *never = (n < need && s->closed[other]) ? 1 : 0;
+    return n;
 }
 int rr_dstream_copy_in(rr_dstream* s, size_t offset, const void* host, size_t n, void* hip_stream) {
     if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }
+    std::lock_guard<std::mutex> g(s->m);
     return guarded([&] {
         rr::DStream& d = *s->s;
         auto st = static_cast<hipStream_t>(hip_stream);
@@ -343,19 +391,27 @@ int rr_dstream_copy_in(rr_dstream* s, size_t offset, const void* host, size_t n,
 }
 int rr_dstream_copy_out(rr_dstream* s, size_t offset, void* host, size_t n, void* hip_stream) {
     if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }
-    return guarded([&] {
-        rr::DStream& d = *s->s;
-        auto st = static_cast<hipStream_t>(hip_stream);
-        if (offset + n > d.used()) throw rr::Error("dstream copy_out: beyond the read window");
-        RR_HIP(hipSetDevice(d.device));
-        d.will_read(st);
-        if (n) RR_HIP(hipMemcpyAsync(host, static_cast<const unsigned char*>(d.read_ptr()) + offset * d.es, n * d.es,
-                                     hipMemcpyDeviceToHost, st));
-        RR_HIP(hipStreamSynchronize(st));           // the host may read `host` on return
-    });
+    auto st = static_cast<hipStream_t>(hip_stream);
+    int rc;
+    {
+        std::lock_guard<std::mutex> g(s->m);
+        rc = guarded([&] {
+            rr::DStream& d = *s->s;
+            if (offset + n > d.used()) throw rr::Error("dstream copy_out: beyond the read window");
+            RR_HIP(hipSetDevice(d.device));
+            d.will_read(st);
+            if (n) RR_HIP(hipMemcpyAsync(host, static_cast<const unsigned char*>(d.read_ptr()) + offset * d.es, n * d.es,
+                                         hipMemcpyDeviceToHost, st));
+        });
+    }
+    if (rc != 0) return rc;
+    // outside the lock: the writer may go on filling the free space while this window crosses the bus (the read window
+    // is not released before the caller's rr_dstream_consume)
+    return guarded([&] { RR_HIP(hipStreamSynchronize(st)); });          // the host may read `host` on return
 }
 int rr_dstream_copy(rr_dstream* dst, size_t dst_offset, rr_dstream* src, size_t src_offset, size_t n, void* hip_stream) {
-    if (!dst || !src) { rr::set_last_error("null dstream"); return RR_ERR; }
+    if (!dst || !src || dst == src) { rr::set_last_error("rr_dstream_copy: null dstream / same ring on both sides"); return RR_ERR; }
+    std::scoped_lock g(src->m, dst->m);
     return guarded([&] {
         rr::DStream& d = *dst->s;
         rr::DStream& r = *src->s;
@@ -375,13 +431,15 @@ int rr_dstream_copy(rr_dstream* dst, size_t dst_offset, rr_dstream* src, size_t 
 int rr_block_work_streams(rr_block* b, rr_dstream* src, rr_dstream* dst, size_t* consumed, size_t* produced,
                           size_t* need, void* hip_stream) {
     size_t c = 0, p = 0, nd = 0;
-    if (!b || !src || !dst) { rr::set_last_error("rr_block_work_streams: null argument"); return RR_ERR; }
+    if (!b || !src || !dst || src == dst) { rr::set_last_error("rr_block_work_streams: null argument / same ring on both sides"); return RR_ERR; }
     if (b->b->out_windows() != 1) { rr::set_last_error("rr_block_work_streams: single-output blocks only"); return RR_ERR; }
     if (src->s->es != b->b->in_es || dst->s->es != b->b->out_es) {
         rr::set_last_error("rr_block_work_streams: stream element size does not match the block");
         return RR_ERR;
     }
     int st = RR_ERR;
+    // both rings for the whole call: windows, enqueue and the consume / produce are one step to every other thread
+    std::scoped_lock g(src->m, dst->m);
     const int rc = guarded([&] {
         auto hs = static_cast<hipStream_t>(hip_stream);
         RR_HIP(hipSetDevice(dst->s->device));
@@ -393,6 +451,8 @@ int rr_block_work_streams(rr_block* b, rr_dstream* src, rr_dstream* dst, size_t*
         src->s->consume(c);
         dst->s->produce(p);
     });
+    if (c) src->cv.notify_all();
+    if (p) dst->cv.notify_all();
     if (consumed) *consumed = c;
     if (produced) *produced = p;
     if (need) *need = nd;

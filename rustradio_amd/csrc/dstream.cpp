@@ -82,6 +82,7 @@ void DStream::will_write(hipStream_t s) {
 
 void* DStream::write_ptr(hipStream_t s) {
     if (vmm) return va + (rb + used_ * es) % phys;
+    if (r == w) r = w = 0;                          // empty: start over at the front (here, on the writer's side, never in consume)
     if (w + free() > 2 * cap) {                     // the write window would run off the end
         const size_t n = used();                    // here r > cap >= n: source and destination are disjoint
         if (n) RR_HIP(hipMemcpyAsync(buf.p, buf.p + r * es, n * es, hipMemcpyDeviceToDevice, s));
@@ -92,13 +93,13 @@ void* DStream::write_ptr(hipStream_t s) {
 void DStream::consume(size_t n) {
     if (n > used()) throw Error("dstream consume: n > readable");
     if (vmm) {
+        // the offsets only ever advance: a writer on another thread may hold the write window it was handed before
+        // this call, and it must stay where it is
         rb = (rb + n * es) % phys;
         used_ -= n;
-        if (used_ == 0) rb = 0;
         return;
     }
     r += n;
-    if (r == w) r = w = 0;
 }
 void DStream::produce(size_t n) {
     if (n > free()) throw Error("dstream produce: n > free");

@@ -21,18 +21,26 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <variant>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include "../../include/rustradio_amd.h"
 
@@ -67,13 +75,16 @@ inline uint64_t& activity() { static thread_local uint64_t a = 0; return a; }   
 }
 
 // ---- streams --------------------------------------------------------------------------------------
-// The reference hands out contiguous windows of a double-mapped ring
-// (src/nowasm/circular_buffer.rs:98-128, 572-615).  This harness keeps the same contract —
-// read_buf() = ALL readable samples, write_buf() = ALL free space, fixed capacity — with a
-// compacting vector; only the window semantics matter to the blocks.
+// The reference hands out contiguous windows of a double-mapped ring shared by a ReadStream and a
+// WriteStream that may live on different threads (src/nowasm/circular_buffer.rs:98-128, 572-615).
+// This harness does the same: one memfd mapped twice back to back, read_buf() = ALL readable samples,
+// write_buf() = ALL free space, fixed capacity; counters and tags under one lock, windows stable while
+// the other end works, a condition variable behind StreamWait::wait (src/stream.rs:114-138).
 struct StreamWait {
     virtual ~StreamWait() = default;
     virtual size_t id() const = 0;
+    // true = `need` will never be satisfied: go ahead and EOF (stream.rs:121-126)
+    virtual bool wait(size_t need) const = 0;
     virtual bool closed() const = 0;
 };
 
@@ -84,46 +95,113 @@ struct StreamWait {
 enum class Memory { Host, Device };
 inline Memory& default_memory() { static thread_local Memory m = Memory::Host; return m; }
 
-template <class T> struct StreamState : StreamWait {
-    std::vector<T> buf;           // host ring: [rpos, buf.size()) readable; capacity `cap` samples
-    size_t rpos = 0;
-    rr_dstream* ds = nullptr;     // device ring (then buf is unused)
+namespace detail {
+// How long one StreamWait::wait sleeps at most before it reports back (the reference's condvar wait has no
+// timeout because every produce / consume / drop notifies; so does this one — the timeout only bounds a lost race).
+constexpr unsigned WAIT_SLICE_MS = 100;
+// One physical range mapped at two consecutive virtual ranges (circular_buffer.rs:98-128).
+struct DoubleMap {
+    unsigned char* base = nullptr;
+    size_t phys = 0;
+    explicit DoubleMap(size_t bytes) {
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+        phys = std::max(page, (bytes + page - 1) / page * page);
+        const int fd = memfd_create("rustradio_ring", 0);
+        if (fd < 0 || ftruncate(fd, (off_t)phys) != 0) { if (fd >= 0) close(fd); throw Error("stream ring: memfd_create failed"); }
+        void* va = mmap(nullptr, 2 * phys, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        bool ok = va != MAP_FAILED;
+        ok = ok && mmap(va, phys, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, 0) != MAP_FAILED;
+        ok = ok && mmap((unsigned char*)va + phys, phys, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, 0) != MAP_FAILED;
+        close(fd);
+        if (!ok) { if (va != MAP_FAILED) munmap(va, 2 * phys); throw Error("stream ring: mmap failed"); }
+        base = static_cast<unsigned char*>(va);
+    }
+    ~DoubleMap() { if (base) munmap(base, 2 * phys); }
+    DoubleMap(const DoubleMap&) = delete;
+};
+}  // namespace detail
+
+template <class T> struct StreamState {
+    std::unique_ptr<detail::DoubleMap> ring;   // host ring: bytes [rb, rb + used * sizeof(T)) readable
+    size_t rb = 0, used_ = 0;
+    rr_dstream* ds = nullptr;     // device ring (then `ring` is unused; its counters live in the library, under its own lock)
     size_t cap;
     std::vector<Tag> tags;        // positions relative to the read window
     bool writer_alive = true, reader_alive = true;
     size_t id_;
-    explicit StreamState(size_t bytes, Memory m = default_memory()) : cap(bytes / sizeof(T)) {
+    mutable std::mutex m;         // rb, used_, tags, the two flags
+    mutable std::condition_variable cv;
+    // the two ends as StreamWait objects: BlockRet::WaitForStream carries one of them (block.rs:61)
+    struct Side : StreamWait {
+        const StreamState* st; bool reader;
+        Side(const StreamState* s, bool r) : st(s), reader(r) {}
+        size_t id() const override { return st->id_; }
+        bool closed() const override { return st->closed(); }
+        bool wait(size_t need) const override { return st->wait(reader, need); }
+    } rside{this, true}, wside{this, false};
+    explicit StreamState(size_t bytes, Memory m_ = default_memory()) : cap(bytes / sizeof(T)) {
         static std::atomic<size_t> next_id{1};
         id_ = next_id++;
-        if (m == Memory::Device) {
+        if (cap == 0) throw Error("stream: capacity smaller than one sample");
+        if (m_ == Memory::Device) {
             ds = rr_dstream_create(sizeof(T), bytes);
             if (!ds) throw Error(rr_last_error());
         } else {
-            buf.reserve(cap);
+            ring = std::make_unique<detail::DoubleMap>(cap * sizeof(T));
         }
     }
-    ~StreamState() override { if (ds) rr_dstream_destroy(ds); }
+    ~StreamState() { if (ds) rr_dstream_destroy(ds); }
     StreamState(const StreamState&) = delete;
     bool device() const { return ds != nullptr; }
-    size_t used() const { return ds ? rr_dstream_read_buf(ds, nullptr) : buf.size() - rpos; }
+    size_t used() const {
+        if (ds) return rr_dstream_read_buf(ds, nullptr);
+        std::lock_guard<std::mutex> g(m);
+        return used_;
+    }
     size_t free() const { return cap - used(); }
-    size_t id() const override { return id_; }
-    bool closed() const override { return !writer_alive || !reader_alive; }   // src/stream.rs:148-150
+    bool closed() const {                                    // src/stream.rs:148-150,166-168: the other end is gone
+        std::lock_guard<std::mutex> g(m);
+        return !writer_alive || !reader_alive;
+    }
+    void drop_end(bool reader) {
+        { std::lock_guard<std::mutex> g(m); (reader ? reader_alive : writer_alive) = false; }
+        if (ds) rr_dstream_close(ds, reader ? RR_SIDE_READER : RR_SIDE_WRITER);
+        cv.notify_all();
+    }
+    // wait_for_read / wait_for_write (stream.rs:222-224,311-313): what is there < need AND the other end dropped
+    bool wait(bool reader, size_t need) const {
+        if (ds) {
+            int never = 0;
+            rr_dstream_wait(ds, reader ? RR_SIDE_READER : RR_SIDE_WRITER, need, detail::WAIT_SLICE_MS, &never);
+            return never != 0;
+        }
+        std::unique_lock<std::mutex> g(m);
+        auto have = [&] { return reader ? used_ : cap - used_; };
+        auto other_gone = [&] { return reader ? !writer_alive : !reader_alive; };
+        cv.wait_for(g, std::chrono::milliseconds(detail::WAIT_SLICE_MS), [&] { return have() >= need || other_gone(); });
+        return have() < need && other_gone();
+    }
 };
 
 template <class T> class BufferReader {   // circular_buffer.rs:233-251
     std::shared_ptr<StreamState<T>> s_;
+    const T* ptr_ = nullptr;      // the window as it was when read_buf() was called (host or DEVICE pointer)
+    size_t len_ = 0;
 public:
-    explicit BufferReader(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {}
-    bool device() const { return s_->device(); }
-    // the window: a host pointer, or a DEVICE pointer when the stream lives in HBM
-    const T* slice() const {
-        if (!s_->ds) return s_->buf.data() + s_->rpos;
-        const void* p = nullptr;
-        rr_dstream_read_buf(s_->ds, &p);
-        return static_cast<const T*>(p);
+    explicit BufferReader(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {
+        if (s_->ds) {
+            const void* p = nullptr;
+            len_ = rr_dstream_read_buf(s_->ds, &p);
+            ptr_ = static_cast<const T*>(p);
+        } else {
+            std::lock_guard<std::mutex> g(s_->m);
+            ptr_ = reinterpret_cast<const T*>(s_->ring->base + s_->rb);
+            len_ = s_->used_;
+        }
     }
-    size_t len() const { return s_->used(); }
+    bool device() const { return s_->device(); }
+    const T* slice() const { return ptr_; }
+    size_t len() const { return len_; }
     bool is_empty() const { return len() == 0; }
     const T* begin() const { host_only(); return slice(); }
     const T* end() const { host_only(); return slice() + len(); }
@@ -135,50 +213,48 @@ public:
         if (rr_dstream_copy_out(s_->ds, 0, host, n, nullptr) != 0) throw Error(rr_last_error());
     }
     void consume(size_t n) {               // circular_buffer.rs:472-513
-        if (n > s_->used()) throw Error("consume: n > used");
+        if (n > len_) throw Error("consume: n > used");
         detail::activity() += n;
-        std::vector<Tag> keep;
-        for (auto& t : s_->tags)
-            if (t.pos() >= n) keep.emplace_back(t.pos() - n, t.key(), t.val());
-        s_->tags.swap(keep);
-        if (s_->ds) { if (rr_dstream_consume(s_->ds, n) != 0) throw Error(rr_last_error()); return; }
-        s_->rpos += n;
-        if (s_->rpos == s_->buf.size()) { s_->buf.clear(); s_->rpos = 0; }
+        {
+            std::lock_guard<std::mutex> g(s_->m);
+            std::vector<Tag> keep;
+            for (auto& t : s_->tags)
+                if (t.pos() >= n) keep.emplace_back(t.pos() - n, t.key(), t.val());
+            s_->tags.swap(keep);
+            if (!s_->ds) {
+                s_->rb = (s_->rb + n * sizeof(T)) % s_->ring->phys;
+                s_->used_ -= n;
+            }
+        }
+        if (s_->ds && rr_dstream_consume(s_->ds, n) != 0) throw Error(rr_last_error());
+        ptr_ += n; len_ -= n;
+        if (n) s_->cv.notify_all();
     }
 private:
     void host_only() const { if (s_->ds) throw Error("host iteration over a device-resident stream: use copy_to()"); }
-public:
 };
 
 template <class T> class BufferWriter {   // circular_buffer.rs:284-310
     std::shared_ptr<StreamState<T>> s_;
-    size_t base_ = 0;             // readable samples in front of the write window
-    T* dptr_ = nullptr;           // device ring: the write window
-    size_t dlen_ = 0;
+    T* ptr_ = nullptr;            // the write window as it was when write_buf() was called (host or DEVICE pointer)
+    size_t len_ = 0;
 public:
     explicit BufferWriter(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {
         if (s_->ds) {
-            base_ = s_->used();
             void* p = nullptr;
-            dlen_ = rr_dstream_write_buf(s_->ds, &p, nullptr);
-            dptr_ = static_cast<T*>(p);
+            len_ = rr_dstream_write_buf(s_->ds, &p, nullptr);
+            ptr_ = static_cast<T*>(p);
             return;
         }
-        // make the free space contiguous after the readable window
-        if (s_->rpos) {
-            s_->buf.erase(s_->buf.begin(), s_->buf.begin() + (std::ptrdiff_t)s_->rpos);
-            s_->rpos = 0;
-        }
-        base_ = s_->buf.size();
-        s_->buf.resize(s_->cap);
+        std::lock_guard<std::mutex> g(s_->m);
+        ptr_ = reinterpret_cast<T*>(s_->ring->base + (s_->rb + s_->used_ * sizeof(T)) % s_->ring->phys);
+        len_ = s_->cap - s_->used_;
     }
-    ~BufferWriter() { if (s_ && !s_->ds && s_->buf.size() == s_->cap && !produced_) s_->buf.resize(base_); }
-    BufferWriter(BufferWriter&& o) noexcept
-        : s_(std::move(o.s_)), base_(o.base_), dptr_(o.dptr_), dlen_(o.dlen_), produced_(o.produced_) { o.s_.reset(); }
+    BufferWriter(BufferWriter&& o) noexcept : s_(std::move(o.s_)), ptr_(o.ptr_), len_(o.len_) { o.s_.reset(); }
     BufferWriter(const BufferWriter&) = delete;
     bool device() const { return s_->device(); }
-    T* slice() { return s_->ds ? dptr_ : s_->buf.data() + base_; }     // host or DEVICE pointer
-    size_t len() const { return s_->ds ? dlen_ : s_->cap - base_; }
+    T* slice() { return ptr_; }                                         // host or DEVICE pointer
+    size_t len() const { return len_; }
     bool is_empty() const { return len() == 0; }
     // n samples of a DEVICE-resident read window into this DEVICE-resident write window: no host hop (rr_dstream_copy)
     void fill_from_device(const BufferReader<T>& src, size_t n) {
@@ -188,20 +264,24 @@ public:
     }
     void fill_from_slice(const T* src, size_t n) {                      // src = host memory
         if (n > len()) throw Error("fill_from_slice: n > free");
-        if (!s_->ds) { std::memcpy(slice(), src, n * sizeof(T)); return; }
+        if (!s_->ds) { if (n) std::memcpy(slice(), src, n * sizeof(T)); return; }
         if (rr_dstream_copy_in(s_->ds, 0, src, n, nullptr) != 0) throw Error(rr_last_error());
     }
     void produce(size_t n, const std::vector<Tag>& tags) {   // circular_buffer.rs:518-557
         if (n > len()) throw Error("produce: n > free");
-        if (n == 0) { if (!s_->ds) s_->buf.resize(base_); produced_ = true; return; }   // tags dropped (:528-533)
+        if (n == 0) return;                                  // tags dropped (:528-533)
         detail::activity() += n;
-        for (auto& t : tags) s_->tags.emplace_back(t.pos() + base_, t.key(), t.val());
-        if (s_->ds) { if (rr_dstream_produce(s_->ds, n) != 0) throw Error(rr_last_error()); }
-        else s_->buf.resize(base_ + n);
-        produced_ = true;
+        {
+            // tag positions are relative to the READ window as it is now (the reader may have consumed since write_buf())
+            std::lock_guard<std::mutex> g(s_->m);
+            const size_t base = s_->ds ? rr_dstream_read_buf(s_->ds, nullptr) : s_->used_;
+            for (auto& t : tags) s_->tags.emplace_back(t.pos() + base, t.key(), t.val());
+            if (!s_->ds) s_->used_ += n;
+            else if (rr_dstream_produce(s_->ds, n) != 0) throw Error(rr_last_error());
+        }
+        ptr_ += n; len_ -= n;
+        s_->cv.notify_all();
     }
-private:
-    bool produced_ = false;
 };
 
 template <class T> class ReadStream {      // src/stream.rs:187-246
@@ -209,22 +289,31 @@ template <class T> class ReadStream {      // src/stream.rs:187-246
 public:
     ReadStream() = default;
     explicit ReadStream(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {}
-    ~ReadStream() { if (s_) s_->reader_alive = false; }
+    ~ReadStream() { if (s_) s_->drop_end(true); }
     ReadStream(ReadStream&&) = default;
     ReadStream& operator=(ReadStream&&) = default;
     ReadStream(const ReadStream&) = delete;
     static ReadStream from_slice(const T* d, size_t n) {    // src/stream.rs:187-195 (test helper)
         auto st = std::make_shared<StreamState<T>>(DEFAULT_STREAM_SIZE, Memory::Host);
-        st->buf.assign(d, d + n);
+        if (n > st->cap) throw Error("from_slice: more samples than the ring holds");
+        if (n) std::memcpy(st->ring->base, d, n * sizeof(T));
+        st->used_ = n;
         st->writer_alive = false;
         return ReadStream(st);
     }
     std::pair<BufferReader<T>, std::vector<Tag>> read_buf() const {   // :208-217
-        return {BufferReader<T>(s_), s_->tags};
+        BufferReader<T> r(s_);
+        std::lock_guard<std::mutex> g(s_->m);
+        std::vector<Tag> t;
+        for (auto& x : s_->tags) if (x.pos() < r.len()) t.push_back(x);
+        return {std::move(r), std::move(t)};
     }
-    bool eof() const { return !s_->writer_alive && s_->used() == 0; }  // :237-246
-    const StreamWait& wait_handle() const { return *s_; }
-    size_t id() const { return s_->id(); }
+    bool eof() const {                                                 // :237-246: writer gone and nothing left
+        { std::lock_guard<std::mutex> g(s_->m); if (s_->writer_alive) return false; }
+        return s_->used() == 0;
+    }
+    const StreamWait& wait_handle() const { return s_->rside; }
+    size_t id() const { return s_->id_; }
 };
 
 template <class T> class WriteStream {     // src/stream.rs:288-310
@@ -232,14 +321,14 @@ template <class T> class WriteStream {     // src/stream.rs:288-310
 public:
     WriteStream() = default;
     explicit WriteStream(std::shared_ptr<StreamState<T>> s) : s_(std::move(s)) {}
-    ~WriteStream() { if (s_) s_->writer_alive = false; }
+    ~WriteStream() { if (s_) s_->drop_end(false); }
     WriteStream(WriteStream&&) = default;
     WriteStream& operator=(WriteStream&&) = default;
     WriteStream(const WriteStream&) = delete;
     BufferWriter<T> write_buf() const { return BufferWriter<T>(s_); }  // :301-310
     size_t free() const { return s_->free(); }
-    const StreamWait& wait_handle() const { return *s_; }
-    size_t id() const { return s_->id(); }
+    const StreamWait& wait_handle() const { return s_->wside; }
+    size_t id() const { return s_->id_; }
 };
 
 // Ring size used by new_stream() when none is given.  The reference's 4,096,000 bytes suit CPU caches; rings
@@ -1022,6 +1111,59 @@ public:
             }
             if (done && detail::activity() == before) break;
         }
+    }
+};
+
+
+// Thread-per-block runner (src/mtgraph.rs:84-135).  Each block runs on its own thread until its work() says EOF, or says
+// WaitForStream and either the block's own eof() holds or the stream's wait(need) reports that `need` can never be met
+// (:109-115); Pending sleeps with a doubling back-off (:116-122).  The block is dropped when its thread ends, which closes
+// its ends of its streams and so wakes and ends its neighbours.  A throwing work() cancels the graph (:99-105).
+class MTGraph {
+    std::vector<std::unique_ptr<Block>> blocks_;
+public:
+    void add(std::unique_ptr<Block> b) { blocks_.push_back(std::move(b)); }
+    void run() {
+        using namespace std::chrono;
+        constexpr auto MIN_IDLE_SLEEP = microseconds(1000), MAX_IDLE_SLEEP = microseconds(100000);   // mtgraph.rs:14-15
+        std::atomic<bool> cancel{false};
+        std::mutex em;
+        std::string err;
+        std::vector<std::thread> threads;
+        for (auto& slot : blocks_) {
+            threads.emplace_back([&cancel, &em, &err, MIN_IDLE_SLEEP, MAX_IDLE_SLEEP, b = std::move(slot)]() mutable {
+                auto idle = MIN_IDLE_SLEEP;
+                bool running = true;
+                while (running && !cancel.load()) {
+                    BlockRet ret = BlockRet::again();
+                    try {
+                        ret = b->work();
+                    } catch (const std::exception& e) {
+                        std::lock_guard<std::mutex> g(em);
+                        if (err.empty()) err = std::string("in block ") + b->block_name() + ": " + e.what();
+                        cancel = true;
+                        break;
+                    }
+                    switch (ret.kind) {
+                    case BlockRet::Again: idle = MIN_IDLE_SLEEP; break;
+                    case BlockRet::EOF_: running = false; break;
+                    case BlockRet::WaitForStream: {
+                        const bool never = ret.stream->wait(ret.need);
+                        if (b->eof() || never) running = false;
+                        break;
+                    }
+                    case BlockRet::Pending:
+                        std::this_thread::sleep_for(idle);
+                        idle = std::min(idle * 2, MAX_IDLE_SLEEP);
+                        break;
+                    }
+                }
+                b.reset();                                   // the drop that closes this block's stream ends
+            });
+        }
+        blocks_.clear();
+        for (auto& t : threads) t.join();
+        if (!err.empty()) throw Error(err);
     }
 };
 

@@ -1,0 +1,68 @@
+"""GPU: the Rust shim's device-resident graph (rust/src/lib.rs: GpuUpload -> GpuResident... -> GpuDownload over the two
+handles of new_gpu_stream()) ENDS, under both of the reference's runners, with the oracle chain's samples.
+
+The Rust file cannot be compiled in this image, so its design is compiled from the C++ twin (rustradio_amd/host/resident.hpp,
+same types, same branches) by tests/cpp/test_resident_graph.cpp and driven by Graph::run (src/graph.rs:126-147) and by
+MTGraph, one thread per block (src/mtgraph.rs:98-116).  A graph that does not terminate by itself hits the timeout."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import rustradio_amd as rr
+from oracle import pyoracle as orc
+from tests import harness
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_resident_graph.bin")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    src = os.path.join(ROOT, "tests", "cpp", "test_resident_graph.cpp")
+    lib = os.path.join(ROOT, "rustradio_amd", "lib")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", src, "-L", lib, "-lrustradio_amd", f"-Wl,-rpath,{lib}", "-o", EXE],
+                   check=True)
+    return EXE
+
+
+def _signal(n, seed):
+    rng = np.random.default_rng(seed)
+    # an FM-ish carrier well above the noise so that |r| stays away from 0 (plain 1e-5 pi applies almost everywhere)
+    ph = np.cumsum(0.3 * np.sin(2 * np.pi * 1e-3 * np.arange(n)))
+    x = np.exp(1j * ph) + 0.02 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    return x.astype(np.complex64)
+
+
+CASES = [
+    # ring bytes, interp, deci, fused, output ring bytes, samples
+    pytest.param(4_096_000, 1, 6, 0, 4_096_000, 1_500_000, id="reference-rings-1:6"),
+    pytest.param(4_096_000, 3, 7, 0, 4_096_000, 700_000, id="reference-rings-3:7"),
+    pytest.param(4_096_000, 5, 1, 0, 40_000, 300_000, id="interp-5:1-small-output-ring-pending-sample"),
+    pytest.param(65_536, 2, 3, 0, 4_096, 200_000, id="tiny-rings"),
+    pytest.param(4_096_000, 1, 6, 1, 4_096_000, 1_500_000, id="fused-fm-chain"),
+]
+
+
+@pytest.mark.parametrize("runner", ["graph", "mt"])
+@pytest.mark.parametrize("ring,interp,deci,fused,out_ring,n", CASES)
+def test_resident_graph_terminates_with_the_oracle_stream(exe, tmp_path, runner, ring, interp, deci, fused, out_ring, n):
+    x = _signal(n, 7)
+    taps = rr.low_pass_complex(2.4e6, 100e3, 50e3)
+    if ring < 8 * (2 * 256):                         # a ring must hold one FftFilter block: shorten the filter for tiny rings
+        taps = taps[:31]
+    fin, ftaps, fout = (str(tmp_path / f) for f in ("in.c32", "taps.c32", "out.f32"))
+    x.tofile(fin)
+    np.asarray(taps, np.complex64).tofile(ftaps)
+    out = subprocess.run([exe, runner, fin, ftaps, fout, str(ring), str(interp), str(deci), str(fused), str(out_ring)],
+                         capture_output=True, text=True, timeout=180)         # hang = TimeoutExpired = failure
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    got = np.fromfile(fout, np.float32)
+    blocks = [orc.FftFilter(taps), orc.RationalResampler(interp, deci), orc.QuadratureDemod(1.0)]
+    want = harness.run_chain(blocks, x)
+    ro = harness.run_chain([orc.FftFilter(taps), orc.RationalResampler(interp, deci)], x)
+    assert len(got) == len(want) and len(want) > 1000, (len(got), len(want))
+    par = harness.angle_parity(got, want, ro)
+    assert par["used"] <= 1.0, par

@@ -15,7 +15,7 @@ C2RUST = {
     "rr_dstream *": "*mut RrDStream", "const rr_dstream *": "*const RrDStream",
     "const void **": "*mut *const c_void", "void **": "*mut *mut c_void", "double *": "*mut f64",
     "unsigned long long *": "*mut u64", "const rr_build_opts *": "*const RrBuildOpts",
-    "unsigned long long": "u64", "rr_fanout *": "*mut RrFanout",
+    "unsigned long long": "u64", "rr_fanout *": "*mut RrFanout", "unsigned": "c_uint", "int *": "*mut c_int",
 }
 
 
@@ -75,3 +75,48 @@ def test_every_block_constructor_of_the_header_is_bound():
     for n in ("rr_block_work", "rr_block_work_dev", "rr_block_work_streams", "rr_block_eof", "rr_block_destroy",
               "rr_dstream_copy_in", "rr_dstream_copy_out", "rr_host_register", "rr_last_error"):
         assert n in r, n
+
+
+def test_no_block_with_an_input_reports_eof_false_or_pending():
+    """a block with an input stream whose eof() is a constant `false`, or that answers "nothing to do"
+    with BlockRet::Pending, never ends under Graph::run (src/graph.rs:130-143) / MTGraph (src/mtgraph.rs:109-122)."""
+    src = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    assert not re.search(r"fn\s+eof\s*\(\s*&mut\s+self\s*\)\s*->\s*bool\s*\{\s*false\s*\}", src)
+    code = re.sub(r"//[^\n]*", "", src)
+    assert "BlockRet::Pending" not in code
+    n_eof = len(re.findall(r"BlockEOF\s+for\s+\w+", code))
+    n_blk = len(re.findall(r"[^\w]Block\s+for\s+\w+", code))
+    assert n_eof == n_blk >= 12, (n_eof, n_blk)
+
+
+def test_resident_streams_are_two_handles_that_implement_streamwait():
+    """The device ring is one buffer behind a writer handle and a reader handle (src/stream.rs:187-190,256-258); dropping
+    one closes that side in the library, both implement StreamWait (id / wait / closed, src/stream.rs:114-138), and the
+    resident blocks wait on those handles."""
+    src = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    for side, other in (("GpuReadStream", "RR_SIDE_WRITER"), ("GpuWriteStream", "RR_SIDE_READER")):
+        m = re.search(r"StreamWait\s+for\s+" + side + r"<T>\s*\{(.*?)\n\}", src, flags=re.S)
+        assert m, side
+        body = m.group(1)
+        for fn in ("fn id(&self) -> usize", "fn wait(&self, need: usize) -> bool", "fn closed(&self) -> bool"):
+            assert fn in body, (side, fn)
+        assert f"rr_dstream_closed(self.ring.s, {other})" in body, side     # closed() = the OTHER end was dropped
+    assert re.search(r"impl<T: Sample> Drop for GpuWriteStream<T>\s*\{[^}]*rr_dstream_close\(self\.ring\.s, RR_SIDE_WRITER\)", src, flags=re.S)
+    assert re.search(r"impl<T: Sample> Drop for GpuReadStream<T>\s*\{[^}]*rr_dstream_close\(self\.ring\.s, RR_SIDE_READER\)", src, flags=re.S)
+    res = re.search(r"Block for GpuResident<I, O>\s*\{(.*?)\n\}", src, flags=re.S).group(1)
+    assert "RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need)" in res
+    assert "RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need)" in res
+    assert "Mutex" not in re.sub(r"//[^\n]*", "", src)          # the ring's lock lives in the library
+
+
+def test_cpp_twin_mirrors_the_rust_resident_design():
+    """tests/cpp/test_resident_graph.cpp runs rustradio_amd/host/resident.hpp; that header must stay the Rust design's twin:
+    the same types and the same status -> BlockRet mapping."""
+    twin = open(os.path.join(ROOT, "rustradio_amd", "host", "resident.hpp")).read()
+    rust = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    for name in ("GpuWriteStream", "GpuReadStream", "new_gpu_stream", "GpuUpload", "GpuDownload", "GpuResident"):
+        assert name in twin and name in rust, name
+    for call in ("rr_dstream_close", "rr_dstream_closed", "rr_dstream_wait", "rr_dstream_id", "rr_block_work_streams", "rr_block_eof"):
+        assert call in twin and call in rust, call
+    assert "case RR_WAIT_SRC: return BlockRet::wait(src_, need);" in twin
+    assert "case RR_WAIT_DST: return BlockRet::wait(dst_, need);" in twin
