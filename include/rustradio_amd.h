@@ -93,9 +93,8 @@ typedef struct {
     int fm_poly;            /* fused FM chains: decimate-first (polyphase) tiles, > 0 wherever supported, < 0 never;
                                8 / 12: also fixes the multi-channel kernel's waves per workgroup (0 / 1: by predicted cost) */
     int dstream_no_vmm;     /* rr_dstream_create: the copying fallback ring instead of the double mapping */
-    int host_sync_copies;   /* rr_block_work: plain staged copies instead of the pinned, overlapped pipeline */
     int fir_poly;           /* decimating FirFilter<Complex>: decimate-first (polyphase) tiles, > 0 wherever supported, < 0 never */
-    int reserved[4];
+    int reserved[5];
 } rr_build_opts;
 int rr_next_create_options(const rr_build_opts *opts);   /* NULL clears a pending override */
 

@@ -58,7 +58,7 @@ def _effective_opts() -> dict:
 @contextlib.contextmanager
 def build_options(**kw):
     """fir_path='direct'|'fft', fir_prune=+-1, fir_half=-1, fir_cfg=0..7, fft_log2f=10..14, fft_no_split=1,
-    fftfloat_complex=1, fm_full=1, fm_poly=-1 (8 / 12: the multi-channel kernel variant), dstream_no_vmm=1, host_sync_copies=1, fir_poly=+-1"""
+    fftfloat_complex=1, fm_full=1, fm_poly=-1 (8 / 12: the multi-channel kernel variant), dstream_no_vmm=1, fir_poly=+-1"""
     prev = getattr(_tls, "opts", None)
     _tls.opts = dict(_effective_opts(), **kw)
     try:
@@ -231,6 +231,11 @@ class Block:
     def eof(self, src_eof: bool) -> bool:
         """BlockEOF::eof (src/block.rs:103-110)."""
         return bool(lib().rr_block_eof(self._h, int(src_eof)))
+
+    def set_rotator_mode(self, mode: int) -> None:
+        """rr_fir_set_rotator_mode on a translating FirFilter / HilbertFir: ROT_REPLAY (default, the reference's recurrence) or ROT_MODEL"""
+        if lib().rr_fir_set_rotator_mode(self._h, mode) != 0:
+            raise ValueError(last_error())
 
     def sync(self) -> None:
         if lib().rr_block_sync(self._h) != 0:

@@ -317,6 +317,7 @@ void FirC32::rotor_generate(size_t upto) {
     if (upto <= rot_gen) return;
     // the slots of [rot_gen, upto) still hold phases [rot_gen - cap, upto - cap): every rotate kernel that reads them has been
     // enqueued before the last ev_used record (callers keep upto - consumed <= cap)
+    if (upto - rot_gen > ring_cap) throw Error("rotator: look-ahead request beyond the phase ring");   // (callers ask for <= cap / 2 at a time)
     if (used_pending) { RR_HIP(hipStreamWaitEvent(rot_stream, ev_used, 0)); used_pending = false; }
     launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, (long)rot_gen, (long)(ring_cap - 1), 0, (long)(upto - rot_gen), rot_stream);
     RR_HIP(hipEventRecord(ev_gen, rot_stream));
@@ -346,6 +347,17 @@ void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
         if (n_rot) launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, 0, (long)(ring_cap - 1), (long)n_rot, 0, rot_stream);
         rot_gen = n_rot;
     }
+    if (rot_gen < n_rot) {
+        // REPLAY -> MODEL -> REPLAY: the model advanced n_rot past what the chain has generated.  Walk the carried phase
+        // on to n_rot without storing (the ring holds nothing this call can use), so that the next generate starts there
+        // and never spans more than a chunk.
+        launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, 0, (long)(ring_cap - 1), (long)(n_rot - rot_gen), 0, rot_stream);
+        rot_gen = n_rot;
+    }
+    // one event remembers the ring's readers: a call on another HIP stream first waits for the previous stream's rotate
+    // kernels, so that the record below still covers every reader enqueued so far
+    if (used_pending && used_stream != s) RR_HIP(hipStreamWaitEvent(s, ev_used, 0));
+    used_stream = s;
     const size_t half = ring_cap / 2;
     for (size_t done = 0; done < out_n;) {
         const size_t chunk = std::min(out_n - done, half);
@@ -863,9 +875,14 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     if (m != RR_ATAN2_EXACT && m != RR_ATAN2_FAST) throw Error("QuadratureDemod: bad atan2 mode");
     // the kernels index (A + y) * I and u * D in 64-bit: with the reduced ratio below 2^31 every product of a stream
     // position (< 2^32 per call, rebased) stays far below 2^63
-    if (interp > (size_t)1 << 31 || deci > (size_t)1 << 31) throw Error("FmChain: interp and deci must be <= 2^31");
+    if (interp > (size_t)1 << 31 || deci > (size_t)1 << 31) throw NotFusedShape("FmChain: interp and deci must be <= 2^31");
     const int64_t gg = gcd64((int64_t)deci, (int64_t)interp);
     D = (int64_t)deci / gg; I = (int64_t)interp / gg;
+    // decided before any table is built: the fused kernels run on LDS-resident tiles of up to 2^max_log2f points
+    {
+        const size_t Lc = fir_taps ? fir_ntaps + ntaps - 1 : ntaps, lim = ((size_t)1 << std::min(max_log2f, 14)) - 1;
+        if (ntaps && Lc > lim) throw NotFusedShape("FmChain: more taps than the largest tile of the fused kernels holds");
+    }
     if (fir_taps) {                      // front FirFilter fused in: composite taps, head fix at stream start
         if (u8) throw Error("FmChain: the front FirFilter takes Complex input");
         const std::vector<rr_c32> gt = FftFilter::composite(fir_taps, fir_ntaps, taps, ntaps);
@@ -875,9 +892,9 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     } else {
         f.reset(new FftFilter(taps, ntaps, true, max_log2f));
     }
-    if (f->big) throw Error("FmChain: at most 16383 taps (the fused kernels run on LDS-resident tiles)");
+    if (f->big) throw NotFusedShape("FmChain: at most 16383 taps (the fused kernels run on LDS-resident tiles)");
     const int64_t G = (D + I - 1) / I;
-    if (G >= (int64_t)(((size_t)1 << f->log2f) - f->L + 1)) throw Error("FmChain: decimation too large for the FFT tile");
+    if (G >= (int64_t)(((size_t)1 << f->log2f) - f->L + 1)) throw NotFusedShape("FmChain: decimation too large for the FFT tile");
     half_ok = !f->nsub && fm_multi_half_supported(f->log2f, I, D, (int)ntaps) && !build_opts().fm_full;
     if (half_ok) {
         const size_t FH = ((size_t)1 << f->log2f) / 2;
@@ -906,8 +923,21 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     RR_HIP(hipStreamSynchronize(stream));
 }
 
-int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
-                      size_t* produced, size_t* need, hipStream_t s) {
+size_t OutTail::drain(float* out, size_t out_stride, size_t out_cap, size_t C, hipStream_t s) {
+    const size_t m = std::min(out_cap, len - pos);
+    if (m) RR_HIP(hipMemcpy2DAsync(out, out_stride * sizeof(float), buf.p + pos, cap * sizeof(float), m * sizeof(float), C,
+                                   hipMemcpyDeviceToDevice, s));
+    pos += m;
+    return m;
+}
+
+size_t FmChain::next_block_outputs() const {
+    auto N3 = [&](uint64_t y) { const uint64_t r = (uint64_t)(((__int128)y * I + D - 1) / D); return r ? r - 1 : 0; };
+    return (size_t)(N3(n1 + f->nsamples) - N3(n1));
+}
+
+int FmChain::work_blocks(const void* in, size_t in_len, float* out, size_t, size_t out_cap, size_t* consumed,
+                         size_t* produced, size_t* need, hipStream_t s, uint64_t max_blocks) {
     *consumed = *produced = *need = 0;
     if (iq8) in_len /= 2;                          // whole I/Q pairs; an odd trailing byte is never consumed (:23)
     bool packed = iq8;
@@ -932,6 +962,7 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     const __int128 X = (__int128)(o_old + out_cap + 1) * D / I;        // (n1 + k S) <= X
     uint64_t k_out = X >= (__int128)n1 ? (uint64_t)((X - n1) / S) : 0;
     while (k_out > 0 && N3(n1 + k_out * S) - o_old > out_cap) k_out--;
+    k_out = std::min(k_out, max_blocks);
     uint64_t k, new_pend;
     int st;
     if (k_in > k_out) {
@@ -966,32 +997,32 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
                              (int64_t)((D + I - 1) / I) < (int64_t)(((size_t)1 << f->alt_log2f) - f->L + 1);
         prof_begin(s);
         if (use_poly && packed)
-            launch_fm_chain_poly_iq8(src8, static_cast<float*>(out), (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+            launch_fm_chain_poly_iq8(src8, out, (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (use_poly)
-            launch_fm_chain_poly(src, static_cast<float*>(out), (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
+            launch_fm_chain_poly(src, out, (int)f->L, poly->d_tw.p, poly->d_h.p, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (use_alt && packed)        // long filter, window of too few split tiles: the plain 4096-point chain tile (see FftFilter)
-            launch_fm_chain_iq8(f->alt_log2f, src8, static_cast<float*>(out), (int)f->L, f->d_tw_alt.p, f->d_hpos_alt.p, a,
+            launch_fm_chain_iq8(f->alt_log2f, src8, out, (int)f->L, f->d_tw_alt.p, f->d_hpos_alt.p, a,
                                 last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (use_alt)
-            launch_fm_chain(f->alt_log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw_alt.p, f->d_hpos_alt.p, a,
+            launch_fm_chain(f->alt_log2f, src, out, (int)f->L, f->d_tw_alt.p, f->d_hpos_alt.p, a,
                             last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (f->nsub && packed)
-            launch_fm_chain_split_iq8(f->nsub, src8, static_cast<float*>(out), (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
+            launch_fm_chain_split_iq8(f->nsub, src8, out, (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
                                       last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (f->nsub)
-            launch_fm_chain_split(f->nsub, src, static_cast<float*>(out), (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
+            launch_fm_chain_split(f->nsub, src, out, (int)f->L, f->d_tw4096.p, f->d_hs.p, f->d_wk.p, a,
                                   last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (use_half && packed)
-            launch_fm_chain_half_iq8(src8, static_cast<float*>(out), (int)f->L, f->d_tw.p, d_tw_half.p, f->d_hpos.p, a,
+            launch_fm_chain_half_iq8(src8, out, (int)f->L, f->d_tw.p, d_tw_half.p, f->d_hpos.p, a,
                                      last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (use_half)
-            launch_fm_chain_half(src, static_cast<float*>(out), (int)f->L, f->d_tw.p, d_tw_half.p, f->d_hpos.p, a,
+            launch_fm_chain_half(src, out, (int)f->L, f->d_tw.p, d_tw_half.p, f->d_hpos.p, a,
                                  last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (packed)
-            launch_fm_chain_iq8(f->log2f, src8, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a,
+            launch_fm_chain_iq8(f->log2f, src8, out, (int)f->L, f->d_tw.p, f->d_hpos.p, a,
                                 last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else
-            launch_fm_chain(f->log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a,
+            launch_fm_chain(f->log2f, src, out, (int)f->L, f->d_tw.p, f->d_hpos.p, a,
                             last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         prof_end(s);
         if (f->front && n1 == 0) {
@@ -1001,7 +1032,7 @@ int FmChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
             const long nz = std::min<long>((long)n_y, L2 - 1 + (long)((D + I - 1) / I) + 1);
             f->d_zhead.reserve((size_t)nz);
             launch_head_z(src, (long)f->hist, f->d_t1.p, (int)(f->front + 1), f->d_zhead.p, nz, s);
-            launch_head_demod(f->d_zhead.p, nz, f->d_t2.p, (int)L2, I, D, gain, mode, a.r_hi, static_cast<float*>(out),
+            launch_head_demod(f->d_zhead.p, nz, f->d_t2.p, (int)L2, I, D, gain, mode, a.r_hi, out,
                               last_r[cur_lr ^ 1].p, s);
         }
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
@@ -1028,8 +1059,8 @@ AudioChain::AudioChain(const float* taps, size_t ntaps, size_t interp, size_t de
     if (ntaps == 0) throw Error("FftFilterFloat: empty taps");
     if (deci == 0) throw Error("RationalResampler created using deci 0");
     if (interp == 0) throw Error("RationalResampler created using interp 0");
-    if (interp > (size_t)1 << 31 || deci > (size_t)1 << 31) throw Error("AudioChain: interp and deci must be <= 2^31");
-    if (ntaps > 3584) throw Error("AudioChain: at most 3584 taps (real-stream tiles of up to 4096 points); use the three blocks");
+    if (interp > (size_t)1 << 31 || deci > (size_t)1 << 31) throw NotFusedShape("AudioChain: interp and deci must be <= 2^31");
+    if (ntaps > 3584) throw NotFusedShape("AudioChain: at most 3584 taps (real-stream tiles of up to 4096 points); use the three blocks");
     const int64_t gg = gcd64((int64_t)deci, (int64_t)interp);
     D = (int64_t)deci / gg; I = (int64_t)interp / gg;
     std::vector<rr_c32> ct(ntaps);
@@ -1039,8 +1070,13 @@ AudioChain::AudioChain(const float* taps, size_t ntaps, size_t interp, size_t de
 
 // Bookkeeping as FmChain's without the demodulator's one-sample lag: a call emits whole filter blocks and every resampled
 // sample whose source lies in them.
-int AudioChain::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed, size_t* produced,
-                         size_t* need, hipStream_t s) {
+size_t AudioChain::next_block_outputs() const {
+    auto N2 = [&](uint64_t y) { return (uint64_t)(((__int128)y * I + D - 1) / D); };
+    return (size_t)(N2(n1 + f->nsamples) - N2(n1));
+}
+
+int AudioChain::work_blocks(const void* in, size_t in_len, float* out, size_t, size_t out_cap, size_t* consumed, size_t* produced,
+                            size_t* need, hipStream_t s, uint64_t max_blocks) {
     *consumed = *produced = *need = 0;
     const uint64_t S = f->nsamples;
     auto N2 = [&](uint64_t y) { return (uint64_t)(((__int128)y * I + D - 1) / D); };
@@ -1051,6 +1087,7 @@ int AudioChain::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     const __int128 X = (__int128)(o_old + out_cap) * D / I;            // N2(n1 + k S) <= o_old + out_cap
     uint64_t k_out = X >= (__int128)n1 ? (uint64_t)((X - n1) / S) : 0;
     while (k_out > 0 && N2(n1 + k_out * S) - o_old > out_cap) k_out--;
+    k_out = std::min(k_out, max_blocks);
     uint64_t k, new_pend;
     int st;
     if (k_in > k_out) {
@@ -1067,7 +1104,7 @@ int AudioChain::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
         AudioChainArgs a{(long)n1, (long)n_y, (long)o_old, (long)N2(n1 + n_y), I, D, scale, {}};
         if (*consumed) a.carry = CarryOut{f->prefix[f->cur ^ 1].p, (long)n_y, (long)(f->hist + new_pend)};
         prof_begin(s);
-        launch_audio_chain(f->log2f, src, static_cast<float*>(out), (int)f->L, f->d_tw.p, f->d_hpos.p, a, s);
+        launch_audio_chain(f->log2f, src, out, (int)f->L, f->d_tw.p, f->d_hpos.p, a, s);
         prof_end(s);
     } else if (*consumed) {
         launch_vcopy_f32(src, (long)n_y, reinterpret_cast<float*>(f->prefix[f->cur ^ 1].p), (long)(f->hist + new_pend), s);
@@ -1088,7 +1125,7 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
     if (nchan == 0 || nchan > 4096) throw Error("FmMulti: channel count must be 1..4096");
     chain.reset(new FmChain(taps, ntaps, interp, deci, g, m, false, 12));   // bookkeeping, carry state, twiddles; 3-pass tiles
     const int lg = chain->f->log2f;
-    if (!fm_multi_supported(lg)) throw Error("FmMulti: at most 4094 taps (3-pass tiles)");
+    if (!fm_multi_supported(lg)) throw NotFusedShape("FmMulti: at most 4094 taps (3-pass tiles)");
     const size_t F = (size_t)1 << lg;
     std::vector<cf> all(C * F), one;
     for (size_t c = 0; c < C; c++) {
@@ -1116,8 +1153,8 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
 
 // `out` holds C windows of out_cap elements each (channel c at out + c*out_cap); all channels
 // consume and produce the same counts, so the bookkeeping is FmChain's.
-int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
-                      size_t* produced, size_t* need, hipStream_t s) {
+int FmMulti::work_blocks(const void* in, size_t in_len, float* out, size_t out_stride, size_t out_cap, size_t* consumed,
+                         size_t* produced, size_t* need, hipStream_t s, uint64_t max_blocks) {
     FmChain& ch = *chain;
     FftFilter* f = ch.f.get();
     *consumed = *produced = *need = 0;
@@ -1140,6 +1177,7 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     const __int128 X = (__int128)(o_old + out_cap + 1) * D / I;
     uint64_t k_out = X >= (__int128)n1 ? (uint64_t)((X - n1) / S) : 0;
     while (k_out > 0 && N3(n1 + k_out * S) - o_old > out_cap) k_out--;
+    k_out = std::min(k_out, max_blocks);
     uint64_t k, new_pend;
     int st;
     if (k_in > k_out) {
@@ -1160,22 +1198,22 @@ int FmMulti::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
         a.multi_waves = poly_waves;
         prof_begin(s);
         if (poly && packed)
-            launch_fm_multi_poly_iq8(src8, static_cast<float*>(out), (long)out_cap, (int)f->L, poly->d_tw.p, poly->d_h.p, (int)C, a,
+            launch_fm_multi_poly_iq8(src8, out, (long)out_stride, (int)f->L, poly->d_tw.p, poly->d_h.p, (int)C, a,
                                      last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (poly)
-            launch_fm_multi_poly(src, static_cast<float*>(out), (long)out_cap, (int)f->L, poly->d_tw.p, poly->d_h.p, (int)C, a,
+            launch_fm_multi_poly(src, out, (long)out_stride, (int)f->L, poly->d_tw.p, poly->d_h.p, (int)C, a,
                                  last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (half_ok && packed)
-            launch_fm_multi_half_iq8(f->log2f, src8, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_tw_half.p,
+            launch_fm_multi_half_iq8(f->log2f, src8, out, (long)out_stride, (int)f->L, f->d_tw.p, d_tw_half.p,
                                      d_hpos_all.p, (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (packed)
-            launch_fm_multi_iq8(f->log2f, src8, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_hpos_all.p,
+            launch_fm_multi_iq8(f->log2f, src8, out, (long)out_stride, (int)f->L, f->d_tw.p, d_hpos_all.p,
                                 (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else if (half_ok)
-            launch_fm_multi_half(f->log2f, src, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_tw_half.p,
+            launch_fm_multi_half(f->log2f, src, out, (long)out_stride, (int)f->L, f->d_tw.p, d_tw_half.p,
                                  d_hpos_all.p, (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         else
-            launch_fm_multi(f->log2f, src, static_cast<float*>(out), (long)out_cap, (int)f->L, f->d_tw.p, d_hpos_all.p,
+            launch_fm_multi(f->log2f, src, out, (long)out_stride, (int)f->L, f->d_tw.p, d_hpos_all.p,
                             (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         prof_end(s);
         if (a.r_hi > a.r_lo) cur_lr ^= 1;

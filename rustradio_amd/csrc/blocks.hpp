@@ -107,6 +107,7 @@ struct FirC32 : Block {
     hipStream_t rot_stream = nullptr;
     hipEvent_t ev_gen = nullptr, ev_used = nullptr;
     bool used_pending = false;
+    hipStream_t used_stream = nullptr;            // stream of the last ev_used record
     void rotor_generate(size_t upto);             // enqueue the chain up to phase index `upto` (exclusive) on rot_stream
     std::vector<std::complex<float>> h_taps;      // caller-order taps after the translate pre-rotation
     // allow_fft = false: bookkeeping / direct form only (HilbertFir's inner object)
@@ -194,6 +195,55 @@ struct FftFilter : Block {
     void filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s, CarryOut carry = {});   // out[m] = y[m d]
 };
 
+// The fused chains end in a RationalResampler (+ demodulator / scaler) whose reference form makes progress on ANY output
+// window: it emits what fits and carries a `pending` sample across a full buffer (rational_resampler.rs:162-173,190-196),
+// and the FftFilter in front of it writes into an inner 4 MB stream, not into the caller's window.  One fused kernel emits
+// whole filter blocks, so when the caller's window is smaller than the next block's outputs that ONE block is run into
+// `buf` (C windows of `cap` elements) and handed out as room appears — the resampler's `pending`, a block long.
+struct OutTail {
+    DevBuf<float> buf;
+    size_t cap = 0, len = 0, pos = 0;          // per window: capacity, valid outputs, outputs already handed out
+    bool pending() const { return pos < len; }
+    // up to out_cap of the pending outputs of each of the C windows -> out (windows out_stride apart); returns the count
+    size_t drain(float* out, size_t out_stride, size_t out_cap, size_t C, hipStream_t s);
+};
+// work_dev of a fused chain B on top of its block-granular core:
+//   B::next_block_outputs()                         outputs the next filter block will add
+//   B::work_blocks(in, n, out, stride, cap, c, p, need, s, max_blocks)   the one-kernel path; needs cap >= next_block_outputs()
+// Protocol: pending outputs first (WAIT_DST need 1 while some remain, like the resampler with a pending sample); a window
+// that holds the next block runs the core unchanged; a smaller one gets ONE block through the tail — WAIT_DST(1), part of
+// it is necessarily left — or WAIT_SRC(need) when there was no full block of input (which is consumed all the same).
+template <class B>
+int trickle_work(B& b, OutTail& t, size_t C, const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed, size_t* produced,
+                 size_t* need, hipStream_t s) {
+    *consumed = *produced = *need = 0;
+    float* o = static_cast<float*>(out);
+    const size_t stride = out_cap;
+    size_t room = out_cap;
+    if (t.pending()) {
+        const size_t m = t.drain(o, stride, room, C, s);
+        *produced = m; o += m; room -= m;
+        if (t.pending()) { *need = 1; return RR_WAIT_DST; }
+    }
+    const size_t nb = b.next_block_outputs();
+    if (nb <= room) {
+        size_t p = 0;
+        const int st = b.work_blocks(in, in_len, o, stride, room, consumed, &p, need, s, ~(uint64_t)0);
+        *produced += p;
+        return st;
+    }
+    if (t.cap < nb) { t.cap = nb + 64; t.buf.reserve(C * t.cap); }
+    size_t p = 0;
+    const int st = b.work_blocks(in, in_len, t.buf.p, t.cap, t.cap, consumed, &p, need, s, 1);
+    if (st == RR_ERR) return st;
+    if (p == 0) return st;                             // no full filter block yet: WAIT_SRC(need) (input joined the pending samples)
+    t.len = p; t.pos = 0;
+    const size_t m = t.drain(o, stride, room, C, s);
+    *produced += m;
+    *need = t.pending() ? 1 : 0;
+    return t.pending() ? RR_WAIT_DST : RR_AGAIN;
+}
+
 // Fused FftFilter -> RationalResampler(interp:deci) -> QuadratureDemod (one kernel per call).
 // Whole-stream output = what the three reference blocks produce in sequence: after N input
 // samples, N1 = floor(N/nsamples)*nsamples filtered, N2 = ceil(N1*I/D) resampled, N2-1 demodulated.
@@ -213,9 +263,15 @@ struct FmChain : Block {
     bool half_ok = false;
     std::unique_ptr<PolyTables> poly; // interp 1, integer deci: decimate-first tiles (k_fm_chain_poly)
     bool window_aware = true;         // windows of too few tiles run on the 2048-point kernels (off when fm_poly is forced)
+    OutTail tail;                     // one block's outputs the caller's window could not take yet
     FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false,
             int max_log2f = 14, const rr_c32* fir_taps = nullptr, size_t fir_ntaps = 0);
-    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+    size_t next_block_outputs() const;
+    int work_blocks(const void*, size_t, float*, size_t, size_t, size_t*, size_t*, size_t*, hipStream_t, uint64_t max_blocks);
+    int work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* c, size_t* p, size_t* need, hipStream_t s) override {
+        return trickle_work(*this, tail, 1, in, in_len, out, out_cap, c, p, need, s);
+    }
+    bool eof(bool src_eof) override { return src_eof && !tail.pending(); }       // as rational_resampler.rs:209-213
 };
 
 // FftFilterFloat(taps) -> RationalResampler(interp, deci) -> MultiplyConst(scale) fused (the audio stage of
@@ -227,8 +283,14 @@ struct AudioChain : Block {
     int64_t I = 1, D = 1;
     float scale;
     uint64_t n1 = 0;                  // filtered samples emitted so far
+    OutTail tail;
     AudioChain(const float* taps, size_t ntaps, size_t interp, size_t deci, float scale);
-    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+    size_t next_block_outputs() const;
+    int work_blocks(const void*, size_t, float*, size_t, size_t, size_t*, size_t*, size_t*, hipStream_t, uint64_t max_blocks);
+    int work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* c, size_t* p, size_t* need, hipStream_t s) override {
+        return trickle_work(*this, tail, 1, in, in_len, out, out_cap, c, p, need, s);
+    }
+    bool eof(bool src_eof) override { return src_eof && !tail.pending(); }
 };
 
 // N fused FM chains (FmChain) on ONE shared input: the reference's Tee fan-out + N x three blocks.
@@ -246,9 +308,15 @@ struct FmMulti : Block {
     // iq8: RTL-SDR byte input, RtlSdrDecode fused in front (windows, `consumed` and WAIT_SRC `need` count BYTES)
     bool iq8 = false;
     DevBuf<cf> decoded;               // odd-addressed byte windows are decoded out of line
+    OutTail tail;                     // [C] windows of one block's outputs
     FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false);
     size_t out_windows() const override { return C; }
-    int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
+    size_t next_block_outputs() const { return chain->next_block_outputs(); }
+    int work_blocks(const void*, size_t, float*, size_t, size_t, size_t*, size_t*, size_t*, hipStream_t, uint64_t max_blocks);
+    int work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* c, size_t* p, size_t* need, hipStream_t s) override {
+        return trickle_work(*this, tail, C, in, in_len, out, out_cap, c, p, need, s);
+    }
+    bool eof(bool src_eof) override { return src_eof && !tail.pending(); }
     int work_host(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*) override;
 };
 

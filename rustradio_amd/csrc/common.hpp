@@ -14,6 +14,12 @@ namespace rr {
 struct Error : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+// Thrown by the constructor of a FUSED block for a shape its kernels do not cover (tap count beyond the tile, ratio beyond
+// the index arithmetic): the factories in compose.cpp catch exactly this and build the unfused composition instead.  Every
+// other failure — a bad argument the reference rejects too, a HIP error, out of memory — stays an Error and propagates.
+struct NotFusedShape : Error {
+    using Error::Error;
+};
 
 void set_last_error(const std::string& m);
 
@@ -31,7 +37,6 @@ struct BuildOpts {
     int fm_full = 0;
     int fm_poly = 0;           // 0 auto, < 0 off: polyphase (decimate-first) tiles of the fused chains
     int dstream_no_vmm = 0;
-    int host_sync_copies = 0;  // host-window work(): the simple staged path (no pinned double buffering)
     int fir_poly = 0;          // 0 auto, > 0 on wherever supported, < 0 off: decimating FirFilter<Complex> on decimate-first tiles
 };
 const BuildOpts& build_opts();

@@ -21,6 +21,10 @@ Series::Series(const char* nm, std::vector<std::unique_ptr<Block>> blocks)
         if (b[i]->out_es != b[i + 1]->in_es) throw Error("Series: element sizes of adjacent blocks differ");
         link[i].es = b[i]->out_es;
         link[i].cap = 4096000 / link[i].es;                           // stream.rs:105,336-339
+        // ... but never smaller than what one work() of a neighbour needs at once: an FftFilter wants room for / a window of
+        // `nsamples` (> 512000 beyond 262144 taps), and a link that can never hold it would stall the chain for good
+        for (Block* nb : {b[i].get(), b[i + 1].get()})
+            if (auto* ff = dynamic_cast<FftFilter*>(nb)) link[i].cap = std::max<size_t>(link[i].cap, 2 * ff->nsamples);
         for (auto& d : link[i].buf) d.reserve(link[i].cap * link[i].es);
     }
 }
@@ -29,8 +33,8 @@ int Series::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
                      size_t* need, hipStream_t s) {
     *consumed = *produced = *need = 0;
     const size_t m = b.size();
-    int first_st = RR_AGAIN, last_st = RR_AGAIN;
-    size_t first_need = 0, last_need = 0;
+    std::vector<int> last(m, RR_AGAIN);       // status and need of each block's most recent work()
+    std::vector<size_t> lneed(m, 0);
     prof_begin(s);
     // rounds of one work() per block, in order, until a round moves nothing (Graph::run's loop over a straight chain)
     for (int round = 0; round < 1 << 20; round++) {
@@ -47,7 +51,8 @@ int Series::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
             size_t c = 0, p = 0, nd = 0;
             const int st = b[i]->work_dev(ip, in_n, op, room, &c, &p, &nd, s);
             if (st == RR_ERR) { prof_end(s); return st; }
-            if (i == 0) { *consumed += c; first_st = st; first_need = nd; }
+            last[i] = st; lneed[i] = nd;
+            if (i == 0) *consumed += c;
             else if (c) {
                 // consume(c) on a linear buffer: what is left moves to the front of the other buffer (a few samples of
                 // carry — QuadratureDemod keeps one, FastFM none, the filters take whole windows)
@@ -57,15 +62,42 @@ int Series::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
                 L.cur ^= 1;
                 L.len = left;
             }
-            if (i + 1 == m) { *produced += p; last_st = st; last_need = nd; }
+            if (i + 1 == m) *produced += p;
             else link[i].len += p;
             if (c || p) progress = true;
         }
         if (!progress) break;
     }
     prof_end(s);
-    if (last_st == RR_WAIT_DST) { *need = last_need; return RR_WAIT_DST; }     // the caller's output window is the limit
-    if (first_st == RR_WAIT_SRC) { *need = first_need; return RR_WAIT_SRC; }
+    if (last[m - 1] == RR_WAIT_DST) { *need = lneed[m - 1]; return RR_WAIT_DST; }     // the caller's output window is the limit
+    if (last[0] == RR_WAIT_SRC) {
+        // The caller's input is the limit.  What it must offer is what the block that is actually starved needs, carried
+        // back through the blocks in front of it — the fused form of the same chain reports exactly this
+        // (FmChain: nsamples - pending + front, in bytes for u8) — not the few samples / bytes block 0 alone asks for,
+        // which would wake a scheduler for nothing.
+        size_t nd = lneed[0];
+        for (size_t j = 1; j < m; j++) {
+            if (last[j] != RR_WAIT_SRC || lneed[j] <= link[j - 1].len) continue;
+            size_t want = lneed[j] - link[j - 1].len;           // more elements block j wants to see in its window
+            bool ok = true;
+            for (size_t i = j; i-- > 0 && ok;) {                 // ... in units of the stream in front of block i
+                if (dynamic_cast<RtlSdrDecode*>(b[i].get())) want *= 2;                       // two bytes per sample
+                else if (auto* fc = dynamic_cast<FirC32*>(b[i].get())) {
+                    if (fc->pl.d != 1) ok = false;
+                    else if (i == 0) want += (size_t)fc->pl.L - 1;                            // the window keeps ntaps - 1 (fir.rs:496-549)
+                } else if (i > 0 || !dynamic_cast<FftFilter*>(b[i].get())) ok = false;        // other blocks: keep block 0's own figure
+            }
+            if (ok) nd = std::max(nd, want);
+            break;
+        }
+        *need = nd;
+        return RR_WAIT_SRC;
+    }
+    if (*consumed == 0 && *produced == 0) {
+        // nothing moved and neither end is the limit: an inner link is both too full for its writer and too short for its
+        // reader.  Saying AGAIN would spin the caller (block.rs:21-40: AGAIN is not for polling).
+        throw Error("Series: an inner stream can hold neither what its writer must emit at once nor what its reader needs");
+    }
     return RR_AGAIN;
 }
 
@@ -144,9 +176,9 @@ Block* make_fm_chain(const rr_c32* taps, size_t ntaps, size_t interp, size_t dec
     if (mode != RR_DEMOD_FASTFM) {
         try {
             return new FmChain(taps, ntaps, interp, deci, gain, mode, u8, 14, fir_taps, fir_ntaps);
-        } catch (const Error&) {
+        } catch (const NotFusedShape&) {
             // not a shape of the fused kernels (more than 16383 taps, a decimation beyond the tile, ...): the unfused
-            // composition takes everything the three blocks take — and re-raises the reference's own argument errors
+            // composition takes everything the three blocks take.  Anything else (HIP failure, bad argument) propagates.
         }
     }
     return fm_chain_unfused(taps, ntaps, interp, deci, gain, mode, u8, fir_taps, fir_ntaps);
@@ -157,7 +189,7 @@ Block* make_fm_multi(const rr_c32* taps, size_t nchan, size_t ntaps, size_t inte
     if (mode != RR_DEMOD_FASTFM) {
         try {
             return new FmMulti(taps, nchan, ntaps, interp, deci, gain, mode, u8);
-        } catch (const Error&) {
+        } catch (const NotFusedShape&) {
         }
     }
     // beyond the shared-forward-transform kernels (more than 4094 taps, ...): one chain per channel on the shared window —
@@ -170,7 +202,7 @@ Block* make_fm_multi(const rr_c32* taps, size_t nchan, size_t ntaps, size_t inte
 Block* make_audio_chain(const float* taps, size_t ntaps, size_t interp, size_t deci, float scale) {
     try {
         return new AudioChain(taps, ntaps, interp, deci, scale);
-    } catch (const Error&) {
+    } catch (const NotFusedShape&) {
     }
     std::vector<std::unique_ptr<Block>> v;
     v.emplace_back(new FftFilterFloat(taps, ntaps));

@@ -133,5 +133,5 @@ def signal_source_complex_fast(samp_rate, freq, amplitude, n):
 def knob(rr, monkeypatch, **opts):
     """Build every block this test creates from now on with the given rr_build_opts overrides (rustradio_amd.build_options
     keys: fir_path, fir_prune, fir_half, fir_cfg, fft_log2f, fft_no_split, fftfloat_complex, fm_full, fm_poly,
-    dstream_no_vmm, host_sync_copies, fir_poly); undone by monkeypatch at the end of the test.  The oracle ignores them."""
+    dstream_no_vmm, fir_poly); undone by monkeypatch at the end of the test.  The oracle ignores them."""
     monkeypatch.setattr(rr, "_build_opts", dict(rr._build_opts, **opts))

@@ -692,14 +692,28 @@ def test_fm_chain_fused_protocol(rr):
     taps = orc.low_pass_complex(2.4e6, 100e3, 12.5e3)       # nsamples 561
     b = rr.FmChain(taps, 1, 6, 1.0)
     x = fm_signal(10_000, 2.4e6, 0.0, 5)
-    assert b.work(x[:100], 50)[:4] == (WAIT_DST, 0, 0, 93)        # ceil(561/6) - 1 outputs needed
-    assert b.work(x[:100], 1000)[:4] == (WAIT_SRC, 100, 0, 461)
+    # an output window smaller than one block's outputs (ceil(561/6) - 1 = 93) does not stop the INPUT side: like the
+    # reference chain (FftFilter writes into its own inner stream) the samples join the pending block
+    assert b.work(x[:100], 50)[:4] == (WAIT_SRC, 100, 0, 461)
     st, c, p, need, out = b.work(x[100:5000], 1000)
     # 100 + 4900 = 5000 = 8 blocks + 512: N1 = 4488, N2 = 748, out 747
     assert (st, c, p, need) == (WAIT_SRC, 4900, 747, 561 - 512)
     st, c, p, need, out = b.work(x[5000:], 100)
     # 512 + 5000 = 9 blocks (5049) + 463; outputs per block ~93.5 -> only one more block fits in 100
     assert st == WAIT_DST and p <= 100 and c == 561 - 512
+    # ... and the window after that is too small for the next block (94 outputs): ONE block goes through the block's
+    # output tail, 40 outputs now, the rest as room appears (WAIT_DST need 1, the resampler's `pending` protocol,
+    # rational_resampler.rs:162-173), no input consumed while outputs are pending
+    pos = 5000 + c
+    st, c, p2, need, o1 = b.work(x[pos:], 40)
+    assert (st, c, p2, need) == (WAIT_DST, 561, 40, 1)
+    assert not b.eof(True)                                        # pending outputs: not EOF even when the source is
+    pos += c
+    st, c, p3, need, o2 = b.work(x[pos:], 40)
+    assert (st, c, p3, need) == (WAIT_DST, 0, 40, 1)
+    st, c, p4, need, o3 = b.work(x[pos:pos + 10], 40)             # the tail is flushed, then the input side goes on
+    assert (st, c, need) == (WAIT_SRC, 10, 551) and p4 in (13, 14)
+    assert b.eof(True)
     with pytest.raises(ValueError):
         rr.FmChain(taps, 0, 6)
     assert rr.FmChain(taps, 1, 100000) is not None              # beyond any tile: composed (test_no_constructor_cliffs_*)
@@ -1025,8 +1039,8 @@ def test_audio_chain_protocol(rr):
     taps = orc.low_pass(200_000.0, 44_100.0, 500.0)           # 963 taps -> nsamples 2048 - 963 = 1085
     b = rr.AudioChain(taps, 48000, 200000, 1.0)                 # 6 : 25
     x = rnd_f(5000, 2)
-    assert b.work(x[:100], 200)[:4] == (WAIT_DST, 0, 0, 261)   # ceil(1085 * 6 / 25) outputs of the first block must fit
-    assert b.work(x[:100], 1000)[:4] == (WAIT_SRC, 100, 0, 985)
+    # a window below one block's outputs (ceil(1085 * 6 / 25) = 261) does not stop the input side (test_fm_chain_fused_protocol)
+    assert b.work(x[:100], 200)[:4] == (WAIT_SRC, 100, 0, 985)
     st, c, p, need, out = b.work(x[100:3000], 1000)             # 3000 = 2 blocks + 830
     assert (st, c, p, need) == (WAIT_SRC, 2900, 521, 1085 - 830)
     with pytest.raises(ValueError):
