@@ -43,6 +43,7 @@ CASES = [
     pytest.param(4_096_000, 5, 1, 0, 40_000, 300_000, id="interp-5:1-small-output-ring-pending-sample"),
     pytest.param(65_536, 2, 3, 0, 4_096, 200_000, id="tiny-rings"),
     pytest.param(4_096_000, 1, 6, 1, 4_096_000, 1_500_000, id="fused-fm-chain"),
+    pytest.param(4_096_000, 1, 5, 1, 64, 100_000, id="fused-fm-chain-output-ring-below-one-block"),
 ]
 
 
