@@ -39,6 +39,25 @@ def test_single_gpu_line():
     assert d["config"]["settle_steps"] >= 40 and d["ms_per_step_from_idle"] > 0 and d["value_from_idle"] > 0
 
 
+def test_default_line_carries_the_metric_chain_and_the_north_star_target():
+    """the metric string names the four-block chain and the north star states ">= 100x" on the FIR + FftFilter
+    pair: both are first-class objects of the driver's line, each with its GPU rate, its roofline fraction and its own
+    single-thread CPU leg (the oracle chain on this host)."""
+    d = _run("--steps", "3", "--warmup", "1", "--cpu-seconds", "4", "--no-dropin")
+    for k in CONTRACT + ("cpu_baseline", "metric_chain", "north_star_target"):
+        assert k in d, k
+    m = d["metric_chain"]
+    assert m["workload_key"] == "full_chain_fused" and "RationalResampler(1:4)" in m["workload"] and m["value"] > 0
+    assert 0 < m["roofline"]["frac"] < 1 and m["roofline"]["peak"] == 8000.0 and m["roofline"]["alg_bytes_per_sample"] == 9.0
+    assert m["cpu_baseline"]["cores"] == 1 and m["cpu_baseline"]["kind"] == "port" and m["cpu_baseline"]["value"] > 0
+    assert abs(m["gpu_over_cpu_1thread_port"] - m["value"] / m["cpu_baseline"]["value"]) < 0.1 * m["gpu_over_cpu_1thread_port"]
+    t = d["north_star_target"]
+    assert t["workload_key"] == "fir_fft_chain" and t["gpu_msamples"] > 0 and t["cpu_msamples_1thread"] > 0
+    assert abs(t["ratio"] - t["gpu_msamples"] / t["cpu_msamples_1thread"]) < 0.1 * t["ratio"]
+    assert t["met"] == (t["ratio"] >= 100.0) and t["met"]
+    assert "configs[1]" in d["config"]["workload"]              # `value` stays the configuration the metric is quoted on
+
+
 def test_two_rank_line():
     d = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu")
     for k in CONTRACT:
