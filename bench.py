@@ -463,7 +463,7 @@ def make_channelizer(dev, rank, world, shared_src, fused=True, rotator=None):
     """BASELINE configs[4]; on N > 1 GPUs rank g runs channel offset f_g through FirFilter::translate(100e6, f_g)
     (src/fir.rs:476-486, SURVEY §8d cfg5: multi.cfg5_translate_hz) — with the library's DEFAULT rotator, the reference's own
     f32 recurrence replayed bit for bit (RR_ROT_REPLAY: on parity for any stream length, one sequential chain per block,
-    ~14 ns per output); `channelizer_model` is the same with the opt-in f64 closed form (parallel, but outside the 1e-5
+    walked ahead of the filter by a host thread at ~2.6 ns per output and copied into the device ring, round 4); `channelizer_model` is the same with the opt-in f64 closed form (parallel, but outside the 1e-5
     parity bar beyond ~1e5 outputs of a stream)."""
     w = Workload()
     f_g = multi.cfg5_translate_hz(rank, world)
@@ -1106,7 +1106,7 @@ def main():
                 wo = WORKLOADS[name](dev, rank, world, shared_src if streamed else (lambda gen, numel, dtype: gen()))
             k = max(3, min(args.steps, 10)) if name != "fir" else 200
             if getattr(wo, "rotator", None) == "replay":
-                k = 3                              # (a step is 1.25e7 sequential rotator phases: ~0.2 s)
+                k = 5                              # (a step is 1.25e7 sequential rotator phases: ~33 ms on the host generator)
             fo = make_fan(wo) if streamed else None
             # (a replay-rotator step is bound by one sequential chain, not by clocks: no settle phase for it)
             u, t, km, ln, du, sm = run_timed(wo, k, 2, dist, stream, fo,

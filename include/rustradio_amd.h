@@ -56,17 +56,20 @@ enum rr_atan2 { RR_ATAN2_EXACT = 0, RR_ATAN2_FAST = 1,
 
 /* Rotator evaluation for FirFilter::translate (src/fir.rs:464-473: `sample *= phase; phase *= step` in f32, never
  * renormalised):
- * RR_ROT_REPLAY = DEFAULT.  The reference's sequential f32 recurrence replayed bit for bit, for any stream length: one
- *                 device lane walks the chain from the phase carried in device memory (~5 ns per output, no host
- *                 involvement).  The chain is data-independent, so the block generates it AHEAD on a side stream — the
- *                 phases of the next window while the filter kernels of this one run — and a call waits only for what
- *                 the chain has not reached.  Back-to-back calls are bounded by the chain (~200 M outputs/s per block).
+ * RR_ROT_REPLAY = DEFAULT.  The reference's sequential f32 recurrence replayed bit for bit, for any stream length.  The
+ *                 chain is data-independent, so it is generated AHEAD of the filter: one host thread per translating
+ *                 block walks it in strict f32 (an x86 core does a step in its multiply + add latency, 2-3 ns) into a
+ *                 pinned ring, and the block copies the phases of the next window into its device ring on a side
+ *                 stream (8 B per output over PCIe) while the filter kernels of this one run; a call waits only for
+ *                 what the chain has not reached.  Back-to-back calls are bounded by the chain.
+ * RR_ROT_REPLAY_DEVICE = the same chain walked by one device lane from the phase carried in device memory (no host
+ *                 thread, no PCIe traffic; 14 ns per output: a lone wave issues every 5-6 clocks).  Bit-identical.
  * RR_ROT_MODEL  = opt-in: closed form phase0 * step^m evaluated in f64 from the SAME f32-rounded phase0 / step
  *                 (parallel, as fast as the filter).  NOT parity-faithful for long streams: it differs from the
  *                 recurrence by its accumulated rounding, <= 1e-7 * n after n outputs (measured 1.5e-8 * n:
  *                 tests/test_gpu_edges_fullsize.py::test_rotator_drift_vs_length), i.e. inside the 1e-5 bar only for
  *                 the first ~1e2 (bound) .. 1e5 (measured) outputs of a stream. */
-enum rr_rotator { RR_ROT_MODEL = 0, RR_ROT_REPLAY = 1 };
+enum rr_rotator { RR_ROT_MODEL = 0, RR_ROT_REPLAY = 1, RR_ROT_REPLAY_DEVICE = 2 };
 
 /* ---- library / device ------------------------------------------------------ */
 int         rr_abi_version(void);
@@ -392,7 +395,7 @@ int rr_fftfilter_dims(const rr_block *b, size_t *fft_size, size_t *nsamples, siz
  * direct-form kernel (introspection for tests and benches; the result of Fir::filter, src/fir.rs:166-197, either way). */
 size_t rr_fir_fft_tile(const rr_block *b);
 /* FirFilter translate (also inside rr_hilbert_fir_create): rotator mode (default RR_ROT_REPLAY, the on-parity one).
- * Switching to REPLAY after outputs were produced walks the chain from the stream start first (once). */
+ * Switching to a REPLAY mode after outputs were produced walks the chain from the stream start first (once). */
 int rr_fir_set_rotator_mode(rr_block *b, int mode);
 
 #ifdef __cplusplus

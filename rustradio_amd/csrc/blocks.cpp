@@ -4,6 +4,7 @@
 // /root/reference/src.  There is no CPU compute path here: every branch that produces
 // samples launches a kernel.
 #include "blocks.hpp"
+#include "rotor_host.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -245,7 +246,10 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
 FirC32::~FirC32() {
     (void)hipSetDevice(device);
     if (rot_stream) {
-        (void)hipStreamSynchronize(rot_stream);
+        (void)hipStreamSynchronize(rot_stream);                      // (every copy out of the host ring has landed)
+        hrot.reset();
+        for (auto& c : copies) (void)hipEventDestroy(c.ev);
+        for (auto& e : free_events) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(rot_stream);
         (void)hipEventDestroy(ev_gen);
         (void)hipEventDestroy(ev_used);
@@ -319,18 +323,62 @@ void FirC32::rotor_generate(size_t upto) {
     // enqueued before the last ev_used record (callers keep upto - consumed <= cap)
     if (upto - rot_gen > ring_cap) throw Error("rotator: look-ahead request beyond the phase ring");   // (callers ask for <= cap / 2 at a time)
     if (used_pending) { RR_HIP(hipStreamWaitEvent(rot_stream, ev_used, 0)); used_pending = false; }
+    // (phases the host generator delivered meanwhile: walk the device chain up to rot_gen without storing)
+    if (dphase_at < rot_gen) launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, 0, (long)(ring_cap - 1), (long)(rot_gen - dphase_at), 0, rot_stream);
     launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, (long)rot_gen, (long)(ring_cap - 1), 0, (long)(upto - rot_gen), rot_stream);
     RR_HIP(hipEventRecord(ev_gen, rot_stream));
+    rot_gen = dphase_at = upto;
+}
+
+// Host-ring ranges whose copy to the device has completed go back to the generator.
+void FirC32::rotor_reap(bool wait_oldest) {
+    while (!copies.empty()) {
+        hipError_t e = wait_oldest ? hipEventSynchronize(copies.front().ev) : hipEventQuery(copies.front().ev);
+        wait_oldest = false;
+        if (e == hipErrorNotReady) break;
+        if (e != hipSuccess) throw Error(std::string("rotator: copy event: ") + hipGetErrorString(e));
+        hrot->release(copies.front().upto);
+        free_events.push_back(copies.front().ev);
+        copies.erase(copies.begin());
+    }
+}
+
+// Phases [rot_gen, upto) from the host generator's pinned ring into d_ring, on rot_stream.  block = false: only if they
+// are all there already (look-ahead).
+bool FirC32::rotor_fetch(size_t upto, bool block) {
+    if (upto <= rot_gen) return true;
+    if (upto - rot_gen > ring_cap) throw Error("rotator: look-ahead request beyond the phase ring");
+    rotor_reap(false);
+    while (hrot->wait_for(upto, block ? 20 : 0) < upto) {
+        if (!block) return false;
+        // the generator stalls on a full ring only while copies of its oldest phases are still in flight
+        if (hrot->gen.load() >= hrot->tail.load() + hrot->cap) rotor_reap(true);
+    }
+    if (used_pending) { RR_HIP(hipStreamWaitEvent(rot_stream, ev_used, 0)); used_pending = false; }
+    for (size_t i = rot_gen; i < upto;) {
+        const size_t hs = i & hrot->mask, ds = i & (ring_cap - 1);
+        const size_t n = std::min({upto - i, hrot->cap - hs, ring_cap - ds});
+        RR_HIP(hipMemcpyAsync(d_ring.p + ds, hrot->ring + hs, n * sizeof(cf), hipMemcpyHostToDevice, rot_stream));
+        i += n;
+    }
+    RR_HIP(hipEventRecord(ev_gen, rot_stream));
+    hipEvent_t ev;
+    if (free_events.empty()) RR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else { ev = free_events.back(); free_events.pop_back(); }
+    RR_HIP(hipEventRecord(ev, rot_stream));
+    copies.push_back({ev, upto});
     rot_gen = upto;
+    return true;
 }
 
 void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
     if (!rot_on || out_n == 0) return;
-    if (rot_mode != RR_ROT_REPLAY) {
+    if (rot_mode == RR_ROT_MODEL) {
         launch_rotate_model(out, (long)out_n, ph0x, ph0y, stx, sty, (long)n_rot, s);
         n_rot += out_n;
         return;
     }
+    const bool host = rot_mode == RR_ROT_REPLAY;
     if (!rot_stream) {
         RR_HIP(hipStreamCreateWithFlags(&rot_stream, hipStreamNonBlocking));
         RR_HIP(hipEventCreateWithFlags(&ev_gen, hipEventDisableTiming));
@@ -343,17 +391,15 @@ void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
         const cf p0 = mkcf(ph0x, ph0y);
         RR_HIP(hipMemcpyAsync(d_phase.p, &p0, sizeof(cf), hipMemcpyHostToDevice, rot_stream));
         RR_HIP(hipStreamSynchronize(rot_stream));                    // (p0 is a stack variable; once per block)
-        // (mode switched to REPLAY after outputs were already rotated: walk the chain up to here without storing)
-        if (n_rot) launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, 0, (long)(ring_cap - 1), (long)n_rot, 0, rot_stream);
-        rot_gen = n_rot;
+        dphase_at = 0;
+        rot_gen = n_rot;                                             // (outputs rotated by the model so far are skipped below)
     }
-    if (rot_gen < n_rot) {
-        // REPLAY -> MODEL -> REPLAY: the model advanced n_rot past what the chain has generated.  Walk the carried phase
-        // on to n_rot without storing (the ring holds nothing this call can use), so that the next generate starts there
-        // and never spans more than a chunk.
-        launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, 0, (long)(ring_cap - 1), (long)(n_rot - rot_gen), 0, rot_stream);
-        rot_gen = n_rot;
-    }
+    if (host && !hrot) hrot.reset(new HostRotor(ph0x, ph0y, stx, sty, 2 * ring_cap));   // (starts walking from phase 0 at once)
+    if (rot_gen < n_rot) rot_gen = n_rot;
+    // REPLAY -> MODEL -> REPLAY, or REPLAY chosen after outputs were produced: nothing below n_rot is needed any more — the
+    // host generator walks through those phases on its own (they are overwritten in its ring), the device chain skips to
+    // rot_gen without storing (rotor_generate); neither ever spans more than a chunk of the ring.
+    if (host) hrot->release(std::min(n_rot, rot_gen > ring_cap ? rot_gen - ring_cap : 0));
     // one event remembers the ring's readers: a call on another HIP stream first waits for the previous stream's rotate
     // kernels, so that the record below still covers every reader enqueued so far
     if (used_pending && used_stream != s) RR_HIP(hipStreamWaitEvent(s, ev_used, 0));
@@ -361,7 +407,8 @@ void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
     const size_t half = ring_cap / 2;
     for (size_t done = 0; done < out_n;) {
         const size_t chunk = std::min(out_n - done, half);
-        rotor_generate(n_rot + done + chunk);                        // (no-op when the look-ahead already covers it)
+        if (host) rotor_fetch(n_rot + done + chunk, true);           // (no-op when the look-ahead already covers it)
+        else rotor_generate(n_rot + done + chunk);
         RR_HIP(hipStreamWaitEvent(s, ev_gen, 0));
         launch_rotate_table(out + done, (long)chunk, d_ring.p, (long)((n_rot + done) & (ring_cap - 1)), (long)(ring_cap - 1), s);
         RR_HIP(hipEventRecord(ev_used, s));
@@ -369,7 +416,14 @@ void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
         done += chunk;
     }
     n_rot += out_n;
-    rotor_generate(n_rot + std::min(out_n, half));                   // look-ahead: the next window of the same size
+    // look-ahead: the next window of the same size (host mode: as far as the generator has got, without waiting)
+    if (host) {
+        const size_t want = n_rot + std::min(out_n, half);
+        const size_t got = (size_t)std::min<uint64_t>(want, hrot->gen.load(std::memory_order_acquire));
+        if (got > rot_gen) rotor_fetch(got, false);
+    } else {
+        rotor_generate(n_rot + std::min(out_n, half));
+    }
 }
 
 // ---- Hilbert -> FirFilter<Complex> as one composite decimating FIR ------------------------------------------

@@ -109,6 +109,15 @@ struct FirC32 : Block {
     bool used_pending = false;
     hipStream_t used_stream = nullptr;            // stream of the last ev_used record
     void rotor_generate(size_t upto);             // enqueue the chain up to phase index `upto` (exclusive) on rot_stream
+    // RR_ROT_REPLAY (default since round 4): the same chain walked by a HOST thread of this block (rotor_host.cpp) into a
+    // pinned ring and copied ahead into d_ring on rot_stream; RR_ROT_REPLAY_DEVICE keeps the one-lane kernel.
+    std::unique_ptr<struct HostRotor> hrot;
+    size_t dphase_at = 0;                         // phase index d_phase holds (the device chain's position)
+    struct CopyDone { hipEvent_t ev; size_t upto; };
+    std::vector<CopyDone> copies;                 // host-ring ranges in flight to the device, oldest first
+    std::vector<hipEvent_t> free_events;
+    bool rotor_fetch(size_t upto, bool block);    // host-generated phases [rot_gen, upto) -> d_ring; false: not generated yet
+    void rotor_reap(bool wait_oldest);
     std::vector<std::complex<float>> h_taps;      // caller-order taps after the translate pre-rotation
     // allow_fft = false: bookkeeping / direct form only (HilbertFir's inner object)
     FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq, bool allow_fft = true);

@@ -39,12 +39,16 @@ def poll():
             return
 th = threading.Thread(target=poll); th.start()
 t0 = time.time()
+calls = 0
 while time.time() - t0 < 6:
     for _ in range(200):
         blk2 = blk
         blk2.work_dev(x.data_ptr(), n, y.data_ptr(), cap)
     torch.cuda.synchronize()
+    calls += 200
+wall = time.time() - t0
 stop = True; th.join()
+print(f"{which}: {wall / calls * 1e3:.4f} ms per call over {calls} back-to-back calls (lib: {os.environ.get('RR_LIB_PATH', 'product')})")
 print(f"{which}: idle-first then loaded samples")
 for s in samples[:2] + samples[-4:]:
     print("  ", s[:300])

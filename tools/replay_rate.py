@@ -37,9 +37,9 @@ def run(n, rotator, calls=6, pause_s=0.0):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    for name, mode in (("replay", rr.ROT_REPLAY), ("model", rr.ROT_MODEL)):
-        t = run(n, mode)
-        print(f"{name:7s} back to back : first call {t[0] * 1e3:8.3f} ms, later {np.median(t[1:]) * 1e3:8.3f} ms per {n} outputs "
+    for name, mode in (("replay (host generator)", rr.ROT_REPLAY), ("replay_device (one lane)", rr.ROT_REPLAY_DEVICE), ("model", rr.ROT_MODEL)):
+        t = run(n, mode, calls=10)
+        print(f"{name:26s} back to back : first call {t[0] * 1e3:8.3f} ms, later {np.median(t[1:]) * 1e3:8.3f} ms per {n} outputs "
               f"= {np.median(t[1:]) / n * 1e9:6.2f} ns/output")
     per = np.median(run(n, rr.ROT_REPLAY)[1:])
     t = run(n, rr.ROT_REPLAY, pause_s=1.3 * per)
