@@ -1027,8 +1027,12 @@ def main():
                     print(f"bench.py: rr_fanout_* failed its self-check on this group ({abi_check['why']}); "
                           "the fan-out runs through torch.distributed instead", file=sys.stderr)
             if abi_check["ok"]:
-                return tag(multi.AbiFanout(rr, dist, rank, k * step_elems, sdtype, dev, produce,
-                                           mesh=args.fanout_algo == "scatter_allgather"))
+                algo, cal = args.fanout_algo, None
+                if algo == "auto":               # timed on this group's fabric at this tile size, like the torch.distributed form
+                    algo, cal = multi.calibrate_abi_fanout(rr, dist, rank, k * step_elems, sdtype, dev)
+                f = tag(multi.AbiFanout(rr, dist, rank, k * step_elems, sdtype, dev, produce, mesh=algo == "scatter_allgather"))
+                f.calibration = cal
+                return f
             args.fanout = "torch"
         try:
             return tag(multi.TileFanout(dist, rank, k * step_elems, sdtype, dev, produce, algo=args.fanout_algo))
@@ -1037,7 +1041,10 @@ def main():
                 print(f"bench.py: fan-out algorithm {args.fanout_algo!r} unavailable ({e}); using bcast", file=sys.stderr)
             return tag(multi.TileFanout(dist, rank, k * step_elems, sdtype, dev, produce, algo="bcast"))
 
-    def collective_report(fan_, kms_, steps_, wall_ms, kernel_ms):
+    def src_fmt(wl):
+        return "u8 I/Q bytes (2 B per sample, the RTL-SDR wire format)" if wl.in_mult == 2 else "Complex<f32> (8 B per sample)"
+
+    def collective_report(fan_, kms_, steps_, wall_ms, kernel_ms, fmt):
         bms_sum, bn = fan_.broadcast_ms()
         bms = bms_sum / max(bn, 1)
         kstep = kernel_ms
@@ -1048,6 +1055,12 @@ def main():
                                       "rr_fanout_* verified on this group (known tiles, both algorithms, checksums on every rank)"
                                       if abi_check["ok"] else f"rr_fanout_* FAILED its self-check ({abi_check['why']}): torch.distributed fan-out used"),
                 "algorithm": getattr(fan_, "algo", "bcast"), "calibration_ms_per_tile": getattr(fan_, "calibration", None),
+                "algorithm_choice": (f"--fanout-algo {args.fanout_algo}" if args.fanout_algo != "auto" else
+                                     "both algorithms timed on this group's fabric at this tile size before the run "
+                                     "(calibration_ms_per_tile, no compute alongside): the faster one"
+                                     if getattr(fan_, "calibration", None) else
+                                     "one broadcast per tile (the only form this backend moves device tensors with)"),
+                "source_format": fmt,
                 "ranks": dist.get_world_size(),
                 "devices_visible": ndev, "tile_bytes": fan_.bytes_per_tile, "tile_steps": ks, "broadcasts_timed": bn,
                 "broadcast_ms_per_tile": round(bms, 4), "broadcast_ms_per_step": round(bstep, 4),
@@ -1133,7 +1146,7 @@ def main():
                 cpu_legs[name] = cpu_1thread(wo, max(2.0, args.cpu_seconds / 2))
             if world > 1 and streamed:
                 others[name]["source"] = "streamed: rank 0 broadcasts every step's tile (double-buffered) inside the timed region"
-                others[name]["collective"] = collective_report(fo, km, k, ta / k * 1e3, avg_s * 1e3)
+                others[name]["collective"] = collective_report(fo, km, k, ta / k * 1e3, avg_s * 1e3, src_fmt(wo))
             elif world > 1:
                 others[name]["source"] = "resident on every rank (a 400 MB f32 tile per 0.14 ms step cannot stream over xGMI)"
             del fo
@@ -1204,7 +1217,7 @@ def main():
             line["scale_anchor"] = anchor
             line["scaling_efficiency_vs_anchor"] = (round(value / (world * anchor["n1_value"]), 4)
                                                     if anchor and anchor["n1_value"] > 0 else None)
-            line["collective"] = collective_report(fan, kms, args.steps, dt / args.steps * 1e3, avg_kernel_s * 1e3)
+            line["collective"] = collective_report(fan, kms, args.steps, dt / args.steps * 1e3, avg_kernel_s * 1e3, src_fmt(w))
             line["source_broadcast_gbs"] = line["collective"]["source_broadcast_gbs"]
             line["resident_source"] = resident
             line["fanout_efficiency"] = round(value / resident["value"], 4) if resident and resident["value"] > 0 else None
@@ -1216,6 +1229,21 @@ def main():
         # The metric string names the FOUR-block chain and the north star states its ">= 100x" target on the FIR + FftFilter
         # pair; `value` stays configs[1] (the configuration the metric is quoted on).  Both chains, with their own roofline
         # and their own CPU leg, as first-class objects of the line:
+        # The 1 -> 8 curve has never been measured (no node with more than one GPU has run this code): what stands in for it is
+        # a PREDICTION, regenerated on every run from THIS run's measured configs[3] step (DESIGN.md §6 prints it
+        # through tools/fanout_table.py).  No scaling claim is made anywhere.
+        fm = others.get("fm_multi")
+        if world == 1 and fm:
+            ks = max(1, args.tile_steps)
+            comp = fm["ms_per_step"] * ks
+            tile_f32, tile_u8 = ks * 19_200_000, ks * 4_800_000
+            line["multi_gpu_prediction"] = {
+                "what": "PREDICTED weak-scaling efficiency of configs[3] (32 channels per GPU, shared source fanned out per tile of "
+                        f"{ks} steps, overlapped with the compute on the previous tile) from this run's measured step; never measured",
+                "measured_fm_multi_ms_per_step": fm["ms_per_step"], "tile_steps": ks,
+                "assumptions": {"xgmi_link_gbs": multi.XGMI_LINK_GBS, "collective_latency_ms": multi.COLLECTIVE_LATENCY_MS},
+                "complex_f32_source": {"tile_bytes": tile_f32, **{str(n): multi.predict_fanout(n, tile_f32, comp) for n in (2, 4, 8)}},
+                "u8_source": {"tile_bytes": tile_u8, **{str(n): multi.predict_fanout(n, tile_u8, comp) for n in (2, 4, 8)}}}
         fc = others.get("full_chain_fused")
         if fc and "full_chain_fused" in cpu_legs:
             cb = cpu_legs["full_chain_fused"]

@@ -399,7 +399,11 @@ void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
     // REPLAY -> MODEL -> REPLAY, or REPLAY chosen after outputs were produced: nothing below n_rot is needed any more — the
     // host generator walks through those phases on its own (they are overwritten in its ring), the device chain skips to
     // rot_gen without storing (rotor_generate); neither ever spans more than a chunk of the ring.
-    if (host) hrot->release(std::min(n_rot, rot_gen > ring_cap ? rot_gen - ring_cap : 0));
+    if (host) {
+        // (only once no copy out of the host ring is in flight: a slot handed back early could be overwritten under a copy)
+        rotor_reap(false);
+        if (copies.empty()) hrot->release(rot_gen);
+    }
     // one event remembers the ring's readers: a call on another HIP stream first waits for the previous stream's rotate
     // kernels, so that the record below still covers every reader enqueued so far
     if (used_pending && used_stream != s) RR_HIP(hipStreamWaitEvent(s, ev_used, 0));
@@ -1177,6 +1181,11 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
     : Block(u8 ? "RtlSdrDecode>Tee>N x (FftFilter>RationalResampler>QuadratureDemod)" : "Tee>N x (FftFilter>RationalResampler>QuadratureDemod)",
             u8 ? 1 : 8, 4), C(nchan), iq8(u8) {
     if (nchan == 0 || nchan > 4096) throw Error("FmMulti: channel count must be 1..4096");
+    // The shared-forward kernels run on tiles of at most 4096 points, which yield 4097 - ntaps filtered samples each: towards
+    // 4094 taps a tile is all overlap (tools/multi_taps_probe.py, 32 channels 1:6, ms per 2.4e6 samples: 2000 taps 0.08, 3000
+    // taps 0.55, 3800 taps 1.80) while one fused chain per channel on 8192-point split tiles (compose.cpp Parallel) costs
+    // 1.26 ms at 5000 taps and less below.  The crossover is where a tile still yields ~768 samples.
+    if (ntaps > 4097 - 768) throw NotFusedShape("FmMulti: beyond 3329 taps one fused chain per channel on larger tiles is cheaper");
     chain.reset(new FmChain(taps, ntaps, interp, deci, g, m, false, 12));   // bookkeeping, carry state, twiddles; 3-pass tiles
     const int lg = chain->f->log2f;
     if (!fm_multi_supported(lg)) throw NotFusedShape("FmMulti: at most 4094 taps (3-pass tiles)");

@@ -405,7 +405,11 @@ struct Series : Block {
 // N blocks of one shape on ONE shared input window, N output windows (the reference's Tee fan-out + N chains).
 struct Parallel : Block {
     std::vector<std::unique_ptr<Block>> ch;
+    static constexpr size_t POOL = 4;             // streams the channels are spread over inside one work() call
+    hipStream_t pool[POOL] = {};
+    hipEvent_t joined[POOL] = {}, forked = nullptr;
     Parallel(const char* name, std::vector<std::unique_ptr<Block>> channels);
+    ~Parallel() override;
     size_t out_windows() const override { return ch.size(); }
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
     int work_host(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*) override;

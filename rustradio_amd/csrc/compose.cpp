@@ -119,16 +119,47 @@ int Parallel::work_dev(const void* in, size_t in_len, void* out, size_t out_cap,
                        size_t* need, hipStream_t s) {
     *consumed = *produced = *need = 0;
     int st0 = RR_AGAIN;
+    // The channels are independent chains on one shared window: they go out on a small pool of streams forked from and
+    // joined back into the caller's stream, so that a chain whose launch does not fill the chip (short windows, the single
+    // workgroup tail of a launch) overlaps with its neighbours instead of queueing behind them.
+    const size_t NP = std::min<size_t>(ch.size(), POOL);
+    if (NP > 1 && !pool[0]) {
+        for (size_t i = 0; i < POOL; i++) {
+            RR_HIP(hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking));
+            RR_HIP(hipEventCreateWithFlags(&joined[i], hipEventDisableTiming));
+        }
+        RR_HIP(hipEventCreateWithFlags(&forked, hipEventDisableTiming));
+    }
     prof_begin(s);
+    if (NP > 1) {
+        RR_HIP(hipEventRecord(forked, s));
+        for (size_t i = 0; i < NP; i++) RR_HIP(hipStreamWaitEvent(pool[i], forked, 0));
+    }
     for (size_t c = 0; c < ch.size(); c++) {
         size_t cc = 0, pp = 0, nn = 0;
-        const int st = ch[c]->work_dev(in, in_len, static_cast<unsigned char*>(out) + c * out_cap * out_es, out_cap, &cc, &pp, &nn, s);
+        const int st = ch[c]->work_dev(in, in_len, static_cast<unsigned char*>(out) + c * out_cap * out_es, out_cap, &cc, &pp, &nn,
+                                       NP > 1 ? pool[c % NP] : s);
         if (c == 0) { st0 = st; *consumed = cc; *produced = pp; *need = nn; }
         else if (st != st0 || cc != *consumed || pp != *produced || nn != *need)
             throw Error("Parallel: channels of one shape disagree on the window protocol");
     }
+    if (NP > 1) {
+        for (size_t i = 0; i < NP; i++) {
+            RR_HIP(hipEventRecord(joined[i], pool[i]));
+            RR_HIP(hipStreamWaitEvent(s, joined[i], 0));
+        }
+    }
     prof_end(s);
     return st0;
+}
+
+Parallel::~Parallel() {
+    (void)hipSetDevice(device);
+    for (size_t i = 0; i < POOL; i++) {
+        if (pool[i]) { (void)hipStreamSynchronize(pool[i]); (void)hipStreamDestroy(pool[i]); }
+        if (joined[i]) (void)hipEventDestroy(joined[i]);
+    }
+    if (forked) (void)hipEventDestroy(forked);
 }
 
 int Parallel::work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed, size_t* produced,

@@ -340,6 +340,42 @@ class AbiFanout:
         return self.fan.stats()
 
 
+def calibrate_abi_fanout(rr, dist, rank, tile_elems, dtype, device, tiles=6):
+    """Time both algorithms of `rr_fanout_*` on THIS group's fabric at the job's tile size, no compute alongside (what
+    TileFanout.calibrate does for the torch.distributed form) -> (the faster algorithm, {algorithm: ms per tile}); identical
+    on every rank (MAX over ranks).  Any failure of one algorithm leaves the other; of both: ("bcast", None)."""
+    res = {}
+    stream = torch.cuda.current_stream()
+    for name, mesh in (("bcast", False), ("scatter_allgather", True)):
+        ok = 1
+        dt = 0.0
+        try:
+            fan = AbiFanout(rr, dist, rank, tile_elems, dtype, device, lambda t, out: None, mesh=mesh, timing=False)
+            fan.prefetch(0)
+            for t in range(tiles + 2):                           # two untimed: connection set-up
+                if t == 2:
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                if t + 1 < tiles + 2:
+                    fan.prefetch(t + 1)
+                fan.acquire(t, stream)
+                fan.release(t, stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            del fan
+        except Exception:                                        # noqa: BLE001 — the other algorithm still counts
+            ok = 0
+        v = torch.tensor([dt if ok else 1e9, float(ok)], dtype=torch.float64, device=device)
+        dist.all_reduce(v[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(v[1:], op=dist.ReduceOp.MIN)
+        if v[1].item() > 0:
+            res[name] = float(v[0].item()) / tiles * 1e3
+    if not res:
+        return "bcast", None
+    return min(res, key=lambda a: res[a]), {k: round(x, 4) for k, x in res.items()}
+
+
 def verify_abi_fanout(rr, dist, rank, device, nbytes=(1 << 20) + 13, ntiles=3):
     """First contact of `rr_fanout_*` with a group of more than one GPU (it has only ever run on one rank: DESIGN §6):
     before a measurement relies on it, fan a few small tiles of known content out with both algorithms and compare a

@@ -56,6 +56,17 @@ def test_default_line_carries_the_metric_chain_and_the_north_star_target():
     assert abs(t["ratio"] - t["gpu_msamples"] / t["cpu_msamples_1thread"]) < 0.1 * t["ratio"]
     assert t["met"] == (t["ratio"] >= 100.0) and t["met"]
     assert "configs[1]" in d["config"]["workload"]              # `value` stays the configuration the metric is quoted on
+    # the multi-GPU prediction is regenerated from THIS run's measured configs[3] step, not from a constant
+    from rustradio_amd import multi
+    pr = d["multi_gpu_prediction"]
+    step = d["others"]["fm_multi"]["ms_per_step"]
+    assert pr["measured_fm_multi_ms_per_step"] == step and pr["tile_steps"] == 4 and "never measured" in pr["what"]
+    for key, tile in (("complex_f32_source", 4 * 19_200_000), ("u8_source", 4 * 4_800_000)):
+        assert pr[key]["tile_bytes"] == tile
+        for n in (2, 4, 8):
+            assert pr[key][str(n)] == multi.predict_fanout(n, tile, 4 * step)
+    assert pr["u8_source"]["8"]["bcast"]["efficiency"] == 1.0                     # bytes hide behind the compute at every N
+    assert pr["complex_f32_source"]["8"]["bcast"]["efficiency"] < 0.6 < pr["complex_f32_source"]["8"]["scatter_allgather"]["efficiency"]
 
 
 def test_two_rank_line():

@@ -266,6 +266,31 @@ def test_translate_default_mode_long_decimating_stream(rr):
     print("opt-in RR_ROT_MODEL after 1.1e7 outputs: max-normalised error", max_norm_err(ym[-100_000:], yo[-100_000:]))
 
 
+def test_device_replay_mode_is_the_same_chain(rr):
+    """RR_ROT_REPLAY_DEVICE (the one-lane kernel, round 3's default) and RR_ROT_REPLAY (the host generator, round 4's) are
+    the same f32 recurrence bit for bit — through reference-sized windows over 3e6 outputs, and switching between the two
+    in the middle of a stream in both directions (the device chain skips what the host delivered and vice versa)."""
+    fs, f = 1.0e6, -234_567.8
+    one = np.ones(1, np.complex64)
+    n = 3_000_000
+    x = rnd_c(n, 79)
+    yo = run_chain([orc.FirFilter(one, translate=(fs, f))], x)
+    yd = run_chain([rr.FirFilter(one, translate=(fs, f), rotator=rr.ROT_REPLAY_DEVICE)], x)
+    assert np.array_equal(yd.view(np.uint32), yo.view(np.uint32))
+    b = rr.FirFilter(one, translate=(fs, f))
+    outs, step = [], 100_000
+    for i, a in enumerate(range(0, n, step)):
+        if i % 7 == 3:
+            b.set_rotator_mode(rr.ROT_REPLAY_DEVICE)
+        if i % 7 == 5:
+            b.set_rotator_mode(rr.ROT_REPLAY)
+        st, c, p, need, out = b.work(x[a:a + step], step)
+        assert c == p == step
+        outs.append(out)
+    y = np.concatenate(outs)
+    assert np.array_equal(y.view(np.uint32), yo.view(np.uint32)), int(np.flatnonzero(y != yo)[0])
+
+
 def test_rotator_drift_vs_length(rr):
     """FirFilter::translate's rotator (fir.rs:464-473) is an un-renormalised f32 recurrence.  The opt-in RR_ROT_MODEL
     evaluates phase0 * step^m in f64 from the same f32-rounded phase0 / step: it reproduces the recurrence's systematic
