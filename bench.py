@@ -126,6 +126,7 @@ class Workload:
     dominant_flops_per_unit = 0.0  # NOMINAL flops per sample it consumes: the REFERENCE's algorithm (5 N log2 N per N-point transform)
     dominant_flops_exec_per_unit = None   # flops of the algorithm the GPU kernel actually EXECUTES per sample (None: the same count)
     kernel = ""                    # name of the dominant kernel (rocprofv3 --kernel-trace shows it)
+    bound_note = None              # when neither roofline is what the kernel is short of: what is, and the evidence
 
     def step(self, stream, src_ptr=None):
         """one pass over the resident batch (or the broadcast tile at src_ptr); returns input samples consumed by the first block"""
@@ -144,6 +145,10 @@ class Workload:
 
 
 chan_taps = multi.channel_taps
+CHAIN_BOUND_NOTE = ("neither roofline binds this kernel: fed RTL-SDR bytes (a third of the input traffic) it is only 12 % faster, its VALU is 37 % "
+                    "busy and the package draws 1182 W of 1400 at full clock; three waves per SIMD are bound by instruction ISSUE (giving its "
+                    "waiting waves redundant work made it 11 % slower, DESIGN.md 4.1d round 4).  Both fractions are reported: "
+                    "dominant_kernel_hbm_frac and dominant_kernel_executed_fp32_frac")
 
 
 def fft_flops(n):
@@ -297,6 +302,7 @@ def make_full_chain(dev, rank, world, shared_src, fused=False):
         w.caps = [oc]
         w.dominant, w.dominant_bytes_per_unit = 0, 9.0
         w.kernel = "k_fm_chain*"
+        w.bound_note = CHAIN_BOUND_NOTE
     else:
         w.name = ("full chain FirFilter(127)->FftFilter(401)->RationalResampler(1:4)->QuadratureDemod, four blocks with "
                   "device-resident intermediates, 10 Msps Complex<f32>, 100,000,000 samples/step")
@@ -330,6 +336,7 @@ def make_fm_chain(dev, rank, world, shared_src, fused=True):
         w.caps = [n // 6 + 1024]
         w.dominant_bytes_per_unit = 8.0 + 4.0 / 6.0
         w.kernel = "k_fm_chain*"
+        w.bound_note = CHAIN_BOUND_NOTE
     else:
         w.blocks = [rr.FftFilter(taps), rr.RationalResampler(1, 6, np.complex64), rr.QuadratureDemod(1.0, rr.ATAN2_EXACT)]
         w.bufs = [src,
@@ -370,6 +377,7 @@ def make_rtl_fm_chain(dev, rank, world, shared_src):
     w.dominant = 0
     w.dominant_flops_per_unit = (2 * fft_flops(1024) + 6 * 1024) / 561 + 40.0 / 6.0
     w.kernel = "k_fm_chain*"
+    w.bound_note = CHAIN_BOUND_NOTE
     w.cpu = ("rtl_fm_chain", taps)
     return w
 
@@ -1142,6 +1150,8 @@ def main():
                             "dominant_kernel_nominal_reference_fp32_frac": None if fl is None else round(fl / FP32_PEAK_TFLOPS, 4)}
             if getattr(wo, "rotator", None):
                 others[name]["rotator"] = wo.rotator
+            if wo.bound_note:
+                others[name]["bound_note"] = wo.bound_note
             if world == 1 and not args.no_cpu and name in ("full_chain_fused", "fir_fft_chain"):
                 cpu_legs[name] = cpu_1thread(wo, max(2.0, args.cpu_seconds / 2))
             if world > 1 and streamed:
@@ -1172,6 +1182,8 @@ def main():
                 "alg_bytes_per_launch": alg_bytes_per_launch,
                 "executed_flops_per_launch": exec_flops_per_launch, "nominal_reference_flops_per_launch": alg_flops_per_launch,
                 "traffic": traffic, "traffic_note": tnote}
+        if w.bound_note:
+            roof["bound_note"] = w.bound_note
         if w.bound == "hbm":
             roof.update({"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                          "frac_counts": "ALGORITHMIC bytes (SURVEY §8d: compulsory input + output of the chain) per launch / mean kernel duration / 8 TB/s",
@@ -1251,7 +1263,7 @@ def main():
                 "workload": fc["workload"], "workload_key": "full_chain_fused", "value": fc["msamples_per_s"], "unit": "Msamples/s",
                 "ms_per_step": fc["ms_per_step"],
                 "roofline": {"kernel": fc["dominant_kernel"], "avg_kernel_ms": fc["dominant_kernel_ms"],
-                             "bound": fc["bound"], "achieved": fc["dominant_kernel_alg_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "bound": fc["bound"], "bound_note": fc.get("bound_note"), "achieved": fc["dominant_kernel_alg_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fc["dominant_kernel_hbm_frac"],
                              "alg_bytes_per_sample": 9.0,
                              "executed_vector_fp32_tflops": fc["dominant_kernel_executed_tflops"],

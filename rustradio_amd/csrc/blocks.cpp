@@ -847,7 +847,7 @@ void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOu
         launch_carry(src, carry, s);
         return;
     }
-    if (nsub && alt_log2f && n_out < small_window_outputs()) launch_fftfilt_os(alt_log2f, src, out, n_out, (int)L, d_tw_alt.p, d_hpos_alt.p, s, carry);
+    if (nsub && alt_log2f && alt_wins(n_out)) launch_fftfilt_os(alt_log2f, src, out, n_out, (int)L, d_tw_alt.p, d_hpos_alt.p, s, carry);
     else if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s, carry);
     else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s, carry);
 }
@@ -1051,7 +1051,7 @@ int FmChain::work_blocks(const void* in, size_t in_len, float* out, size_t, size
         // (and below ~1.2 M samples the plain 2048-point tiles — more, smaller workgroups — beat the half-size inverse,
         //  which finishes two tiles per workgroup: 512 k samples 15.4 against 18.8 us)
         const bool use_half = half_ok && (!window_aware || n_y >= chip_units(1200000));
-        const bool use_alt = f->nsub && f->alt_log2f && window_aware && (long)n_y < f->small_window_outputs() &&
+        const bool use_alt = f->nsub && f->alt_log2f && window_aware && f->alt_wins((long)n_y) &&
                              (int64_t)((D + I - 1) / I) < (int64_t)(((size_t)1 << f->alt_log2f) - f->L + 1);
         prof_begin(s);
         if (use_poly && packed)

@@ -167,8 +167,16 @@ struct FftFilter : Block {
     int alt_log2f = 0;
     DevBuf<cf> d_tw_alt, d_hpos_alt;
     // below ~520 split tiles (two resident workgroups per CU) the alternate tile wins
-    long small_window_outputs() const {
-        return (520L * (long)device_cu_count() + 128) / 256 * (long)(((size_t)1 << log2f) - L + 1);   // (520 on the 256 CUs it was measured on)
+    // Does the plain 4096-point tile beat the split tile on a window of n_out filtered samples?  Fitted costs in us on the
+    // 256 CUs they were measured on (tools/call_overhead.py, 2467 taps, 512 k / 2 M / 8 M samples: plain 16.8 / 25.3 / 64.3,
+    // split 26.2 / 30.3 / 57.4): plain 13 + 0.0104 per tile, split max(25 + 0.015, 0.041) per tile — so the answer depends
+    // on how many MORE tiles the plain form needs (3.5x at 2467 taps, 6.3x at 3330: round 3 compared tile counts of the
+    // split form only, and a 3330-tap chain on a 2.4 M-sample window ran 1.8x slower on the plain tile it was handed).
+    bool alt_wins(long n_out) const {
+        const double cu = (double)device_cu_count() / 256.0;
+        const double na = (double)n_out / (double)(((size_t)1 << alt_log2f) - L + 1) / cu;
+        const double ns = (double)n_out / (double)(((size_t)1 << log2f) - L + 1) / cu;
+        return 13.0 + 0.0104 * na < std::max(25.0 + 0.015 * ns, 0.041 * ns);
     }
     // more than 16383 taps: overlap-save frames of M = 2^m >= 2 L points through the any-size transform (AnyFft)
     std::unique_ptr<AnyFft> big;
