@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 1
+#define RR_ABI_VERSION 2   /* 2 (round 4): rr_dstream_close / _closed / _wait / _id, RR_ROT_REPLAY_DEVICE; rr_build_opts.host_sync_copies removed */
 
 /* Complex<f32>: interleaved [re, im], 8 bytes (src/lib.rs:268-271). */
 typedef struct { float re, im; } rr_c32;

@@ -397,3 +397,60 @@ def test_fuzz_compositions_and_fastfm(rr, seed):
                 dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
                 dd = np.minimum(dd, 2 * np.pi - dd)
                 assert np.all(dd <= bound[:len(dd)])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_fused_chains_any_output_window(rr, seed):
+    """Round 4: the fused chains on output windows of ANY size — random tap counts, ratios (interpolating ones included) and
+    ring sizes down to a handful of slots, where round 3's blocks waited for ever.  Whole-stream output
+    against the oracle's separate blocks; the run must end (run_chain raises otherwise)."""
+    from test_gpu_trickle import _drive
+    rng = np.random.default_rng(17000 + seed)
+    L = int(rng.choice([7, 63, 300, 463, 1200, 2467]))
+    I, D = int(rng.integers(1, 6)), int(rng.integers(1, 9))
+    n = int(rng.integers(2 * L + 500, 2 * L + 30_000))
+    out_cap = int(rng.choice([1, 2, 5, 17, 64, 200, 1500]))
+    in_cap = int(rng.choice([512_000, 2 * L + int(rng.integers(10, 5000))]))
+    x = _c(rng, n)
+    taps = _c(rng, L) / max(1, L // 4)
+    kind = seed % 4
+    if kind in (0, 1):                               # FmChain, Complex or RTL-SDR byte input
+        if kind == 1:
+            xb = rng.integers(0, 256, 2 * n, dtype=np.uint8)
+            yo = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(I, D), orc.QuadratureDemod(0.8)], xb)
+            ro = run_chain([orc.RtlSdrDecode(), orc.FftFilter(taps), orc.RationalResampler(I, D)], xb)
+            yg, _ = _drive(rr.FmChainU8(taps, I, D, 0.8), xb, 2 * in_cap, out_cap)
+        else:
+            yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D), orc.QuadratureDemod(0.8)], x)
+            ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(I, D)], x)
+            yg, _ = _drive(rr.FmChain(taps, I, D, 0.8), x, in_cap, out_cap)
+        assert yg.shape[1] == len(yo)
+        if len(yo):
+            eps = TOL * float(np.max(np.abs(ro)))
+            mag = np.abs(ro.astype(np.complex128))
+            bound = 0.8 * (TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30))
+            dd = np.abs(yg[0].astype(np.float64) - yo.astype(np.float64))
+            dd = np.minimum(dd, 0.8 * 2 * np.pi - dd)
+            assert np.all(dd <= bound[:len(dd)])
+    elif kind == 2:                                  # the audio stage
+        xf = rng.uniform(-1, 1, n).astype(np.float32)
+        tf = (rng.uniform(-1, 1, L) / max(1, L // 8)).astype(np.float32)
+        yo = run_chain([orc.FftFilterFloat(tf), orc.RationalResampler(I, D, np.float32), orc.MultiplyConst(0.5)], xf)
+        yg, _ = _drive(rr.AudioChain(tf, I, D, 0.5), xf, 2 * in_cap, out_cap)
+        assert yg.shape[1] == len(yo)
+        if len(yo):
+            assert max_norm_err(yg[0], yo) <= TOL
+    else:                                            # three channels on one window
+        t3 = np.stack([taps, np.conj(taps), taps[::-1].copy()])
+        yg, _ = _drive(rr.FmMulti(t3, I, D, 1.0), x, in_cap, out_cap)
+        for c in range(3):
+            yo = run_chain([orc.FftFilter(t3[c]), orc.RationalResampler(I, D), orc.QuadratureDemod(1.0)], x)
+            ro = run_chain([orc.FftFilter(t3[c]), orc.RationalResampler(I, D)], x)
+            assert yg.shape[1] == len(yo)
+            if len(yo):
+                eps = TOL * float(np.max(np.abs(ro)))
+                mag = np.abs(ro.astype(np.complex128))
+                bound = TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30)
+                dd = np.abs(yg[c].astype(np.float64) - yo.astype(np.float64))
+                dd = np.minimum(dd, 2 * np.pi - dd)
+                assert np.all(dd <= bound[:len(dd)])

@@ -27,7 +27,7 @@ def _fm(n, seed):
     return (np.exp(1j * ph) + 0.02 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
 
 
-def _drive(blk, x, in_cap, out_cap, max_calls=200_000):
+def _drive(blk, x, in_cap, out_cap, max_calls=400_000):
     """Graph::run around ONE block with fixed ring sizes: push what fits, work(), drain the output ring completely.
     Returns (outputs [windows][n], log of (status, consumed, produced, need)); raises if the block stops making progress
     while input is left (the wait-for-ever this file is about)."""
@@ -181,3 +181,30 @@ def test_rotator_mode_switch_replay_model_replay(rr):
     # a second block created afterwards still works: nothing was corrupted on the device
     b2 = rr.FirFilter(one, translate=(fs, f))
     assert np.array_equal(b2.work(x[:1000], 1000)[4], yo[:1000])
+
+
+def test_unfused_composition_reports_the_starved_blocks_need(rr):
+    """behind rr_fm_chain_u8_create / rr_fir_fm_chain_create the UNFUSED composition (filters beyond the fused
+    tiles) must report the same WAIT_SRC `need` as the fused block of the same chain — what the starved FftFilter wants,
+    carried back through RtlSdrDecode (bytes) / the front FirFilter (its ntaps - 1 kept samples) — not the one byte pair /
+    ntaps samples block 0 alone asks for, which would wake a scheduler for nothing."""
+    rng = np.random.default_rng(5)
+    L = 20_000                                                  # > 16383: composed (nsamples = 2 * 32768 - L = 45536)
+    taps = ((rng.standard_normal(L) + 1j * rng.standard_normal(L)) / L).astype(np.complex64)
+    b = rr.FmChainU8(taps, 1, 6, 1.0)
+    assert "unfused" in b.name
+    xb = rng.integers(0, 256, 1000, dtype=np.uint8)
+    st, c, p, need, _ = b.work(xb, 100_000)
+    assert (st, c, p, need) == (WAIT_SRC, 1000, 0, 2 * (45536 - 500))
+    small = ((rng.standard_normal(463) + 1j * rng.standard_normal(463)) / 463).astype(np.complex64)
+    f = rr.FmChainU8(small, 1, 6, 1.0)                          # the fused block of the same chain shape: same rule
+    assert "unfused" not in f.name
+    st, c, p, need, _ = f.work(xb, 100_000)
+    assert (st, c, p, need) == (WAIT_SRC, 1000, 0, 2 * (561 - 500))
+    fir = np.ones(5, np.complex64) / 5
+    g = rr.FirFmChain(fir, taps, 1, 6, 1.0)
+    assert "unfused" in g.name
+    x = (rng.standard_normal(3000) + 1j * rng.standard_normal(3000)).astype(np.complex64)
+    st, c, p, need, _ = g.work(x, 100_000)
+    # the FirFilter keeps ntaps - 1 = 4 samples in the window; FftFilter has 2996 of its 45536 pending
+    assert (st, c, p) == (WAIT_SRC, 2996, 0) and need == 45536 - 2996 + 4
