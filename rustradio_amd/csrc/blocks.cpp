@@ -221,7 +221,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     // decimations the last radix cannot prune (3, 5, 6, 7 ...): decimate-first tiles — deci phase transforms and ONE inverse
     // per 1024 output positions (kernels_poly.hip; VERDICT r1 #3 "likewise for FirFilter decimations divisible by 3").
     // Where they win is measured (tools/fir_poly_probe.py); fir_poly > 0 forces them wherever the kernel exists.
-    if (allow_fft && !force_direct && deci >= 2 && bo.fir_poly >= 0 &&
+    if (allow_fft && !force_direct && deci >= 2 && bo.fir_poly >= 0 && (ntaps + deci - 1) / deci <= 448 &&   // (measured up to 448 taps per phase)
         fm_poly_supported(1, (long)std::min<size_t>(deci, 1 << 20), (int)std::min<size_t>(ntaps, 1 << 24), false)) {
         const bool poly_default = fir_poly_wins(ntaps, deci);
         if (bo.fir_poly > 0 || poly_default) {
@@ -969,7 +969,11 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     // 1:12 0.159 / 0.149 — every decimation up to 6 (7 phases and more run in two register batches per wave), and up to
     // 10 for filters long enough to push the other kernels onto 4096-point or split tiles.  fm_poly > 0 forces them.
     window_aware = build_opts().fm_poly == 0;          // any forced choice is used at every window size
-    const bool poly_wins = D <= 6 || (D <= 10 && f->L >= 800);
+    // Round 4: up to 768 taps per phase (256 of a tile's 1024 positions are output) instead of 448 — measured for 1:4 … 1:10
+    // (tools/poly_long_probe.py, ms per 2.4e7 samples, decimate-first / best other: 1:6 3599 taps 0.104 / 0.171, 4559 taps
+    // 0.158 / 0.217; 1:4 3039 taps 0.158 / 0.162; 1:10 7599 taps 0.168 / 0.252); 1:2 and 1:3 keep the old limit (not measured).
+    const uint64_t Lsp = (f->L + (uint64_t)D - 1) / (uint64_t)D;
+    const bool poly_wins = (D <= 6 || (D <= 10 && f->L >= 800)) && (Lsp <= 448 || D >= 4);
     if ((build_opts().fm_poly > 0 || (build_opts().fm_poly == 0 && poly_wins)) && !build_opts().fm_full && I == 1 && D >= 2) {
         std::vector<rr_c32> ct(f->L);
         if (fir_taps) ct = FftFilter::composite(fir_taps, fir_ntaps, taps, f->L - (fir_ntaps - 1));
@@ -1181,34 +1185,47 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
     : Block(u8 ? "RtlSdrDecode>Tee>N x (FftFilter>RationalResampler>QuadratureDemod)" : "Tee>N x (FftFilter>RationalResampler>QuadratureDemod)",
             u8 ? 1 : 8, 4), C(nchan), iq8(u8) {
     if (nchan == 0 || nchan > 4096) throw Error("FmMulti: channel count must be 1..4096");
-    // The shared-forward kernels run on tiles of at most 4096 points, which yield 4097 - ntaps filtered samples each: towards
-    // 4094 taps a tile is all overlap (tools/multi_taps_probe.py, 32 channels 1:6, ms per 2.4e6 samples: 2000 taps 0.08, 3000
-    // taps 0.55, 3800 taps 1.80) while one fused chain per channel on 8192-point split tiles (compose.cpp Parallel) costs
-    // 1.26 ms at 5000 taps and less below.  The crossover is where a tile still yields ~768 samples.
-    if (ntaps > 4097 - 768) throw NotFusedShape("FmMulti: beyond 3329 taps one fused chain per channel on larger tiles is cheaper");
-    chain.reset(new FmChain(taps, ntaps, interp, deci, g, m, false, 12));   // bookkeeping, carry state, twiddles; 3-pass tiles
-    const int lg = chain->f->log2f;
-    if (!fm_multi_supported(lg)) throw NotFusedShape("FmMulti: at most 4094 taps (3-pass tiles)");
-    const size_t F = (size_t)1 << lg;
-    std::vector<cf> all(C * F), one;
-    for (size_t c = 0; c < C; c++) {
-        compute_hpos(taps + c * ntaps, ntaps, lg, one);
-        std::copy(one.begin(), one.end(), all.begin() + c * F);
-    }
-    d_hpos_all.upload(all.data(), all.size(), stream);
-    half_ok = fm_multi_half_supported(lg, chain->I, chain->D, (int)ntaps) && !build_opts().fm_full;
-    if (half_ok) {
-        std::vector<cf> th(F / 2);
-        for (size_t k = 0; k < F / 2; k++) {
-            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)(F / 2);
-            th[k] = mkcf((float)std::cos(a), (float)std::sin(a));
-        }
-        d_tw_half.upload(th.data(), th.size(), stream);
-    }
-    if (build_opts().fm_poly >= 0 && !build_opts().fm_full && chain->I == 1) {
+    if (deci == 0) throw Error("RationalResampler created using deci 0");
+    if (interp == 0) throw Error("RationalResampler created using interp 0");
+    // Integer decimations up to 8 run on the decimate-first tiles (kernels_poly.hip) for up to 768 taps PER PHASE — they
+    // beat everything else there (tools/poly_long_probe.py, 32 channels, ms per 2.4e6 samples, decimate-first / other: 1:6
+    // 2687 taps 0.097 / 0.426, 3119 taps 0.106 / 0.569; 1:4 3039 taps 0.210 / 0.566) and need nothing of the 4096-point
+    // shared-forward kernels, so the filter may be longer than those take.
+    const int64_t gg0 = gcd64((int64_t)std::min<size_t>(deci, (size_t)1 << 31), (int64_t)std::min<size_t>(interp, (size_t)1 << 31));
+    const bool want_poly = build_opts().fm_poly >= 0 && !build_opts().fm_full && interp <= ((size_t)1 << 31) && deci <= ((size_t)1 << 31) &&
+                           (int64_t)interp / gg0 == 1 && ntaps <= 16383 &&
+                           fm_poly_supported(1, (long)((int64_t)deci / gg0), (int)ntaps, true);
+    // Everything else is the shared-forward kernels on tiles of at most 4096 points, which yield 4097 - ntaps filtered samples
+    // each: towards 4094 taps a tile is all overlap (tools/multi_taps_probe.py, 32 channels 1:6 without decimate-first
+    // tiles, ms per 2.4e6 samples: 3000 taps 0.55, 3800 taps 1.80) while one fused chain per channel on 8192-point split tiles
+    // (compose.cpp Parallel) costs 0.83 ms at 5000 taps and less below.  The crossover is where a tile still yields ~768 samples.
+    if (!want_poly && ntaps > 4097 - 768)
+        throw NotFusedShape("FmMulti: beyond 3329 taps one fused chain per channel on larger tiles is cheaper");
+    chain.reset(new FmChain(taps, ntaps, interp, deci, g, m, false, want_poly ? 14 : 12));   // bookkeeping, carry state; tile-agnostic
+    if (want_poly) {
         poly.reset(new PolyTables());
         if (!poly->build(taps, C, ntaps, (size_t)chain->D, true, stream)) poly.reset();
         if (build_opts().fm_poly == 8 || build_opts().fm_poly == 12) poly_waves = build_opts().fm_poly;
+    }
+    if (!poly) {
+        const int lg = chain->f->log2f;
+        if (chain->f->nsub || !fm_multi_supported(lg)) throw NotFusedShape("FmMulti: at most 4094 taps (3-pass tiles)");
+        const size_t F = (size_t)1 << lg;
+        std::vector<cf> all(C * F), one;
+        for (size_t c = 0; c < C; c++) {
+            compute_hpos(taps + c * ntaps, ntaps, lg, one);
+            std::copy(one.begin(), one.end(), all.begin() + c * F);
+        }
+        d_hpos_all.upload(all.data(), all.size(), stream);
+        half_ok = fm_multi_half_supported(lg, chain->I, chain->D, (int)ntaps) && !build_opts().fm_full;
+        if (half_ok) {
+            std::vector<cf> th(F / 2);
+            for (size_t k = 0; k < F / 2; k++) {
+                const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)(F / 2);
+                th[k] = mkcf((float)std::cos(a), (float)std::sin(a));
+            }
+            d_tw_half.upload(th.data(), th.size(), stream);
+        }
     }
     for (auto& b : last_r) { b.reserve(C); RR_HIP(hipMemsetAsync(b.p, 0, C * sizeof(cf), stream)); }
     RR_HIP(hipStreamSynchronize(stream));

@@ -864,7 +864,10 @@ bool fm_poly_supported(long I, long D, int L, bool multi) {
     const bool dok = multi ? (D >= 2 && D <= 8) : (D == 2 || D == 3 || D == 4 || D == 5 || D == 6 || D == 7 || D == 8 || D == 10 || D == 12 || D == 16);
     if (!dok || L < 1) return false;
     const long Ls = (L + D - 1) / D;
-    return Ls <= 448;                                    // at least 576 of the 1024 positions of a tile are output
+    // taps per phase: a tile yields 1024 - Ls outputs.  One chain: up to 768 (beyond, the 8192-point split tiles win:
+    // tools/poly_long_probe.py); N channels: up to 928 — what a long filter falls back to there is one chain per channel
+    // (0.95 ms per 2.4e6 samples x 32 channels at 5000 taps against ~0.3 for these tiles at 96 outputs each)
+    return Ls <= (multi ? 928 : 768);
 }
 int fm_poly_bin(int j, int t) {                          // frequency bin held by register j of lane t after the forward transform
     using G = PassGeom<PLG, 2>;

@@ -834,6 +834,47 @@ def test_fm_multi_u8_shared_source(rr, D, odd):
         _demod_close(yg, yo, ro)
 
 
+@pytest.mark.parametrize("L,D", [(3599, 6), (4559, 6), (3039, 4), (7599, 10), (4607, 6), (4608, 6), (1519, 2)])
+def test_fm_chain_long_phases_on_decimate_first_tiles(rr, monkeypatch, L, D):
+    """Round 4: the decimate-first tiles take up to 768 taps per phase (256 of a tile's 1024 positions are output), default
+    for 1:4 … 1:10; both sides of the limit and the forced form for 1:2 against the oracle chain, small rings included."""
+    if D == 2:
+        knob(rr, monkeypatch, fm_poly=1)
+    n = 250_000
+    x = fm_signal(n, 2.4e6, 0.0, L)
+    taps = (rnd_c(L, L) / max(1, L // 4)).astype(np.complex64)
+    for stream_bytes in (4_096_000, 8 * (2 * 8192)):
+        yo = run_chain([orc.FftFilter(taps), orc.RationalResampler(1, D), orc.QuadratureDemod(1.0)], x, stream_bytes=4_096_000)
+        ro = run_chain([orc.FftFilter(taps), orc.RationalResampler(1, D)], x, stream_bytes=4_096_000)
+        yg = run_chain([rr.FmChain(taps, 1, D, 1.0)], x, stream_bytes=stream_bytes)
+        _demod_close(yg, yo, ro)
+
+
+@pytest.mark.parametrize("L,D,nch", [(3119, 6, 3), (4500, 6, 2), (3039, 4, 2), (6143, 8, 2), (1500, 2, 3), (5500, 6, 2), (5568, 6, 2)])
+def test_fm_multi_long_phases_on_decimate_first_tiles(rr, L, D, nch):
+    """... and FmMulti with them beyond the 4096-point shared-forward kernels' 4094 taps (the bookkeeping object is
+    tile-agnostic): every channel against its own oracle chain, through reference-sized windows."""
+    n = 300_000
+    x = fm_signal(n, 2.4e6, 0.0, L + 1)
+    taps = np.stack([(rnd_c(L, L + c) / max(1, L // 4)).astype(np.complex64) for c in range(nch)])
+    blk = rr.FmMulti(taps, 1, D, 1.0)
+    assert "per channel" not in blk.name
+    outs, ring, pos = [[] for _ in range(nch)], np.zeros(0, np.complex64), 0
+    while True:
+        take = min(512_000 - len(ring), n - pos)
+        ring = np.concatenate([ring, x[pos:pos + take]]); pos += take
+        st, c, p, need, out = blk.work(ring, 1_024_000)
+        ring = ring[c:]
+        for ch in range(nch):
+            outs[ch].append(out[ch])
+        if take == 0 and c == 0 and p == 0:
+            break
+    for ch in range(nch):
+        yo = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(1, D), orc.QuadratureDemod(1.0)], x)
+        ro = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(1, D)], x)
+        _demod_close(np.concatenate(outs[ch]), yo, ro)
+
+
 def test_fm_multi_long_filters(rr):
     """FmMulti with the rtl_fm-sized filter (2467 taps -> 4096-point tiles); beyond 4094 taps: test_no_constructor_cliffs"""
     fs, n = 1.024e6, 250_000

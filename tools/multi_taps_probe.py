@@ -14,7 +14,7 @@ x = torch.rand(2 * n, device="cuda") * 2 - 1
 cap = n // 6 + 4096
 y = torch.empty(32 * cap, device="cuda")
 rng = np.random.default_rng(0)
-for L in (463, 2000, 3000, 3200, 3329, 3330, 3600, 3800, 4094, 5000, 8000):
+for L in (463, 2000, 3000, 3800, 4094, 4600, 5000, 5400, 5568, 5569, 8000):
     taps = (rng.standard_normal((32, L)) + 1j * rng.standard_normal((32, L))).astype(np.complex64) / L
     b = rr.FmMulti(taps, 1, 6, 1.0)
     for _ in range(3):
