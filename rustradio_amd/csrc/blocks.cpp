@@ -973,7 +973,14 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     // (tools/poly_long_probe.py, ms per 2.4e7 samples, decimate-first / best other: 1:6 3599 taps 0.104 / 0.171, 4559 taps
     // 0.158 / 0.217; 1:4 3039 taps 0.158 / 0.162; 1:10 7599 taps 0.168 / 0.252); 1:2 and 1:3 keep the old limit (not measured).
     const uint64_t Lsp = (f->L + (uint64_t)D - 1) / (uint64_t)D;
-    const bool poly_wins = (D <= 6 || (D <= 10 && f->L >= 800)) && (Lsp <= 448 || D >= 4);
+    // Decimations 9 and 11 … 16 (round 4; they fell to the 2048-point / split tiles before: 2467 taps 1:9 0.177 ms per 2.4e7
+    // samples against 0.081 now) — tools/poly_probe.py, forced decimate-first / other: 1:9 1000 taps 0.079 / 0.105, 1:11 2467
+    // 0.090 / 0.140, 1:12 2467 0.092 / 0.139, 1:13 2467 0.120 / 0.138, 1:14 4000 0.141 / 0.185, 1:16 4000 0.150 / 0.182; the
+    // two-wave kernel takes a third batch of phases from 1:13 on, hence the later crossovers.
+    const bool d_wins = D <= 6 || (D <= 11 && f->L >= 800) || (D == 12 && f->L >= 1000) || (D == 13 && f->L >= 2000) ||
+                        (D >= 14 && D <= 16 && f->L >= 2000);
+    // (1:2 wins up to 500 taps per phase — 1000 taps 0.122 / 0.126, 1300 taps 0.159 / 0.141 — and 1:3 up to 600)
+    const bool poly_wins = d_wins && Lsp <= (D == 2 ? 500u : D == 3 ? 600u : 768u);
     if ((build_opts().fm_poly > 0 || (build_opts().fm_poly == 0 && poly_wins)) && !build_opts().fm_full && I == 1 && D >= 2) {
         std::vector<rr_c32> ct(f->L);
         if (fir_taps) ct = FftFilter::composite(fir_taps, fir_ntaps, taps, f->L - (fir_ntaps - 1));

@@ -861,7 +861,7 @@ void k_fm_multi_poly12(SRC src, float* __restrict__ out, long out_stride, long n
 // ---- launchers -----------------------------------------------------------------------------------------------------
 bool fm_poly_supported(long I, long D, int L, bool multi) {
     if (I != 1) return false;
-    const bool dok = multi ? (D >= 2 && D <= 8) : (D == 2 || D == 3 || D == 4 || D == 5 || D == 6 || D == 7 || D == 8 || D == 10 || D == 12 || D == 16);
+    const bool dok = multi ? (D >= 2 && D <= 8) : (D >= 2 && D <= 16);
     if (!dok || L < 1) return false;
     const long Ls = (L + D - 1) / D;
     // taps per phase: a tile yields 1024 - Ls outputs.  One chain: up to 768 (beyond, the 8192-point split tiles win:
@@ -920,7 +920,7 @@ static void launch_chain_poly_t(SRC src, float* out, int L, const cf* tw, const 
     switch (h.D) {
 #define RR_POLY_CASE(DV) case DV: launch_chain_poly_d<DV>(src, out, L, tw, hreg, h, last_in, last_out, s); break
     RR_POLY_CASE(2); RR_POLY_CASE(3); RR_POLY_CASE(4); RR_POLY_CASE(5); RR_POLY_CASE(6); RR_POLY_CASE(7); RR_POLY_CASE(8);
-    RR_POLY_CASE(10); RR_POLY_CASE(12); RR_POLY_CASE(16);
+    RR_POLY_CASE(9); RR_POLY_CASE(10); RR_POLY_CASE(11); RR_POLY_CASE(12); RR_POLY_CASE(13); RR_POLY_CASE(14); RR_POLY_CASE(15); RR_POLY_CASE(16);
 #undef RR_POLY_CASE
     default: throw Error("fm_chain_poly: unsupported decimation");
     }

@@ -834,11 +834,12 @@ def test_fm_multi_u8_shared_source(rr, D, odd):
         _demod_close(yg, yo, ro)
 
 
-@pytest.mark.parametrize("L,D", [(3599, 6), (4559, 6), (3039, 4), (7599, 10), (4607, 6), (4608, 6), (1519, 2)])
+@pytest.mark.parametrize("L,D", [(3599, 6), (4559, 6), (3039, 4), (7599, 10), (4607, 6), (4608, 6), (1519, 2),
+                                 (1000, 9), (2467, 11), (1000, 12), (2467, 13), (3001, 14), (4000, 15), (3500, 16), (300, 13)])
 def test_fm_chain_long_phases_on_decimate_first_tiles(rr, monkeypatch, L, D):
     """Round 4: the decimate-first tiles take up to 768 taps per phase (256 of a tile's 1024 positions are output), default
     for 1:4 … 1:10; both sides of the limit and the forced form for 1:2 against the oracle chain, small rings included."""
-    if D == 2:
+    if D == 2 or L == 300:
         knob(rr, monkeypatch, fm_poly=1)
     n = 250_000
     x = fm_signal(n, 2.4e6, 0.0, L)
