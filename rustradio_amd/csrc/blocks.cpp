@@ -971,7 +971,7 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     window_aware = build_opts().fm_poly == 0;          // any forced choice is used at every window size
     // Round 4: up to 768 taps per phase (256 of a tile's 1024 positions are output) instead of 448 — measured for 1:4 … 1:10
     // (tools/poly_long_probe.py, ms per 2.4e7 samples, decimate-first / best other: 1:6 3599 taps 0.104 / 0.171, 4559 taps
-    // 0.158 / 0.217; 1:4 3039 taps 0.158 / 0.162; 1:10 7599 taps 0.168 / 0.252); 1:2 and 1:3 keep the old limit (not measured).
+    // 0.158 / 0.217; 1:4 3039 taps 0.158 / 0.162; 1:10 7599 taps 0.168 / 0.252).
     const uint64_t Lsp = (f->L + (uint64_t)D - 1) / (uint64_t)D;
     // Decimations 9 and 11 … 16 (round 4; they fell to the 2048-point / split tiles before: 2467 taps 1:9 0.177 ms per 2.4e7
     // samples against 0.081 now) — tools/poly_probe.py, forced decimate-first / other: 1:9 1000 taps 0.079 / 0.105, 1:11 2467
