@@ -114,13 +114,20 @@ static void compute_hpos(const rr_c32* taps, size_t ntaps, int log2f, std::vecto
 //   /7: 255 0.274 / 0.311, 2467 0.348 / 0.583     /8: 1000 0.321 / 0.306, 2467 0.355 / 0.593 (pruned inverse below that)
 //   /10: 31 0.317 / 0.355, 255 0.319 / 0.518, 2467 0.349 / 0.580      /12: 2467 0.519 / 0.579      /2, /16: never
 static bool fir_poly_wins(size_t ntaps, size_t deci) {
+    // round 4: every decimation up to 16, and up to 768 taps per phase (tools/fir_long_probe.py, ms per 1e8 samples, other /
+    // decimate-first: /6 3599 taps 0.747 / 0.458, /8 4799 taps 0.823 / 0.458, /10 7599 taps 1.058 / 0.804; /4 wins up to ~700
+    // per phase, /3 up to ~560) — and tools/fir_cliff_probe.py for the new decimations: /9 1000 taps 0.396 / 0.310, /11 2467
+    // 0.601 / 0.359, /13 2467 0.597 / 0.450, /16 5000 0.836 / 0.588; /8 1000 taps 0.312 / 0.240
+    const size_t Ls = (ntaps + deci - 1) / deci;
+    if (Ls > (deci == 3 ? 560u : deci == 4 ? 700u : 768u)) return false;
     switch (deci) {
-    case 3: case 10: return ntaps >= 24;
+    case 3: case 10: case 11: return ntaps >= 24;
     case 4: return ntaps >= 400;
     case 5: case 6: return ntaps >= 100;
     case 7: return ntaps >= 200;
-    case 8: return ntaps >= 1500;
-    case 12: return ntaps >= 2000;
+    case 8: case 12: return ntaps >= 700;
+    case 9: return ntaps >= 300;
+    case 13: case 14: case 15: case 16: return ntaps >= 2000;
     default: return false;
     }
 }
@@ -182,7 +189,11 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     // (tools/fir_deci_probe.py: 401 taps /16 0.69 vs 0.32 ms, 1000 taps /16 95 vs 0.43 ms per 1e8 samples).
     const size_t min_taps = real_taps ? 40 : 28, min_per_phase = real_taps ? 36 : 16;
     const bool fits = ntaps <= 16383 && deci <= 4096;
-    const bool wins = deci == 1 ? ntaps >= min_taps : (ntaps >= 320 || ntaps / deci >= min_per_phase);
+    // Round 4 (tools/fir_cliff_probe.py): from /11 on the direct form's tile shapes get small or stop fitting (127 taps: /9
+    // 0.20, /11 0.44, /15 0.60, /20 9.6 ms per 1e8 samples — the last one is the one-thread-per-output fallback) while the
+    // tiles with a decimating store stay at 0.33 for any decimation
+    const bool wins = deci == 1 ? ntaps >= min_taps
+                                : (ntaps >= 320 || ntaps / deci >= min_per_phase || deci >= 11 || !fir_direct_has_tile(pl, sizeof(cf), sizeof(cf)));
     // deci 4 / 8 / 16: the tile whose last radix is the decimation, inverse transform pruned to 1/deci
     // (tools/prune_probe.py, ms per 1e8 samples, direct / decimating store / pruned: 255 Complex taps /8 0.31 / 0.31 /
     //  0.21, 401 taps /4 0.60 / 0.34 / 0.27, 1000 taps /16 98 / 0.45 / 0.29; short /8 filters stay direct: 127 taps 0.195 / 0.27 / 0.207)
@@ -221,7 +232,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     // decimations the last radix cannot prune (3, 5, 6, 7 ...): decimate-first tiles — deci phase transforms and ONE inverse
     // per 1024 output positions (kernels_poly.hip; VERDICT r1 #3 "likewise for FirFilter decimations divisible by 3").
     // Where they win is measured (tools/fir_poly_probe.py); fir_poly > 0 forces them wherever the kernel exists.
-    if (allow_fft && !force_direct && deci >= 2 && bo.fir_poly >= 0 && (ntaps + deci - 1) / deci <= 448 &&   // (measured up to 448 taps per phase)
+    if (allow_fft && !force_direct && deci >= 2 && bo.fir_poly >= 0 &&
         fm_poly_supported(1, (long)std::min<size_t>(deci, 1 << 20), (int)std::min<size_t>(ntaps, 1 << 24), false)) {
         const bool poly_default = fir_poly_wins(ntaps, deci);
         if (bo.fir_poly > 0 || poly_default) {
@@ -292,7 +303,7 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
         const double t_direct = 5.0 + 7.8e-8 * (double)n * ((double)L / (double)d) * (pl.complex_taps ? 2.0 : 1.0);
         const double t_tiles = 9.0 + 3.1e-6 * (double)n;
         // (beyond ~320 taps the direct form's LDS tile stops fitting and it collapses: never there)
-        small_direct = !fftk || (L <= 320 && t_direct <= t_tiles);
+        small_direct = !fftk || (L <= 320 && t_direct <= t_tiles && fir_direct_has_tile(pl, sizeof(cf), sizeof(cf)));
     }
     if (use_poly) launch_fir_poly(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, poly->d_tw.p, poly->d_h.p, s);
     else if (small_direct) launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
@@ -521,7 +532,8 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
     const BuildOpts& bo = build_opts();
     const bool force_direct = bo.fir_path == RR_PATH_DIRECT, force_fft = bo.fir_path == RR_PATH_FFT;
     const bool fits = ntaps <= 3584 && deci <= 4096;
-    const bool wins = deci == 1 ? ntaps >= 24 : (ntaps >= 320 || ntaps / deci >= 40);
+    const bool wins = deci == 1 ? ntaps >= 24
+                                : (ntaps >= 320 || ntaps / deci >= 40 || !fir_direct_has_tile(pl, sizeof(float), sizeof(float)));   // (see FirC32)
     const size_t per_phase = ntaps / deci;
     const bool prune_default = deci == 4 ? per_phase >= 8 : deci == 8 ? per_phase >= 16 : per_phase >= 4;
     const bool prune_wins = bo.fir_prune ? bo.fir_prune > 0 : prune_default;
@@ -557,7 +569,7 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
         const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - L + 1) * d;
         use_prune = n >= chip_units(d == 4 ? 2000 : d == 8 ? 1700 : 370) * per_batch;   // (tools/prune_window_probe2.py)
     }
-    const bool small_direct = prune && !use_prune && (!fftk || L <= 320);
+    const bool small_direct = prune && !use_prune && (!fftk || (L <= 320 && fir_direct_has_tile(pl, sizeof(float), sizeof(float))));
     if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
     else if (small_direct) launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
     else if (fftk) fftk->filter_real(src, static_cast<float*>(out), (long)(n / d), (int)d, s);

@@ -150,6 +150,7 @@ struct FirPlan {             // host-prepared polyphase tap table
 };
 // y[m] = sum_k rev[k] * x[m*d + k], m < n_out  (rev = reversed taps), x = virtual stream.
 // tp = device polyphase table [d][qpad] (float if real taps else cf), rev = device reversed taps.
+bool fir_direct_has_tile(const FirPlan& pl, size_t es_in, size_t es_out);   // false: only the slow one-thread-per-output fallback
 void launch_fir_c32(const FirPlan& pl, const void* tp, const void* rev, VSrc<cf> src, cf* out,
                     long n_out, hipStream_t s);
 void launch_fir_f32(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src,

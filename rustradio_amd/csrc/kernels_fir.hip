@@ -404,6 +404,16 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
     RR_HIP(hipGetLastError());
 }
 
+// Does any tile shape of the direct form fit the LDS budget for this plan?  When none does, launch_fir_any falls back to
+// k_fir_direct — one thread per output walking the taps in global memory, 10-30x slower (127 taps /20: 9.6 ms per 1e8 samples
+// against 0.33 on overlap-save tiles with a decimating store) — so the block's path selection asks before it relies on it.
+bool fir_direct_has_tile(const FirPlan& pl, size_t es_in, size_t es_out) {
+    static const int shapes[8][3] = {{256, 8, 1}, {128, 8, 1}, {64, 8, 1}, {256, 2, 1}, {128, 2, 1}, {256, 4, 2}, {256, 8, 2}, {256, 8, 4}};
+    for (auto& c : shapes)
+        if (fir_geom(c[0] / c[2], c[1], pl.d, pl.qpad, es_in, es_out, c[2]).lds_bytes <= 40 * 1024) return true;
+    return false;
+}
+
 void launch_fir_c32(const FirPlan& pl, const void* tp, const void* rev, VSrc<cf> src, cf* out, long n_out,
                     hipStream_t s) {
     if (pl.complex_taps)

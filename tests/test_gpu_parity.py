@@ -96,7 +96,11 @@ def test_fir_nondecimating_both_paths(rr, monkeypatch, path, L, cplx):
 @pytest.mark.parametrize("L,deci,cplx", [(5, 4, True), (40, 4, False), (500, 4, True), (64, 8, False), (1020, 8, True), (3, 16, False), (2049, 16, True),
                                          (5, 2, False), (127, 2, False), (128, 2, True), (600, 2, False), (601, 2, True), (401, 6, True), (90, 10, False), (700, 14, True), (33, 4096, True), (64, 22, False), (127, 3, True), (255, 8, True), (401, 7, False),
                                          (1000, 16, True), (64, 100, False), (2000, 5, False), (3584, 4096, False), (5000, 3, True), (9000, 16, False),
-                                         (300, 3000, True)])
+                                         (300, 3000, True),
+                                         # round 4: decimations 9, 11, 13-15 and long phases on the decimate-first tiles; decimations
+                                         # beyond 10 with short filters (off the direct form's one-thread-per-output fallback)
+                                         (127, 20, False), (31, 32, True), (127, 13, False), (1000, 9, True), (2467, 11, False), (2467, 13, True),
+                                         (3599, 6, False), (4799, 8, True), (5000, 15, False), (2279, 3, True), (3039, 4, False), (31, 11, True)])
 def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
     """Decimating FirFilter through the direct-form kernel and through the overlap-save tiles with a decimating
     store: same protocol, same outputs (1e-5), incl. decimations beyond the tile's useful width and small rings."""
