@@ -481,6 +481,21 @@ HilbertFir::HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c3
         RR_HIP(hipMemsetAsync(h.p, 0, hn * sizeof(float), stream));
     }
     RR_HIP(hipStreamSynchronize(stream));
+    // Two stages or one composite?  Fitted on MI355X (tools/misc_cliff_probe.py, ms per 1e8 real samples): the composite
+    // direct form 0.1 + 0.0039 x (ntaps + hn - 1) / deci (255 taps: /1 1.42, /2 0.70, /5 0.40; 1000 taps /1 3.98; no tile at
+    // all for 2467 taps /32: 114 ms on the one-thread-per-output fallback); Hilbert 0.23 + the FirFilter's own kernels 0.30
+    // (up to ~1200 taps) / 0.45 (~3000) / 0.85 (beyond).  rr_build_opts.fir_path = direct keeps the composite.
+    if (!prune && build_opts().fir_path != RR_PATH_DIRECT) {
+        const double est_direct = fir_direct_has_tile(plG, sizeof(float), sizeof(cf)) ? 0.1 + 0.0039 * (double)G.size() / (double)deci : 1e9;
+        const double est_two = 0.23 + (ntaps <= 1200 ? 0.30 : ntaps <= 3000 ? 0.45 : 0.85);
+        two_stage = est_two < est_direct;
+    }
+    if (two_stage) {
+        hil.reset(new Hilbert(hn, window, parm));
+        std::vector<rr_c32> pt(ntaps);
+        for (size_t k = 0; k < ntaps; k++) pt[k] = rr_c32{fir->h_taps[k].real(), fir->h_taps[k].imag()};
+        fir2.reset(new FirC32(pt.data(), ntaps, deci, false, 0.0f, 0.0f, true));
+    }
 }
 
 // One input sample = one analytic sample, so the FirFilter bookkeeping (fir.rs:496-549) applies to the
@@ -506,6 +521,26 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     // (the hn samples before the new window become the next call's history: written by the tile kernel itself)
     const CarryOut carry{hist[cur ^ 1].p, (long)n, (long)hn};
     if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s, carry);
+    else if (two_stage && (n >= 16384 || !fir_direct_has_tile(plG, sizeof(float), sizeof(cf)))) {
+        // a[k] = (iv[k + hn/2], sum_j rev_h[j] iv[k + j]) over the virtual stream iv = hist ++ window (hilbert.rs:113-116), then
+        // y[m] = sum_k rev[k] a[m d + k]: outputs [m0, m1) take a[m0 d, m1 d + L - 1).  In chunks, so that the analytic buffer
+        // stays at 128 MB whatever the window.
+        const size_t CH = (size_t)1 << 24;
+        // (the FirFilter stage produces floor((len - L + 1) / d) outputs, fir.rs:503-510: k outputs take k d + L - 1 samples)
+        const size_t per = std::max<size_t>(1, (CH - L) / d);
+        analytic.reserve(std::min(CH, out_n * d + L - 1) + 8);
+        for (size_t m0 = 0; m0 < out_n; m0 += per) {
+            const size_t m1 = std::min(out_n, m0 + per), k0 = m0 * d, na = (m1 - m0) * d + L - 1;
+            VSrc<float> sa = src;
+            if (k0 >= hn) sa = VSrc<float>{hist[cur].p, 0, static_cast<const float*>(in) + (k0 - hn), (long)(in_len - (k0 - hn))};
+            else if (k0 != 0) throw Error("HilbertFir: chunk inside the history");   // (per >> hn: only the first chunk starts in it)
+            if (!(hil->skip_ok && launch_hilbert_skip(hil->pl.L, hil->par, hil->Q, hil->d_hq.p, sa, analytic.p, (long)na, s)))
+                launch_hilbert(hil->pl, hil->d_tp.p, hil->d_rev.p, sa, analytic.p, (long)na, s);
+            size_t c2 = 0, p2 = 0, n2 = 0;
+            fir2->work_dev(analytic.p, na, static_cast<cf*>(out) + m0, m1 - m0, &c2, &p2, &n2, s);
+            if (p2 != m1 - m0) throw Error("HilbertFir: the FirFilter stage disagrees on the output count");
+        }
+    }
     else launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s);
     prof_end(s);
     fir->rotate_output(static_cast<cf*>(out), out_n, s);
@@ -533,7 +568,8 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
     const bool force_direct = bo.fir_path == RR_PATH_DIRECT, force_fft = bo.fir_path == RR_PATH_FFT;
     const bool fits = ntaps <= 3584 && deci <= 4096;
     const bool wins = deci == 1 ? ntaps >= 24
-                                : (ntaps >= 320 || ntaps / deci >= 40 || !fir_direct_has_tile(pl, sizeof(float), sizeof(float)));   // (see FirC32)
+                                : (ntaps >= 320 || ntaps / deci >= 40 || deci >= 10 ||   // (/10 on: 0.27-0.46 ms per 1e8 direct, 0.20 on the tiles)
+                                   !fir_direct_has_tile(pl, sizeof(float), sizeof(float)));   // (see FirC32)
     const size_t per_phase = ntaps / deci;
     const bool prune_default = deci == 4 ? per_phase >= 8 : deci == 8 ? per_phase >= 16 : per_phase >= 4;
     const bool prune_wins = bo.fir_prune ? bo.fir_prune > 0 : prune_default;
@@ -549,6 +585,11 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {taps[i], 0.0f};
         fftk.reset(new FftFilter(ct.data(), ntaps, false, 12, true));
+    }
+    if (!fftk && !prune && !force_direct && ntaps > 320) {   // (see blocks.hpp; shorter filters have direct-form tiles that fit)
+        std::vector<rr_c32> ct(ntaps);
+        for (size_t i = 0; i < ntaps; i++) ct[i] = {taps[i], 0.0f};
+        wide.reset(new FirC32(ct.data(), ntaps, deci, false, 0.0f, 0.0f, true));
     }
 }
 FirF32::~FirF32() = default;
@@ -570,7 +611,21 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
         use_prune = n >= chip_units(d == 4 ? 2000 : d == 8 ? 1700 : 370) * per_batch;   // (tools/prune_window_probe2.py)
     }
     const bool small_direct = prune && !use_prune && (!fftk || (L <= 320 && fir_direct_has_tile(pl, sizeof(float), sizeof(float))));
-    if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
+    if (wide) {
+        // outputs [m0, m1) take samples [m0 d, m1 d + L - 1) (fir.rs:503-510); chunks keep the work buffers at 128 + 128 / d MB
+        const size_t out_n = n / d, CH = (size_t)1 << 24, per = std::max<size_t>(1, (CH - L) / d);
+        wide_in.reserve(std::min(CH, out_n * d + L - 1) + 8);
+        wide_out.reserve(std::min(per, out_n) + 8);
+        for (size_t m0 = 0; m0 < out_n; m0 += per) {
+            const size_t m1 = std::min(out_n, m0 + per), na = (m1 - m0) * d + L - 1;
+            launch_f32_to_c32(static_cast<const float*>(in) + m0 * d, wide_in.p, (long)na, s);
+            size_t c2 = 0, p2 = 0, n2 = 0;
+            wide->work_dev(wide_in.p, na, wide_out.p, m1 - m0, &c2, &p2, &n2, s);
+            if (p2 != m1 - m0) throw Error("FirFilter<Float>: the Complex stage disagrees on the output count");
+            launch_c32_re(wide_out.p, static_cast<float*>(out) + m0, (long)(m1 - m0), s);
+        }
+    }
+    else if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
     else if (small_direct) launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
     else if (fftk) fftk->filter_real(src, static_cast<float*>(out), (long)(n / d), (int)d, s);
     else launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
@@ -752,6 +807,10 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
         if (log2f < 0 || c < best) { best = c; log2f = lg; }
     }
     if (log2f < 0) log2f = 15;                                        // -> the any-size path (or refused) below
+    // Towards 16383 taps the largest tile is all overlap (16385 - L samples per 16384-point tile: 16383 taps = 2 samples,
+    // tools/misc_cliff_probe.py: 1795 ms per 5e7 samples against 3.7 ms for 16385 taps on the any-size frames).  The frames
+    // cost ~7.4 units of the tile model: from 15293 taps on they are cheaper.
+    if (log2f == 14 && !real && !for_chain && max_log2f >= 14 && 7900.0 / (double)(16385 - L) + 0.17 > 7.4) log2f = 15;
     if (const int v = build_opts().fft_log2f) {            // rr_build_opts: force a tile size
         if (v >= 10 && v <= max_log2f && ((size_t)1 << v) >= L + 1) log2f = v;
     }

@@ -132,8 +132,16 @@ struct FirC32 : Block {
 // y[m] = sum_k rev[k] a[m d + k] (fir.rs:166-197) is y[m] = sum_n G[n] iv[m d + n] with the composite
 // Complex taps G = rev (*) c of length ntaps + hn - 1, applied to the REAL input: 4 B in + 8/d B out
 // per sample, neither the analytic stream nor a second kernel.  iv = hn zeros || input (hilbert.rs:55).
+struct Hilbert;
 struct HilbertFir : Block {
     std::unique_ptr<FirC32> fir;      // taps incl. translation, rotator state, decimation bookkeeping
+    // Round 4: where the composite direct form loses — it costs ~0.004 ms x composite taps / deci per 1e8 samples, nothing
+    // like the 0.23 + 0.3 ms of the two blocks on their own kernels — the SAME handle runs the two stages through an
+    // analytic buffer in HBM: Hilbert's kernel, then the FirFilter's own path selection (tiles, decimate-first, pruned).
+    std::unique_ptr<Hilbert> hil;     // tables of the Hilbert stage
+    std::unique_ptr<FirC32> fir2;     // the FirFilter stage (pre-rotated taps, no rotator: `fir` rotates the output)
+    DevBuf<cf> analytic;
+    bool two_stage = false;
     size_t hn = 0;                    // Hilbert ntaps
     FirPlan plG;
     DevBuf<cf> d_tpG, d_revG;
@@ -151,6 +159,12 @@ struct FirF32 : Block {
     std::unique_ptr<FftFilter> fftk;   // long filters: overlap-save tiles on the real stream (see FirC32::fftk)
     std::unique_ptr<PruneTables> prune; // deci 4 / 8 / 16: pruned inverse (k_fftfilt_prune, real stream x real taps)
     bool window_aware = true;           // per-call choice by window size (off when a path is forced)
+    // Beyond 3584 taps the real-stream tiles (4096 points at most) end and the direct form costs 0.0026 ms per tap and 1e8
+    // samples — or has no tile at all (5000 taps: 12.9 ms, /32: 224 ms on the one-thread-per-output fallback).  Then the block
+    // filters Complex(x, 0) with the FirFilter<Complex> kernels (tiles up to 16383 taps, decimate-first, pruned) in chunks
+    // through two work buffers and keeps the real parts — what FftFilterFloat does for the same reason (fft_filter.rs:431-445).
+    std::unique_ptr<FirC32> wide;
+    DevBuf<cf> wide_in, wide_out;
     ~FirF32() override;
     FirF32(const float* taps, size_t ntaps, size_t deci);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;

@@ -191,7 +191,7 @@ def test_fir_translate_on_tiles(rr, deci, f):
     assert max_norm_err(yg, yo) <= TOL
 
 
-@pytest.mark.parametrize("L", [1, 2, 5, 193, 401, 463, 512, 513, 1025, 2467, 3100, 3300, 5000, 8193, 12000, 16383])
+@pytest.mark.parametrize("L", [1, 2, 5, 193, 401, 463, 512, 513, 1025, 2467, 3100, 3300, 5000, 8193, 12000, 15292, 15293, 16383])
 def test_fftfilter(rr, L):
     n = 200_000 if L < 1025 else 400_000
     x = rnd_c(n, L)
@@ -279,7 +279,9 @@ def test_fftfilter_float_lengths(rr, L):
 @pytest.mark.parametrize("path", ["direct", "fft", "auto", "prune"])
 @pytest.mark.parametrize("L,deci", [(1, 1), (5, 1), (39, 1), (40, 1), (65, 1), (463, 1), (463, 6), (128, 3), (1000, 16),
                                     (3584, 1), (3584, 4096), (64, 100), (330, 50), (2000, 7), (3, 4), (64, 4), (513, 4),
-                                    (255, 8), (1025, 8), (2049, 16), (31, 16)])
+                                    (255, 8), (1025, 8), (2049, 16), (31, 16),
+                                    # round 4: beyond the real-stream tiles (3584 taps) on the FirFilter<Complex> kernels; /20, /32 short
+                                    (3585, 1), (5000, 1), (5000, 20), (9000, 3), (4000, 32), (127, 20), (31, 32)])
 def test_fir_float_both_paths(rr, monkeypatch, path, L, deci):
     """FirFilter<Float> through the direct-form kernel, the real-stream overlap-save tiles (decimating store) and —
     deci 4 / 8 / 16 — the tiles with the pruned inverse transform."""
@@ -564,6 +566,23 @@ def test_hilbert_fir_fused_block(rr, monkeypatch, hn, L, deci, cplx, tr, stream_
     # (the reference's rotator is a drifting f32 recurrence, fir.rs:465 TODO: replay it for long streams)
     kg = dict(kw, rotator=rr.ROT_REPLAY) if tr else {}
     yg = run_chain([rr.HilbertFir(hn, taps, deci, **kg)], x, stream_bytes=max(stream_bytes, 4 * (L + deci + 8)))
+    assert len(yg) == len(yo) and len(yo) > 0
+    assert max_norm_err(yg, yo) <= TOL
+
+
+@pytest.mark.parametrize("hn,L,deci,tr", [(65, 255, 1, None), (65, 255, 2, (100e6, 7e6)), (65, 1000, 5, None), (33, 127, 1, None),
+                                          (65, 2467, 32, None), (129, 2467, 6, (8.0, 1.0)), (65, 1000, 20, None), (65, 600, 3, None)])
+@pytest.mark.parametrize("stream_bytes", [4_096_000, 4 * 30_000])
+def test_hilbert_fir_two_stage_shapes(rr, hn, L, deci, tr, stream_bytes):
+    """Round 4: shapes where the composite direct form loses (long filters at small decimations, or no tile at all) run the
+    two stages through an analytic buffer behind the same handle: Hilbert's kernel, then the FirFilter's own path selection.
+    Same protocol, same stream as Hilbert -> FirFilter<Complex> of the oracle; chunked windows included."""
+    x = rnd_f(400_000, hn + L + deci)
+    taps = rnd_c(L, L + 5) / max(1, L // 8)
+    kw = {"translate": tr} if tr else {}
+    lo, lg = [], []
+    yo = run_chain([orc.Hilbert(hn), orc.FirFilter(taps, deci=deci, **kw)], x)
+    yg = run_chain([rr.HilbertFir(hn, taps, deci, **kw)], x, stream_bytes=max(stream_bytes, 4 * (L + deci + 8)))
     assert len(yg) == len(yo) and len(yo) > 0
     assert max_norm_err(yg, yo) <= TOL
 
