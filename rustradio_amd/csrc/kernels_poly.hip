@@ -655,7 +655,7 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
                      const cf* __restrict__ hreg, int nchan, PolyArgs a, const cf* __restrict__ last_r_in,
                      cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg, PolyPart part) {
     carry_store<cf>(src, a.carry);
-    static_assert(D <= 8, "one phase per wave");
+    static_assert(D <= 11, "the D parked spectra + eight exchange areas must fit the CU's LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     creg* lds = reinterpret_cast<creg*>(smem_raw);
     creg* park = lds + 8 * PLE;                          // D spectra, register-major [p][16][64]
@@ -691,12 +691,14 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
         const long u0 = a.r_lo + tile_ * Sa;
         const long vbase = (u0 - a.Ls) * D + a.off;
         const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
-        if (w < D) {
+        // (one phase per wave up to 1:8; 1:9 ... 1:11 — round 4 — give waves 0 ... D - 9 a second one)
+#pragma unroll 1
+        for (int ph = w; ph < D; ph += 8) {
             creg v[16];
-            poly_load<D>(v, src, vbase, w, t, interior, ex);
+            poly_load<D>(v, src, vbase, ph, t, interior, ex);
             poly_forward(v, t, ex, tw0, tab1);
 #pragma unroll
-            for (int j = 0; j < 16; j++) park[(w * 16 + j) * PT + t] = v[j];
+            for (int j = 0; j < 16; j++) park[(ph * 16 + j) * PT + t] = v[j];
         }
         PSTAMP(1);
         tile_sync<512>();
@@ -861,7 +863,7 @@ void k_fm_multi_poly12(SRC src, float* __restrict__ out, long out_stride, long n
 // ---- launchers -----------------------------------------------------------------------------------------------------
 bool fm_poly_supported(long I, long D, int L, bool multi) {
     if (I != 1) return false;
-    const bool dok = multi ? (D >= 2 && D <= 8) : (D >= 2 && D <= 16);
+    const bool dok = multi ? (D >= 2 && D <= 11) : (D >= 2 && D <= 16);
     if (!dok || L < 1) return false;
     const long Ls = (L + D - 1) / D;
     // taps per phase: a tile yields 1024 - Ls outputs.  One chain: up to 768 (beyond, the 8192-point split tiles win:
@@ -1039,6 +1041,7 @@ static void launch_multi_poly_t(SRC src, float* out, long out_stride, int L, con
     switch (h.D) {
 #define RR_POLY_CASE(DV) case DV: launch_multi_poly_d<DV>(src, out, out_stride, L, tw, hreg, nchan, h, last_in, last_out, s); break
     RR_POLY_CASE(2); RR_POLY_CASE(3); RR_POLY_CASE(4); RR_POLY_CASE(5); RR_POLY_CASE(6); RR_POLY_CASE(7); RR_POLY_CASE(8);
+    RR_POLY_CASE(9); RR_POLY_CASE(10); RR_POLY_CASE(11);
 #undef RR_POLY_CASE
     default: throw Error("fm_multi_poly: unsupported decimation");
     }

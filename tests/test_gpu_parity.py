@@ -784,7 +784,8 @@ def test_fm_multi_shared_source(rr, monkeypatch, stream_bytes, kernel):
 
 @pytest.mark.parametrize("kernel", ["auto", "half"])
 @pytest.mark.parametrize("L,D,nch", [(463, 2, 1), (463, 4, 2), (400, 10, 3), (300, 64, 2), (513, 6, 4), (463, 200, 1), (700, 6, 2),
-                                     (463, 3, 2), (461, 5, 3), (300, 7, 2), (463, 8, 9), (2467, 6, 2), (3, 6, 2)])
+                                     (463, 3, 2), (461, 5, 3), (300, 7, 2), (463, 8, 9), (2467, 6, 2), (3, 6, 2),
+                                     (463, 9, 3), (2467, 10, 9), (700, 11, 2), (5000, 9, 2)])
 def test_fm_multi_even_decimations(rr, monkeypatch, L, D, nch, kernel):
     """FmMulti with interp 1 and integer decimations — auto: decimations 2..8 on decimate-first tiles (k_fm_multi_poly), the
     others as half: even decimations with half-size inverse transforms on 2048-point tiles where the tile choice allows,
