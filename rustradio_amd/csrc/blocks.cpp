@@ -1763,7 +1763,20 @@ Hilbert::Hilbert(size_t ntaps, int window, float parm) : Block("Hilbert", 4, 8) 
         RR_HIP(hipMemsetAsync(h.p, 0, ntaps * sizeof(float), stream));
     }
     RR_HIP(hipStreamSynchronize(stream));
+    if (build_opts().fir_path != RR_PATH_DIRECT && (ntaps >= 200 || build_opts().fir_path == RR_PATH_FFT)) {
+        if (ntaps <= 3584) {
+            std::vector<rr_c32> ct(ntaps);
+            for (size_t i = 0; i < ntaps; i++) ct[i] = {taps[i], 0.0f};
+            fftk.reset(new FftFilter(ct.data(), ntaps, false, 12, true));
+        } else if (ntaps <= 16383) {
+            // a[k] = sum_j c[j] xp[k + j], c[j] = delta[j - L/2] + i rev[j]: caller-order taps t[k] = c[L - 1 - k]
+            std::vector<rr_c32> ct(ntaps);
+            for (size_t k = 0; k < ntaps; k++) ct[k] = {k == ntaps / 2 ? 1.0f : 0.0f, taps[k]};
+            wide.reset(new FirC32(ct.data(), ntaps, 1, false, 0.0f, 0.0f, true));
+        }
+    }
 }
+Hilbert::~Hilbert() = default;
 int Hilbert::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                       size_t* produced, size_t* need, hipStream_t s) {
     *consumed = *produced = 0; *need = 1;
@@ -1772,7 +1785,28 @@ int Hilbert::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     const size_t n = std::min(in_len, out_cap);                                 // :85-87
     VSrc<float> src{hist[cur].p, (long)pl.L, static_cast<const float*>(in), (long)in_len};
     prof_begin(s);
-    if (!(skip_ok && launch_hilbert_skip(pl.L, par, Q, d_hq.p, src, static_cast<cf*>(out), (long)n, s)))
+    // (windows of a few tiles leave the chip idle: the pair-sample / direct kernels keep those, as in FirC32::work_dev)
+    if (fftk && n >= 16 * (((size_t)1 << fftk->log2f) - (size_t)pl.L + 1)) {
+        launch_fftfilt_real_hilbert(fftk->log2f, src, static_cast<cf*>(out), (long)n, pl.L, fftk->d_tw.p, fftk->d_hpos.p, s, CarryOut{});
+    } else if (wide && n >= 4096) {
+        // a[k] over the virtual stream xp = hist ++ window needs xp[k, k + L): Complex(xp, 0) in chunks, then the filter
+        const size_t L = (size_t)pl.L, CH = (size_t)1 << 24, per = CH - L;
+        wide_in.reserve(std::min(CH, n + L - 1) + 8);
+        for (size_t m0 = 0; m0 < n; m0 += per) {
+            const size_t m1 = std::min(n, m0 + per), na = (m1 - m0) + L - 1;
+            // xp[m0 + i], i < na: the first L of the stream come from hist
+            size_t done = 0;
+            if (m0 < L) {
+                const size_t nh = std::min(na, L - m0);
+                launch_f32_to_c32(hist[cur].p + m0, wide_in.p, (long)nh, s);
+                done = nh;
+            }
+            if (done < na) launch_f32_to_c32(static_cast<const float*>(in) + (m0 + done - L), wide_in.p + done, (long)(na - done), s);
+            size_t c2 = 0, p2 = 0, n2 = 0;
+            wide->work_dev(wide_in.p, na, static_cast<cf*>(out) + m0, m1 - m0, &c2, &p2, &n2, s);
+            if (p2 != m1 - m0) throw Error("Hilbert: the Complex filter stage disagrees on the output count");
+        }
+    } else if (!(skip_ok && launch_hilbert_skip(pl.L, par, Q, d_hq.p, src, static_cast<cf*>(out), (long)n, s)))
         launch_hilbert(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)n, s);
     prof_end(s);
     launch_vcopy_f32(src, (long)n, hist[cur ^ 1].p, (long)pl.L, s);            // :125

@@ -454,7 +454,15 @@ struct Hilbert : Block {
     bool skip_ok = false;
     int par = 0, Q = 0;
     DevBuf<float> d_hq;
+    // Round 4: long transformers.  The pair-sample kernel costs 0.24 ms per 1e8 samples up to ~129 taps and then grows with
+    // the taps (255: 0.41, 1001: 1.2, 4001: 17.5 on the generic fallback); the real-stream overlap-save tiles with a Complex
+    // store (k_fftfilt_real<.., HILB>) stay flat up to 3584 taps, and beyond them the transformer is the Complex filter
+    // delta[j - L/2] + i h[j] on Complex(x, 0) (FirFilter<Complex>'s kernels, in chunks through two work buffers).
+    std::unique_ptr<FftFilter> fftk;
+    std::unique_ptr<FirC32> wide;
+    DevBuf<cf> wide_in;
     Hilbert(size_t ntaps, int window, float parm);
+    ~Hilbert() override;
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
 };
 

@@ -24,6 +24,8 @@ void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, in
 
 // Real stream, real taps (hpos from Complex(t, 0)): out[m] = y[m d], y[n] = sum_k t[k] xx[n + L - 1 - k]; two
 // overlap-save segments ride in the real / imaginary lanes of one Complex tile (tiles of 1024..4096 points).
+void launch_fftfilt_real_hilbert(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s,
+                                 CarryOut carry);
 void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
                          hipStream_t s, CarryOut carry = {});
 

@@ -394,10 +394,14 @@ __device__ __attribute__((noinline)) void stage_pair_slow(creg* lds, VSrc<float>
         lds[lds_pad(p)] = mk(src.load(va + p), src.load(vb + p));
     }
 }
-template <int LOG2F, bool DECI>
+// HILB (round 4): the Hilbert block on these tiles (hilbert.rs:113-116) — taps = the transformer, and the stored sample is
+// Complex: out[k] = (xp[k + L/2], y[k]).  The real part is the input delayed by half the filter: re-read from the window
+// (this workgroup loaded the line a moment ago) at tile position idx - L/2.
+template <int LOG2F, bool DECI, bool HILB = false>
 __global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
 void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L, int d, long ntiles,
                     const cf* __restrict__ tw, const cf* __restrict__ hpos, CarryOut carry) {
+    static_assert(!(DECI && HILB), "the Hilbert form does not decimate");
     carry_store<float>(src, carry);
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
@@ -424,7 +428,24 @@ void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L,
         }
         RR_PHASE();
         X.run(v, lds, 0, nullptr);
-        if constexpr (!DECI) {
+        if constexpr (HILB) {
+            const long oa = va - first;
+            const int half = first / 2;
+            creg* pc = reinterpret_cast<creg*>(out) + oa + t;
+            if (va >= src.plen && vb - src.plen + F <= src.in_len && oa + S + F <= n_out) {
+                const gptr<float> px = as_global(src.in + (va - src.plen) - half + t);   // (only positions >= first are read: >= window start)
+#pragma unroll
+                for (int n = 0; n < 16; n++)
+                    if (n * T + t >= first) { pc[n * T] = mk(px[n * T], v[n].x); pc[S + n * T] = mk(px[S + n * T], v[n].y); }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 16; n++) {
+                    const int idx = n * T + t;
+                    if (idx >= first && oa + idx < n_out) pc[n * T] = mk(src.load(va + idx - half), v[n].x);
+                    if (idx >= first && oa + S + idx < n_out) pc[S + n * T] = mk(src.load(vb + idx - half), v[n].y);
+                }
+            }
+        } else if constexpr (!DECI) {
             const long oa = va - first;                      // output index of position 0 of segment A
             float* po = out + oa + t;
             if (oa + S + F <= n_out) {
@@ -1896,6 +1917,30 @@ static void launch_real_one(VSrc<float> src, float* out, long n_out, int L, int 
     hipLaunchKernelGGL((k_fftfilt_real<LOG2F, DECI>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L, d,
                        ntiles, tw, hpos, carry);
     RR_HIP(hipGetLastError());
+}
+template <int LOG2F>
+static void launch_real_hilbert_one(VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s, CarryOut carry) {
+    constexpr int F = 1 << LOG2F;
+    constexpr int T = F / 16;
+    const long S = F - L + 1;
+    if (n_out <= 0) { launch_carry(src, carry, s); return; }
+    const long ntiles = ((n_out + S - 1) / S + 1) / 2;
+    const size_t smem = sizeof(cf) * lds_elems(F);
+    const long grid = grid_for_tiles(k_fftfilt_real<LOG2F, false, true>, T, smem, ntiles);
+    hipLaunchKernelGGL((k_fftfilt_real<LOG2F, false, true>), dim3((unsigned)grid), dim3(T), smem, s, src, reinterpret_cast<float*>(out), n_out, L, 1,
+                       ntiles, tw, hpos, carry);
+    RR_HIP(hipGetLastError());
+}
+// Hilbert on real-stream tiles: out[k] = (xp[k + L/2], sum_j rev[j] xp[k + j]), k < n_out (L odd)
+void launch_fftfilt_real_hilbert(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s,
+                                 CarryOut carry) {
+    if (2L * ((1L << log2f) - L + 1) <= 0 || !(L & 1)) throw Error("fftfilt_real_hilbert: bad filter length for the tile");
+    switch (log2f) {
+    case 10: launch_real_hilbert_one<10>(src, out, n_out, L, tw, hpos, s, carry); break;
+    case 11: launch_real_hilbert_one<11>(src, out, n_out, L, tw, hpos, s, carry); break;
+    case 12: launch_real_hilbert_one<12>(src, out, n_out, L, tw, hpos, s, carry); break;
+    default: throw Error("fftfilt_real_hilbert: unsupported tile size");
+    }
 }
 void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
                          hipStream_t s, CarryOut carry) {
