@@ -397,6 +397,17 @@ __device__ __attribute__((noinline)) void stage_pair_slow(creg* lds, VSrc<float>
 // HILB (round 4): the Hilbert block on these tiles (hilbert.rs:113-116) — taps = the transformer, and the stored sample is
 // Complex: out[k] = (xp[k + L/2], y[k]).  The real part is the input delayed by half the filter: re-read from the window
 // (this workgroup loaded the line a moment ago) at tile position idx - L/2.
+template <int T>
+__device__ __attribute__((noinline)) void hilbert_store_slow(const creg* lds, VSrc<float> src, creg* out, long va, long S, int first, long n_out, int t) {
+    const long oa = va - first, vb = va + S;
+    const int half = first / 2;
+    for (int n = 0; n < 16; n++) {
+        const int idx = n * T + t;
+        const creg v = lds[lds_pad(idx)];
+        if (idx >= first && oa + idx < n_out) out[oa + idx] = mk(src.load(va + idx - half), v.x);
+        if (idx >= first && oa + S + idx < n_out) out[oa + S + idx] = mk(src.load(vb + idx - half), v.y);
+    }
+}
 template <int LOG2F, bool DECI, bool HILB = false>
 __global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
 void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L, int d, long ntiles,
@@ -429,22 +440,42 @@ void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L,
         RR_PHASE();
         X.run(v, lds, 0, nullptr);
         if constexpr (HILB) {
+            // The kernel sits at 243 of 256 registers without this epilogue, and a spilled register is poison here (a scratch
+            // access waits on the whole in-order vmcnt queue: 0.44 instead of ~0.25 ms per 1e8 samples with 18 spilled).  So the
+            // thread parks its 16 values in its OWN slots of the idle exchange area (no barrier: it reads back only what it
+            // wrote), and the epilogue walks them four rows at a time: read back, re-read the delayed input, store.
+#pragma unroll
+            for (int n = 0; n < 16; n++) lds[lds_pad(n * T + t)] = v[n];
+            __builtin_amdgcn_sched_barrier(0);
             const long oa = va - first;
             const int half = first / 2;
-            creg* pc = reinterpret_cast<creg*>(out) + oa + t;
             if (va >= src.plen && vb - src.plen + F <= src.in_len && oa + S + F <= n_out) {
+                creg* pc = reinterpret_cast<creg*>(out) + oa + t;
                 const gptr<float> px = as_global(src.in + (va - src.plen) - half + t);   // (only positions >= first are read: >= window start)
+                constexpr int HG = LOG2F == 11 ? 2 : 4;      // rows per group (2048-point tiles: 4 spill two registers)
 #pragma unroll
-                for (int n = 0; n < 16; n++)
-                    if (n * T + t >= first) { pc[n * T] = mk(px[n * T], v[n].x); pc[S + n * T] = mk(px[S + n * T], v[n].y); }
-            } else {
+                for (int g = 0; g < 16 / HG; g++) {
+                    float xa[HG], xb[HG];
+                    creg y[HG];
 #pragma unroll
-                for (int n = 0; n < 16; n++) {
-                    const int idx = n * T + t;
-                    if (idx >= first && oa + idx < n_out) pc[n * T] = mk(src.load(va + idx - half), v[n].x);
-                    if (idx >= first && oa + S + idx < n_out) pc[S + n * T] = mk(src.load(vb + idx - half), v[n].y);
+                    for (int i = 0; i < HG; i++) {
+                        const int n = HG * g + i;
+                        const bool ok = n * T + t >= first;
+                        xa[i] = ok ? px[n * T] : 0.0f;
+                        xb[i] = ok ? px[S + n * T] : 0.0f;
+                        y[i] = lds[lds_pad(n * T + t)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < HG; i++) {
+                        const int n = HG * g + i;
+                        if (n * T + t >= first) { pc[n * T] = mk(xa[i], y[i].x); pc[S + n * T] = mk(xb[i], y[i].y); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            } else {
+                hilbert_store_slow<T>(lds, src, reinterpret_cast<creg*>(out), va, S, first, n_out, t);   // boundary tiles, out of line
             }
+            tile_sync<T>();                                  // (the next tile's first exchange rewrites those slots)
         } else if constexpr (!DECI) {
             const long oa = va - first;                      // output index of position 0 of segment A
             float* po = out + oa + t;
