@@ -123,8 +123,7 @@ static bool fir_poly_wins(size_t ntaps, size_t deci) {
     switch (deci) {
     case 3: case 10: case 11: return ntaps >= 24;
     case 4: return ntaps >= 400;
-    case 5: case 6: return ntaps >= 100;
-    case 7: return ntaps >= 200;
+    case 5: case 6: case 7: return ntaps >= 100;   // (/7 on the three-waves-per-SIMD kernel since round 4: 127 taps 0.225 / 0.250)
     case 8: case 12: return ntaps >= 700;
     case 9: return ntaps >= 300;
     case 13: case 14: case 15: case 16: return ntaps >= 2000;
@@ -1048,7 +1047,8 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
     // samples against 0.081 now) — tools/poly_probe.py, forced decimate-first / other: 1:9 1000 taps 0.079 / 0.105, 1:11 2467
     // 0.090 / 0.140, 1:12 2467 0.092 / 0.139, 1:13 2467 0.120 / 0.138, 1:14 4000 0.141 / 0.185, 1:16 4000 0.150 / 0.182; the
     // two-wave kernel takes a third batch of phases from 1:13 on, hence the later crossovers.
-    const bool d_wins = D <= 6 || (D <= 11 && f->L >= 800) || (D == 12 && f->L >= 1000) || (D == 13 && f->L >= 2000) ||
+    // (1:7 on the three-waves-per-SIMD kernel, four waves of 2 + 2 + 2 + 1 phases: 463 taps 0.090 -> 0.059, wins at every length)
+    const bool d_wins = D <= 7 || (D <= 11 && f->L >= 800) || (D == 12 && f->L >= 1000) || (D == 13 && f->L >= 2000) ||
                         (D >= 14 && D <= 16 && f->L >= 2000);
     // (1:2 wins up to 500 taps per phase — 1000 taps 0.122 / 0.126, 1300 taps 0.159 / 0.141 — and 1:3 up to 600)
     const bool poly_wins = d_wins && Lsp <= (D == 2 ? 500u : D == 3 ? 600u : 768u);

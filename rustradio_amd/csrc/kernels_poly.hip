@@ -545,8 +545,10 @@ __global__ __launch_bounds__(64 * NW, 3)
 void k_fm_chain_polyw(SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
                       PolyArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
     carry_store<cf>(src, a.carry);
-    static_assert(D % NW == 0 && D / NW <= 2, "at most two phases per wave");
-    constexpr int PPW = D / NW;
+    static_assert((D + NW - 1) / NW <= 2, "at most two phases per wave");
+    constexpr int PPW = (D + NW - 1) / NW;               // (odd decimations, round 4: the last wave has one phase; its loads still
+                                                         //  fetch the pair — the sample in front of phase D - 1 is the neighbouring
+                                                         //  position's phase 0 — and tile_geom keeps that sample inside the window)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     creg* lds = reinterpret_cast<creg*>(smem_raw);
     creg* ldsR = lds;                                    // the tile's resampled samples, natural order (= wave 0's area)
@@ -573,7 +575,7 @@ void k_fm_chain_polyw(SRC src, float* __restrict__ out, long ntiles, const cf* _
     auto tile_geom = [&](long tile, long& u0, long& vbase, bool& interior) {
         u0 = a.r_lo + tile * Sa;
         vbase = (u0 - a.Ls) * D + a.off;
-        interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
+        interior = vbase - (NW * PPW - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
     };
     // Pipelined for two-phase waves on Complex streams (the byte stream's samples are converted where they are loaded).  The
     // prefetch is issued on EVERY iteration — for a boundary or missing next tile from the response table, 48 KB that are
@@ -612,11 +614,13 @@ void k_fm_chain_polyw(SRC src, float* __restrict__ out, long ntiles, const cf* _
             if (interior) poly_issue<D, PPW>(v, src, vbase, t, w * PPW);
             else {
 #pragma unroll
-                for (int i = 0; i < PPW; i++) poly_load<D>(v[i], src, vbase, w * PPW + i, t, false, ex);
+                for (int i = 0; i < PPW; i++)
+                    if (D % PPW == 0 || w * PPW + i < D) poly_load<D>(v[i], src, vbase, w * PPW + i, t, false, ex);
             }
         }
 #pragma unroll
-        for (int i = 0; i < PPW; i++) poly_xform_mac(z, v[i], t, ex, tw0, tab1, hr, w * PPW + i);
+        for (int i = 0; i < PPW; i++)
+            if (D % PPW == 0 || w * PPW + i < D) poly_xform_mac(z, v[i], t, ex, tw0, tab1, hr, w * PPW + i);
         long vbn = 0; bool intn = false;
         if constexpr (PIPE) {
             if (it.tile + it.step < it.end) { long u0n; tile_geom(it.tile + it.step, u0n, vbn, intn); }
@@ -885,7 +889,7 @@ static PolyArgs poly_args(const FmChainArgs& h, int L) {
     return a;
 }
 
-template <int D> struct ChainWaves { static constexpr int NW = D == 6 ? 3 : D == 4 ? 2 : D == 8 ? 4 : D == 3 ? 3 : D == 2 ? 2 : 0; };
+template <int D> struct ChainWaves { static constexpr int NW = D == 6 ? 3 : D == 4 ? 2 : D == 8 ? 4 : D == 3 ? 3 : D == 2 ? 2 : D == 5 ? 3 : D == 7 ? 4 : 0; };
 template <int D, class SRC>
 static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& h, const cf* last_in,
                                 cf* last_out, hipStream_t s) {
@@ -894,8 +898,10 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
     if (nr <= 0) { launch_carry(src, h.carry, s); return; }
     const long ntiles = (nr + Sa - 1) / Sa;
 #if RR_POLY_CHAIN_W3
-    if constexpr (ChainWaves<D>::NW != 0) {
-        constexpr int NW = ChainWaves<D>::NW;
+    // (1:5 and 1:7 from RTL-SDR bytes keep the two-wave kernel: their wave-dependent phase count spills 48-76 registers there)
+    constexpr int NWsel = (std::is_same<SRC, VSrcIQ8>::value && (D == 5 || D == 7)) ? 0 : ChainWaves<D>::NW;
+    if constexpr (NWsel != 0) {
+        constexpr int NW = NWsel;
         const size_t smemw = sizeof(cf) * (NW * PLE + 64 + 15 * PT);
         long gridw = grid_for_tiles(k_fm_chain_polyw<D, NW, SRC>, 64 * NW, smemw, ntiles);
         if (ntiles > gridw && ntiles < 12 * gridw) gridw = std::min(ntiles, (long)RR_POLY_OVERSUB * gridw);
