@@ -889,6 +889,7 @@ static PolyArgs poly_args(const FmChainArgs& h, int L) {
     return a;
 }
 
+// (1:9 ... 1:12 on five / six waves per workgroup were tried: two workgroups per CU, 0.092-0.133 against 0.081-0.096 ms on the two-wave kernel)
 template <int D> struct ChainWaves { static constexpr int NW = D == 6 ? 3 : D == 4 ? 2 : D == 8 ? 4 : D == 3 ? 3 : D == 2 ? 2 : D == 5 ? 3 : D == 7 ? 4 : 0; };
 template <int D, class SRC>
 static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& h, const cf* last_in,
@@ -899,7 +900,7 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
     const long ntiles = (nr + Sa - 1) / Sa;
 #if RR_POLY_CHAIN_W3
     // (1:5 and 1:7 from RTL-SDR bytes keep the two-wave kernel: their wave-dependent phase count spills 48-76 registers there)
-    constexpr int NWsel = (std::is_same<SRC, VSrcIQ8>::value && (D == 5 || D == 7)) ? 0 : ChainWaves<D>::NW;
+    constexpr int NWsel = (std::is_same<SRC, VSrcIQ8>::value && (D % 2 == 1) && D >= 5) ? 0 : ChainWaves<D>::NW;
     if constexpr (NWsel != 0) {
         constexpr int NW = NWsel;
         const size_t smemw = sizeof(cf) * (NW * PLE + 64 + 15 * PT);
