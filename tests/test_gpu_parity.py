@@ -552,7 +552,8 @@ def test_channelizer_cfg5(rr):
 @pytest.mark.parametrize("hn,L,deci,cplx,tr", [(65, 255, 8, False, None), (65, 255, 8, False, (100e6, 7e6)), (31, 64, 5, True, None),
                                                (129, 33, 1, False, None), (3, 1, 1, False, None), (63, 100, 12, True, (8.0, 2.0)),
                                                (65, 401, 16, False, None), (33, 90, 4, True, None), (65, 900, 8, True, None),
-                                               (7, 2, 16, True, (8.0, 1.0)), (65, 1900, 16, False, None)])
+                                               (7, 2, 16, True, (8.0, 1.0)), (65, 1900, 16, False, None),
+                                               (65, 1400, 8, True, None), (65, 700, 4, False, None), (129, 2900, 16, True, None)])
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 4 * 5_003])
 @pytest.mark.parametrize("prune", ["1", "0"])
 def test_hilbert_fir_fused_block(rr, monkeypatch, hn, L, deci, cplx, tr, stream_bytes, prune):
