@@ -454,3 +454,83 @@ def test_fuzz_fused_chains_any_output_window(rr, seed):
                 dd = np.abs(yg[c].astype(np.float64) - yo.astype(np.float64))
                 dd = np.minimum(dd, 2 * np.pi - dd)
                 assert np.all(dd <= bound[:len(dd)])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_round4_paths(rr, seed):
+    """Round 4 widened the path selection: decimate-first tiles for every decimation up to 16 and up to 768 / 928
+    taps per phase, tiles for large decimations, FirFilter<Float> beyond 3584 taps, long Hilbert transformers, the two-stage
+    HilbertFir, FmMulti up to 1:11.  Random shapes over those ranges, windows large enough for the large-window kernels AND
+    small rings, against the oracle blocks."""
+    rng = np.random.default_rng(19000 + seed)
+    kind = seed % 6
+    if kind == 0:                                    # FirFilter<Complex>, any decimation, long filters
+        L = int(rng.choice([31, 127, 700, 1500, 2467, 3599, 4600, 6000]))
+        d = int(rng.integers(1, 41))
+        n = int(rng.integers(L + d + 200_000, L + d + 900_000))
+        x = _c(rng, n)
+        taps = _c(rng, L) / max(1, L // 8)
+        if rng.integers(0, 2):
+            taps = taps.real.astype(np.complex64)
+        ring = int(rng.choice([4_096_000 * 4, 8 * (L + d + int(rng.integers(8, 20_000)))]))
+        _both(rr, lambda m: [m.FirFilter(taps, deci=d)], x, ring)
+    elif kind == 1:                                  # FirFilter<Float> on both sides of 3584 taps
+        L = int(rng.choice([31, 300, 3584, 3585, 4100, 5000, 7000]))
+        d = int(rng.integers(1, 41))
+        n = int(rng.integers(L + d + 100_000, L + d + 700_000))
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        taps = (rng.uniform(-1, 1, L) / max(1, L // 8)).astype(np.float32)
+        ring = int(rng.choice([4_096_000 * 4, 4 * (L + d + int(rng.integers(8, 20_000)))]))
+        _both(rr, lambda m: [m.FirFilter(taps, deci=d)], x, ring)
+    elif kind == 2:                                  # Hilbert, long transformers
+        hn = int(rng.choice([129, 199, 201, 255, 999, 2047, 3583, 3585, 6001]))
+        n = int(rng.integers(hn + 50_000, hn + 600_000))
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        ring = int(rng.choice([4_096_000 * 4, 4 * (2 * hn + int(rng.integers(100, 30_000)))]))
+        w = int(rng.integers(0, 3))
+        _both(rr, lambda m: [m.Hilbert(hn, w)], x, ring)
+    elif kind == 3:                                  # HilbertFir: composite, pruned (down to a quarter of a tile) or two stages
+        hn = int(rng.choice([31, 65, 129]))
+        L = int(rng.choice([33, 255, 700, 1000, 1400, 2467]))
+        d = int(rng.integers(1, 41))
+        n = int(rng.integers(L + d + hn + 100_000, L + d + hn + 600_000))
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        taps = _c(rng, L) / max(1, L // 8)
+        ring = int(rng.choice([4_096_000 * 4, 4 * (L + d + int(rng.integers(8, 20_000)))]))
+        yo = run_chain([orc.Hilbert(hn), orc.FirFilter(taps, deci=d)], x)
+        yg = run_chain([rr.HilbertFir(hn, taps, d)], x, stream_bytes=ring)
+        assert len(yg) == len(yo) and len(yo)
+        assert max_norm_err(yg, yo) <= TOL
+    else:                                            # fused chains: 1:2 ... 1:16, long phases; one chain or three channels
+        D = int(rng.integers(2, 17))
+        L = int(rng.choice([127, 463, 1000, 2467, D * 500, D * 760, min(16000, D * 900)]))
+        n = int(rng.integers(3 * L + 200_000, 3 * L + 700_000))
+        x = _c(rng, n)
+        multi = kind == 5
+        nch = 3 if multi else 1
+        taps = np.stack([_c(rng, L) / max(1, L // 4) for _ in range(nch)])
+        blk = rr.FmMulti(taps, 1, D, 1.0) if multi else rr.FmChain(taps[0], 1, D, 1.0)
+        outs, ringbuf, pos = [[] for _ in range(nch)], np.zeros(0, np.complex64), 0
+        cap_in = int(rng.choice([2_000_000, 2 * L + int(rng.integers(1000, 60_000))]))
+        for _ in range(1_000_000):
+            take = min(cap_in - len(ringbuf), n - pos)
+            ringbuf = np.concatenate([ringbuf, x[pos:pos + take]]); pos += take
+            st, c, p, need, out = blk.work(ringbuf, 1_000_000)
+            ringbuf = ringbuf[c:]
+            out = np.atleast_2d(out)
+            for ch in range(nch):
+                outs[ch].append(out[ch])
+            if take == 0 and c == 0 and p == 0:
+                break
+        for ch in range(nch):
+            yo = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(1, D), orc.QuadratureDemod(1.0)], x)
+            ro = run_chain([orc.FftFilter(taps[ch]), orc.RationalResampler(1, D)], x)
+            yg = np.concatenate(outs[ch])
+            assert len(yg) == len(yo)
+            if len(yo):
+                eps = TOL * float(np.max(np.abs(ro)))
+                mag = np.abs(ro.astype(np.complex128))
+                bound = TOL * np.pi + eps / np.maximum(mag[:-1], 1e-30) + eps / np.maximum(mag[1:], 1e-30)
+                dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
+                dd = np.minimum(dd, 2 * np.pi - dd)
+                assert np.all(dd <= bound[:len(dd)])
