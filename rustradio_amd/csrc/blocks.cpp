@@ -113,6 +113,11 @@ static void compute_hpos(const rr_c32* taps, size_t ntaps, int log2f, std::vecto
 //   /5: 127 0.251 / 0.320, 1000 0.276 / 0.417     /6: 127 0.248 / 0.259, 401 0.256 / 0.316, 2467 0.321 / 0.575
 //   /7: 255 0.274 / 0.311, 2467 0.348 / 0.583     /8: 1000 0.321 / 0.306, 2467 0.355 / 0.593 (pruned inverse below that)
 //   /10: 31 0.317 / 0.355, 255 0.319 / 0.518, 2467 0.349 / 0.580      /12: 2467 0.519 / 0.579      /2, /16: never
+// deci = D * sub on the pruned tile of D (every sub-th kept sample stored): it beats or ties the block's other kernels wherever
+// its tables exist (tools/prune_sub_probe.py, ms per 1e8 samples, pruned / other: 255 taps /32 0.222 / 0.295, 401 taps /24
+// 0.215 / 0.320, 1000 taps /64 0.236 / 0.389, 31 taps /12 0.189 / 0.268; FirFilter<Float> 401 taps /40 0.120 / 0.190;
+// Hilbert(65) -> FirFilter 255 taps /32 0.172 / 0.508, 401 taps /24 0.149 / 0.709, 2000 taps /32 0.255 / 0.823)
+static bool FIR_PRUNE_SUB_DEFAULT(size_t, size_t, size_t) { return true; }
 static bool fir_poly_wins(size_t ntaps, size_t deci) {
     // round 4: every decimation up to 16, and up to 768 taps per phase (tools/fir_long_probe.py, ms per 1e8 samples, other /
     // decimate-first: /6 3599 taps 0.747 / 0.458, /8 4799 taps 0.823 / 0.458, /10 7599 taps 1.058 / 0.804; /4 wins up to ~700
@@ -196,14 +201,19 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     // deci 4 / 8 / 16: the tile whose last radix is the decimation, inverse transform pruned to 1/deci
     // (tools/prune_probe.py, ms per 1e8 samples, direct / decimating store / pruned: 255 Complex taps /8 0.31 / 0.31 /
     //  0.21, 401 taps /4 0.60 / 0.34 / 0.27, 1000 taps /16 98 / 0.45 / 0.29; short /8 filters stay direct: 127 taps 0.195 / 0.27 / 0.207)
-    const size_t per_phase = ntaps / deci;
-    const bool prune_default = deci == 4 ? per_phase >= 8 : deci == 8 ? per_phase >= (real_taps ? 28 : 16) : per_phase >= 4;
+    // Round 4: multiples of those — deci = D * sub, D the largest of 16 / 8 / 4 dividing it — run the tile of D and store every
+    // sub-th kept sample (thresholds: tools/prune_sub_probe.py).
+    const bool have_split = prune_split(deci, prune_D, prune_sub);
+    const size_t per_phase = have_split ? ntaps / prune_D : 0;
+    const bool prune_default = !have_split ? false
+                               : prune_sub > 1 ? FIR_PRUNE_SUB_DEFAULT(ntaps, prune_D, prune_sub)
+                               : prune_D == 4 ? per_phase >= 8 : prune_D == 8 ? per_phase >= (real_taps ? 28 : 16) : per_phase >= 4;
     const bool prune_wins = bo.fir_prune ? bo.fir_prune > 0 : prune_default;
-    if (allow_fft && !force_direct && prune_wins && prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
+    if (allow_fft && !force_direct && prune_wins && have_split) {
         std::vector<std::complex<double>> td(ntaps);
         for (size_t i = 0; i < ntaps; i++) td[i] = {t[i].real(), t[i].imag()};
         prune.reset(new PruneTables());
-        if (!prune->build(td, deci, false, stream)) prune.reset();
+        if (!prune->build(td, prune_D, false, stream)) prune.reset();
     }
     // other even decimations: 2048-point tiles, folded 1024-point inverse (k_fftfilt_half); same bar as the tiles with a
     // decimating store, which it replaces where it applies
@@ -289,10 +299,10 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
             const size_t Ls = (L + d - 1) / d, per_tile = 1024 - Ls;
             use_poly = out_n >= chip_units(1000) * per_tile;                   // one tile per resident workgroup slot
         } else {
-            const size_t F = (size_t)1 << prune->log2f, per_batch = (F - L + 1) / d * d * d;   // D tiles of F - L + 1 inputs
+            const size_t pd = prune_D, F = (size_t)1 << prune->log2f, per_batch = (F - L + 1) / pd * pd * pd;   // D tiles of F - L + 1 inputs
             // (crossover in batches, tools/prune_window_probe.py: ~1.0-1.5x the resident workgroup slots of the tile —
             //  64-thread tiles at /4: 2000, 128-thread at /8: 1500, 256-thread at /16: 550)
-            use_prune = n >= chip_units(d == 4 ? 2000 : d == 8 ? 1500 : 550) * per_batch;
+            use_prune = n >= chip_units(pd == 4 ? 2000 : pd == 8 ? 1500 : 550) * per_batch;
         }
     }
     bool small_direct = false;
@@ -307,7 +317,7 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     if (use_poly) launch_fir_poly(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, poly->d_tw.p, poly->d_h.p, s);
     else if (small_direct) launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
     else if (half_ok) launch_fftfilt_half(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, d_htw.p, d_htw_half.p, d_hhpos.p, s);
-    else if (use_prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
+    else if (use_prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s, (int)prune_sub);
     else if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s);
     else if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s);
     else if (fftk) fftk->filter(src, static_cast<cf*>(out), (long)out_n, s);
@@ -465,15 +475,15 @@ HilbertFir::HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c3
     d_tpG.upload(tp.data(), tp.size(), stream);
     // deci 4 / 8 / 16: real-stream tiles with the pruned inverse; taps in caller order t[k] = G[Lg - 1 - k]
     // (tools/prune_probe.py: 65 (*) 255 taps /8 0.219 -> 0.191 ms per 1e8 real samples, /4 0.37 -> 0.23, /16 a tie)
-    const size_t g_per_phase = G.size() / std::max<size_t>(deci, 1);
+    const bool have_split = prune_split(deci, prune_D, prune_sub);         // (deci = D * sub: FirC32)
+    const size_t g_per_phase = have_split ? G.size() / prune_D : 0;
     // (/16: 65 * 255 taps at 1.28e8 samples 202 us pruned against 376 us direct, tools/prune_window_probe2.py)
-    const bool prune_default = deci == 4 ? g_per_phase >= 8 : deci == 8 ? g_per_phase >= 24 : g_per_phase >= 8;
-    if (build_opts().fir_path != RR_PATH_DIRECT && (build_opts().fir_prune ? build_opts().fir_prune > 0 : prune_default) &&
-        prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
+    const bool prune_default = have_split && (prune_sub > 1 || (prune_D == 4 ? g_per_phase >= 8 : prune_D == 8 ? g_per_phase >= 24 : g_per_phase >= 8));
+    if (build_opts().fir_path != RR_PATH_DIRECT && (build_opts().fir_prune ? build_opts().fir_prune > 0 : prune_default) && have_split) {
         std::vector<std::complex<double>> td(G.size());
         for (size_t k = 0; k < G.size(); k++) td[k] = G[G.size() - 1 - k];
         prune.reset(new PruneTables());
-        if (!prune->build(td, deci, true, stream)) prune.reset();
+        if (!prune->build(td, prune_D, true, stream)) prune.reset();
     }
     for (auto& h : hist) {                                                      // hilbert.rs:55 — hn zeros
         h.reserve(hn);
@@ -514,12 +524,12 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     //  65 * 255 taps / 8 — the direct form is faster: 1 M samples 31.7 -> 10.1 us, 8 M 34.0 -> 22.7 us)
     bool use_prune = prune != nullptr;
     if (use_prune && fir->window_aware) {
-        const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - (size_t)plG.L + 1) * (d / 2);
-        use_prune = n >= chip_units(d == 4 ? 1500 : d == 8 ? 1500 : 350) * per_batch;   // (tools/prune_window_probe2.py)
+        const size_t pd = prune_D, F = (size_t)1 << prune->log2f, per_batch = 2 * (F - (size_t)plG.L + 1) * (pd / 2);
+        use_prune = n >= chip_units(pd == 4 ? 1500 : pd == 8 ? 1500 : 350) * per_batch;   // (tools/prune_window_probe2.py)
     }
     // (the hn samples before the new window become the next call's history: written by the tile kernel itself)
     const CarryOut carry{hist[cur ^ 1].p, (long)n, (long)hn};
-    if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s, carry);
+    if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s, carry, (int)prune_sub);
     else if (two_stage && (n >= 16384 || !fir_direct_has_tile(plG, sizeof(float), sizeof(cf)))) {
         // a[k] = (iv[k + hn/2], sum_j rev_h[j] iv[k + j]) over the virtual stream iv = hist ++ window (hilbert.rs:113-116), then
         // y[m] = sum_k rev[k] a[m d + k]: outputs [m0, m1) take a[m0 d, m1 d + L - 1).  In chunks, so that the analytic buffer
@@ -569,14 +579,15 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
     const bool wins = deci == 1 ? ntaps >= 24
                                 : (ntaps >= 320 || ntaps / deci >= 40 || deci >= 10 ||   // (/10 on: 0.27-0.46 ms per 1e8 direct, 0.20 on the tiles)
                                    !fir_direct_has_tile(pl, sizeof(float), sizeof(float)));   // (see FirC32)
-    const size_t per_phase = ntaps / deci;
-    const bool prune_default = deci == 4 ? per_phase >= 8 : deci == 8 ? per_phase >= 16 : per_phase >= 4;
+    const bool have_split = prune_split(deci, prune_D, prune_sub);         // (deci = D * sub: FirC32)
+    const size_t per_phase = have_split ? ntaps / prune_D : 0;
+    const bool prune_default = have_split && (prune_sub > 1 || (prune_D == 4 ? per_phase >= 8 : prune_D == 8 ? per_phase >= 16 : per_phase >= 4));
     const bool prune_wins = bo.fir_prune ? bo.fir_prune > 0 : prune_default;
-    if (!force_direct && prune_wins && prune_log2f_for_deci((int)std::min<size_t>(deci, 64))) {
+    if (!force_direct && prune_wins && have_split) {
         std::vector<std::complex<double>> td(ntaps);
         for (size_t i = 0; i < ntaps; i++) td[i] = {(double)taps[i], 0.0};
         prune.reset(new PruneTables());
-        if (!prune->build(td, deci, false, stream)) prune.reset();
+        if (!prune->build(td, prune_D, false, stream)) prune.reset();
     }
     window_aware = bo.fir_prune <= 0 && !force_fft;
     // (with the pruned inverse the tiles stay beside it as the small-window path of long filters, see work_dev)
@@ -606,8 +617,8 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     // 255 taps / 8) the direct form or the plain tiles finish a call sooner (1 M samples: 33.9 -> 6.7 us, 8 M: 38.5 -> 14.6)
     bool use_prune = prune != nullptr;
     if (use_prune && window_aware) {
-        const size_t F = (size_t)1 << prune->log2f, per_batch = 2 * (F - L + 1) * d;
-        use_prune = n >= chip_units(d == 4 ? 2000 : d == 8 ? 1700 : 370) * per_batch;   // (tools/prune_window_probe2.py)
+        const size_t pd = prune_D, F = (size_t)1 << prune->log2f, per_batch = 2 * (F - L + 1) * pd;
+        use_prune = n >= chip_units(pd == 4 ? 2000 : pd == 8 ? 1700 : 370) * per_batch;   // (tools/prune_window_probe2.py)
     }
     const bool small_direct = prune && !use_prune && (!fftk || (L <= 320 && fir_direct_has_tile(pl, sizeof(float), sizeof(float))));
     if (wide) {
@@ -624,7 +635,7 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
             launch_c32_re(wide_out.p, static_cast<float*>(out) + m0, (long)(m1 - m0), s);
         }
     }
-    else if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s);
+    else if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s, (int)prune_sub);
     else if (small_direct) launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
     else if (fftk) fftk->filter_real(src, static_cast<float*>(out), (long)(n / d), (int)d, s);
     else launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);

@@ -86,6 +86,7 @@ struct FirC32 : Block {
     // forces the direct kernel or the tiles for any length (read at construction).
     std::unique_ptr<FftFilter> fftk;
     std::unique_ptr<PruneTables> prune;           // deci 4 / 8 / 16: pruned inverse transform (k_fftfilt_prune)
+    size_t prune_D = 0, prune_sub = 1;            // round 4: deci = prune_D * prune_sub (every prune_sub-th kept sample stored)
     // other even decimations, <= 600 taps: 2048-point tiles with the half-size inverse (k_fftfilt_half)
     bool half_ok = false;
     // decimations 3 / 5 / 6 / 7 ...: decimate-first tiles (k_fm_chain_poly with the samples stored, kernels_poly.hip)
@@ -148,6 +149,7 @@ struct HilbertFir : Block {
     DevBuf<float> hist[2];            // the hn input samples before the window start
     int cur = 0;
     std::unique_ptr<PruneTables> prune;   // deci 4 / 8 / 16: two real segments per tile, pruned inverse (k_fftfilt_prune)
+    size_t prune_D = 0, prune_sub = 1;    // deci = prune_D * prune_sub
     HilbertFir(size_t hilbert_ntaps, int window, float parm, const rr_c32* taps, size_t ntaps, size_t deci,
                bool translate, float samp_rate, float freq);
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
@@ -158,6 +160,7 @@ struct FirF32 : Block {
     DevBuf<float> d_tp, d_rev;
     std::unique_ptr<FftFilter> fftk;   // long filters: overlap-save tiles on the real stream (see FirC32::fftk)
     std::unique_ptr<PruneTables> prune; // deci 4 / 8 / 16: pruned inverse (k_fftfilt_prune, real stream x real taps)
+    size_t prune_D = 0, prune_sub = 1;  // deci = prune_D * prune_sub
     bool window_aware = true;           // per-call choice by window size (off when a path is forced)
     // Beyond 3584 taps the real-stream tiles (4096 points at most) end and the direct form costs 0.0026 ms per tap and 1e8
     // samples — or has no tile at all (5000 taps: 12.9 ms, /32: 224 ms on the one-thread-per-output fallback).  Then the block

@@ -43,14 +43,15 @@ void launch_audio_chain(int log2f, VSrc<float> src, float* out, int L, const cf*
 // (k_fftfilt_prune): out[m] = y[m D], m < n_out.  Tables (see the kernel): hpos2 = H in position order with the
 // factors w_D^(-c k3) w_16D^(-c k2), c = (L - 1) % D, folded in; twb[n2 * 16 + k1] = exp(+2 pi i k1 (n2 D + c) / F).
 int prune_log2f_for_deci(int d);                 // 0 when d is not 4 / 8 / 16
+bool prune_split(size_t d, size_t& D, size_t& sub);   // d = D * sub, D in {16, 8, 4} (the pruned tile), sub <= 64
 void launch_fftfilt_prune_c32(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                              const cf* twb, hipStream_t s);
+                              const cf* twb, hipStream_t s, int sub = 1);
 // real stream, real taps, f32 output (decimating FirFilter<Float>)
 void launch_fftfilt_prune_f32(int log2f, VSrc<float> src, float* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                              const cf* twb, hipStream_t s);
+                              const cf* twb, hipStream_t s, int sub = 1);
 // real stream, Complex taps t = Gr + i Gi: hpos2r / hpos2i from the real tap sets Gr / Gi; Complex output
 void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
-                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry = {});
+                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry = {}, int sub = 1);
 
 // Even decimations on 2048-point tiles with the half-size inverse (k_fftfilt_half): out[m] = y[m d], m < n_out.
 // tw = w_2048^k, tw_half = w_1024^k, hpos = H / F in the 2048-point position order.

@@ -547,7 +547,22 @@ template <int LOG2F, int MODE>
 __global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
 void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long n_out, int L, long S, long ntiles,
                      const cf* __restrict__ tw, const cf* __restrict__ hpos2, const cf* __restrict__ hpos2b,
-                     const cf* __restrict__ twb_tab, CarryOut carry) {
+                     const cf* __restrict__ twb_tab, CarryOut carry, int sub) {
+    // sub > 1 (round 4): a decimation d = D * sub.  The tail's kept samples are the stream's y[D m]; of those only m = sub q
+    // are stored, at out[q] (n_out counts the D-decimated samples).  Per thread the 16 candidates are m0 + 16 n1: m0 is split
+    // once into sub * base + r0, and r0 + 16 n1 < sub + 256 is small enough for an exact float reciprocal.
+    const float inv_sub = 1.0f / (float)sub;
+    auto sub_split = [&](long m0, long& base, int& r0) {
+        long r = m0 % sub;
+        if (r < 0) r += sub;
+        r0 = (int)r;
+        base = (m0 - r) / sub;
+    };
+    auto sub_hit = [&](int r0, int n1, int& q) {
+        const int x = r0 + 16 * n1;
+        q = (int)(((float)x + 0.5f) * inv_sub);
+        return q * sub == x;
+    };
     if constexpr (MODE == 0) carry_store<cf>(csrc, carry); else carry_store<float>(rsrc, carry);
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
@@ -671,10 +686,22 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             const int lima = ra < hi ? (int)ra : hi, limb = rb < hi ? (int)rb : hi;
             float* pa = reinterpret_cast<float*>(out) + ma;
             float* pb = reinterpret_cast<float*>(out) + mb;
+            if (sub == 1) {
 #pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                if (16 * n1 >= lo && 16 * n1 < lima) pa[16 * n1] = p[n1].x;
-                if (16 * n1 >= lo && 16 * n1 < limb) pb[16 * n1] = p[n1].y;
+                for (int n1 = 0; n1 < 16; n1++) {
+                    if (16 * n1 >= lo && 16 * n1 < lima) pa[16 * n1] = p[n1].x;
+                    if (16 * n1 >= lo && 16 * n1 < limb) pb[16 * n1] = p[n1].y;
+                }
+            } else {
+                long ba, bb; int ra, rb2;
+                sub_split(ma, ba, ra); sub_split(mb, bb, rb2);
+                float* of = reinterpret_cast<float*>(out);
+#pragma unroll
+                for (int n1 = 0; n1 < 16; n1++) {
+                    int q;
+                    if (16 * n1 >= lo && 16 * n1 < lima && sub_hit(ra, n1, q)) of[ba + q] = p[n1].x;
+                    if (16 * n1 >= lo && 16 * n1 < limb && sub_hit(rb2, n1, q)) of[bb + q] = p[n1].y;
+                }
             }
         } else if constexpr (!REAL2) {
             creg p[16];
@@ -683,9 +710,19 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             const long room = n_out - m0;
             const int lim = room < hi ? (int)room : hi;
             creg* po = out_reg + m0;
+            if (sub == 1) {
 #pragma unroll
-            for (int n1 = 0; n1 < 16; n1++)
-                if (16 * n1 >= lo && 16 * n1 < lim) po[16 * n1] = p[n1];
+                for (int n1 = 0; n1 < 16; n1++)
+                    if (16 * n1 >= lo && 16 * n1 < lim) po[16 * n1] = p[n1];
+            } else {
+                long bs; int rs;
+                sub_split(m0, bs, rs);
+#pragma unroll
+                for (int n1 = 0; n1 < 16; n1++) {
+                    int q;
+                    if (16 * n1 >= lo && 16 * n1 < lim && sub_hit(rs, n1, q)) out_reg[bs + q] = p[n1];
+                }
+            }
         } else {
             // slot = (tile b2, response c): c = 0 holds (Gr*a) + i (Gr*b), the real parts of y_a (segment 2 tile) and
             // y_b (segment 2 tile + 1); c = 1 holds (Gi*a) + i (Gi*b), their imaginary parts.  The two threads of a
@@ -708,11 +745,18 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             const long room = n_out - m0;
             const int lim = room < hi ? (int)room : hi;
             creg* po = out_reg + m0;
+            long bs = 0; int rs = 0;
+            if (sub != 1) sub_split(m0, bs, rs);
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
                 const creg q = other[n1];
                 if (RR_ABLATE(2)) { if (q.x == 1234.5678f) po[16 * n1] = q; }
-                else if (16 * n1 >= lo && 16 * n1 < lim) po[16 * n1] = c ? mk(q.y, p[n1].y) : mk(p[n1].x, q.x);
+                else if (16 * n1 >= lo && 16 * n1 < lim) {
+                    const creg val = c ? mk(q.y, p[n1].y) : mk(p[n1].x, q.x);
+                    int qi;
+                    if (sub == 1) po[16 * n1] = val;
+                    else if (sub_hit(rs, n1, qi)) out_reg[bs + qi] = val;
+                }
             }
         }
         tile_sync<T>();                                  // the next batch parks into the slots just read
@@ -1989,8 +2033,10 @@ void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int
 }
 
 template <int LOG2F, int MODE>
-static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                             const cf* hpos2b, const cf* twb, hipStream_t s, CarryOut carry = {}) {
+static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_final, int L, const cf* tw, const cf* hpos2,
+                             const cf* hpos2b, const cf* twb, hipStream_t s, int sub, CarryOut carry = {}) {
+    if (sub < 1 || sub > 64) throw Error("fftfilt_prune: sub-decimation out of range");
+    const long n_out = n_final > 0 ? (n_final - 1) * (long)sub + 1 : 0;        // in units of the tile's own decimation
     constexpr int F = 1 << LOG2F, T = F / 16, D = F / 256;
     const long S = (F - L + 1) / D * D;                  // tiles advance by a multiple of D: one phase c for all tiles
     if (S <= 0) throw Error("fftfilt_prune: filter too long for the tile");
@@ -2002,38 +2048,44 @@ static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_ou
     constexpr int BT = MODE == 1 ? D / 2 : D;             // tiles per batch (MODE 1: two responses per tile)
     const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, MODE>, T, smem, (ntiles + BT - 1) / BT);
     hipLaunchKernelGGL((k_fftfilt_prune<LOG2F, MODE>), dim3((unsigned)grid), dim3(T), smem, s, csrc, rsrc, out, n_out, L, S,
-                       ntiles, tw, hpos2, hpos2b, twb, carry);
+                       ntiles, tw, hpos2, hpos2b, twb, carry, sub);
     RR_HIP(hipGetLastError());
 }
 int prune_log2f_for_deci(int d) { return d == 4 ? 10 : d == 8 ? 11 : d == 16 ? 12 : 0; }
+// d = D * sub with D the largest of 16 / 8 / 4 that divides d (sub <= 64): the pruned tile of D, every sub-th kept sample stored
+bool prune_split(size_t d, size_t& D, size_t& sub) {
+    for (size_t c : {(size_t)16, (size_t)8, (size_t)4})
+        if (d >= c && d % c == 0 && d / c <= 64) { D = c; sub = d / c; return true; }
+    return false;
+}
 void launch_fftfilt_prune_c32(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                              const cf* twb, hipStream_t s) {
+                              const cf* twb, hipStream_t s, int sub) {
     VSrc<float> none{nullptr, 0, nullptr, 0};
     switch (log2f) {
-    case 10: launch_prune_one<10, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
-    case 11: launch_prune_one<11, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
-    case 12: launch_prune_one<12, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    case 10: launch_prune_one<10, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
+    case 11: launch_prune_one<11, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
+    case 12: launch_prune_one<12, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
     default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }
 void launch_fftfilt_prune_f32(int log2f, VSrc<float> src, float* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                              const cf* twb, hipStream_t s) {
+                              const cf* twb, hipStream_t s, int sub) {
     VSrc<cf> none{nullptr, 0, nullptr, 0};
     cf* o = reinterpret_cast<cf*>(out);
     switch (log2f) {
-    case 10: launch_prune_one<10, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s); break;
-    case 11: launch_prune_one<11, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s); break;
-    case 12: launch_prune_one<12, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s); break;
+    case 10: launch_prune_one<10, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
+    case 11: launch_prune_one<11, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
+    case 12: launch_prune_one<12, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
     default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }
 void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
-                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry) {
+                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry, int sub) {
     VSrc<cf> none{nullptr, 0, nullptr, 0};
     switch (log2f) {
-    case 10: launch_prune_one<10, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, carry); break;
-    case 11: launch_prune_one<11, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, carry); break;
-    case 12: launch_prune_one<12, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, carry); break;
+    case 10: launch_prune_one<10, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, sub, carry); break;
+    case 11: launch_prune_one<11, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, sub, carry); break;
+    case 12: launch_prune_one<12, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, sub, carry); break;
     default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }

@@ -100,7 +100,9 @@ def test_fir_nondecimating_both_paths(rr, monkeypatch, path, L, cplx):
                                          # round 4: decimations 9, 11, 13-15 and long phases on the decimate-first tiles; decimations
                                          # beyond 10 with short filters (off the direct form's one-thread-per-output fallback)
                                          (127, 20, False), (31, 32, True), (127, 13, False), (1000, 9, True), (2467, 11, False), (2467, 13, True),
-                                         (3599, 6, False), (4799, 8, True), (5000, 15, False), (2279, 3, True), (3039, 4, False), (31, 11, True)])
+                                         (3599, 6, False), (4799, 8, True), (5000, 15, False), (2279, 3, True), (3039, 4, False), (31, 11, True),
+                                         # decimations D * sub on the pruned tile of D = 16 / 8 / 4 (every sub-th kept sample stored)
+                                         (255, 32, True), (401, 12, False), (1000, 48, True), (127, 64, False), (64, 20, True), (300, 24, True), (500, 1024, True)])
 def test_fir_decimating_both_paths(rr, monkeypatch, path, L, deci, cplx):
     """Decimating FirFilter through the direct-form kernel and through the overlap-save tiles with a decimating
     store: same protocol, same outputs (1e-5), incl. decimations beyond the tile's useful width and small rings."""
@@ -281,7 +283,8 @@ def test_fftfilter_float_lengths(rr, L):
                                     (3584, 1), (3584, 4096), (64, 100), (330, 50), (2000, 7), (3, 4), (64, 4), (513, 4),
                                     (255, 8), (1025, 8), (2049, 16), (31, 16),
                                     # round 4: beyond the real-stream tiles (3584 taps) on the FirFilter<Complex> kernels; /20, /32 short
-                                    (3585, 1), (5000, 1), (5000, 20), (9000, 3), (4000, 32), (127, 20), (31, 32)])
+                                    (3585, 1), (5000, 1), (5000, 20), (9000, 3), (4000, 32), (127, 20), (31, 32),
+                                    (255, 32), (401, 12), (1000, 48), (127, 64), (64, 20), (300, 24)])
 def test_fir_float_both_paths(rr, monkeypatch, path, L, deci):
     """FirFilter<Float> through the direct-form kernel, the real-stream overlap-save tiles (decimating store) and —
     deci 4 / 8 / 16 — the tiles with the pruned inverse transform."""
@@ -553,7 +556,8 @@ def test_channelizer_cfg5(rr):
                                                (129, 33, 1, False, None), (3, 1, 1, False, None), (63, 100, 12, True, (8.0, 2.0)),
                                                (65, 401, 16, False, None), (33, 90, 4, True, None), (65, 900, 8, True, None),
                                                (7, 2, 16, True, (8.0, 1.0)), (65, 1900, 16, False, None),
-                                               (65, 1400, 8, True, None), (65, 700, 4, False, None), (129, 2900, 16, True, None)])
+                                               (65, 1400, 8, True, None), (65, 700, 4, False, None), (129, 2900, 16, True, None),
+                                               (65, 255, 32, True, None), (65, 401, 24, False, (100e6, 3e6)), (33, 127, 12, True, None), (65, 600, 64, True, None)])
 @pytest.mark.parametrize("stream_bytes", [4_096_000, 4 * 5_003])
 @pytest.mark.parametrize("prune", ["1", "0"])
 def test_hilbert_fir_fused_block(rr, monkeypatch, hn, L, deci, cplx, tr, stream_bytes, prune):
