@@ -291,11 +291,11 @@ size_t rr_fir_fft_tile(const rr_block* b) {
 // ---- host memory registration -----------------------------------------------------------------------
 int rr_host_register(void* ptr, size_t bytes) {
     if (!ptr || !bytes) { rr::set_last_error("rr_host_register: null / empty range"); return RR_ERR; }
-    return guarded([&] { RR_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault)); });
+    return guarded([&] { RR_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault)); rr::host_range_add(ptr, bytes); });
 }
 int rr_host_unregister(void* ptr) {
     if (!ptr) { rr::set_last_error("rr_host_unregister: null"); return RR_ERR; }
-    return guarded([&] { RR_HIP(hipHostUnregister(ptr)); });
+    return guarded([&] { rr::host_range_remove(ptr); RR_HIP(hipHostUnregister(ptr)); });
 }
 
 // ---- device-resident streams ------------------------------------------------------------------------

@@ -4,6 +4,8 @@
 // /root/reference/src.  There is no CPU compute path here: every branch that produces
 // samples launches a kernel.
 #include "blocks.hpp"
+
+#include <mutex>
 #include "rotor_host.hpp"
 
 #include <algorithm>
@@ -81,17 +83,70 @@ void Block::prof_read(double* total_ms, size_t* launches, bool reset) {
 }
 bool Block::eof(bool src_eof) { return src_eof; }   // rustradio_macros_code/src/lib.rs:596-623
 
-// Host-window work(): stage the windows through device memory around work_dev().
+// The device's view of a PAGE-LOCKED host range (hipHostMalloc, or the caller's stream ring after rr_host_register), or
+// nullptr for pageable memory.
+// Ranges page-locked through rr_host_register are remembered with their device address (one hipHostGetDevicePointer at
+// registration): a window inside one costs a short scan.  Other page-locked memory (hipHostMalloc by the caller) is asked
+// about per call — hipPointerGetAttributes costs ~8 us, so the last few answers are kept by exact pointer.
+namespace {
+struct HostRange { const unsigned char* base; size_t bytes; unsigned char* dev; };
+std::mutex g_host_m;
+std::vector<HostRange> g_host_ranges;
+struct Seen { const void* host; void* dev; };
+thread_local Seen g_seen[8];
+thread_local unsigned g_seen_next = 0;
+}  // namespace
+void host_range_add(void* base, size_t bytes) {
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, base, 0) != hipSuccess || !dev) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> g(g_host_m);
+    g_host_ranges.push_back({static_cast<const unsigned char*>(base), bytes, static_cast<unsigned char*>(dev)});
+}
+void host_range_remove(void* base) {
+    std::lock_guard<std::mutex> g(g_host_m);
+    for (size_t i = 0; i < g_host_ranges.size(); i++)
+        if (g_host_ranges[i].base == base) { g_host_ranges.erase(g_host_ranges.begin() + (long)i); break; }
+    for (auto& e : g_seen) e = Seen{nullptr, nullptr};
+}
+void* device_view_of_host(const void* host) {
+    if (!host) return nullptr;
+    const unsigned char* h = static_cast<const unsigned char*>(host);
+    {
+        std::lock_guard<std::mutex> g(g_host_m);
+        for (auto& r : g_host_ranges)
+            if (h >= r.base && h < r.base + r.bytes) return r.dev + (h - r.base);
+    }
+    for (auto& e : g_seen) if (e.host == host) return e.dev;
+    hipPointerAttribute_t a{};
+    void* dev = nullptr;
+    if (hipPointerGetAttributes(&a, host) != hipSuccess) (void)hipGetLastError();        // (pageable: an error, cleared)
+    else if (a.type == hipMemoryTypeHost && a.devicePointer) dev = a.devicePointer;
+    if (dev) { g_seen[g_seen_next % 8] = Seen{host, dev}; g_seen_next++; }             // (pageable answers are not kept: the memory may be registered later)
+    return dev;
+}
+
+// Host-window work().  Page-locked windows (round 4): the kernels read the input window and write the output window over
+// PCIe THEMSELVES — the link is full duplex, so the window going down overlaps the one coming up, which two DMA copies on
+// this pool do not (tools/zerocopy_probe.py, 4,096,000-byte windows: FftFilter 193 -> 148 us, the fused
+// RTL-SDR chain 175 -> 109, Hilbert -> FirFilter /8 316 -> 120).  Pageable windows are staged through device memory.
 int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                      size_t* produced, size_t* need) {
     RR_HIP(hipSetDevice(device));
     last_stream = stream;
+    void* din = zero_copy_in && in_len ? device_view_of_host(in) : nullptr;
+    void* dout = out_cap ? device_view_of_host(out) : nullptr;
     const size_t in_use = in_len;   // whole window: kernels may touch (zero-weighted) samples past the consumed range
-    st_in.reserve(std::max<size_t>(in_use * in_es, 16));
-    st_out.reserve(std::max<size_t>(out_cap * out_es, 16));
-    if (in_use) RR_HIP(hipMemcpyAsync(st_in.p, in, in_use * in_es, hipMemcpyHostToDevice, stream));
-    int st = work_dev(st_in.p, in_len, st_out.p, out_cap, consumed, produced, need, stream);
-    if (*produced) RR_HIP(hipMemcpyAsync(out, st_out.p, *produced * out_es, hipMemcpyDeviceToHost, stream));
+    if (!din) {
+        st_in.reserve(std::max<size_t>(in_use * in_es, 16));
+        if (in_use) RR_HIP(hipMemcpyAsync(st_in.p, in, in_use * in_es, hipMemcpyHostToDevice, stream));
+        din = st_in.p;
+    }
+    if (!dout) st_out.reserve(std::max<size_t>(out_cap * out_es * out_windows(), 16));
+    int st = work_dev(din, in_len, dout ? dout : st_out.p, out_cap, consumed, produced, need, stream);
+    if (!dout && *produced) {
+        if (out_windows() == 1) RR_HIP(hipMemcpyAsync(out, st_out.p, *produced * out_es, hipMemcpyDeviceToHost, stream));
+        else RR_HIP(hipMemcpy2DAsync(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, out_windows(), hipMemcpyDeviceToHost, stream));
+    }
     RR_HIP(hipStreamSynchronize(stream));
     return st;
 }
@@ -1078,8 +1133,9 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
 
 size_t OutTail::drain(float* out, size_t out_stride, size_t out_cap, size_t C, hipStream_t s) {
     const size_t m = std::min(out_cap, len - pos);
+    // (hipMemcpyDefault: `out` is a device window, or a page-locked host window the kernels write in place)
     if (m) RR_HIP(hipMemcpy2DAsync(out, out_stride * sizeof(float), buf.p + pos, cap * sizeof(float), m * sizeof(float), C,
-                                   hipMemcpyDeviceToDevice, s));
+                                   hipMemcpyDefault, s));
     pos += m;
     return m;
 }
@@ -1276,6 +1332,7 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
     : Block(u8 ? "RtlSdrDecode>Tee>N x (FftFilter>RationalResampler>QuadratureDemod)" : "Tee>N x (FftFilter>RationalResampler>QuadratureDemod)",
             u8 ? 1 : 8, 4), C(nchan), iq8(u8) {
     if (nchan == 0 || nchan > 4096) throw Error("FmMulti: channel count must be 1..4096");
+    zero_copy_in = false;                            // (its kernels read a tile once per run of channel rounds: upload it)
     if (deci == 0) throw Error("RationalResampler created using deci 0");
     if (interp == 0) throw Error("RationalResampler created using interp 0");
     // Integer decimations up to 8 run on the decimate-first tiles (kernels_poly.hip) for up to 768 taps PER PHASE — they
@@ -1405,21 +1462,6 @@ int FmMulti::work_blocks(const void* in, size_t in_len, float* out, size_t out_s
     return st;
 }
 
-int FmMulti::work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
-                       size_t* produced, size_t* need) {
-    RR_HIP(hipSetDevice(device));
-    last_stream = stream;
-    st_in.reserve(std::max<size_t>(in_len * in_es, 16));
-    st_out.reserve(std::max<size_t>(C * out_cap * out_es, 16));
-    if (in_len) RR_HIP(hipMemcpyAsync(st_in.p, in, in_len * in_es, hipMemcpyHostToDevice, stream));
-    const int st = work_dev(st_in.p, in_len, st_out.p, out_cap, consumed, produced, need, stream);
-    if (*produced)
-        RR_HIP(hipMemcpy2DAsync(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, C,
-                                hipMemcpyDeviceToHost, stream));
-    RR_HIP(hipStreamSynchronize(stream));
-    return st;
-}
-
 // ---- FftFilterFloat (fft_filter.rs:365-491) ---------------------------------------------------------
 FftFilterFloat::FftFilterFloat(const float* taps, size_t ntaps) : Block("FftFilterFloat", 4, 4) {
     if (ntaps == 0) throw Error("FftFilterFloat: empty taps");
@@ -1443,7 +1485,7 @@ int FftFilterFloat::work_dev(const void* in, size_t in_len, void* out, size_t ou
     // outer input -> inner_in as Complex(x, 0)   (fft_filter.rs:431-445)
     const size_t n = std::min(in_len, cap - iin_len);
     if (real_inner) {
-        if (n) RR_HIP(hipMemcpyAsync(fin[ci].p + iin_len, in, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (n) RR_HIP(hipMemcpyAsync(fin[ci].p + iin_len, in, n * sizeof(float), hipMemcpyDefault, s));
     } else {
         launch_f32_to_c32(static_cast<const float*>(in), iin[ci].p + iin_len, (long)n, s);
     }
@@ -1469,7 +1511,7 @@ int FftFilterFloat::work_dev(const void* in, size_t in_len, void* out, size_t ou
     const size_t m = std::min(iout_len, out_cap);
     if (m == 0 && iout_len != 0) { *need = 1; return RR_WAIT_DST; }   // :457-459
     if (real_inner) {
-        if (m) RR_HIP(hipMemcpyAsync(out, fout[co].p, m * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (m) RR_HIP(hipMemcpyAsync(out, fout[co].p, m * sizeof(float), hipMemcpyDefault, s));
     } else {
         launch_c32_re(iout[co].p, static_cast<float*>(out), (long)m, s);
     }
@@ -1543,7 +1585,7 @@ int Resampler::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     counter = (int64_t)((__int128)c0 + (__int128)(kstar + 1) * I - (__int128)capp * D);
     if (counter > 0) {
         RR_HIP(hipMemcpyAsync(d_pending.p, static_cast<const unsigned char*>(in) + (size_t)kstar * in_es, in_es,
-                              hipMemcpyDeviceToDevice, s));
+                              hipMemcpyDefault, s));     // (`in`: a device window or a page-locked host window read in place)
         has_pending = true;
     }
     *consumed = (size_t)(kstar + 1); *produced = out_cap;

@@ -11,6 +11,10 @@ namespace rr {
 
 void set_thread_device(int d);
 int thread_device();
+// page-locked host ranges the library was told about (rr_host_register): their device view, for zero-copy host windows
+void host_range_add(void* base, size_t bytes);
+void host_range_remove(void* base);
+void* device_view_of_host(const void* host);      // nullptr: pageable (staged copies)
 
 struct Block {
     const char* name;
@@ -18,7 +22,10 @@ struct Block {
     int device = 0;
     hipStream_t stream = nullptr;         // private stream: host-window work() and setup copies
     hipStream_t last_stream = nullptr;    // stream of the most recent work call (what sync() waits for)
-    DevBuf<unsigned char> st_in, st_out;   // staging for host-window work()
+    DevBuf<unsigned char> st_in, st_out;   // staging for host-window work() (pageable windows)
+    // page-locked host INPUT windows are read by the kernels in place (zero copy); blocks whose kernels read the window more
+    // than once (the N-channel blocks: every run of channel rounds re-reads its tiles) keep the upload
+    bool zero_copy_in = true;
 
     Block(const char* nm, size_t ies, size_t oes);
     virtual ~Block();
@@ -351,7 +358,6 @@ struct FmMulti : Block {
         return trickle_work(*this, tail, C, in, in_len, out, out_cap, c, p, need, s);
     }
     bool eof(bool src_eof) override { return src_eof && !tail.pending(); }
-    int work_host(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*) override;
 };
 
 struct FftFilterFloat : Block {
@@ -437,7 +443,6 @@ struct Parallel : Block {
     ~Parallel() override;
     size_t out_windows() const override { return ch.size(); }
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
-    int work_host(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*) override;
     bool eof(bool src_eof) override;
 };
 // What rr_fm_chain*_create / rr_fm_multi*_create / rr_audio_chain_create build: the fused block where its kernels reach, the

@@ -111,6 +111,7 @@ Parallel::Parallel(const char* nm, std::vector<std::unique_ptr<Block>> channels)
     : Block(nm, channels.front()->in_es, channels.front()->out_es), ch(std::move(channels)) {
     for (auto& c : ch)
         if (c->in_es != in_es || c->out_es != out_es) throw Error("Parallel: channels of different stream types");
+    zero_copy_in = false;                            // (every channel reads the whole window: upload it once)
 }
 
 // `out` holds ch.size() windows of out_cap elements; every channel sees the same input window.  The channels are built
@@ -160,21 +161,6 @@ Parallel::~Parallel() {
         if (joined[i]) (void)hipEventDestroy(joined[i]);
     }
     if (forked) (void)hipEventDestroy(forked);
-}
-
-int Parallel::work_host(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed, size_t* produced,
-                        size_t* need) {
-    RR_HIP(hipSetDevice(device));
-    last_stream = stream;
-    const size_t C = ch.size();
-    st_in.reserve(std::max<size_t>(in_len * in_es, 16));
-    st_out.reserve(std::max<size_t>(C * out_cap * out_es, 16));
-    if (in_len) RR_HIP(hipMemcpyAsync(st_in.p, in, in_len * in_es, hipMemcpyHostToDevice, stream));
-    const int st = work_dev(st_in.p, in_len, st_out.p, out_cap, consumed, produced, need, stream);
-    if (*produced)
-        RR_HIP(hipMemcpy2DAsync(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, C, hipMemcpyDeviceToHost, stream));
-    RR_HIP(hipStreamSynchronize(stream));
-    return st;
 }
 
 bool Parallel::eof(bool src_eof) {

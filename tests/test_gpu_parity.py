@@ -1238,3 +1238,80 @@ def test_translate_replay_on_device_matches_the_oracle_bit_for_bit_rotator(rr):
     assert len(yo) == len(yg) >= 600_000
     assert max_norm_err(yg, yo) <= TOL
     assert max_norm_err(yg[-50_000:], yo[-50_000:]) <= TOL      # no growth towards the end of the stream
+
+
+def _drive_registered(rr, blk, x, in_cap, out_cap):
+    """Graph::run around one block on PAGE-LOCKED rings (rr_host_register, what the shim does once per stream): windows are
+    slices of the two registered arrays, work_into() on them — the zero-copy path of Block::work_host."""
+    nw = int(rr.lib().rr_block_out_windows(blk._h))
+    ring_in = np.zeros(in_cap, blk.in_dtype)
+    ring_out = np.zeros(nw * out_cap, blk.out_dtype)
+    rr.host_register(ring_in); rr.host_register(ring_out)
+    try:
+        have, pos, outs, log = 0, 0, [], []
+        for _ in range(200_000):
+            take = min(in_cap - have, len(x) - pos)
+            ring_in[have:have + take] = x[pos:pos + take]; have += take; pos += take
+            st, c, p, need = blk.work_into(ring_in[:have], ring_out, out_cap)
+            log.append((st, c, p, need))
+            ring_in[:have - c] = ring_in[c:have].copy(); have -= c
+            outs.append(ring_out.reshape(nw, out_cap)[:, :p].copy())
+            if take == 0 and c == 0 and p == 0:
+                break
+        else:
+            raise AssertionError("no termination")
+        return np.concatenate(outs, axis=1), log
+    finally:
+        rr.host_unregister(ring_in); rr.host_unregister(ring_out)
+
+
+def _drive_pageable(blk, x, in_cap, out_cap):
+    have, pos, outs, log = 0, 0, [], []
+    ring = np.zeros(0, blk.in_dtype)
+    for _ in range(200_000):
+        take = min(in_cap - len(ring), len(x) - pos)
+        ring = np.concatenate([ring, x[pos:pos + take]]); pos += take
+        st, c, p, need, out = blk.work(ring, out_cap)
+        log.append((st, c, p, need))
+        ring = ring[c:]
+        outs.append(np.atleast_2d(out))
+        if take == 0 and c == 0 and p == 0:
+            break
+    else:
+        raise AssertionError("no termination")
+    return np.concatenate(outs, axis=1), log
+
+
+def test_zero_copy_host_windows_equal_staged_windows(rr):
+    """Round 4: page-locked host windows are read and written by the kernels in place (Block::work_host: zero copy, the
+    upload and the download overlap on the full-duplex link); pageable ones are staged through device memory.  Same kernels,
+    same protocol, the same bits — for every kind of block, multi-window ones, blocks that copy from / to the caller's
+    windows themselves (FftFilterFloat's inner streams, the resampler's pending sample, the fused chains' output tail)."""
+    rng = np.random.default_rng(5)
+    xc = rnd_c(300_000, 1)
+    xf = rnd_f(300_000, 2)
+    xb = rng.integers(0, 256, 600_001, dtype=np.uint8)
+    tc = orc.low_pass_complex(2.4e6, 100e3, 12.5e3)
+    tf = orc.low_pass(200_000.0, 44_100.0, 500.0)
+    t3 = np.stack([tc, np.conj(tc), tc[::-1].copy()])
+    long_taps = (rnd_c(20_000, 3) / 5000).astype(np.complex64)
+    cases = [
+        (lambda: rr.FirFilter(tc, deci=6), xc, 100_000, 50_000), (lambda: rr.FirFilter(tf, deci=4), xf, 120_000, 50_000),
+        (lambda: rr.FirFilter(tc, translate=(2.4e6, 1e5)), xc, 100_000, 100_000),
+        (lambda: rr.FftFilter(tc), xc, 80_000, 80_000), (lambda: rr.FftFilterFloat(tf), xf, 90_000, 90_000),
+        (lambda: rr.RationalResampler(5, 3, np.complex64), xc, 50_000, 1_000), (lambda: rr.QuadratureDemod(0.7), xc, 70_000, 70_000),
+        (lambda: rr.Hilbert(65), xf, 60_000, 60_000), (lambda: rr.Hilbert(1001), xf, 120_000, 120_000),
+        (lambda: rr.HilbertFir(65, tc, 8), xf, 200_000, 50_000), (lambda: rr.HilbertFir(65, tc, 3), xf, 200_000, 100_000),
+        (lambda: rr.FmChain(tc, 1, 6, 1.0), xc, 100_000, 50_000), (lambda: rr.FmChain(tc, 1, 6, 1.0), xc, 100_000, 7),
+        (lambda: rr.FmChainU8(tc, 1, 6, 1.0), xb, 200_001, 50_000), (lambda: rr.AudioChain(tf, 6, 25, 0.5), xf, 100_000, 33),
+        (lambda: rr.FmMulti(t3, 1, 6, 1.0), xc, 100_000, 20_000), (lambda: rr.FmMulti(t3, 2, 5, 1.0), xc, 100_000, 11),
+        (lambda: rr.FmChain(long_taps, 1, 6, 1.0), xc, 200_000, 100_000),
+        (lambda: rr.RtlSdrDecode(), xb, 100_001, 40_000), (lambda: rr.FftStream(1024), xc, 50_000, 50_000),
+        (lambda: rr.MultiplyConst(0.5), xf, 50_000, 50_000),
+    ]
+    for mk, x, in_cap, out_cap in cases:
+        ya, la = _drive_pageable(mk(), x, in_cap, out_cap)
+        yb, lb = _drive_registered(rr, mk(), x, in_cap, out_cap)
+        assert la == lb, mk().name
+        assert ya.shape == yb.shape and ya.shape[1] > 0, mk().name
+        assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8)), mk().name
