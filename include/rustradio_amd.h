@@ -330,7 +330,9 @@ size_t      rr_dstream_id(const rr_dstream *s);                                 
  * from every stream that read since, before a write; from the last writer before a read); with one stream driving a ring it
  * costs nothing.  rr_dstream_read_buf hands out a raw window without a stream: callers that launch their own work on it are
  * ordered like a block if they go through rr_block_work_streams, and on their own otherwise. */
-/* BufferWriter::fill_from_slice from HOST memory into the write window at `offset` (not yet produced) */
+/* BufferWriter::fill_from_slice from HOST memory into the write window at `offset` (not yet produced).  `host` is the
+ * caller's again on return (the call waits for the DMA out of a page-locked ring), so the source window can be consumed
+ * and overwritten straight away. */
 int         rr_dstream_copy_in(rr_dstream *s, size_t offset, const void *host, size_t n, void *hip_stream);
 /* copy `n` elements at `offset` of the read window to HOST memory; waits for the stream (data valid on return) */
 int         rr_dstream_copy_out(rr_dstream *s, size_t offset, void *host, size_t n, void *hip_stream);

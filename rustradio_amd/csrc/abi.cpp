@@ -378,16 +378,24 @@ size_t rr_dstream_wait(rr_dstream* s, int side, size_t need, unsigned timeout_ms
 }
 int rr_dstream_copy_in(rr_dstream* s, size_t offset, const void* host, size_t n, void* hip_stream) {
     if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }
-    std::lock_guard<std::mutex> g(s->m);
-    return guarded([&] {
-        rr::DStream& d = *s->s;
-        auto st = static_cast<hipStream_t>(hip_stream);
-        RR_HIP(hipSetDevice(d.device));
-        d.will_write(st);
-        unsigned char* w = static_cast<unsigned char*>(d.write_ptr(st));
-        if (offset + n > d.free()) throw rr::Error("dstream copy_in: beyond the write window");
-        if (n) RR_HIP(hipMemcpyAsync(w + offset * d.es, host, n * d.es, hipMemcpyHostToDevice, st));
-    });
+    auto st = static_cast<hipStream_t>(hip_stream);
+    int rc;
+    {
+        std::lock_guard<std::mutex> g(s->m);
+        rc = guarded([&] {
+            rr::DStream& d = *s->s;
+            RR_HIP(hipSetDevice(d.device));
+            d.will_write(st);
+            unsigned char* w = static_cast<unsigned char*>(d.write_ptr(st));
+            if (offset + n > d.free()) throw rr::Error("dstream copy_in: beyond the write window");
+            if (n) RR_HIP(hipMemcpyAsync(w + offset * d.es, host, n * d.es, hipMemcpyHostToDevice, st));
+        });
+    }
+    if (rc != 0 || n == 0) return rc;
+    // `host` is the caller's to reuse on return: a source ring's window is consumed right after this call and its writer
+    // overwrites it.  From pageable memory the runtime has already staged the bytes; from a page-locked (rr_host_register'd)
+    // ring the DMA is still reading, so wait for it -- outside the lock, the reader may go on consuming meanwhile.
+    return guarded([&] { RR_HIP(hipStreamSynchronize(st)); });
 }
 int rr_dstream_copy_out(rr_dstream* s, size_t offset, void* host, size_t n, void* hip_stream) {
     if (!s) { rr::set_last_error("null dstream"); return RR_ERR; }

@@ -148,9 +148,16 @@ template <class T> struct StreamState {
             if (!ds) throw Error(rr_last_error());
         } else {
             ring = std::make_unique<detail::DoubleMap>(cap * sizeof(T));
+            // page-lock the whole double mapping once: GPU blocks then read and write the windows of this
+            // ring in place over PCIe (zero copy).  Without a GPU the call fails and the ring is an ordinary host ring.
+            registered = rr_host_register(ring->base, 2 * ring->phys) == 0;
         }
     }
-    ~StreamState() { if (ds) rr_dstream_destroy(ds); }
+    ~StreamState() {
+        if (ds) rr_dstream_destroy(ds);
+        if (registered) rr_host_unregister(ring->base);
+    }
+    bool registered = false;
     StreamState(const StreamState&) = delete;
     bool device() const { return ds != nullptr; }
     size_t used() const {
