@@ -10,6 +10,7 @@
 using namespace rustradio;
 using window::WindowType;
 
+template <class G = Graph>
 static double run(Memory mem, size_t ring_bytes, const std::vector<Complex>& x, uint64_t repeats, bool fused_free_blocks) {
     (void)fused_free_blocks;
     default_memory() = mem;
@@ -20,7 +21,7 @@ static double run(Memory mem, size_t ring_bytes, const std::vector<Complex>& x, 
     auto [rs, s2] = RationalResampler<Complex>::new_(std::move(s1), 1, 6);
     auto [qd, s3] = QuadratureDemod::new_(std::move(s2), 1.0f);
     auto sink = std::make_unique<NullSink<Float>>(std::move(s3));
-    Graph g;
+    G g;
     g.add(std::move(src)); g.add(std::move(fft)); g.add(std::move(rs)); g.add(std::move(qd)); g.add(std::move(sink));
     const auto t0 = std::chrono::steady_clock::now();
     g.run();
@@ -39,5 +40,9 @@ int main() {
     printf("HBM rings    4,096,000 B : %8.1f Msamples/s\n", run(Memory::Device, DEFAULT_STREAM_SIZE, x, 8, false));
     printf("HBM rings   64,000,000 B : %8.1f Msamples/s\n", run(Memory::Device, 64'000'000, x, 16, false));
     printf("HBM rings  512,000,000 B : %8.1f Msamples/s\n", run(Memory::Device, 512'000'000, x, 32, false));
+    // the same graphs under the thread-per-block runner (mtgraph.rs): source copy, PCIe and kernels of different windows overlap
+    printf("host rings   4,096,000 B, MTGraph : %8.1f Msamples/s\n", run<MTGraph>(Memory::Host, DEFAULT_STREAM_SIZE, x, 4, false));
+    printf("HBM rings    4,096,000 B, MTGraph : %8.1f Msamples/s\n", run<MTGraph>(Memory::Device, DEFAULT_STREAM_SIZE, x, 8, false));
+    printf("HBM rings   64,000,000 B, MTGraph : %8.1f Msamples/s\n", run<MTGraph>(Memory::Device, 64'000'000, x, 16, false));
     return 0;
 }

@@ -1030,6 +1030,25 @@ def test_device_stream_ring_contract(rr, monkeypatch, no_vmm):
         rr.DeviceStream(np.uint32, 2)                      # smaller than one element
 
 
+def test_push_from_a_page_locked_window_is_done_on_return(rr):
+    """A source ring's window is consumed right after GpuUpload's copy_in and its writer overwrites it: out of a
+    page-locked (rr_host_register'd) ring the DMA is really asynchronous, so the call has to wait for it (round 4: the
+    thread-per-block runner saw the overwritten samples)."""
+    n = 64 << 20                                           # 256 MB: the DMA takes several ms, the overwrite microseconds
+    s = rr.DeviceStream(np.uint32, 4 * n)
+    x = np.arange(n, dtype=np.uint32)
+    rr.host_register(x)
+    try:
+        for k in range(3):
+            assert s.push(x) == n
+            x[:] = 0xDEADBEEF                              # the upstream writer reuses the window
+            got = s.pop()
+            assert np.array_equal(got, np.arange(n, dtype=np.uint32)), k
+            x[:] = np.arange(n, dtype=np.uint32)
+    finally:
+        rr.host_unregister(x)
+
+
 # ---- FirFilter -> FftFilter fused into one convolution (the north star's "127-tap FIR + 1024-pt FftFilter chain") ----
 @pytest.mark.parametrize("L1,L2,cplx", [(127, 401, False), (1, 1, True), (5, 300, True), (64, 64, False), (200, 17, True),
                                         (127, 2467, False), (33, 1000, True), (2, 512, True)])
@@ -1242,20 +1261,25 @@ def test_translate_replay_on_device_matches_the_oracle_bit_for_bit_rotator(rr):
 
 def _drive_registered(rr, blk, x, in_cap, out_cap):
     """Graph::run around one block on PAGE-LOCKED rings (rr_host_register, what the shim does once per stream): windows are
-    slices of the two registered arrays, work_into() on them — the zero-copy path of Block::work_host."""
+    slices of the two registered arrays, work_into() on them — the zero-copy path of Block::work_host.  Like a ring's, the
+    windows START ANYWHERE: the read window moves on by what was consumed (element-aligned only: 1 byte for the RTL-SDR
+    stream, 4 for Float), the write window begins at a different odd offset on every call."""
     nw = int(rr.lib().rr_block_out_windows(blk._h))
-    ring_in = np.zeros(in_cap, blk.in_dtype)
-    ring_out = np.zeros(nw * out_cap, blk.out_dtype)
+    ring_in = np.zeros(3 * in_cap + 16, blk.in_dtype)
+    ring_out = np.zeros(nw * out_cap + 16, blk.out_dtype)
     rr.host_register(ring_in); rr.host_register(ring_out)
     try:
-        have, pos, outs, log = 0, 0, [], []
-        for _ in range(200_000):
+        rpos, have, pos, outs, log = 3, 0, 0, [], []
+        for k in range(200_000):
+            if rpos + in_cap > len(ring_in):                          # the ring "wraps": move what is left to another odd start
+                ring_in[5:5 + have] = ring_in[rpos:rpos + have].copy(); rpos = 5
             take = min(in_cap - have, len(x) - pos)
-            ring_in[have:have + take] = x[pos:pos + take]; have += take; pos += take
-            st, c, p, need = blk.work_into(ring_in[:have], ring_out, out_cap)
+            ring_in[rpos + have:rpos + have + take] = x[pos:pos + take]; have += take; pos += take
+            wo = (7 * k + 1) % 13
+            st, c, p, need = blk.work_into(ring_in[rpos:rpos + have], ring_out[wo:], out_cap)
             log.append((st, c, p, need))
-            ring_in[:have - c] = ring_in[c:have].copy(); have -= c
-            outs.append(ring_out.reshape(nw, out_cap)[:, :p].copy())
+            rpos += c; have -= c
+            outs.append(ring_out[wo:wo + nw * out_cap].reshape(nw, out_cap)[:, :p].copy())
             if take == 0 and c == 0 and p == 0:
                 break
         else:
