@@ -135,3 +135,51 @@ def knob(rr, monkeypatch, **opts):
     keys: fir_path, fir_prune, fir_half, fir_cfg, fft_log2f, fft_no_split, fftfloat_complex, fm_full, fm_poly,
     dstream_no_vmm, fir_poly); undone by monkeypatch at the end of the test.  The oracle ignores them."""
     monkeypatch.setattr(rr, "_build_opts", dict(rr._build_opts, **opts))
+
+
+# ---- one block under a Graph::run-style loop on host windows: pageable (staged copies) and page-locked (zero copy) ----
+def drive_registered(rr, blk, x, in_cap, out_cap):
+    """Graph::run around one block on PAGE-LOCKED rings (rr_host_register, what the shim does once per stream): windows are
+    slices of the two registered arrays, work_into() on them — the zero-copy path of Block::work_host.  Like a ring's, the
+    windows START ANYWHERE: the read window moves on by what was consumed (element-aligned only: 1 byte for the RTL-SDR
+    stream, 4 for Float), the write window begins at a different odd offset on every call."""
+    nw = int(rr.lib().rr_block_out_windows(blk._h))
+    ring_in = np.zeros(3 * in_cap + 16, blk.in_dtype)
+    ring_out = np.zeros(nw * out_cap + 16, blk.out_dtype)
+    rr.host_register(ring_in); rr.host_register(ring_out)
+    try:
+        rpos, have, pos, outs, log = 3, 0, 0, [], []
+        for k in range(200_000):
+            if rpos + in_cap > len(ring_in):                          # the ring "wraps": move what is left to another odd start
+                ring_in[5:5 + have] = ring_in[rpos:rpos + have].copy(); rpos = 5
+            take = min(in_cap - have, len(x) - pos)
+            ring_in[rpos + have:rpos + have + take] = x[pos:pos + take]; have += take; pos += take
+            wo = (7 * k + 1) % 13
+            st, c, p, need = blk.work_into(ring_in[rpos:rpos + have], ring_out[wo:], out_cap)
+            log.append((st, c, p, need))
+            rpos += c; have -= c
+            outs.append(ring_out[wo:wo + nw * out_cap].reshape(nw, out_cap)[:, :p].copy())
+            if take == 0 and c == 0 and p == 0:
+                break
+        else:
+            raise AssertionError("no termination")
+        return np.concatenate(outs, axis=1), log
+    finally:
+        rr.host_unregister(ring_in); rr.host_unregister(ring_out)
+
+
+def drive_pageable(blk, x, in_cap, out_cap):
+    have, pos, outs, log = 0, 0, [], []
+    ring = np.zeros(0, blk.in_dtype)
+    for _ in range(200_000):
+        take = min(in_cap - len(ring), len(x) - pos)
+        ring = np.concatenate([ring, x[pos:pos + take]]); pos += take
+        st, c, p, need, out = blk.work(ring, out_cap)
+        log.append((st, c, p, need))
+        ring = ring[c:]
+        outs.append(np.atleast_2d(out))
+        if take == 0 and c == 0 and p == 0:
+            break
+    else:
+        raise AssertionError("no termination")
+    return np.concatenate(outs, axis=1), log

@@ -5,7 +5,7 @@ cases that fixed parameter lists miss."""
 import numpy as np
 import pytest
 
-from harness import knob, max_norm_err, run_chain
+from harness import drive_pageable, drive_registered, knob, max_norm_err, run_chain
 from oracle import pyoracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -534,3 +534,48 @@ def test_fuzz_round4_paths(rr, seed):
                 dd = np.abs(yg.astype(np.float64) - yo.astype(np.float64))
                 dd = np.minimum(dd, 2 * np.pi - dd)
                 assert np.all(dd <= bound[:len(dd)])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_zero_copy_windows(rr, seed):
+    """Round 4: a block on PAGE-LOCKED windows (kernels read / write them in place over PCIe, windows start at odd, moving
+    offsets like a ring's) against the same block on pageable windows (staged through device memory, the path every other
+    test compares with the oracle): same protocol log, same bits — random block, taps, ratio and window sizes."""
+    rng = np.random.default_rng(9000 + seed)
+    L = int(rng.choice([1, 3, 17, 65, 127, 200, 463, 1000, 2467, 5000]))
+    I, D = int(rng.integers(1, 7)), int(rng.integers(1, 17))
+    tc = (_c(rng, L) / max(1, L // 4)).astype(np.complex64)
+    if rng.integers(0, 2):
+        tc = tc.real.astype(np.complex64)
+    tf = (rng.uniform(-1, 1, L) / max(1, L // 4)).astype(np.float32)
+    n = int(rng.integers(2 * L + 64, int(rng.choice([2 * L + 20_000, 400_000]))))
+    xc, xf = _c(rng, n), rng.uniform(-1, 1, n).astype(np.float32)
+    xb = rng.integers(0, 256, 2 * n + int(rng.integers(0, 2)), dtype=np.uint8)
+    hn = int(rng.choice([3, 33, 65, 129, 301, 1001])) | 1
+    kinds = [
+        (lambda: rr.FirFilter(tc, deci=D), xc), (lambda: rr.FirFilter(tf, deci=D), xf), (lambda: rr.FftFilter(tc), xc),
+        (lambda: rr.FftFilterFloat(tf), xf), (lambda: rr.RationalResampler(I, D, np.complex64), xc),
+        (lambda: rr.RationalResampler(I, D, np.float32), xf), (lambda: rr.QuadratureDemod(0.5), xc), (lambda: rr.Hilbert(hn), xf),
+        (lambda: rr.HilbertFir(hn, tc, D), xf), (lambda: rr.FmChain(tc, I, D, 1.0), xc), (lambda: rr.FmChainU8(tc, I, D, 1.0), xb),
+        (lambda: rr.AudioChain(tf, I, D, 0.5), xf), (lambda: rr.FmMulti(np.stack([tc, np.conj(tc)]), I, D, 1.0), xc),
+        (lambda: rr.RtlSdrDecode(), xb), (lambda: rr.FirFilter(tc, deci=D, translate=(2.4e6, 1.3e5)), xc),
+    ]
+    for k in rng.choice(len(kinds), 4, replace=False):
+        mk, x = kinds[int(k)]
+        try:
+            blk = mk()
+        except Exception:
+            continue                                        # shape refused by the constructor: nothing to compare
+        # windows: at least what the block may ask for in one go (a filter block of the longest filter), at most ~3e5 elements
+        floor_in = 4 * (1 << int(np.ceil(np.log2(max(L, hn, 2))))) * (2 if x.dtype == np.uint8 else 1) + 64
+        in_cap = int(rng.integers(floor_in, floor_in + 300_000))
+        out_cap = int(rng.choice([int(rng.integers(1, 64)), int(rng.integers(64, 5000)), in_cap * I + 16]))
+        out_cap = max(out_cap, n * I // 1500 + 1)           # (bounds the number of calls of a trial)
+        try:
+            ya, la = drive_pageable(mk(), x, in_cap, out_cap)
+        except AssertionError:
+            continue                                        # a window pair the block can never move through ("no termination")
+        yb, lb = drive_registered(rr, mk(), x, in_cap, out_cap)
+        assert la == lb, (blk.name, seed)
+        assert ya.shape == yb.shape, (blk.name, seed)
+        assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8)), (blk.name, seed)
