@@ -923,6 +923,32 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+_STAGE = {"name": "start", "t0": time.monotonic()}
+
+
+def stage(name):
+    """N > 1: where this rank is — the watchdog names it if a collective never returns"""
+    _STAGE["name"], _STAGE["t0"] = name, time.monotonic()
+
+
+def start_watchdog(rank, limit_s):
+    """N > 1 only.  A collective that one rank never enters blocks every other rank for ever and the job dies without a word
+    when its launcher's own limit expires; this thread says WHICH stage of WHICH rank stood still (all thread stacks on
+    stderr) and ends the rank, so the launcher tears the job down at once.  No number is invented: there is no JSON line."""
+    import faulthandler
+
+    def watch():
+        while True:
+            time.sleep(min(5.0, max(0.05, limit_s / 4)))
+            held = time.monotonic() - _STAGE["t0"]
+            if held > limit_s:
+                print(f"bench.py: rank {rank} has been in stage {_STAGE['name']!r} for {held:.0f} s (limit {limit_s:.0f} s, "
+                      "--stage-timeout): giving up, no result line", file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                os._exit(4)
+    threading.Thread(target=watch, name="bench-watchdog", daemon=True).start()
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script with torch.distributed.run —
     from this still GPU-free process (nothing here has initialised HIP) — and exit with their code."""
@@ -955,6 +981,9 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="untimed passes of the workload before the warm-up steps, until the power controller's start-up "
                          "transient is over (tools/step_series.py); 0 = none")
+    ap.add_argument("--stage-timeout", type=float, default=600.0,
+                    help="N > 1: seconds one stage of a rank (group set-up, fan-out self-check, calibration, a timed run) may take "
+                         "before the rank reports where it stands and exits (a collective one rank never entered hangs the others)")
     ap.add_argument("--tile-steps", type=int, default=4,
                     help="N > 1: steps of source per fanned-out tile (the fan-out of a tile costs the host ~0.1 ms through "
                          "torch.distributed, as much as one 0.09 ms step: tools/fanout_overhead.py)")
@@ -985,6 +1014,8 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        start_watchdog(rank, args.stage_timeout)
+        stage("init_process_group")
         # RCCL needs one GPU per rank; with fewer visible devices (the 1-GPU box) the ranks share devices and the
         # collective runs over gloo — same code path, not a performance configuration (stated in the JSON line)
         backend = "nccl" if ndev >= world else "gloo"
@@ -1002,6 +1033,7 @@ def main():
 
     wname = args.workload or ("fftfilter" if world == 1 else "fm_multi")
     stream = torch.cuda.current_stream()
+    stage("build workload")
     with rr.build_options(**opts):
         w = WORKLOADS[wname](dev, rank, world, shared_src)
     abi_check = {}
@@ -1030,6 +1062,7 @@ def main():
             if backend != "nccl":
                 raise SystemExit("bench.py --fanout abi: rr_fanout_* binds RCCL, which needs one GPU per rank")
             if "ok" not in abi_check:            # once per job: known tiles through both algorithms, checksums on every rank
+                stage("rr_fanout_* self-check (RCCL communicator of the C ABI)")
                 abi_check["ok"], abi_check["why"] = multi.verify_abi_fanout(rr, dist, rank, dev)
                 if not abi_check["ok"] and rank == 0:
                     print(f"bench.py: rr_fanout_* failed its self-check on this group ({abi_check['why']}); "
@@ -1037,6 +1070,7 @@ def main():
             if abi_check["ok"]:
                 algo, cal = args.fanout_algo, None
                 if algo == "auto":               # timed on this group's fabric at this tile size, like the torch.distributed form
+                    stage("rr_fanout_* calibration (bcast against scatter + all-gather)")
                     algo, cal = multi.calibrate_abi_fanout(rr, dist, rank, k * step_elems, sdtype, dev)
                 f = tag(multi.AbiFanout(rr, dist, rank, k * step_elems, sdtype, dev, produce, mesh=algo == "scatter_allgather"))
                 f.calibration = cal
@@ -1088,6 +1122,7 @@ def main():
     # channel-samples — VERDICT r2 weak #9.)
     anchor = None
     if world > 1:
+        stage("N = 1 anchor on rank 0 (the other ranks wait at the barrier)")
         if rank == 0:
             ua, ta, _, _, _, sma = run_timed(w, args.steps, args.warmup, None, stream, None, None, settle_ms=args.settle_ms)
             anchor = {"workload": w.name, "workload_key": wname, "n1_value": round(ua / ta / 1e6, 2), "unit": "Msamples/s",
@@ -1095,8 +1130,10 @@ def main():
                       "how": "rank 0 alone with the source resident in its HBM, before the collective run; scaling efficiency of "
                              "this line = value / (n_gpus * n1_value)"}
         dist.barrier()
+    stage("fan-out set-up")
     fan = make_fan(w)
     w.report_cold = True
+    stage("timed run (fan-out + compute)")
     units, dt, kms, launches, dom_units, step_ms = run_timed(w, args.steps, args.warmup, dist, stream, fan, settle_ms=args.settle_ms)
     settle_main = getattr(w, "settle_steps", 0)
 
@@ -1108,6 +1145,7 @@ def main():
     # workload, configs[1]: this is the same-workload reference for the N > 1 lines.)
     resident = None
     if fan is not None:
+        stage("resident reference run (no fan-out)")
         torch.cuda.synchronize()
         tile = fan.buf[0] if hasattr(fan, "buf") else fan.acquire(fan.issued, stream)      # (its first step's worth is read)
         u1, t1, _, _, _, sm1 = run_timed(w, args.steps, 2, dist, stream, None, tile.data_ptr(), settle_ms=args.settle_ms / 2)
@@ -1123,6 +1161,7 @@ def main():
                  [n for n in ("fm_multi_u8", "channelizer", "channelizer_model") if n != wname])
         for name in names:
             streamed = world > 1 and name.startswith("fm_multi")
+            stage(f"others: {name}")
             with rr.build_options(**opts):
                 wo = WORKLOADS[name](dev, rank, world, shared_src if streamed else (lambda gen, numel, dtype: gen()))
             k = max(3, min(args.steps, 10)) if name != "fir" else 200

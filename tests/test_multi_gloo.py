@@ -5,6 +5,8 @@ ranks on the visible GPU, each driving its real rr.FmMulti block on the streamed
 two shards against its own oracle chain."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -299,3 +301,13 @@ def test_fanout_prediction_table():
     u8 = multi.predict_fanout(8, tile // 4, comp)            # the RTL-SDR wire format: 2 B per sample
     assert u8["bcast"]["efficiency"] == 1.0
     assert multi.predict_fanout(1, tile, comp)["bcast"]["fanout_ms_per_tile"] == 0.0
+
+
+def test_bench_watchdog_names_the_stage_and_ends_the_rank():
+    """bench.py --gpus N: a rank that stands in one stage longer than --stage-timeout (a collective another rank never
+    entered) says where, dumps its stacks and exits 4 — instead of the whole job waiting for the launcher's limit in silence."""
+    code = ("import sys, time; sys.argv = ['bench.py']; import bench; bench.start_watchdog(3, 0.3); "
+            "bench.stage('fan-out self-check'); time.sleep(20); print('survived')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 4, (out.returncode, out.stderr[-500:])
+    assert "rank 3" in out.stderr and "'fan-out self-check'" in out.stderr and "survived" not in out.stdout
