@@ -286,8 +286,9 @@ int         rr_block_sync(rr_block *b);
  * window going down overlaps the one coming up on the full-duplex link — two DMA copies do not on this
  * pool (4,096,000-byte windows: FftFilter 193 -> 148 us per call, the fused RTL-SDR chain 175 -> 109);
  * rr_dstream_copy_in/out run as direct DMA instead of staged pageable copies (35 -> 40 GB/s).  Windows
- * in pageable memory are staged through device memory as before.  Optional; unregister before the
- * memory is unmapped. */
+ * that are not WHOLLY inside a range registered here (pageable memory, memory the caller page-locked by
+ * other means) are staged through device memory as before.  Optional; unregister before the memory is
+ * unmapped, and not while a work call on one of its windows is running. */
 int rr_host_register(void *ptr, size_t bytes);
 int rr_host_unregister(void *ptr);
 

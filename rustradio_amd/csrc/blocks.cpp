@@ -83,18 +83,15 @@ void Block::prof_read(double* total_ms, size_t* launches, bool reset) {
 }
 bool Block::eof(bool src_eof) { return src_eof; }   // rustradio_macros_code/src/lib.rs:596-623
 
-// The device's view of a PAGE-LOCKED host range (hipHostMalloc, or the caller's stream ring after rr_host_register), or
-// nullptr for pageable memory.
-// Ranges page-locked through rr_host_register are remembered with their device address (one hipHostGetDevicePointer at
-// registration): a window inside one costs a short scan.  Other page-locked memory (hipHostMalloc by the caller) is asked
-// about per call — hipPointerGetAttributes costs ~8 us, so the last few answers are kept by exact pointer.
+// The device's view of a host window that lies WHOLLY inside a range page-locked through rr_host_register (the caller's
+// stream ring; the device address is taken once, at registration: a window costs a short scan under a lock), or nullptr
+// for any other memory, which is staged through device memory.  Only ranges the library was told about qualify: memory
+// page-locked behind its back (hipHostMalloc by the caller) can be freed behind its back too, and an answer remembered for
+// such a pointer would outlive the mapping — it takes the staged path, whose copies are DMA from page-locked memory anyway.
 namespace {
 struct HostRange { const unsigned char* base; size_t bytes; unsigned char* dev; };
 std::mutex g_host_m;
 std::vector<HostRange> g_host_ranges;
-struct Seen { const void* host; void* dev; };
-thread_local Seen g_seen[8];
-thread_local unsigned g_seen_next = 0;
 }  // namespace
 void host_range_add(void* base, size_t bytes) {
     void* dev = nullptr;
@@ -106,23 +103,14 @@ void host_range_remove(void* base) {
     std::lock_guard<std::mutex> g(g_host_m);
     for (size_t i = 0; i < g_host_ranges.size(); i++)
         if (g_host_ranges[i].base == base) { g_host_ranges.erase(g_host_ranges.begin() + (long)i); break; }
-    for (auto& e : g_seen) e = Seen{nullptr, nullptr};
 }
-void* device_view_of_host(const void* host) {
+void* device_view_of_host(const void* host, size_t bytes) {
     if (!host) return nullptr;
     const unsigned char* h = static_cast<const unsigned char*>(host);
-    {
-        std::lock_guard<std::mutex> g(g_host_m);
-        for (auto& r : g_host_ranges)
-            if (h >= r.base && h < r.base + r.bytes) return r.dev + (h - r.base);
-    }
-    for (auto& e : g_seen) if (e.host == host) return e.dev;
-    hipPointerAttribute_t a{};
-    void* dev = nullptr;
-    if (hipPointerGetAttributes(&a, host) != hipSuccess) (void)hipGetLastError();        // (pageable: an error, cleared)
-    else if (a.type == hipMemoryTypeHost && a.devicePointer) dev = a.devicePointer;
-    if (dev) { g_seen[g_seen_next % 8] = Seen{host, dev}; g_seen_next++; }             // (pageable answers are not kept: the memory may be registered later)
-    return dev;
+    std::lock_guard<std::mutex> g(g_host_m);
+    for (auto& r : g_host_ranges)
+        if (h >= r.base && bytes <= r.bytes && (size_t)(h - r.base) <= r.bytes - bytes) return r.dev + (h - r.base);
+    return nullptr;
 }
 
 // Host-window work().  Page-locked windows (round 4): the kernels read the input window and write the output window over
@@ -133,8 +121,8 @@ int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, s
                      size_t* produced, size_t* need) {
     RR_HIP(hipSetDevice(device));
     last_stream = stream;
-    void* din = zero_copy_in && in_len ? device_view_of_host(in) : nullptr;
-    void* dout = out_cap ? device_view_of_host(out) : nullptr;
+    void* din = zero_copy_in && in_len ? device_view_of_host(in, in_len * in_es) : nullptr;
+    void* dout = out_cap ? device_view_of_host(out, out_cap * out_es * out_windows()) : nullptr;
     const size_t in_use = in_len;   // whole window: kernels may touch (zero-weighted) samples past the consumed range
     if (!din) {
         st_in.reserve(std::max<size_t>(in_use * in_es, 16));

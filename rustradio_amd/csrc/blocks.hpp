@@ -14,7 +14,7 @@ int thread_device();
 // page-locked host ranges the library was told about (rr_host_register): their device view, for zero-copy host windows
 void host_range_add(void* base, size_t bytes);
 void host_range_remove(void* base);
-void* device_view_of_host(const void* host);      // nullptr: pageable (staged copies)
+void* device_view_of_host(const void* host, size_t bytes);      // nullptr: not wholly inside an rr_host_register'd range (staged copies)
 
 struct Block {
     const char* name;

@@ -7,6 +7,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import rustradio_amd as rr
 s = torch.cuda.current_stream().cuda_stream
+def per_call(fn, reps):
+    """us per call, the better of two passes (the second block instance of a process meets a one-time ~40 ms stall of the
+    runtime somewhere in its first passes — seen as 340-470 us averages that no later pass repeats)"""
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        dt = (time.perf_counter() - t0) / reps * 1e6
+        best = dt if best is None else min(best, dt)
+    return best
 def bench(name, mk, in_dtype, n_in, out_dtype, cap, reps=200):
     xin = torch.empty(n_in, dtype=in_dtype).pin_memory()
     if in_dtype == torch.uint8: xin.random_(0, 255)
@@ -22,32 +32,31 @@ def bench(name, mk, in_dtype, n_in, out_dtype, cap, reps=200):
     nin_elems = n_in if in_dtype == torch.uint8 else (n_in // 2 if blk.in_dtype == np.complex64 else n_in)
     cap_elems = cap // 2 if blk.out_dtype == np.complex64 else cap
     xv = xin_np.view(blk.in_dtype); yv = yout_np.view(blk.out_dtype)
-    # (1) staged: the shim's call on caller-owned (registered) host windows
-    for _ in range(5): blk.work_into(xv, yv, cap_elems)
-    t0 = time.perf_counter()
-    for _ in range(reps): blk.work_into(xv, yv, cap_elems)
-    res["staged"] = (time.perf_counter() - t0) / reps * 1e6
-    # (2) zero-copy both ways
+    # (1) the product call, rr_block_work, on pageable windows (staged) and on windows of rr_host_register'd arrays (zero copy)
+    xp, yp = xv.copy(), yv.copy()
+    for _ in range(5): blk.work_into(xp, yp, cap_elems)
+    res["rr_block_work pageable"] = per_call(lambda: blk.work_into(xp, yp, cap_elems), reps)
+    xr, yr = xv.copy(), yv.copy()
+    rr.host_register(xr); rr.host_register(yr)
+    blk = mk()
+    for _ in range(5): blk.work_into(xr, yr, cap_elems)
+    res["rr_block_work registered"] = per_call(lambda: blk.work_into(xr, yr, cap_elems), reps)
+    rr.host_unregister(xr); rr.host_unregister(yr)
+    # (2) the forms by hand (torch page-locked tensors as device windows): zero-copy both ways
     blk = mk()
     for _ in range(5): blk.work_dev(xin.data_ptr(), nin_elems, yout.data_ptr(), cap_elems, s); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        blk.work_dev(xin.data_ptr(), nin_elems, yout.data_ptr(), cap_elems, s); torch.cuda.synchronize()
-    res["zero-copy in+out"] = (time.perf_counter() - t0) / reps * 1e6
+    def f2(): blk.work_dev(xin.data_ptr(), nin_elems, yout.data_ptr(), cap_elems, s); torch.cuda.synchronize()
+    res["zero-copy in+out"] = per_call(f2, reps)
     # (3) DMA in, kernel writes the host window
     blk = mk()
     for _ in range(5): xd.copy_(xin, non_blocking=True); blk.work_dev(xd.data_ptr(), nin_elems, yout.data_ptr(), cap_elems, s); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        xd.copy_(xin, non_blocking=True); blk.work_dev(xd.data_ptr(), nin_elems, yout.data_ptr(), cap_elems, s); torch.cuda.synchronize()
-    res["DMA in, zero-copy out"] = (time.perf_counter() - t0) / reps * 1e6
+    def f3(): xd.copy_(xin, non_blocking=True); blk.work_dev(xd.data_ptr(), nin_elems, yout.data_ptr(), cap_elems, s); torch.cuda.synchronize()
+    res["DMA in, zero-copy out"] = per_call(f3, reps)
     # (4) kernel reads the host window, DMA out
     blk = mk()
     for _ in range(5): blk.work_dev(xin.data_ptr(), nin_elems, yd.data_ptr(), cap_elems, s); yout.copy_(yd, non_blocking=True); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        blk.work_dev(xin.data_ptr(), nin_elems, yd.data_ptr(), cap_elems, s); yout.copy_(yd, non_blocking=True); torch.cuda.synchronize()
-    res["zero-copy in, DMA out"] = (time.perf_counter() - t0) / reps * 1e6
+    def f4(): blk.work_dev(xin.data_ptr(), nin_elems, yd.data_ptr(), cap_elems, s); yout.copy_(yd, non_blocking=True); torch.cuda.synchronize()
+    res["zero-copy in, DMA out"] = per_call(f4, reps)
     print(f"{name}: " + "  ".join(f"{k} {v:.1f} us" for k, v in res.items()), flush=True)
 taps = rr.low_pass_complex(10e6, 1e6, 60e3)
 bench("FftFilter 401 taps, 512,000 Complex in / out", lambda: rr.FftFilter(taps), torch.float32, 2 * 512_000, torch.float32, 2 * 512_000)
