@@ -45,6 +45,7 @@ void HostRotor::run() {
         }
         g += n;
         gen.store(g, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(m); }                    // (a waiter between its test and its sleep must not miss this)
         cv.notify_all();
     }
 }
@@ -60,6 +61,7 @@ uint64_t HostRotor::wait_for(uint64_t upto, unsigned ms) {
 void HostRotor::release(uint64_t upto) {
     uint64_t t = tail.load(std::memory_order_relaxed);
     while (t < upto && !tail.compare_exchange_weak(t, upto, std::memory_order_release)) {}
+    { std::lock_guard<std::mutex> lk(m); }
     cv.notify_all();
 }
 
