@@ -993,6 +993,9 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    # (ranks started by a launcher of the caller's: the host driver of this pool only supports dmabuf IPC, and RCCL's
+    #  buffer exchange between processes fails without this — nothing has touched the GPU yet)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
