@@ -88,21 +88,49 @@ bool Block::eof(bool src_eof) { return src_eof; }   // rustradio_macros_code/src
 // for any other memory, which is staged through device memory.  Only ranges the library was told about qualify: memory
 // page-locked behind its back (hipHostMalloc by the caller) can be freed behind its back too, and an answer remembered for
 // such a pointer would outlive the mapping — it takes the staged path, whose copies are DMA from page-locked memory anyway.
+//
+// RETIRED addresses.  tools/zerocopy_churn.py (round 4): register fresh arrays, run kernels on them in place, unregister,
+// free, again — the allocator hands the same virtual addresses out with new pages behind them, and on this pool a kernel
+// that reads or writes such a RE-registered range in place now and then misses (runs of outputs never written, or computed
+// from the previous contents: 24 of 4,500 calls in a bad pass, none in others; never on a range registered once — 12,000
+// calls — and never through DMA copies or pageable windows in the same churn).  So an address range that has been
+// unregistered once is retired for the life of the process: registering it again still page-locks it (the staged copies are
+// direct DMA), but its windows are no longer handed to kernels in place.  The reference registers a ring once, at stream
+// creation: it never meets this; a process that builds and drops graphs all day keeps its throughput on fresh addresses
+// and its correctness on recycled ones.
 namespace {
 struct HostRange { const unsigned char* base; size_t bytes; unsigned char* dev; };
 std::mutex g_host_m;
 std::vector<HostRange> g_host_ranges;
+std::vector<std::pair<const unsigned char*, const unsigned char*>> g_retired;    // [lo, hi) of ranges unregistered before
 }  // namespace
 void host_range_add(void* base, size_t bytes) {
+    const unsigned char* lo = static_cast<const unsigned char*>(base);
+    const unsigned char* hi = lo + bytes;
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, base, 0) != hipSuccess || !dev) { (void)hipGetLastError(); return; }
     std::lock_guard<std::mutex> g(g_host_m);
-    g_host_ranges.push_back({static_cast<const unsigned char*>(base), bytes, static_cast<unsigned char*>(dev)});
+    for (auto& r : g_retired)
+        if (lo < r.second && r.first < hi) return;            // overlaps a retired range: page-locked, but never zero-copy again
+    g_host_ranges.push_back({lo, bytes, static_cast<unsigned char*>(dev)});
 }
 void host_range_remove(void* base) {
     std::lock_guard<std::mutex> g(g_host_m);
     for (size_t i = 0; i < g_host_ranges.size(); i++)
-        if (g_host_ranges[i].base == base) { g_host_ranges.erase(g_host_ranges.begin() + (long)i); break; }
+        if (g_host_ranges[i].base == base) {
+            const unsigned char* lo = g_host_ranges[i].base;
+            const unsigned char* hi = lo + g_host_ranges[i].bytes;
+            // merge with overlapping / adjacent retired ranges so that the list stays short under churn
+            for (size_t k = 0; k < g_retired.size();) {
+                if (lo <= g_retired[k].second && g_retired[k].first <= hi) {
+                    lo = std::min(lo, g_retired[k].first); hi = std::max(hi, g_retired[k].second);
+                    g_retired.erase(g_retired.begin() + (long)k);
+                } else k++;
+            }
+            g_retired.emplace_back(lo, hi);
+            g_host_ranges.erase(g_host_ranges.begin() + (long)i);
+            break;
+        }
 }
 void* device_view_of_host(const void* host, size_t bytes) {
     if (!host) return nullptr;
@@ -223,6 +251,11 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
         d_rev.upload(reinterpret_cast<unsigned char*>(rev.data()), rev.size() * 8, stream);
         d_tp.upload(reinterpret_cast<unsigned char*>(tp.data()), tp.size() * 8, stream);
     }
+    {   // (nan_fix.hpp: the reference's fold over the reversed taps, Complex whatever the specialisation above)
+        std::vector<cf> rev(ntaps);
+        for (size_t j = 0; j < ntaps; j++) rev[j] = mkcf(t[ntaps - 1 - j].real(), t[ntaps - 1 - j].imag());
+        d_fix.upload(rev.data(), rev.size(), stream);
+    }
     RR_HIP(hipStreamSynchronize(stream));
     // d = 1: overlap-save tiles cost a flat ~0.32 ms per 1e8 samples; the direct form stays at its 0.30 ms of
     // staging up to ~32 real / ~24 Complex taps and then grows by 0.004 / 0.007 ms per tap
@@ -304,6 +337,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
         for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
         fftk.reset(new FftFilter(ct.data(), ntaps));
         if (deci > 1 && fftk->log2f >= 13 && !fftk->nsub) fftk.reset();   // (RR_FFT_NO_SPLIT measurement runs)
+        if (fftk) { fftk->nanfix = nanfix(); fftk->nanfix.d = 1; }        // (fftk->filter is the full-rate form)
     }
 }
 FirC32::~FirC32() {
@@ -357,14 +391,14 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
         // (beyond ~320 taps the direct form's LDS tile stops fitting and it collapses: never there)
         small_direct = !fftk || (L <= 320 && t_direct <= t_tiles && fir_direct_has_tile(pl, sizeof(cf), sizeof(cf)));
     }
-    if (use_poly) launch_fir_poly(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, poly->d_tw.p, poly->d_h.p, s);
-    else if (small_direct) launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
-    else if (half_ok) launch_fftfilt_half(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, d_htw.p, d_htw_half.p, d_hhpos.p, s);
-    else if (use_prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s, (int)prune_sub);
-    else if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s);
-    else if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s);
+    if (use_poly) launch_fir_poly(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, poly->d_tw.p, poly->d_h.p, s, nanfix());
+    else if (small_direct) launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s, nanfix());
+    else if (half_ok) launch_fftfilt_half(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, d_htw.p, d_htw_half.p, d_hhpos.p, s, nanfix());
+    else if (use_prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s, (int)prune_sub, nanfix());
+    else if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s, nanfix());
+    else if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s, nanfix());
     else if (fftk) fftk->filter(src, static_cast<cf*>(out), (long)out_n, s);
-    else launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s);
+    else launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s, nanfix());
     prof_end(s);
     rotate_output(static_cast<cf*>(out), out_n, s);                  // fir.rs:531
     *consumed = n; *produced = out_n;
@@ -572,7 +606,7 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
     }
     // (the hn samples before the new window become the next call's history: written by the tile kernel itself)
     const CarryOut carry{hist[cur ^ 1].p, (long)n, (long)hn};
-    if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s, carry, (int)prune_sub);
+    if (use_prune) launch_fftfilt_prune_real(prune->log2f, src, static_cast<cf*>(out), (long)out_n, plG.L, prune->d_tw.p, prune->d_h2.p, prune->d_h2b.p, prune->d_twb.p, s, carry, (int)prune_sub, nanfixG());
     else if (two_stage && (n >= 16384 || !fir_direct_has_tile(plG, sizeof(float), sizeof(cf)))) {
         // a[k] = (iv[k + hn/2], sum_j rev_h[j] iv[k + j]) over the virtual stream iv = hist ++ window (hilbert.rs:113-116), then
         // y[m] = sum_k rev[k] a[m d + k]: outputs [m0, m1) take a[m0 d, m1 d + L - 1).  In chunks, so that the analytic buffer
@@ -586,14 +620,14 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
             VSrc<float> sa = src;
             if (k0 >= hn) sa = VSrc<float>{hist[cur].p, 0, static_cast<const float*>(in) + (k0 - hn), (long)(in_len - (k0 - hn))};
             else if (k0 != 0) throw Error("HilbertFir: chunk inside the history");   // (per >> hn: only the first chunk starts in it)
-            if (!(hil->skip_ok && launch_hilbert_skip(hil->pl.L, hil->par, hil->Q, hil->d_hq.p, sa, analytic.p, (long)na, s)))
-                launch_hilbert(hil->pl, hil->d_tp.p, hil->d_rev.p, sa, analytic.p, (long)na, s);
+            if (!(hil->skip_ok && launch_hilbert_skip(hil->pl.L, hil->par, hil->Q, hil->d_hq.p, sa, analytic.p, (long)na, s, hil->nanfix())))
+                launch_hilbert(hil->pl, hil->d_tp.p, hil->d_rev.p, sa, analytic.p, (long)na, s, hil->nanfix());
             size_t c2 = 0, p2 = 0, n2 = 0;
             fir2->work_dev(analytic.p, na, static_cast<cf*>(out) + m0, m1 - m0, &c2, &p2, &n2, s);
             if (p2 != m1 - m0) throw Error("HilbertFir: the FirFilter stage disagrees on the output count");
         }
     }
-    else launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s);
+    else launch_fir_f32c(plG, d_tpG.p, d_revG.p, src, static_cast<cf*>(out), (long)out_n, s, nanfixG());
     prof_end(s);
     fir->rotate_output(static_cast<cf*>(out), out_n, s);
     if (!use_prune) launch_carry(src, carry, s);
@@ -638,6 +672,7 @@ FirF32::FirF32(const float* taps, size_t ntaps, size_t deci) : Block("FirFilter<
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {taps[i], 0.0f};
         fftk.reset(new FftFilter(ct.data(), ntaps, false, 12, true));
+        fftk->nanfix = nanfix();
     }
     if (!fftk && !prune && !force_direct && ntaps > 320) {   // (see blocks.hpp; shorter filters have direct-form tiles that fit)
         std::vector<rr_c32> ct(ntaps);
@@ -678,10 +713,10 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
             launch_c32_re(wide_out.p, static_cast<float*>(out) + m0, (long)(m1 - m0), s);
         }
     }
-    else if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s, (int)prune_sub);
-    else if (small_direct) launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
+    else if (use_prune) launch_fftfilt_prune_f32(prune->log2f, src, static_cast<float*>(out), (long)(n / d), (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s, (int)prune_sub, nanfix());
+    else if (small_direct) launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s, nanfix());
     else if (fftk) fftk->filter_real(src, static_cast<float*>(out), (long)(n / d), (int)d, s);
-    else launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s);
+    else launch_fir_f32(pl, d_tp.p, d_rev.p, src, static_cast<float*>(out), (long)(n / d), s, nanfix());
     prof_end(s);
     *consumed = n; *produced = n / d;
     return RR_AGAIN;
@@ -973,13 +1008,14 @@ void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOu
         launch_carry(src, carry, s);
         return;
     }
-    if (nsub && alt_log2f && alt_wins(n_out)) launch_fftfilt_os(alt_log2f, src, out, n_out, (int)L, d_tw_alt.p, d_hpos_alt.p, s, carry);
-    else if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s, carry);
-    else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s, carry);
+    if (nsub && alt_log2f && alt_wins(n_out)) launch_fftfilt_os(alt_log2f, src, out, n_out, (int)L, d_tw_alt.p, d_hpos_alt.p, s, carry, nanfix);
+    else if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s, carry, nanfix);
+    else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s, carry, nanfix);
 }
 
 void FftFilter::filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s, CarryOut carry) {
-    launch_fftfilt_real(log2f, src, out, n_out, (int)L, d, d_tw.p, d_hpos.p, s, carry);
+    NanFix fx = nanfix; fx.d = d;
+    launch_fftfilt_real(log2f, src, out, n_out, (int)L, d, d_tw.p, d_hpos.p, s, carry, fx);
 }
 
 int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
@@ -1830,7 +1866,7 @@ int Hilbert::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     prof_begin(s);
     // (windows of a few tiles leave the chip idle: the pair-sample / direct kernels keep those, as in FirC32::work_dev)
     if (fftk && n >= 16 * (((size_t)1 << fftk->log2f) - (size_t)pl.L + 1)) {
-        launch_fftfilt_real_hilbert(fftk->log2f, src, static_cast<cf*>(out), (long)n, pl.L, fftk->d_tw.p, fftk->d_hpos.p, s, CarryOut{});
+        launch_fftfilt_real_hilbert(fftk->log2f, src, static_cast<cf*>(out), (long)n, pl.L, fftk->d_tw.p, fftk->d_hpos.p, s, CarryOut{}, nanfix());
     } else if (wide && n >= 4096) {
         // a[k] over the virtual stream xp = hist ++ window needs xp[k, k + L): Complex(xp, 0) in chunks, then the filter
         const size_t L = (size_t)pl.L, CH = (size_t)1 << 24, per = CH - L;
@@ -1849,8 +1885,8 @@ int Hilbert::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
             wide->work_dev(wide_in.p, na, static_cast<cf*>(out) + m0, m1 - m0, &c2, &p2, &n2, s);
             if (p2 != m1 - m0) throw Error("Hilbert: the Complex filter stage disagrees on the output count");
         }
-    } else if (!(skip_ok && launch_hilbert_skip(pl.L, par, Q, d_hq.p, src, static_cast<cf*>(out), (long)n, s)))
-        launch_hilbert(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)n, s);
+    } else if (!(skip_ok && launch_hilbert_skip(pl.L, par, Q, d_hq.p, src, static_cast<cf*>(out), (long)n, s, nanfix())))
+        launch_hilbert(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)n, s, nanfix());
     prof_end(s);
     launch_vcopy_f32(src, (long)n, hist[cur ^ 1].p, (long)pl.L, s);            // :125
     cur ^= 1;

@@ -101,6 +101,8 @@ struct FirC32 : Block {
     bool window_aware = true;                     // per-call choice by window size (off when a path is forced: tests, probes)
     DevBuf<cf> d_htw, d_htw_half, d_hhpos;
     DevBuf<unsigned char> d_tp, d_rev;
+    DevBuf<cf> d_fix;                             // the taps reversed, Complex: what the non-finite repair folds with (nan_fix.hpp)
+    NanFix nanfix() const { NanFix f; f.rev = d_fix.p; f.L = pl.L; f.d = pl.d; f.kind = NANFIX_CC; return f; }
     bool rot_on = false;
     int rot_mode = RR_ROT_REPLAY;                 // the reference's own recurrence is the default (fir.rs:464-473)
     float ph0x = 1, ph0y = 0, stx = 1, sty = 0;   // f32-rounded phase0 / step (fir.rs:453-461)
@@ -153,6 +155,7 @@ struct HilbertFir : Block {
     size_t hn = 0;                    // Hilbert ntaps
     FirPlan plG;
     DevBuf<cf> d_tpG, d_revG;
+    NanFix nanfixG() const { NanFix f; f.rev = d_revG.p; f.L = plG.L; f.d = plG.d; f.kind = NANFIX_FC; return f; }
     DevBuf<float> hist[2];            // the hn input samples before the window start
     int cur = 0;
     std::unique_ptr<PruneTables> prune;   // deci 4 / 8 / 16: two real segments per tile, pruned inverse (k_fftfilt_prune)
@@ -165,6 +168,7 @@ struct HilbertFir : Block {
 struct FirF32 : Block {
     FirPlan pl;
     DevBuf<float> d_tp, d_rev;
+    NanFix nanfix() const { NanFix f; f.rev = d_rev.p; f.L = pl.L; f.d = pl.d; f.kind = NANFIX_FF; return f; }
     std::unique_ptr<FftFilter> fftk;   // long filters: overlap-save tiles on the real stream (see FirC32::fftk)
     std::unique_ptr<PruneTables> prune; // deci 4 / 8 / 16: pruned inverse (k_fftfilt_prune, real stream x real taps)
     size_t prune_D = 0, prune_sub = 1;  // deci = prune_D * prune_sub
@@ -203,6 +207,7 @@ struct FftFilter : Block {
         return 13.0 + 0.0104 * na < std::max(25.0 + 0.015 * ns, 0.041 * ns);
     }
     // more than 16383 taps: overlap-save frames of M = 2^m >= 2 L points through the any-size transform (AnyFft)
+    NanFix nanfix;                    // set by a FirFilter that runs on these tiles (default: none — FftFilter's own reference is a transform)
     std::unique_ptr<AnyFft> big;
     size_t bigM = 0;
     DevBuf<cf> d_hbig, bframes, bspec;
@@ -456,6 +461,7 @@ Block* make_audio_chain(const float* taps, size_t ntaps, size_t interp, size_t d
 struct Hilbert : Block {
     FirPlan pl;
     DevBuf<float> d_tp, d_rev;
+    NanFix nanfix() const { NanFix f; f.rev = d_rev.p; f.L = pl.L; f.d = 1; f.kind = NANFIX_HILBERT; return f; }
     DevBuf<float> hist[2];
     int cur = 0;
     // zero-tap skipping (kernels_fir.hip k_hilbert): taps of one parity only

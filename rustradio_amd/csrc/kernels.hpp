@@ -1,6 +1,7 @@
 // kernels.hpp — host-callable launchers of the HIP kernels (one TU per kernel family).
 #pragma once
 #include "common.hpp"
+#include "nan_fix.hpp"
 
 namespace rr {
 
@@ -14,20 +15,21 @@ bool fftfilt_supported(int log2f);
 int fft_read_stamps(unsigned long long* host16);   // measurement builds only (else returns 0)
 // (carry: the caller's carry-state update, done by this launch — every launcher below that takes one falls back to a
 //  separate copy kernel when it has nothing to launch)
+// (fx: FirFilter on these tiles — non-finite input samples get the reference's locality, nan_fix.hpp; default: none)
 void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw,
-                       const cf* hpos, hipStream_t s, CarryOut carry = {});
+                       const cf* hpos, hipStream_t s, CarryOut carry = {}, NanFix fx = {});
 
 // The same filter keeping every d-th output: out[m] = y[m d], m < n_out (tiles of 1024..4096 points, d <= 4096) —
 // the decimating FirFilter (fir.rs:181-189) on overlap-save tiles.
 void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
-                         hipStream_t s);
+                         hipStream_t s, NanFix fx = {});
 
 // Real stream, real taps (hpos from Complex(t, 0)): out[m] = y[m d], y[n] = sum_k t[k] xx[n + L - 1 - k]; two
 // overlap-save segments ride in the real / imaginary lanes of one Complex tile (tiles of 1024..4096 points).
 void launch_fftfilt_real_hilbert(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s,
-                                 CarryOut carry);
+                                 CarryOut carry, NanFix fx = {});
 void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
-                         hipStream_t s, CarryOut carry = {});
+                         hipStream_t s, CarryOut carry = {}, NanFix fx = {});
 
 // FftFilterFloat -> RationalResampler(I:D) -> MultiplyConst fused on the real-stream tiles: out[m - r_lo] = scale *
 // y[floor(m D / I)] for the resampled samples m in [r_lo, r_hi) whose source lies in this call's y[A .. A + n_y).
@@ -45,27 +47,27 @@ void launch_audio_chain(int log2f, VSrc<float> src, float* out, int L, const cf*
 int prune_log2f_for_deci(int d);                 // 0 when d is not 4 / 8 / 16
 bool prune_split(size_t d, size_t& D, size_t& sub);   // d = D * sub, D in {16, 8, 4} (the pruned tile), sub <= 64
 void launch_fftfilt_prune_c32(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                              const cf* twb, hipStream_t s, int sub = 1);
+                              const cf* twb, hipStream_t s, int sub = 1, NanFix fx = {});
 // real stream, real taps, f32 output (decimating FirFilter<Float>)
 void launch_fftfilt_prune_f32(int log2f, VSrc<float> src, float* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                              const cf* twb, hipStream_t s, int sub = 1);
+                              const cf* twb, hipStream_t s, int sub = 1, NanFix fx = {});
 // real stream, Complex taps t = Gr + i Gi: hpos2r / hpos2i from the real tap sets Gr / Gi; Complex output
 void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
-                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry = {}, int sub = 1);
+                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry = {}, int sub = 1, NanFix fx = {});
 
 // Even decimations on 2048-point tiles with the half-size inverse (k_fftfilt_half): out[m] = y[m d], m < n_out.
 // tw = w_2048^k, tw_half = w_1024^k, hpos = H / F in the 2048-point position order.
 bool fftfilt_half_supported(int L, long d);
 void launch_fftfilt_half(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* tw_half, const cf* hpos,
-                         hipStream_t s);
+                         hipStream_t s, NanFix fx = {});
 
 // The same filter with an 8192 / 16384-point tile built from nsub = 2 / 4 sub-transforms of 4096 points
 // (k_fftfilt_split).  tw4096: w_4096^k;  wk[t] = w_F^t, t < 256;  hs[r][p] = H[nsub bin(p) + r] / F with
 // bin(p) = fftfilt_split_bin(p), the bin at position p of the 4096-point spectrum layout.
 void launch_fftfilt_split(int nsub, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw4096, const cf* hs, const cf* wk,
-                          hipStream_t s, CarryOut carry = {});
+                          hipStream_t s, CarryOut carry = {}, NanFix fx = {});
 void launch_fftfilt_split_deci(int nsub, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw4096, const cf* hs,
-                               const cf* wk, hipStream_t s);   // out[m] = y[m d], m < n_out
+                               const cf* wk, hipStream_t s, NanFix fx = {});   // out[m] = y[m d], m < n_out
 int fftfilt_split_bin(int p);
 
 // FftStream: out = forward unnormalised FFT of each of `nframes` consecutive 2^log2n-point frames
@@ -89,6 +91,7 @@ struct FmChainArgs {
     int mode;          // RR_ATAN2_*
     CarryOut carry;    // the block's carry-state update (new prefix), written by this launch (common.hpp)
     int multi_waves = 0;   // multi-channel decimate-first kernel: 0 = by predicted cost, 8 / 12 = that many waves per workgroup
+    NanFix fx;             // mode 2 only (launch_fir_poly): nan_fix.hpp
 };
 // out[(u-1) - o_base] = gain * atan2(conj(r[u-1]) r[u]) for u in [max(r_lo,1), r_hi); r[r_lo-1] is
 // *last_in (previous call), r[r_hi-1] is written to *last_out.
@@ -138,7 +141,7 @@ void launch_fm_chain_poly(VSrc<cf> src, float* out, int L, const cf* tw, const c
 void launch_fm_chain_poly_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, const cf* hreg, const FmChainArgs& a, const cf* last_in,
                               cf* last_out, hipStream_t s);
 // decimating FirFilter<Complex> (deci = D) on the decimate-first tiles: out[m] = sum_k t[k] x[m D + L - 1 - k]
-void launch_fir_poly(VSrc<cf> src, cf* out, long n_out, int L, int D, const cf* tw, const cf* hreg, hipStream_t s);
+void launch_fir_poly(VSrc<cf> src, cf* out, long n_out, int L, int D, const cf* tw, const cf* hreg, hipStream_t s, NanFix fx = {});
 void launch_fm_multi_poly(VSrc<cf> src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
                           const FmChainArgs& a, const cf* last_in, cf* last_out, hipStream_t s);
 void launch_fm_multi_poly_iq8(VSrcIQ8 src, float* out, long out_stride, int L, const cf* tw, const cf* hreg, int nchan,
@@ -155,18 +158,18 @@ struct FirPlan {             // host-prepared polyphase tap table
 // tp = device polyphase table [d][qpad] (float if real taps else cf), rev = device reversed taps.
 bool fir_direct_has_tile(const FirPlan& pl, size_t es_in, size_t es_out);   // false: only the slow one-thread-per-output fallback
 void launch_fir_c32(const FirPlan& pl, const void* tp, const void* rev, VSrc<cf> src, cf* out,
-                    long n_out, hipStream_t s);
+                    long n_out, hipStream_t s, NanFix fx = {});
 void launch_fir_f32(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src,
-                    float* out, long n_out, hipStream_t s);
+                    float* out, long n_out, hipStream_t s, NanFix fx = {});
 // Hilbert: out[k] = (xp[k + L/2], sum_j rev[j] xp[k + j]), xp = virtual stream (history ++ in).
 // real samples, Complex taps, Complex output (the composite Hilbert -> FirFilter filter)
 void launch_fir_f32c(const FirPlan& pl, const cf* tp, const cf* rev, VSrc<float> src, cf* out, long n_out,
-                     hipStream_t s);
+                     hipStream_t s, NanFix fx = {});
 void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, cf* out,
-                    long n_out, hipStream_t s);
+                    long n_out, hipStream_t s, NanFix fx = {});
 // Hilbert with the zero taps skipped: hq[q] = rev[2q + par] (Q entries, padded to a multiple of 8).
 // Returns false if the shape is not covered (use launch_hilbert).
-bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src, cf* out, long n_out, hipStream_t s);
+bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src, cf* out, long n_out, hipStream_t s, NanFix fx = {});
 // y[m] *= phase0 * step^(m0 + m) evaluated in f64 (RR_ROT_MODEL)
 void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, double sy, long m0,
                          hipStream_t s);

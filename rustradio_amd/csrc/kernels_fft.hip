@@ -18,6 +18,7 @@
 
 #include "kernels.hpp"
 #include "tile_common.hpp"
+#include "nan_fix.hpp"
 
 // Measurement builds (never shipped; make ABLATE=<bits> / TIMING=1 OUT=../lib_ablate):
 //   -DRR_FFT_ABLATE_BITS=<bits>  compile-time phase ablation: 1 no input loads, 2 no output stores,
@@ -269,11 +270,13 @@ __device__ __forceinline__ void store_stream(creg* p, creg v) {
 }
 
 // ---- FftFilter -----------------------------------------------------------------------------------
-template <int LOG2F, int VAR>
+// (FIX: FirFilter on these tiles — nan_fix.hpp; FftFilter's own instantiation carries none of it)
+template <int LOG2F, int VAR, bool FIX = false>
 __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
-void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles,
+void k_fftfilt_os(NanFixCtx nfx, VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles,
                   const cf* __restrict__ tw, const cf* __restrict__ hpos, int ablate,
                   unsigned long long* __restrict__ dbg, long tile_base, CarryOut carry) {
+    (void)nfx;                                   // (nan_fix.hpp: read from the argument segment by nf_finish, never by the body)
     carry_store<cf>(src, carry);
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
@@ -281,6 +284,7 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
     creg* lds = reinterpret_cast<creg*>(smem_raw);
     const int t = threadIdx.x;
     const long S = F - L + 1;
+    if constexpr (FIX) nf_init();
     const int first = L - 1;                 // first valid position of a tile
     TileXform<LOG2F, VAR> X;
     X.init(t, tw, hpos);
@@ -308,6 +312,7 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
 #endif
         RR_PHASE(); RR_STAMP(1);
         X.run(v, lds, ablate, stamps);
+        if constexpr (FIX) nf_mark(nf_bad(v[15]));   // (a non-finite input makes every output of the tile non-finite)
 
         if (RR_ABLATE(2)) {          // measurement only: no output traffic (keeps v live)
             bool odd = false;
@@ -334,6 +339,7 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
         RR_PHASE(); RR_STAMP(12);
         // next tile's first lds_store touches exactly the slots this thread just read
     }
+    if constexpr (FIX) nf_finish<cf, cf>();       // FirFilter on these tiles: the reference's locality for non-finite samples
 }
 
 // ---- decimating FirFilter on the same tiles ----------------------------------------------------------
@@ -345,8 +351,9 @@ void k_fftfilt_os(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long nt
 // (x < d + F <= 8192 here, so floor((x + 0.5) / d) in f32 is exact).
 template <int LOG2F, int VAR>
 __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
-void k_fftfilt_deci(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d, long ntiles,
+void k_fftfilt_deci(NanFixCtx nfx, VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d, long ntiles,
                     const cf* __restrict__ tw, const cf* __restrict__ hpos) {
+    (void)nfx;
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -355,6 +362,7 @@ void k_fftfilt_deci(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d
     const long S = F - L + 1;
     const int first = L - 1;
     const long K = (first + d - 1) / d;
+    nf_init();
     const float inv_d = 1.0f / (float)d;
     TileXform<LOG2F, VAR> X;
     X.init(t, tw, hpos);
@@ -365,6 +373,7 @@ void k_fftfilt_deci(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d
         load_tile16<LOG2F>(v, src, tile * S, t, lds);
         RR_PHASE();
         X.run(v, lds, 0, nullptr);
+        nf_mark(nf_bad(v[15]));
         const long gb = tile * S + (K * d - first);
         const long qb = gb / d;
         const int rb = (int)(gb - qb * d) + t;             // (gb + t) - qb d, in [0, d + T)
@@ -378,6 +387,7 @@ void k_fftfilt_deci(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d
         }
         RR_PHASE();
     }
+    nf_finish<cf, cf>();
 }
 
 // ---- real streams: two segments per Complex tile -------------------------------------------------------
@@ -410,8 +420,9 @@ __device__ __attribute__((noinline)) void hilbert_store_slow(const creg* lds, VS
 }
 template <int LOG2F, bool DECI, bool HILB = false>
 __global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
-void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L, int d, long ntiles,
+void k_fftfilt_real(NanFixCtx nfx, VSrc<float> src, float* __restrict__ out, long n_out, int L, int d, long ntiles,
                     const cf* __restrict__ tw, const cf* __restrict__ hpos, CarryOut carry) {
+    (void)nfx;
     static_assert(!(DECI && HILB), "the Hilbert form does not decimate");
     carry_store<float>(src, carry);
     constexpr int F = 1 << LOG2F;
@@ -420,6 +431,9 @@ void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L,
     creg* lds = reinterpret_cast<creg*>(smem_raw);
     const int t = threadIdx.x;
     const long S = F - L + 1;
+    // (nan_fix.hpp; not in the Hilbert form: it sits at 255 of 256 registers and anything more spills into its tile loop —
+    //  a Hilbert transformer of 200 ... 3584 taps keeps the tile-wide spread of a non-finite sample, DESIGN.md "known deviations")
+    if constexpr (!HILB) nf_init();
     const int first = L - 1;
     const long K = DECI ? (first + d - 1) / d : 0;
     const float inv_d = DECI ? 1.0f / (float)d : 0.0f;
@@ -439,6 +453,7 @@ void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L,
         }
         RR_PHASE();
         X.run(v, lds, 0, nullptr);
+        if constexpr (!HILB) nf_mark(nf_bad(v[15]));         // (either segment: the transform mixes the two)
         if constexpr (HILB) {
             // The kernel sits at 243 of 256 registers without this epilogue, and a spilled register is poison here (a scratch
             // access waits on the whole in-order vmcnt queue: 0.44 instead of ~0.25 ms per 1e8 samples with 18 spilled).  So the
@@ -508,6 +523,7 @@ void k_fftfilt_real(VSrc<float> src, float* __restrict__ out, long n_out, int L,
         }
         RR_PHASE();
     }
+    if constexpr (!HILB) nf_finish<float, float>();
 }
 
 // ---- decimation by the last radix of the tile plan: pruned inverse transform ---------------------------------
@@ -545,9 +561,11 @@ __device__ __forceinline__ void prune_tail(creg* v, creg* park, int t, const cre
 //   FirFilter<Float>): one response, one tail, y_a / y_b are its real / imaginary parts, f32 output.
 template <int LOG2F, int MODE>
 __global__ __launch_bounds__((KCfg<LOG2F, 0>::T), (KCfg<LOG2F, 0>::WAVES_PER_SIMD))
-void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long n_out, int L, long S, long ntiles,
+void k_fftfilt_prune(NanFixCtx nfx, VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long n_out, int L, long S, long ntiles,
                      const cf* __restrict__ tw, const cf* __restrict__ hpos2, const cf* __restrict__ hpos2b,
                      const cf* __restrict__ twb_tab, CarryOut carry, int sub) {
+    (void)nfx;
+    nf_init();
     // sub > 1 (round 4): a decimation d = D * sub.  The tail's kept samples are the stream's y[D m]; of those only m = sub q
     // are stored, at out[q] (n_out counts the D-decimated samples).  Per thread the 16 candidates are m0 + 16 n1: m0 is split
     // once into sub * base + r0, and r0 + 16 n1 < sub + 256 is small enough for an exact float reciprocal.
@@ -681,6 +699,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
         if constexpr (MODE == 2) {                       // real taps: (t*a) + i (t*b), f32 output
             creg p[16];
             prune_tail<T>(p, park, t, twb);
+            nf_mark(nf_bad(p[15]));                      // (nan_fix.hpp: this thread's tile: non-finite iff its input was)
             const long ma = 2 * (tile0 + b) * Sd - fq + n2, mb = ma + Sd;
             const long ra = n_out - ma, rb = n_out - mb;
             const int lima = ra < hi ? (int)ra : hi, limb = rb < hi ? (int)rb : hi;
@@ -706,6 +725,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
         } else if constexpr (!REAL2) {
             creg p[16];
             prune_tail<T>(p, park, t, twb);
+            nf_mark(nf_bad(p[15]));
             const long m0 = (tile0 + b) * Sd - fq + n2;
             const long room = n_out - m0;
             const int lim = room < hi ? (int)room : hi;
@@ -736,6 +756,7 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
             } else {
                 prune_tail<T>(p, park, t, twb);
             }
+            nf_mark(nf_bad(p[15]));
             creg* stash = lds + 17 * t;
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) stash[n1] = p[n1];
@@ -761,6 +782,9 @@ void k_fftfilt_prune(VSrc<cf> csrc, VSrc<float> rsrc, cf* __restrict__ out, long
         }
         tile_sync<T>();                                  // the next batch parks into the slots just read
     }
+    if constexpr (MODE == 0) nf_finish<cf, cf>();
+    else if constexpr (MODE == 1) nf_finish<float, cf>();
+    else nf_finish<float, float>();
 }
 
 // ---- FftFilter tiles of 8192 / 16384 points as NSUB = 2 / 4 sub-transforms of 4096 points ---------------------
@@ -797,12 +821,14 @@ __device__ __forceinline__ creg window_at(const VSrcIQ8& src, long i) {
 
 // DECI: keep every d-th filtered sample (out[m] = y[m d], n_out counts kept samples) — the index arithmetic of
 // k_fftfilt_deci; the decimating FirFilter with more taps than a 4096-point tile takes.
-template <int NSUB, bool DECI>
+template <int NSUB, bool DECI, bool FIX = false>
 __global__ __launch_bounds__(256, 2)
-void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d, long ntiles, const cf* __restrict__ tw,
+void k_fftfilt_split(NanFixCtx nfx, VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d, long ntiles, const cf* __restrict__ tw,
                      const cf* __restrict__ hs, const cf* __restrict__ wk, CarryOut carry) {
+    (void)nfx;
     carry_store<cf>(src, carry);
     constexpr int LOG2M = 12, M = 1 << LOG2M, T = M / 16, F = NSUB * M;
+    if constexpr (FIX) nf_init();
     constexpr int NP = Plan<LOG2M>::NP;
     constexpr int LE = lds_elems(M);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -871,6 +897,7 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int 
             X.inverse(v, lds);
             lds_store<LOG2M, 0>(v, t, lds);
         }
+        if constexpr (FIX) nf_mark(nf_bad(area[lds_pad(t)]));   // (z_0 of this thread: non-finite iff the tile's input was)
         // ---- output twiddle + butterfly, lane-consecutive stores
         const long o0 = it.tile * S - first;            // output index of tile position 0
         creg* po = out_reg + o0 + t;
@@ -916,34 +943,41 @@ void k_fftfilt_split(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int 
         }
         // (the next tile's first writes go to the own natural slots this thread just read)
     }
+    if constexpr (FIX) nf_finish<cf, cf>();
 }
 
 int fftfilt_split_bin(int p) { return bin_of_pos<12>(p); }
 
 template <int NSUB, bool DECI>
 static void launch_split_one(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hs, const cf* wk, hipStream_t s,
-                             CarryOut carry = {}) {
+                             CarryOut carry = {}, NanFix fx = {}) {
     constexpr int M = 4096, F = NSUB * M;
     const long S = F - L + 1;
     if (n_out <= 0) { launch_carry(src, carry, s); return; }
     const long n_full = DECI ? (n_out - 1) * (long)d + 1 : n_out;
     const long ntiles = (n_full + S - 1) / S;
     const size_t smem = sizeof(cf) * lds_elems(M) * NSUB;
-    const long grid = grid_for_tiles(k_fftfilt_split<NSUB, DECI>, 256, smem, ntiles);
-    hipLaunchKernelGGL((k_fftfilt_split<NSUB, DECI>), dim3((unsigned)grid), dim3(256), smem, s, src, out, n_out, L, d, ntiles, tw, hs, wk, carry);
+    const NanFixCtx nfx = nanfix_ctx(fx, src, out, S, DECI ? d : 1, n_out, ntiles);
+    if (fx.rev) {
+        const long grid = grid_for_tiles(k_fftfilt_split<NSUB, DECI, true>, 256, smem, ntiles);
+        hipLaunchKernelGGL((k_fftfilt_split<NSUB, DECI, true>), dim3((unsigned)grid), dim3(256), smem, s, nfx, src, out, n_out, L, d, ntiles, tw, hs, wk, carry);
+    } else {
+        const long grid = grid_for_tiles(k_fftfilt_split<NSUB, DECI, false>, 256, smem, ntiles);
+        hipLaunchKernelGGL((k_fftfilt_split<NSUB, DECI, false>), dim3((unsigned)grid), dim3(256), smem, s, nfx, src, out, n_out, L, d, ntiles, tw, hs, wk, carry);
+    }
     RR_HIP(hipGetLastError());
 }
 void launch_fftfilt_split(int nsub, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw4096, const cf* hs, const cf* wk,
-                          hipStream_t s, CarryOut carry) {
-    if (nsub == 2) launch_split_one<2, false>(src, out, n_out, L, 1, tw4096, hs, wk, s, carry);
-    else if (nsub == 4) launch_split_one<4, false>(src, out, n_out, L, 1, tw4096, hs, wk, s, carry);
+                          hipStream_t s, CarryOut carry, NanFix fx) {
+    if (nsub == 2) launch_split_one<2, false>(src, out, n_out, L, 1, tw4096, hs, wk, s, carry, fx);
+    else if (nsub == 4) launch_split_one<4, false>(src, out, n_out, L, 1, tw4096, hs, wk, s, carry, fx);
     else throw Error("fftfilt_split: 2 or 4 sub-transforms");
 }
 void launch_fftfilt_split_deci(int nsub, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw4096, const cf* hs,
-                               const cf* wk, hipStream_t s) {
+                               const cf* wk, hipStream_t s, NanFix fx) {
     if (d < 1 || d > 4096) throw Error("fftfilt_split_deci: decimation out of range");
-    if (nsub == 2) launch_split_one<2, true>(src, out, n_out, L, d, tw4096, hs, wk, s);
-    else if (nsub == 4) launch_split_one<4, true>(src, out, n_out, L, d, tw4096, hs, wk, s);
+    if (nsub == 2) launch_split_one<2, true>(src, out, n_out, L, d, tw4096, hs, wk, s, CarryOut{}, fx);
+    else if (nsub == 4) launch_split_one<4, true>(src, out, n_out, L, d, tw4096, hs, wk, s, CarryOut{}, fx);
     else throw Error("fftfilt_split: 2 or 4 sub-transforms");
 }
 
@@ -1766,9 +1800,11 @@ void k_fm_chain_half(SRC src, float* __restrict__ out, int L, long ntiles, long 
 // half-rate sequence; lane-consecutive for d = 2).  Decimations 4 / 8 / 16 have k_fftfilt_prune.
 template <int LOG2F>
 __global__ __launch_bounds__((1 << (LOG2F - 4)), 2)
-void k_fftfilt_half(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d2, long ntiles, long S,
+void k_fftfilt_half(NanFixCtx nfx, VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d2, long ntiles, long S,
                     const cf* __restrict__ tw, const cf* __restrict__ tw_half, const cf* __restrict__ hpos) {
+    (void)nfx;
     constexpr int F = 1 << LOG2F, T = F / 16, LH = LOG2F - 1, FH = F / 2, TH = T / 2;
+    nf_init();
     constexpr int NP = Plan<LOG2F>::NP;
     constexpr int D3 = F / 256, DH = D3 / 2, U = 16 / D3;
     constexpr int N1 = PassGeom<LOG2F, 1>::R * PassGeom<LOG2F, 1>::P;
@@ -1852,6 +1888,7 @@ void k_fftfilt_half(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d
             lds_load<LH, 0>(w, th, ldsH);
             RR_PHASE();
             inv_pass<LH, 0>(w, tw0h);                    // w[n] = y[2 (n 64 + th)] of the tile
+            nf_mark(nf_bad(w[15].x));
             RR_PHASE();
             // half-rate index of tile position 2 n': hb + n', hb = (tile S - delta - first) / 2; this tile owns the
             // full-rate indices [tile S, (tile + 1) S), i.e. n' in [n_lo, n_hi)
@@ -1881,6 +1918,7 @@ void k_fftfilt_half(VSrc<cf> src, cf* __restrict__ out, long n_out, int L, int d
         }
         tile_sync<T>();
     }
+    nf_finish<cf, cf>();
 }
 
 // measurement builds (make TIMING=1): 32 s_memtime stamps of one tile (see RR_STAMP; the two-wave kernels of
@@ -1925,7 +1963,7 @@ int device_cu_count() {
 
 
 template <int LOG2F, int VAR>
-static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s, CarryOut carry, long tile_lo = 0, long tile_hi = -1) {
+static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s, CarryOut carry, NanFix fx = {}, long tile_lo = 0, long tile_hi = -1) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     const long S = F - L + 1;
@@ -1933,27 +1971,34 @@ static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, c
     const long ntiles = tile_hi - tile_lo;
     if (ntiles <= 0) { launch_carry(src, carry, s); return; }
     const size_t smem = sizeof(cf) * lds_elems(F);
-    const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR>, T, smem, ntiles);
     const int ablate = 0;
-    hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L,
-                       ntiles, tw, hpos, ablate, fft_stamp_buffer(), tile_lo, carry);
+    const NanFixCtx nfx = nanfix_ctx(fx, src, out, S, 1, n_out, ntiles, 0, tile_lo);
+    if (fx.rev) {
+        const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR, true>, T, smem, ntiles);
+        hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR, true>), dim3((unsigned)grid), dim3(T), smem, s, nfx, src, out, n_out, L,
+                           ntiles, tw, hpos, ablate, fft_stamp_buffer(), tile_lo, carry);
+    } else {
+        const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR, false>, T, smem, ntiles);
+        hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR, false>), dim3((unsigned)grid), dim3(T), smem, s, nfx, src, out, n_out, L,
+                           ntiles, tw, hpos, ablate, fft_stamp_buffer(), tile_lo, carry);
+    }
     RR_HIP(hipGetLastError());
 }
 
 void launch_fftfilt_os(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw,
-                       const cf* hpos, hipStream_t s, CarryOut carry) {
+                       const cf* hpos, hipStream_t s, CarryOut carry, NanFix fx) {
     switch (log2f) {
-    case 10: launch_one<10, 0>(src, out, n_out, L, tw, hpos, s, carry); break;
-    case 11: launch_one<11, 0>(src, out, n_out, L, tw, hpos, s, carry); break;
-    case 12: launch_one<12, 0>(src, out, n_out, L, tw, hpos, s, carry); break;
-    case 13: launch_one<13, 3>(src, out, n_out, L, tw, hpos, s, carry); break;
-    case 14: launch_one<14, 3>(src, out, n_out, L, tw, hpos, s, carry); break;
+    case 10: launch_one<10, 0>(src, out, n_out, L, tw, hpos, s, carry, fx); break;
+    case 11: launch_one<11, 0>(src, out, n_out, L, tw, hpos, s, carry, fx); break;
+    case 12: launch_one<12, 0>(src, out, n_out, L, tw, hpos, s, carry, fx); break;
+    case 13: launch_one<13, 3>(src, out, n_out, L, tw, hpos, s, carry, fx); break;
+    case 14: launch_one<14, 3>(src, out, n_out, L, tw, hpos, s, carry, fx); break;
     default: throw Error("fftfilt: unsupported tile size");
     }
 }
 
 template <int LOG2F, int VAR>
-static void launch_deci_one(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hpos, hipStream_t s) {
+static void launch_deci_one(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hpos, hipStream_t s, NanFix fx) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     const long S = F - L + 1;
@@ -1962,24 +2007,25 @@ static void launch_deci_one(VSrc<cf> src, cf* out, long n_out, int L, int d, con
     const long ntiles = (n_full + S - 1) / S;
     const size_t smem = sizeof(cf) * lds_elems(F);
     const long grid = grid_for_tiles(k_fftfilt_deci<LOG2F, VAR>, T, smem, ntiles);
-    hipLaunchKernelGGL((k_fftfilt_deci<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L, d,
-                       ntiles, tw, hpos);
+    // (nan_fix.hpp: the tile keeps the outputs m with m d in [tile S, tile S + S))
+    hipLaunchKernelGGL((k_fftfilt_deci<LOG2F, VAR>), dim3((unsigned)grid), dim3(T), smem, s, nanfix_ctx(fx, src, out, S, d, n_out, ntiles),
+                       src, out, n_out, L, d, ntiles, tw, hpos);
     RR_HIP(hipGetLastError());
 }
 
 void launch_fftfilt_deci(int log2f, VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
-                         hipStream_t s) {
+                         hipStream_t s, NanFix fx) {
     if (d < 1 || d > 4096) throw Error("fftfilt_deci: decimation out of range");
     switch (log2f) {
-    case 10: launch_deci_one<10, 0>(src, out, n_out, L, d, tw, hpos, s); break;
-    case 11: launch_deci_one<11, 0>(src, out, n_out, L, d, tw, hpos, s); break;
-    case 12: launch_deci_one<12, 0>(src, out, n_out, L, d, tw, hpos, s); break;
+    case 10: launch_deci_one<10, 0>(src, out, n_out, L, d, tw, hpos, s, fx); break;
+    case 11: launch_deci_one<11, 0>(src, out, n_out, L, d, tw, hpos, s, fx); break;
+    case 12: launch_deci_one<12, 0>(src, out, n_out, L, d, tw, hpos, s, fx); break;
     default: throw Error("fftfilt_deci: unsupported tile size");
     }
 }
 
 template <int LOG2F, bool DECI>
-static void launch_real_one(VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos, hipStream_t s, CarryOut carry) {
+static void launch_real_one(VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos, hipStream_t s, CarryOut carry, NanFix fx) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     const long S = F - L + 1;
@@ -1989,12 +2035,13 @@ static void launch_real_one(VSrc<float> src, float* out, long n_out, int L, int 
     const long ntiles = (nseg + 1) / 2;
     const size_t smem = sizeof(cf) * lds_elems(F);
     const long grid = grid_for_tiles(k_fftfilt_real<LOG2F, DECI>, T, smem, ntiles);
-    hipLaunchKernelGGL((k_fftfilt_real<LOG2F, DECI>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L, d,
-                       ntiles, tw, hpos, carry);
+    // (nan_fix.hpp: a tile = the segments 2 k, 2 k + 1: full-rate outputs [2 k S, 2 k S + 2 S))
+    hipLaunchKernelGGL((k_fftfilt_real<LOG2F, DECI>), dim3((unsigned)grid), dim3(T), smem, s, nanfix_ctx(fx, src, out, 2 * S, DECI ? d : 1, n_out, ntiles),
+                       src, out, n_out, L, d, ntiles, tw, hpos, carry);
     RR_HIP(hipGetLastError());
 }
 template <int LOG2F>
-static void launch_real_hilbert_one(VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s, CarryOut carry) {
+static void launch_real_hilbert_one(VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s, CarryOut carry, NanFix fx) {
     constexpr int F = 1 << LOG2F;
     constexpr int T = F / 16;
     const long S = F - L + 1;
@@ -2002,39 +2049,39 @@ static void launch_real_hilbert_one(VSrc<float> src, cf* out, long n_out, int L,
     const long ntiles = ((n_out + S - 1) / S + 1) / 2;
     const size_t smem = sizeof(cf) * lds_elems(F);
     const long grid = grid_for_tiles(k_fftfilt_real<LOG2F, false, true>, T, smem, ntiles);
-    hipLaunchKernelGGL((k_fftfilt_real<LOG2F, false, true>), dim3((unsigned)grid), dim3(T), smem, s, src, reinterpret_cast<float*>(out), n_out, L, 1,
-                       ntiles, tw, hpos, carry);
+    hipLaunchKernelGGL((k_fftfilt_real<LOG2F, false, true>), dim3((unsigned)grid), dim3(T), smem, s, nanfix_ctx(fx, src, out, 2 * S, 1, n_out, ntiles),
+                       src, reinterpret_cast<float*>(out), n_out, L, 1, ntiles, tw, hpos, carry);
     RR_HIP(hipGetLastError());
 }
 // Hilbert on real-stream tiles: out[k] = (xp[k + L/2], sum_j rev[j] xp[k + j]), k < n_out (L odd)
 void launch_fftfilt_real_hilbert(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos, hipStream_t s,
-                                 CarryOut carry) {
+                                 CarryOut carry, NanFix fx) {
     if (2L * ((1L << log2f) - L + 1) <= 0 || !(L & 1)) throw Error("fftfilt_real_hilbert: bad filter length for the tile");
     switch (log2f) {
-    case 10: launch_real_hilbert_one<10>(src, out, n_out, L, tw, hpos, s, carry); break;
-    case 11: launch_real_hilbert_one<11>(src, out, n_out, L, tw, hpos, s, carry); break;
-    case 12: launch_real_hilbert_one<12>(src, out, n_out, L, tw, hpos, s, carry); break;
+    case 10: launch_real_hilbert_one<10>(src, out, n_out, L, tw, hpos, s, carry, fx); break;
+    case 11: launch_real_hilbert_one<11>(src, out, n_out, L, tw, hpos, s, carry, fx); break;
+    case 12: launch_real_hilbert_one<12>(src, out, n_out, L, tw, hpos, s, carry, fx); break;
     default: throw Error("fftfilt_real_hilbert: unsupported tile size");
     }
 }
 void launch_fftfilt_real(int log2f, VSrc<float> src, float* out, long n_out, int L, int d, const cf* tw, const cf* hpos,
-                         hipStream_t s, CarryOut carry) {
+                         hipStream_t s, CarryOut carry, NanFix fx) {
     if (d < 1 || d > 4096) throw Error("fftfilt_real: decimation out of range");
     if (2L * ((1L << log2f) - L + 1) <= 0) throw Error("fftfilt_real: tile too small");
     switch (log2f * 2 + (d > 1)) {
-    case 20: launch_real_one<10, false>(src, out, n_out, L, d, tw, hpos, s, carry); break;
-    case 21: launch_real_one<10, true>(src, out, n_out, L, d, tw, hpos, s, carry); break;
-    case 22: launch_real_one<11, false>(src, out, n_out, L, d, tw, hpos, s, carry); break;
-    case 23: launch_real_one<11, true>(src, out, n_out, L, d, tw, hpos, s, carry); break;
-    case 24: launch_real_one<12, false>(src, out, n_out, L, d, tw, hpos, s, carry); break;
-    case 25: launch_real_one<12, true>(src, out, n_out, L, d, tw, hpos, s, carry); break;
+    case 20: launch_real_one<10, false>(src, out, n_out, L, d, tw, hpos, s, carry, fx); break;
+    case 21: launch_real_one<10, true>(src, out, n_out, L, d, tw, hpos, s, carry, fx); break;
+    case 22: launch_real_one<11, false>(src, out, n_out, L, d, tw, hpos, s, carry, fx); break;
+    case 23: launch_real_one<11, true>(src, out, n_out, L, d, tw, hpos, s, carry, fx); break;
+    case 24: launch_real_one<12, false>(src, out, n_out, L, d, tw, hpos, s, carry, fx); break;
+    case 25: launch_real_one<12, true>(src, out, n_out, L, d, tw, hpos, s, carry, fx); break;
     default: throw Error("fftfilt_real: unsupported tile size");
     }
 }
 
 template <int LOG2F, int MODE>
 static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_final, int L, const cf* tw, const cf* hpos2,
-                             const cf* hpos2b, const cf* twb, hipStream_t s, int sub, CarryOut carry = {}) {
+                             const cf* hpos2b, const cf* twb, hipStream_t s, int sub, CarryOut carry = {}, NanFix fx = {}) {
     if (sub < 1 || sub > 64) throw Error("fftfilt_prune: sub-decimation out of range");
     const long n_out = n_final > 0 ? (n_final - 1) * (long)sub + 1 : 0;        // in units of the tile's own decimation
     constexpr int F = 1 << LOG2F, T = F / 16, D = F / 256;
@@ -2046,8 +2093,12 @@ static void launch_prune_one(VSrc<cf> csrc, VSrc<float> rsrc, cf* out, long n_fi
     const long ntiles = MODE ? (nseg + 1) / 2 : nseg;
     const size_t smem = sizeof(cf) * (lds_elems(F) + lds_elems(256 * D) + (MODE ? 16 * D : 0));
     constexpr int BT = MODE == 1 ? D / 2 : D;             // tiles per batch (MODE 1: two responses per tile)
-    const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, MODE>, T, smem, (ntiles + BT - 1) / BT);
-    hipLaunchKernelGGL((k_fftfilt_prune<LOG2F, MODE>), dim3((unsigned)grid), dim3(T), smem, s, csrc, rsrc, out, n_out, L, S,
+    const long nbatch = (ntiles + BT - 1) / BT;
+    const long grid = grid_for_tiles(k_fftfilt_prune<LOG2F, MODE>, T, smem, nbatch);
+    // (nan_fix.hpp: a batch = BT tiles (real streams: 2 BT segments) of Sd kept samples y[D m] each; stored are the m = sub q, at out[q])
+    const NanFixCtx nfx = MODE == 0 ? nanfix_ctx(fx, csrc, out, (long)BT * Sd, sub, n_final, nbatch)
+                                    : nanfix_ctx(fx, rsrc, out, 2L * BT * Sd, sub, n_final, nbatch);
+    hipLaunchKernelGGL((k_fftfilt_prune<LOG2F, MODE>), dim3((unsigned)grid), dim3(T), smem, s, nfx, csrc, rsrc, out, n_out, L, S,
                        ntiles, tw, hpos2, hpos2b, twb, carry, sub);
     RR_HIP(hipGetLastError());
 }
@@ -2059,33 +2110,33 @@ bool prune_split(size_t d, size_t& D, size_t& sub) {
     return false;
 }
 void launch_fftfilt_prune_c32(int log2f, VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                              const cf* twb, hipStream_t s, int sub) {
+                              const cf* twb, hipStream_t s, int sub, NanFix fx) {
     VSrc<float> none{nullptr, 0, nullptr, 0};
     switch (log2f) {
-    case 10: launch_prune_one<10, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
-    case 11: launch_prune_one<11, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
-    case 12: launch_prune_one<12, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
+    case 10: launch_prune_one<10, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s, sub, CarryOut{}, fx); break;
+    case 11: launch_prune_one<11, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s, sub, CarryOut{}, fx); break;
+    case 12: launch_prune_one<12, 0>(src, none, out, n_out, L, tw, hpos2, nullptr, twb, s, sub, CarryOut{}, fx); break;
     default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }
 void launch_fftfilt_prune_f32(int log2f, VSrc<float> src, float* out, long n_out, int L, const cf* tw, const cf* hpos2,
-                              const cf* twb, hipStream_t s, int sub) {
+                              const cf* twb, hipStream_t s, int sub, NanFix fx) {
     VSrc<cf> none{nullptr, 0, nullptr, 0};
     cf* o = reinterpret_cast<cf*>(out);
     switch (log2f) {
-    case 10: launch_prune_one<10, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
-    case 11: launch_prune_one<11, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
-    case 12: launch_prune_one<12, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s, sub); break;
+    case 10: launch_prune_one<10, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s, sub, CarryOut{}, fx); break;
+    case 11: launch_prune_one<11, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s, sub, CarryOut{}, fx); break;
+    case 12: launch_prune_one<12, 2>(none, src, o, n_out, L, tw, hpos2, nullptr, twb, s, sub, CarryOut{}, fx); break;
     default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }
 void launch_fftfilt_prune_real(int log2f, VSrc<float> src, cf* out, long n_out, int L, const cf* tw, const cf* hpos2r,
-                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry, int sub) {
+                               const cf* hpos2i, const cf* twb, hipStream_t s, CarryOut carry, int sub, NanFix fx) {
     VSrc<cf> none{nullptr, 0, nullptr, 0};
     switch (log2f) {
-    case 10: launch_prune_one<10, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, sub, carry); break;
-    case 11: launch_prune_one<11, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, sub, carry); break;
-    case 12: launch_prune_one<12, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, sub, carry); break;
+    case 10: launch_prune_one<10, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, sub, carry, fx); break;
+    case 11: launch_prune_one<11, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, sub, carry, fx); break;
+    case 12: launch_prune_one<12, 1>(none, src, out, n_out, L, tw, hpos2r, hpos2i, twb, s, sub, carry, fx); break;
     default: throw Error("fftfilt_prune: unsupported tile size");
     }
 }
@@ -2341,7 +2392,7 @@ void launch_fm_chain_half_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, cons
 // (beyond ~600 taps the 4096-point tiles with a decimating store win again: 1000 taps /2 0.43 vs 0.50 ms)
 bool fftfilt_half_supported(int L, long d) { return d >= 2 && (d & 1) == 0 && d / 2 <= 2048 && L >= 1 && L <= 600; }
 void launch_fftfilt_half(VSrc<cf> src, cf* out, long n_out, int L, int d, const cf* tw, const cf* tw_half, const cf* hpos,
-                         hipStream_t s) {
+                         hipStream_t s, NanFix fx) {
     constexpr int LOG2F = 11, F = 1 << LOG2F, T = F / 16;
     if (!fftfilt_half_supported(L, d)) throw Error("fftfilt_half: unsupported shape");
     if (n_out <= 0) return;
@@ -2350,8 +2401,9 @@ void launch_fftfilt_half(VSrc<cf> src, cf* out, long n_out, int L, int d, const 
     const long ntiles = (n_full + S - 1) / S;
     const size_t smem = sizeof(cf) * (lds_elems(F) + 2 * lds_elems(F / 2) + 128 + 64);
     const long grid = grid_for_tiles(k_fftfilt_half<LOG2F>, T, smem, (ntiles + 1) / 2);
-    hipLaunchKernelGGL((k_fftfilt_half<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, src, out, n_out, L, d / 2, ntiles, S,
-                       tw, tw_half, hpos);
+    // (nan_fix.hpp: tile k keeps the outputs m with m d in [k S, k S + S); tiles go in pairs)
+    hipLaunchKernelGGL((k_fftfilt_half<LOG2F>), dim3((unsigned)grid), dim3(T), smem, s, nanfix_ctx(fx, src, out, 2 * S, d, n_out, (ntiles + 1) / 2),
+                       src, out, n_out, L, d / 2, ntiles, S, tw, tw_half, hpos);
     RR_HIP(hipGetLastError());
 }
 

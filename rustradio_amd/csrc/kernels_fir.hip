@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "nan_fix.hpp"
 
 namespace rr {
 
@@ -78,9 +79,10 @@ constexpr int FIR_MAXPRE = 20;
 // output staging buffer.  Same tile, same thread count, S times fewer LDS reads per multiply-add.
 // A group is a whole number of waves, so taps stay wave-uniform.
 template <class T, class TapT, class OutT, int NT, int R, int S, int PRE, int RSC, bool HILBERT>
-__global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
+__global__ __launch_bounds__(NT, 4) void k_fir(NanFixCtx nfx, VSrc<T> src, OutT* __restrict__ out, long n_out, int L, int d,
                                             int qpad, int np, int rstride_arg, int pstride_arg,
                                             const TapT* __restrict__ tp) {
+    (void)nfx;                                         // (nan_fix.hpp: read from the argument segment by nf_finish, never by the body)
     using AccT = typename std::conditional<HILBERT, T, OutT>::type;   // real samples x complex taps accumulate Complex
     // RSC > 0: the row stride is a compile-time constant, so the R window reads of a tap block are one
     // address register + immediates (the d = 1 shapes; the host sizes the tile for it)
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
     OutT* lds_o = reinterpret_cast<OutT*>(smem_raw);
     const int t = threadIdx.x;
     const long ntiles = (n_out + NOUT - 1) / NOUT;
+    nf_init();                                         // (the zero-padded taps spread a NaN up to 8 outputs too far)
     const int total = np * d;
     const int cnt_k = (total + NT - 1) / NT;           // staged values per thread
     const bool piped = cnt_k <= PRE;                   // PRE = staged values per thread the kernel is built for
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
 #pragma unroll
         for (int j = 0; j < R; j++) lds_o[t * (R + 1) + j] = res[j];
         __syncthreads();
+        bool tile_bad = false;
 #pragma unroll
         for (int c = 0; c < R / S; c++) {
             const int i = c * NT + t;
@@ -259,18 +263,21 @@ __global__ __launch_bounds__(NT, 4) void k_fir(VSrc<T> src, OutT* __restrict__ o
 #pragma unroll
                 for (int g = 1; g < S; g++) v = add_of(v, lds_o[(g * NTC + i / R) * (R + 1) + i % R]);
             }
+            tile_bad |= nf_bad(v);
             hold[c] = v;
         }
+        nf_mark(tile_bad);
         hold_m0 = m0;
     }
     flush();
+    nf_finish<T, OutT>();
 }
 
 // Fallback for shapes whose tile does not fit LDS (very large d or L): one output per thread,
 // inputs through L1/L2.
 template <class T, class TapT, class OutT, bool HILBERT>
 __global__ __launch_bounds__(256) void k_fir_direct(VSrc<T> src, OutT* __restrict__ out, long n_out, int L,
-                                                    int d, const TapT* __restrict__ rev) {
+                                                    int d, const TapT* __restrict__ rev, NanFix fx) {
     for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < n_out; m += (long)gridDim.x * blockDim.x) {
         using AccT = typename std::conditional<HILBERT, T, OutT>::type;
         AccT acc = zero_of<AccT>();
@@ -278,6 +285,9 @@ __global__ __launch_bounds__(256) void k_fir_direct(VSrc<T> src, OutT* __restric
         for (int k = 0; k < L; k++) mac(acc, rev[k], src.load(b + k));
         if constexpr (HILBERT) out[m] = mkcf(src.load(b + L / 2), acc);
         else out[m] = acc;
+        if (fx.rev && nf_bad(acc)) {                   // (real-valued Complex taps skip the cross terms the reference's 0 * NaN keeps)
+            out[m] = nf_direct<T, OutT>(src, fx.rev, fx.L, fx.d, fx.kind, m);
+        }
     }
 }
 
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(256) void k_fir_direct(VSrc<T> src, OutT* __restric
 // are penalised, so small inputs get small tiles.
 template <class T, class TapT, class OutT, bool HILBERT>
 static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, VSrc<T> src, OutT* out,
-                           long n_out, hipStream_t s) {
+                           long n_out, hipStream_t s, NanFix fx) {
     if (n_out <= 0) return;
     const int cus = device_cu_count();
     struct Cfg { int NT, R, S; };
@@ -336,7 +346,7 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
         long grid = (n_out + 255) / 256;
         if (grid > (long)cus * 16) grid = (long)cus * 16;
         hipLaunchKernelGGL((k_fir_direct<T, TapT, OutT, HILBERT>), dim3((unsigned)grid), dim3(256), 0, s, src, out,
-                           n_out, pl.L, pl.d, rev);
+                           n_out, pl.L, pl.d, rev, fx);
         RR_HIP(hipGetLastError());
         return;
     }
@@ -370,10 +380,10 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
     }
 #define RR_FIR_LAUNCH(NTV, RV, SV, PREV)                                                                                \
     hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, SV, PREV, 0, HILBERT>), dim3((unsigned)grid), dim3(NTV), g.lds_bytes, \
-                       s, src, out, n_out, pl.L, pl.d, qrun, g.np, g.rstride, g.pstride, tp)
+                       s, nanfix_ctx(fx, src, out, (long)(NTV / SV * RV), 1, n_out, ntiles, 1), src, out, n_out, pl.L, pl.d, qrun, g.np, g.rstride, g.pstride, tp)
 #define RR_FIR_LAUNCH_RSC(NTV, RV, PREV)                                                                                \
     hipLaunchKernelGGL((k_fir<T, TapT, OutT, NTV, RV, 1, PREV, NTV + 66, HILBERT>), dim3((unsigned)grid), dim3(NTV),     \
-                       g.lds_bytes, s, src, out, n_out, pl.L, pl.d, qrun, g.np, g.rstride, g.pstride, tp)
+                       g.lds_bytes, s, nanfix_ctx(fx, src, out, (long)(NTV * RV), 1, n_out, ntiles, 1), src, out, n_out, pl.L, pl.d, qrun, g.np, g.rstride, g.pstride, tp)
 #define RR_FIR_LAUNCH2(NTV, RV, SV)                                                   \
     do {                                                                              \
         if (fixed_rs) RR_FIR_LAUNCH_RSC(NTV, RV, 10);                                 \
@@ -415,23 +425,23 @@ bool fir_direct_has_tile(const FirPlan& pl, size_t es_in, size_t es_out) {
 }
 
 void launch_fir_c32(const FirPlan& pl, const void* tp, const void* rev, VSrc<cf> src, cf* out, long n_out,
-                    hipStream_t s) {
+                    hipStream_t s, NanFix fx) {
     if (pl.complex_taps)
-        launch_fir_any<cf, cf, cf, false>(pl, (const cf*)tp, (const cf*)rev, src, out, n_out, s);
+        launch_fir_any<cf, cf, cf, false>(pl, (const cf*)tp, (const cf*)rev, src, out, n_out, s, fx);
     else
-        launch_fir_any<cf, float, cf, false>(pl, (const float*)tp, (const float*)rev, src, out, n_out, s);
+        launch_fir_any<cf, float, cf, false>(pl, (const float*)tp, (const float*)rev, src, out, n_out, s, fx);
 }
 void launch_fir_f32(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, float* out,
-                    long n_out, hipStream_t s) {
-    launch_fir_any<float, float, float, false>(pl, tp, rev, src, out, n_out, s);
+                    long n_out, hipStream_t s, NanFix fx) {
+    launch_fir_any<float, float, float, false>(pl, tp, rev, src, out, n_out, s, fx);
 }
 void launch_fir_f32c(const FirPlan& pl, const cf* tp, const cf* rev, VSrc<float> src, cf* out, long n_out,
-                     hipStream_t s) {
-    launch_fir_any<float, cf, cf, false>(pl, tp, rev, src, out, n_out, s);
+                     hipStream_t s, NanFix fx) {
+    launch_fir_any<float, cf, cf, false>(pl, tp, rev, src, out, n_out, s, fx);
 }
 void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<float> src, cf* out,
-                    long n_out, hipStream_t s) {
-    launch_fir_any<float, float, cf, true>(pl, tp, rev, src, out, n_out, s);
+                    long n_out, hipStream_t s, NanFix fx) {
+    launch_fir_any<float, float, cf, true>(pl, tp, rev, src, out, n_out, s, fx);
 }
 
 // ---- Hilbert with the zero taps skipped -------------------------------------------------------------
@@ -451,14 +461,19 @@ constexpr int HIL_PRE = 10;
 // (compute queues run in unaligned access mode); with the honest alignment the compiler splits every
 // load in two.  Covered by the Hilbert tests with even and odd L/2 and odd window offsets.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict__ out, long n_out, int L, int par,
+__global__ __launch_bounds__(NT, 4) void k_hilbert(NanFixCtx nfx, VSrc<float> src, cf* __restrict__ out, long n_out, int L, int par,
                                                    int Q, int np, int rstride, const float* __restrict__ hq) {
+    (void)nfx;
     constexpr int R = 8, NP = NT * R;                   // pairs per tile (2*NP outputs)
+    // The taps this kernel skips are zero, and the reference multiplies them all the same: 0 * NaN = NaN reaches outputs this
+    // kernel leaves finite.  So the test is on the INPUT of a tile (every sample any of its outputs reads is staged by it),
+    // and a workgroup that staged a non-finite sample recomputes ALL outputs of its tiles (nan_fix.hpp, force).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);          // pair n at (n % R)*rstride + n / R
     cf* lds_o = reinterpret_cast<cf*>(smem_raw);
     const int t = threadIdx.x;
     const long ntiles = (n_out + 2 * NP - 1) / (2 * NP);
+    nf_init();
     const int cnt_k = (np + NT - 1) / NT;               // <= HIL_PRE (host checks)
 
     cf pre[HIL_PRE];
@@ -489,16 +504,21 @@ __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict_
         int cnt = cnt_k;
         asm volatile("" : "+s"(cnt));
         cf* slot = lds + (tt % R) * rstride + tt / R;   // R divides NT: round c lands NT/R columns further
+        bool bad = false;
 #pragma unroll
         for (int c = 0; c < HIL_PRE; c++) {
-            if (c < cnt - 1) slot[c * (NT / R)] = pre[c];
-            else if (c == cnt - 1 && tt + c * NT < (unsigned)np) slot[c * (NT / R)] = pre[c];
+            if (c < cnt - 1) { slot[c * (NT / R)] = pre[c]; bad |= nf_bad(pre[c]); }
+            else if (c == cnt - 1 && tt + c * NT < (unsigned)np) { slot[c * (NT / R)] = pre[c]; bad |= nf_bad(pre[c]); }
         }
+        nf_mark(bad);
     };
     auto stage_direct = [&](long tile) {                // tiles touching the carried history / window end
         const long g0 = tile * 2 * NP + par;
-        for (int i = t; i < np; i += NT)
-            lds[(i % R) * rstride + i / R] = mkcf(src.load(g0 + 2L * i), src.load(g0 + 2L * i + 1));
+        for (int i = t; i < np; i += NT) {
+            const cf pr = mkcf(src.load(g0 + 2L * i), src.load(g0 + 2L * i + 1));
+            lds[(i % R) * rstride + i / R] = pr;
+            nf_mark(nf_bad(pr));
+        }
     };
 
     long tile = blockIdx.x;
@@ -545,11 +565,12 @@ __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict_
             if (m0 + i < n_out) out[m0 + i] = lds_o[(i / (2 * R)) * (2 * R + 1) + i % (2 * R)];
         }
     }
+    nf_finish<float, cf>(true);
 }
 
 // hq = device [Q] (Q = taps per phase padded to a multiple of 8); returns false when the shape is
 // not covered (caller falls back to the generic FIR kernel).
-bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src, cf* out, long n_out, hipStream_t s) {
+bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src, cf* out, long n_out, hipStream_t s, NanFix fx) {
     if (n_out <= 0) return true;
     constexpr int NT = 256, R = 8;
     const int np = NT * R + Q + 8;                      // pairs a tile may touch (taps, window refill, Re parts)
@@ -564,7 +585,8 @@ bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src
     if (per_cu < 1) per_cu = 1;
     const long cap = (long)device_cu_count() * per_cu;
     const long grid = ntiles < cap ? ntiles : cap;
-    hipLaunchKernelGGL((k_hilbert<NT>), dim3((unsigned)grid), dim3(NT), smem, s, src, out, n_out, L, par, Q, np, rs, hq);
+    hipLaunchKernelGGL((k_hilbert<NT>), dim3((unsigned)grid), dim3(NT), smem, s, nanfix_ctx(fx, src, out, (long)NT * 2 * R, 1, n_out, ntiles, 1),
+                       src, out, n_out, L, par, Q, np, rs, hq);
     RR_HIP(hipGetLastError());
     return true;
 }

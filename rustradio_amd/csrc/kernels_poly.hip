@@ -32,6 +32,7 @@
 
 #include "kernels.hpp"
 #include "tile_common.hpp"
+#include "nan_fix.hpp"
 
 namespace rr {
 
@@ -457,11 +458,17 @@ __device__ __forceinline__ void poly_store_tile(const creg* ldsR, int lane0, int
     for (int i = lane0; i < nv; i += stride, pu += stride, o += stride) *o = *pu;
 }
 
-template <int D, class SRC>
+// mode 2 (decimating FirFilter): the reference's locality for non-finite samples (nan_fix.hpp; the context is the kernels'
+// first argument, built by launch_chain_poly_d)
+
+// (FIR = the FirFilter instantiation, launch_fir_poly: the chains' own carry none of the repair's code)
+template <int D, class SRC, bool FIR = false>
 __global__ __launch_bounds__(128, RR_POLY_WAVES)
-void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
+void k_fm_chain_poly(NanFixCtx nfx, SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
                      PolyArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out, unsigned long long* __restrict__ dbg) {
     carry_store<cf>(src, a.carry);
+    (void)nfx;
+    if constexpr (FIR) nf_init();
     constexpr int PHA = (D + 1) / 2, PHB = D - PHA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     creg* lds = reinterpret_cast<creg*>(smem_raw);
@@ -523,6 +530,7 @@ void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __
 #else
             poly_inverse(z, t, ex, tw0, tab1);
 #endif
+            if constexpr (FIR) nf_mark(nf_bad(z[15].x));
             nat_store(z, t, ldsR);
         }
         PSTAMP(3);
@@ -534,17 +542,20 @@ void k_fm_chain_poly(SRC src, float* __restrict__ out, long ntiles, const cf* __
         PSTAMP(5);
         // (the next tile rewrites exB / ldsR only after its first barrier, which both waves reach after these reads)
     }
+    if constexpr (FIR) nf_finish<cf, cf>();
 }
 
 // ---- the same with three waves per SIMD: NW waves per workgroup, D / NW phases each ---------------------------------------
 // (1:6 -> 3 waves x 2 phases, 1:4 -> 2 x 2, 1:8 -> 4 x 2, 1:3 -> 3 x 1, 1:2 -> 2 x 1: at most two phases per wave, pass-0
 // twiddles in the LDS table, 16-byte response loads = 168 VGPRs.)  The natural-order tile shares wave 0's exchange area —
 // one more barrier per tile, 8.7 KB less per workgroup — so that 12 waves' workgroups fit the CU's LDS.
-template <int D, int NW, class SRC>
+template <int D, int NW, class SRC, bool FIR = false>
 __global__ __launch_bounds__(64 * NW, 3)
-void k_fm_chain_polyw(SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
+void k_fm_chain_polyw(NanFixCtx nfx, SRC src, float* __restrict__ out, long ntiles, const cf* __restrict__ tw, const cf* __restrict__ hreg,
                       PolyArgs a, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
     carry_store<cf>(src, a.carry);
+    (void)nfx;
+    if constexpr (FIR) nf_init();
     static_assert((D + NW - 1) / NW <= 2, "at most two phases per wave");
     constexpr int PPW = (D + NW - 1) / NW;               // (odd decimations, round 4: the last wave has one phase; its loads still
                                                          //  fetch the pair — the sample in front of phase D - 1 is the neighbouring
@@ -641,6 +652,7 @@ void k_fm_chain_polyw(SRC src, float* __restrict__ out, long ntiles, const cf* _
                 for (int j = 0; j < 16; j++) z[j] = cadd(z[j], lds[k * PLE + j * PT + t]);
             }
             poly_inverse_tab(z, t, ex, tw0, tab1);
+            if constexpr (FIR) nf_mark(nf_bad(z[15].x));
             nat_store(z, t, ldsR);
         }
         if constexpr (PIPE) poly_issue_raw<D, RR_POLY_PIPE_SPLIT, 16>(raw, nb, t);
@@ -650,6 +662,7 @@ void k_fm_chain_polyw(SRC src, float* __restrict__ out, long ntiles, const cf* _
         else poly_store_tile(ldsR, w * PT + t, NW * PT, u0, Sa, a, reinterpret_cast<creg*>(out));
         tile_sync<64 * NW>();                            // wave 0's next transforms rewrite the area the others read here
     }
+    if constexpr (FIR) nf_finish<cf, cf>();
 }
 
 // ---- N channels on one input -------------------------------------------------------------------------------------
@@ -898,6 +911,9 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
     const long Sa = PF - a.Ls, nr = a.r_hi - a.r_lo;
     if (nr <= 0) { launch_carry(src, h.carry, s); return; }
     const long ntiles = (nr + Sa - 1) / Sa;
+    // (nan_fix.hpp, mode 2 = launch_fir_poly: r_lo = o_base = 0, tile k owns the outputs [k Sa, k Sa + Sa))
+    NanFixCtx nfx{};
+    if constexpr (std::is_same<SRC, VSrc<cf>>::value) nfx = nanfix_ctx(h.mode == 2 ? h.fx : NanFix{}, src, out, Sa, 1, a.r_hi - a.o_base, ntiles);
 #if RR_POLY_CHAIN_W3
     // (1:5 and 1:7 from RTL-SDR bytes keep the two-wave kernel: their wave-dependent phase count spills 48-76 registers there)
     constexpr int NWsel = (std::is_same<SRC, VSrcIQ8>::value && (D % 2 == 1) && D >= 5) ? 0 : ChainWaves<D>::NW;
@@ -906,7 +922,15 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
         const size_t smemw = sizeof(cf) * (NW * PLE + 64 + 15 * PT);
         long gridw = grid_for_tiles(k_fm_chain_polyw<D, NW, SRC>, 64 * NW, smemw, ntiles);
         if (ntiles > gridw && ntiles < 12 * gridw) gridw = std::min(ntiles, (long)RR_POLY_OVERSUB * gridw);
-        hipLaunchKernelGGL((k_fm_chain_polyw<D, NW, SRC>), dim3((unsigned)gridw), dim3(64 * NW), smemw, s, src, out, ntiles, tw, hreg, a,
+        if constexpr (std::is_same<SRC, VSrc<cf>>::value) {
+            if (h.mode == 2) {
+                hipLaunchKernelGGL((k_fm_chain_polyw<D, NW, SRC, true>), dim3((unsigned)gridw), dim3(64 * NW), smemw, s, nfx, src, out, ntiles, tw, hreg, a,
+                                   last_in, last_out);
+                RR_HIP(hipGetLastError());
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_fm_chain_polyw<D, NW, SRC>), dim3((unsigned)gridw), dim3(64 * NW), smemw, s, nfx, src, out, ntiles, tw, hreg, a,
                            last_in, last_out);
         RR_HIP(hipGetLastError());
         return;
@@ -919,7 +943,15 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
     // hand the tiles out as slots free up (tools/percu_sweep.sh: 0.0685 -> 0.063 ms; 1 tile per workgroup 0.0645; with 17
     // tiles per slot, full_chain_fused, the persistent grid stays ahead: 0.319 vs 0.330).
     if (ntiles > grid && ntiles < 12 * grid) grid = std::min(ntiles, (long)RR_POLY_OVERSUB * grid);
-    hipLaunchKernelGGL((k_fm_chain_poly<D, SRC>), dim3((unsigned)grid), dim3(128), smem, s, src, out, ntiles, tw, hreg, a, last_in, last_out,
+    if constexpr (std::is_same<SRC, VSrc<cf>>::value) {
+        if (h.mode == 2) {
+            hipLaunchKernelGGL((k_fm_chain_poly<D, SRC, true>), dim3((unsigned)grid), dim3(128), smem, s, nfx, src, out, ntiles, tw, hreg, a, last_in, last_out,
+                               fft_stamp_buffer());
+            RR_HIP(hipGetLastError());
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_fm_chain_poly<D, SRC>), dim3((unsigned)grid), dim3(128), smem, s, nfx, src, out, ntiles, tw, hreg, a, last_in, last_out,
                        fft_stamp_buffer());
     RR_HIP(hipGetLastError());
 }
@@ -945,9 +977,10 @@ void launch_fm_chain_poly_iq8(VSrcIQ8 src, float* out, int L, const cf* tw, cons
 // Decimating FirFilter<Complex> on the same tiles: out[m] = sum_k t[k] x[m D + L - 1 - k], m < n_out (Fir::filter_n, fir.rs:181-189;
 // "valid" mode: the window itself holds the L - 1 samples of history) = the chain's r[u] with the stream origin at V[L - 1]
 // and the samples stored instead of demodulated.
-void launch_fir_poly(VSrc<cf> src, cf* out, long n_out, int L, int D, const cf* tw, const cf* hreg, hipStream_t s) {
+void launch_fir_poly(VSrc<cf> src, cf* out, long n_out, int L, int D, const cf* tw, const cf* hreg, hipStream_t s, NanFix fx) {
     FmChainArgs h{};
     h.A = 0; h.n_y = n_out * (long)D; h.r_lo = 0; h.r_hi = n_out; h.o_base = 0; h.I = 1; h.D = D; h.gain = 1.0f; h.mode = 2;
+    h.fx = fx;
     launch_chain_poly_t(src, reinterpret_cast<float*>(out), L, tw, hreg, h, nullptr, nullptr, s);
 }
 
