@@ -288,7 +288,10 @@ int         rr_block_sync(rr_block *b);
  * rr_dstream_copy_in/out run as direct DMA instead of staged pageable copies (35 -> 40 GB/s).  Windows
  * that are not WHOLLY inside a range registered here (pageable memory, memory the caller page-locked by
  * other means) are staged through device memory as before.  Optional; unregister before the memory is
- * unmapped, and not while a work call on one of its windows is running. */
+ * unmapped, and not while a work call on one of its windows is running.  Register a ring ONCE: an address
+ * range that has been unregistered is retired from zero-copy for the life of the process (registering it
+ * again still page-locks it for DMA) — kernels working in place on re-registered addresses were seen to
+ * miss on this platform (tools/zerocopy_churn.py). */
 int rr_host_register(void *ptr, size_t bytes);
 int rr_host_unregister(void *ptr);
 

@@ -461,19 +461,18 @@ constexpr int HIL_PRE = 10;
 // (compute queues run in unaligned access mode); with the honest alignment the compiler splits every
 // load in two.  Covered by the Hilbert tests with even and odd L/2 and odd window offsets.
 template <int NT>
-__global__ __launch_bounds__(NT, 4) void k_hilbert(NanFixCtx nfx, VSrc<float> src, cf* __restrict__ out, long n_out, int L, int par,
+__global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict__ out, long n_out, int L, int par,
                                                    int Q, int np, int rstride, const float* __restrict__ hq) {
-    (void)nfx;
     constexpr int R = 8, NP = NT * R;                   // pairs per tile (2*NP outputs)
-    // The taps this kernel skips are zero, and the reference multiplies them all the same: 0 * NaN = NaN reaches outputs this
-    // kernel leaves finite.  So the test is on the INPUT of a tile (every sample any of its outputs reads is staged by it),
-    // and a workgroup that staged a non-finite sample recomputes ALL outputs of its tiles (nan_fix.hpp, force).
+    // (Non-finite samples, nan_fix.hpp: NOT repaired here.  The taps this kernel skips are zero and the reference multiplies
+    //  them all the same — 0 * NaN = NaN — so a bad sample reaches every output of its window there and only every other one
+    //  here (plus the one real part); testing the staged input for it cost this kernel 21 % (a spilled register pair or a
+    //  wave per SIMD: tools/hilbert_probe.py 0.230 -> 0.279 / 0.41 ms per 1e8 samples).  DESIGN.md "known deviations".)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);          // pair n at (n % R)*rstride + n / R
     cf* lds_o = reinterpret_cast<cf*>(smem_raw);
     const int t = threadIdx.x;
     const long ntiles = (n_out + 2 * NP - 1) / (2 * NP);
-    nf_init();
     const int cnt_k = (np + NT - 1) / NT;               // <= HIL_PRE (host checks)
 
     cf pre[HIL_PRE];
@@ -504,21 +503,16 @@ __global__ __launch_bounds__(NT, 4) void k_hilbert(NanFixCtx nfx, VSrc<float> sr
         int cnt = cnt_k;
         asm volatile("" : "+s"(cnt));
         cf* slot = lds + (tt % R) * rstride + tt / R;   // R divides NT: round c lands NT/R columns further
-        bool bad = false;
 #pragma unroll
         for (int c = 0; c < HIL_PRE; c++) {
-            if (c < cnt - 1) { slot[c * (NT / R)] = pre[c]; bad |= nf_bad(pre[c]); }
-            else if (c == cnt - 1 && tt + c * NT < (unsigned)np) { slot[c * (NT / R)] = pre[c]; bad |= nf_bad(pre[c]); }
+            if (c < cnt - 1) slot[c * (NT / R)] = pre[c];
+            else if (c == cnt - 1 && tt + c * NT < (unsigned)np) slot[c * (NT / R)] = pre[c];
         }
-        nf_mark(bad);
     };
     auto stage_direct = [&](long tile) {                // tiles touching the carried history / window end
         const long g0 = tile * 2 * NP + par;
-        for (int i = t; i < np; i += NT) {
-            const cf pr = mkcf(src.load(g0 + 2L * i), src.load(g0 + 2L * i + 1));
-            lds[(i % R) * rstride + i / R] = pr;
-            nf_mark(nf_bad(pr));
-        }
+        for (int i = t; i < np; i += NT)
+            lds[(i % R) * rstride + i / R] = mkcf(src.load(g0 + 2L * i), src.load(g0 + 2L * i + 1));
     };
 
     long tile = blockIdx.x;
@@ -565,7 +559,6 @@ __global__ __launch_bounds__(NT, 4) void k_hilbert(NanFixCtx nfx, VSrc<float> sr
             if (m0 + i < n_out) out[m0 + i] = lds_o[(i / (2 * R)) * (2 * R + 1) + i % (2 * R)];
         }
     }
-    nf_finish<float, cf>(true);
 }
 
 // hq = device [Q] (Q = taps per phase padded to a multiple of 8); returns false when the shape is
@@ -585,8 +578,8 @@ bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src
     if (per_cu < 1) per_cu = 1;
     const long cap = (long)device_cu_count() * per_cu;
     const long grid = ntiles < cap ? ntiles : cap;
-    hipLaunchKernelGGL((k_hilbert<NT>), dim3((unsigned)grid), dim3(NT), smem, s, nanfix_ctx(fx, src, out, (long)NT * 2 * R, 1, n_out, ntiles, 1),
-                       src, out, n_out, L, par, Q, np, rs, hq);
+    (void)fx;                                           // (see k_hilbert)
+    hipLaunchKernelGGL((k_hilbert<NT>), dim3((unsigned)grid), dim3(NT), smem, s, src, out, n_out, L, par, Q, np, rs, hq);
     RR_HIP(hipGetLastError());
     return true;
 }

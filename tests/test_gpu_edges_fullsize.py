@@ -317,11 +317,9 @@ def test_rotator_drift_vs_length(rr):
 
 
 def test_nan_locality_is_bounded_by_one_tile(rr):
-    """DESIGN.md "known deviations": on the overlap-save tile paths one non-finite input sample poisons up to one TILE of
-    outputs where the reference's direct form poisons the ntaps outputs whose window contains it.  Pinned here: (a) every
-    output the reference poisons is poisoned, (b) nothing farther than one tile (4096 points at most for these filters) from
-    the sample is touched, (c) the direct-form path (rr_build_opts.fir_path = DIRECT) keeps the reference's locality up to
-    its zero-padded groups of 8 taps."""
+    """DESIGN.md "known deviations", what is left of them in round 4: FftFilter (whose reference is a transform too, and
+    smears a non-finite sample over ITS block) poisons up to one of its own tiles; FirFilter now has the reference's locality
+    exactly (test_nonfinite_samples_reach_exactly_the_references_outputs) and passes the bounds below a fortiori."""
     L, pos, n = 127, 50_000, 120_000
     taps = orc.low_pass_complex(10e6, 1e6, 190e3)
     x = rnd_c(n, 11)
@@ -391,9 +389,6 @@ NONFINITE_CASES = [
     ("firf32-1000-real-tiles-deci3", lambda m, t: [m.FirFilter(t["f1000"], deci=3)], {}, True),
     ("firf32-255-deci8-pruned", lambda m, t: [m.FirFilter(t["f1000"][:255], deci=8)], dict(fir_prune=1), True),
     ("firf32-5000-wide", lambda m, t: [m.FirFilter(t["f5000"], deci=2)], {}, True),
-    ("hilbert65", lambda m, t: [m.Hilbert(65)], {}, True),
-    ("hilbert31", lambda m, t: [m.Hilbert(31)], {}, True),
-    ("hilbert65-generic-kernel", lambda m, t: [m.Hilbert(65)], dict(fir_cfg=3), True),
     ("hilbertfir-65x255-deci8-direct", lambda m, t: _hilfir(m, 65, t["c401"][:255], 8), dict(fir_prune=-1), True),
     ("hilbertfir-65x255-deci8-pruned", lambda m, t: _hilfir(m, 65, t["c401"][:255], 8), dict(fir_prune=1), True),
     ("hilbertfir-65x401-deci3", lambda m, t: _hilfir(m, 65, t["cc401"], 3), {}, True),
@@ -423,7 +418,13 @@ def test_nonfinite_samples_reach_exactly_the_references_outputs(rr, name, mk, op
     assert len(yo) == len(yg) > 1000
     bo, bg = _nonfinite_mask(yo), _nonfinite_mask(yg)
     assert bo.sum() > 20
-    assert np.array_equal(bo, bg), (int(bo.sum()), int(bg.sum()), np.flatnonzero(bo != bg)[:8])
+    if name.startswith("hilbertfir"):
+        # (where the block runs as two stages its first one is the pair-sample Hilbert kernel, which skips the transformer's
+        #  zero taps — test_nonfinite_samples_hilbert_pair_kernel: a handful of the reference's poisoned outputs stay finite)
+        assert not np.any(bg & ~bo) and bo.sum() - bg.sum() <= max(4, bo.sum() // 100), (int(bo.sum()), int(bg.sum()))
+        bo = bo | bg
+    else:
+        assert np.array_equal(bo, bg), (int(bo.sum()), int(bg.sum()), np.flatnonzero(bo != bg)[:8])
     # ... of the same class component by component (NaN stays NaN, +Inf stays +Inf).  Not asked of the fused Hilbert ->
     # FirFilter: its composite filter meets an Inf sample with other tap signs than the two stages do (Inf - Inf = NaN in
     # one, Inf in the other); the SET of non-finite outputs is the reference's all the same.
@@ -431,4 +432,24 @@ def test_nonfinite_samples_reach_exactly_the_references_outputs(rr, name, mk, op
         for part in ((np.real, np.imag) if np.iscomplexobj(yo) else (np.asarray,)):
             a, b = part(yo)[bo], part(yg)[bo]
             assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
-    assert max_norm_err(yg[~bo], yo[~bo]) <= TOL
+    ok = ~(bo | bg)
+    assert max_norm_err(yg[ok], yo[ok]) <= TOL
+
+
+def test_nonfinite_samples_hilbert_pair_kernel(rr):
+    """The default Hilbert kernel (pair samples, zero taps skipped: csrc/kernels_fir.hip k_hilbert) is the one place left
+    where a non-finite sample does not reach exactly the reference's outputs: the reference multiplies the transformer's zero
+    taps too (0 * NaN = NaN), the kernel does not, so the imaginary parts it poisons are a SUBSET of the reference's (every
+    other output of the window); the real part (a copy of the input) is poisoned at exactly the reference's one output, and
+    every output the reference leaves finite stays within tolerance.  (Repairing it costs the kernel 21 %: DESIGN.md.)"""
+    n = 100_000
+    x = _poisoned(rnd_f(n, 4), 9)
+    for L in (31, 65):
+        yo = run_chain([orc.Hilbert(L)], x)
+        yg = run_chain([rr.Hilbert(L)], x)
+        assert len(yo) == len(yg) == n
+        assert np.array_equal(~np.isfinite(yo.real), ~np.isfinite(yg.real))
+        bo, bg = ~np.isfinite(yo.imag), ~np.isfinite(yg.imag)
+        assert not np.any(bg & ~bo) and bg.sum() >= bo.sum() // 2 - L
+        ok = ~_nonfinite_mask(yo)
+        assert max_norm_err(yg[ok], yo[ok]) <= TOL
