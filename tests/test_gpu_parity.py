@@ -1030,6 +1030,27 @@ def test_device_stream_ring_contract(rr, monkeypatch, no_vmm):
         rr.DeviceStream(np.uint32, 2)                      # smaller than one element
 
 
+def test_reregistered_addresses_keep_working(rr):
+    """csrc/blocks.cpp "RETIRED addresses": an address range that has been unregistered is page-locked again by a second
+    rr_host_register but never handed to kernels in place again (tools/zerocopy_churn.py: on this pool kernels working in
+    place on re-registered addresses now and then miss).  Whatever path a window takes, the samples are the same."""
+    n = 200_000
+    x = rnd_f(n, 8)
+    a, b = np.zeros(n + 32, np.float32), np.zeros(n + 32, np.float32)
+    want = x * np.float32(0.25)
+    blk = rr.MultiplyConst(0.25)
+    for cycle in range(4):                                 # first cycle: zero copy; later ones: retired, staged through DMA
+        rr.host_register(a); rr.host_register(b)
+        try:
+            for k in range(3):
+                a[7:7 + n] = x
+                b[:] = -1.0
+                st, c, p, need = blk.work_into(a[7:7 + n], b[3:], n)
+                assert (c, p) == (n, n) and np.array_equal(b[3:3 + n], want), (cycle, k)
+        finally:
+            rr.host_unregister(a); rr.host_unregister(b)
+
+
 def test_push_from_a_page_locked_window_is_done_on_return(rr):
     """A source ring's window is consumed right after GpuUpload's copy_in and its writer overwrites it: out of a
     page-locked (rr_host_register'd) ring the DMA is really asynchronous, so the call has to wait for it (round 4: the
