@@ -14,6 +14,8 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 variant = sys.argv[2] if len(sys.argv) > 2 else "plain"      # plain | touch (write every page first) | nohuge (touch + MADV_NOHUGEPAGE)
                                                              # dma: page-locked behind the library's back (hipHostRegister): staged DMA copies
                                                              # pageable: no registration at all
+                                                             # byhand: hipHostRegister + hipHostGetDevicePointer here, the block's
+                                                             #         work_dev on the device views (no work_host, no registry)
 import ctypes
 _libc = ctypes.CDLL("libc.so.6", use_errno=True)
 def prepare(a):
@@ -24,14 +26,18 @@ def prepare(a):
         lo = a.ctypes.data & ~4095
         hi = (a.ctypes.data + a.nbytes + 4095) & ~4095
         _libc.madvise(ctypes.c_void_p(lo), ctypes.c_size_t(hi - lo), 15)       # MADV_NOHUGEPAGE
-_hip = ctypes.CDLL("libamdhip64.so") if variant == "dma" else None
+_hip = ctypes.CDLL("libamdhip64.so") if variant in ("dma", "byhand") else None
+def devptr(a):
+    p = ctypes.c_void_p()
+    assert _hip.hipHostGetDevicePointer(ctypes.byref(p), ctypes.c_void_p(a.ctypes.data), 0) == 0
+    return p.value
 def reg(a):
-    if variant == "dma":
+    if variant in ("dma", "byhand"):
         assert _hip.hipHostRegister(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 0) == 0
     elif variant != "pageable":
         rr.host_register(a)
 def unreg(a):
-    if variant == "dma":
+    if variant in ("dma", "byhand"):
         assert _hip.hipHostUnregister(ctypes.c_void_p(a.ctypes.data)) == 0
     elif variant != "pageable":
         rr.host_unregister(a)
@@ -50,7 +56,11 @@ for k in range(rounds):
             x = rng.standard_normal(n).astype(np.float32)
             ring_in[3:3 + n] = x
             ring_out[:] = -7.0
-            st, c, p, need = blk.work_into(ring_in[3:3 + n], ring_out[5:], n)
+            if variant == "byhand":
+                st, c, p, need = blk.work_dev(devptr(ring_in) + 12, n, devptr(ring_out) + 20, n, 0)
+                assert _hip.hipDeviceSynchronize() == 0
+            else:
+                st, c, p, need = blk.work_into(ring_in[3:3 + n], ring_out[5:], n)
             y = ring_out[5:5 + n]
             if not np.array_equal(y, x * np.float32(0.5)):
                 d = np.flatnonzero(y != x * np.float32(0.5))

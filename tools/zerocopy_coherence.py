@@ -12,7 +12,7 @@ import rustradio_amd as rr
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 rng = np.random.default_rng(3)
-N = 400_000
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 400_000
 ring_in = np.zeros(N + 64, np.float32); ring_out = np.zeros(N + 64, np.float32)
 rr.host_register(ring_in); rr.host_register(ring_out)
 blk = rr.MultiplyConst(0.5)
