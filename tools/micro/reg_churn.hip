@@ -5,6 +5,8 @@
 //   mode 2: one mapping, registered once                   mode 3: fresh mmap per round, never unmapped (addresses never recycled)
 //   mode 4: malloc from the HEAP per round (unaligned, the two arrays and their neighbours share pages), freed after each round
 //   flags : hipHostRegister flags (0 default, 1 portable, 2 mapped, ...)
+//   [temps]   : 1 = like a numpy caller, every call builds its input in two large temporaries (calloc'ed f64 + f32 arrays,
+//               mmap'ed and unmapped again by the allocator) before copying it into the window with memcpy
 //   [pause_us]: host work of a random 0 .. pause_us microseconds after every unregister / before every register (a Python
 //               caller has such gaps; a tight loop serialises behind whatever the driver still has to do for the old mapping)
 #include <hip/hip_runtime.h>
@@ -28,6 +30,7 @@ int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 2000, mode = argc > 2 ? atoi(argv[2]) : 0;
     const unsigned flags = argc > 3 ? (unsigned)atoi(argv[3]) : 0;
     const unsigned pause_us = argc > 4 ? (unsigned)atoi(argv[4]) : 0;
+    const int temps = argc > 5 ? atoi(argv[5]) : 0;
     if (mode == 4) { mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); }
     hipStream_t s; CK(hipStreamCreate(&s));
     unsigned lcg = 12345;
@@ -48,6 +51,14 @@ int main(int argc, char** argv) {
         CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&dy), yout, 0));
         const int ncall = 1 + rnd() % 5;
         for (int c = 0; c < ncall; c++) {
+            if (temps) {
+                double* t64 = static_cast<double*>(calloc(n, 8));
+                float* t32 = static_cast<float*>(calloc(n, 4));
+                for (size_t i = 0; i < n; i++) { t64[i] = (double)(rnd() >> 8) * (1.0 / 8388608.0) - 1.0; t32[i] = (float)t64[i]; ref[i] = 0.5f * t32[i]; }
+                memcpy(xin + 3, t32, n * 4);                              // (glibc: non-temporal stores beyond its threshold)
+                for (size_t i = 0; i < n + 59; i++) yout[i] = -7.0f;
+                free(t64); free(t32);
+            } else
             for (size_t i = 0; i < n; i++) { xin[3 + i] = (float)(rnd() >> 8) * (1.0f / 8388608.0f) - 1.0f; ref[i] = 0.5f * xin[3 + i]; yout[5 + i] = -7.0f; }
             hipLaunchKernelGGL(k_half, dim3(1024), dim3(256), 0, s, dx + 3, dy + 5, (long)n);
             CK(hipGetLastError());
