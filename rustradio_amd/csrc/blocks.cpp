@@ -9,6 +9,7 @@
 #include "rotor_host.hpp"
 
 #include <algorithm>
+#include <cstdint>
 #include <cmath>
 #include <complex>
 #include <cstdlib>
@@ -104,22 +105,26 @@ std::mutex g_host_m;
 std::vector<HostRange> g_host_ranges;
 std::vector<std::pair<const unsigned char*, const unsigned char*>> g_retired;    // [lo, hi) of ranges unregistered before
 }  // namespace
+// (retirement is by PAGE: a page-lock covers whole pages, and the ranges that missed were heap arrays sharing pages with
+//  their neighbours — a range whose first or last page was part of an earlier registration counts as re-registered)
+static const unsigned char* page_floor(const unsigned char* p) { return reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)4095); }
+static const unsigned char* page_ceil(const unsigned char* p) { return page_floor(p + 4095); }
 void host_range_add(void* base, size_t bytes) {
-    const unsigned char* lo = static_cast<const unsigned char*>(base);
-    const unsigned char* hi = lo + bytes;
+    const unsigned char* lo = page_floor(static_cast<const unsigned char*>(base));
+    const unsigned char* hi = page_ceil(static_cast<const unsigned char*>(base) + bytes);
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, base, 0) != hipSuccess || !dev) { (void)hipGetLastError(); return; }
     std::lock_guard<std::mutex> g(g_host_m);
     for (auto& r : g_retired)
         if (lo < r.second && r.first < hi) return;            // overlaps a retired range: page-locked, but never zero-copy again
-    g_host_ranges.push_back({lo, bytes, static_cast<unsigned char*>(dev)});
+    g_host_ranges.push_back({static_cast<const unsigned char*>(base), bytes, static_cast<unsigned char*>(dev)});
 }
 void host_range_remove(void* base) {
     std::lock_guard<std::mutex> g(g_host_m);
     for (size_t i = 0; i < g_host_ranges.size(); i++)
         if (g_host_ranges[i].base == base) {
-            const unsigned char* lo = g_host_ranges[i].base;
-            const unsigned char* hi = lo + g_host_ranges[i].bytes;
+            const unsigned char* lo = page_floor(g_host_ranges[i].base);
+            const unsigned char* hi = page_ceil(g_host_ranges[i].base + g_host_ranges[i].bytes);
             // merge with overlapping / adjacent retired ranges so that the list stays short under churn
             for (size_t k = 0; k < g_retired.size();) {
                 if (lo <= g_retired[k].second && g_retired[k].first <= hi) {
