@@ -838,11 +838,10 @@ def _registered_ring(which, like):
     """a 4,096,000-byte page-locked ring per direction, registered once; returned as a view of `like`'s dtype and length"""
     a = _RINGS.get(which)
     if a is None:
-        a = np.zeros(4_096_000 + 64, np.uint8)
+        a = rr.host_ring(4_096_000)             # page-aligned whole pages: what the library grants zero-copy windows on
         rr.host_register(a)
         _RINGS[which] = a
-    off = (-a.ctypes.data) % 64
-    return a[off:off + like.nbytes].view(like.dtype)
+    return a[:like.nbytes].view(like.dtype)
 
 
 

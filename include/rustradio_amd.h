@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 2   /* 2 (round 4): rr_dstream_close / _closed / _wait / _id, RR_ROT_REPLAY_DEVICE; rr_build_opts.host_sync_copies removed */
+#define RR_ABI_VERSION 3   /* 3 (round 5): rr_block_tag_rule; zero-copy host windows only for page-aligned ranges (rr_host_register), RR_ZERO_COPY=0.  2 (round 4): rr_dstream_close / _closed / _wait / _id, RR_ROT_REPLAY_DEVICE; rr_build_opts.host_sync_copies removed */
 
 /* Complex<f32>: interleaved [re, im], 8 bytes (src/lib.rs:268-271). */
 typedef struct { float re, im; } rr_c32;
@@ -274,6 +274,24 @@ int rr_block_work_dev(rr_block *b, const void *d_in, size_t in_len, void *d_out,
 int         rr_block_eof(rr_block *b, int src_eof);
 /* BlockName::block_name() (src/block.rs:91-97). */
 const char *rr_block_name(const rr_block *b);
+
+/* What the reference block(s) behind this handle do with stream tags (src/stream.rs:48-93).  Tags never cross the
+ * C ABI: the shim keeps them on the host and re-bases them from `consumed` / `produced`.  This call
+ * tells a GENERIC shim block (GpuResident, GpuFused: one type for every handle) which of the reference's rules
+ * applies, in whole-stream positions — a tag on input sample a (counted from the start of the stream):
+ *   RR_TAGS_DROP     not forwarded: RationalResampler (rational_resampler.rs:156), QuadratureDemod
+ *                    (quadrature_demod.rs:46-113), RtlSdrDecode (rtlsdr_decode.rs:21), every chain containing one.
+ *   RR_TAGS_FORWARD  re-emitted on output sample a / *param (integer division) once that output exists:
+ *                    FirFilter `pos < n` kept at `pos / deci` (fir.rs:536-545; every window starts at a multiple
+ *                    of deci, so the window-relative rule is this one), *param = deci; FftFilter / FftFilterFloat
+ *                    (fft_filter.rs:307-313,343 / :441-445,467-472), Hilbert (hilbert.rs:119-123), MultiplyConst,
+ *                    FastFM (the sync macro, rustradio_macros_code/src/lib.rs:458-515): *param = 1; the fused
+ *                    FirFilter -> FftFilter: 1; Hilbert -> FirFilter(deci): deci.
+ *   RR_TAGS_FRAMES   input tags dropped, frame tags added per *param = frame size outputs: FftStream
+ *                    (fft_stream.rs:98-111).
+ * Returns the rule, or RR_ERR for a NULL handle. */
+enum rr_tag_rule { RR_TAGS_DROP = 0, RR_TAGS_FORWARD = 1, RR_TAGS_FRAMES = 2 };
+int rr_block_tag_rule(const rr_block *b, size_t *param);
 size_t      rr_block_in_elem_size(const rr_block *b);
 size_t      rr_block_out_elem_size(const rr_block *b);
 /* Wait for everything the block enqueued (its private stream and the stream of the last work call). */
@@ -288,11 +306,17 @@ int         rr_block_sync(rr_block *b);
  * rr_dstream_copy_in/out run as direct DMA instead of staged pageable copies (35 -> 40 GB/s).  Windows
  * that are not WHOLLY inside a range registered here (pageable memory, memory the caller page-locked by
  * other means) are staged through device memory as before.  Optional; unregister before the memory is
- * unmapped, and not while a work call on one of its windows is running.  Register a ring ONCE: an address
- * range that has been unregistered is retired from zero-copy for the life of the process (registering it
- * again still page-locks it for DMA) — kernels working in place on re-registered addresses were seen to
- * miss on this platform (tools/zerocopy_churn.py). */
+ * unmapped, and not while a work call on one of its windows is running.
+ * Zero-copy is granted only to a range whose base and size are multiples of the page size (4096) and none of
+ * whose pages is, or ever was, part of another registration in this process — the reference's ring qualifies
+ * (one page-aligned mmap, registered once).  Any other range is still page-locked (its staged copies run as
+ * direct DMA) but is never handed to kernels in place: kernels working in place on pages that had been
+ * page-locked, released and page-locked again were seen to miss on this platform (csrc/blocks.cpp "WHICH ranges
+ * run zero-copy").  RR_ZERO_COPY=0 in the environment turns the in-place path off altogether. */
 int rr_host_register(void *ptr, size_t bytes);
+/* 1 when rr_block_work would let kernels work IN PLACE on the host window [ptr, ptr + bytes), 0 when it would be staged
+ * through device memory (tests assert the path they mean to exercise; a shim can log it once per ring). */
+int rr_host_window_in_place(const void *ptr, size_t bytes);
 int rr_host_unregister(void *ptr);
 
 /* ---- device-resident streams ----------------------------------------------------------

@@ -8,7 +8,7 @@
 //! against the header — and the C++ mirror `rustradio_amd/host/rustradio.hpp` implements the same shim
 //! logic and IS tested (`tests/cpp/test_host_api.cpp`).
 use std::ffi::{c_int, c_uint, c_void, CStr};
-use std::sync::Arc;
+use std::sync::{Arc, Condvar, Mutex};
 
 use rustradio::block::{Block, BlockEOF, BlockName, BlockRet};
 use rustradio::stream::{new_stream, ReadStream, StreamWait, Tag, TagValue, WriteStream};
@@ -34,6 +34,9 @@ const RR_WAIT_SRC: c_int = 1;
 const RR_WAIT_DST: c_int = 2;
 const RR_EOF: c_int = 3;
 const RR_ERR: c_int = -1;
+// enum rr_tag_rule
+const RR_TAGS_FORWARD: c_int = 1;
+const RR_TAGS_FRAMES: c_int = 2;
 // enum { RR_SIDE_WRITER, RR_SIDE_READER }
 const RR_SIDE_WRITER: c_int = 0;
 const RR_SIDE_READER: c_int = 1;
@@ -76,11 +79,13 @@ unsafe extern "C" {
     fn rr_block_work(b: *mut RrBlock, inp: *const c_void, in_len: usize, out: *mut c_void, out_cap: usize,
                      consumed: *mut usize, produced: *mut usize, need: *mut usize) -> c_int;
     fn rr_block_eof(b: *mut RrBlock, src_eof: c_int) -> c_int;
+    fn rr_block_tag_rule(b: *const RrBlock, param: *mut usize) -> c_int;
     fn rr_block_work_dev(b: *mut RrBlock, d_in: *const c_void, in_len: usize, d_out: *mut c_void, out_cap: usize,
                          consumed: *mut usize, produced: *mut usize, need: *mut usize, hip_stream: *mut c_void) -> c_int;
     fn rr_block_sync(b: *mut RrBlock) -> c_int;
     fn rr_fir_set_rotator_mode(b: *mut RrBlock, mode: c_int) -> c_int;
     fn rr_host_register(ptr: *mut c_void, bytes: usize) -> c_int;
+    fn rr_host_window_in_place(ptr: *const c_void, bytes: usize) -> c_int;
     fn rr_host_unregister(ptr: *mut c_void) -> c_int;
     fn rr_dstream_create(elem_size: usize, capacity_bytes: usize) -> *mut RrDStream;
     fn rr_dstream_destroy(s: *mut RrDStream);
@@ -133,22 +138,70 @@ impl Handle {
     }
 }
 
+/// Tags through a block that is known only by its handle (`GpuFused`, `GpuResident`): the reference rule of the block(s)
+/// behind the handle as `rr_block_tag_rule` states it in whole-stream positions.  `step` takes the tags of the read
+/// window (positions relative to it; only those on consumed samples travel, the rest stay in the stream) and returns the
+/// tags of the `produced` outputs of this call, relative to the first of them.  A tag whose output sample does not exist
+/// yet waits here, as it does in FftFilter's `self.tags` (src/fft_filter.rs:309-313).
+/// C++ twin: `detail::TagForwarder` (rustradio_amd/host/rustradio.hpp), tested by tests/cpp/test_resident_graph.cpp.
+struct TagForwarder {
+    rule: c_int,
+    param: usize,
+    pending: Vec<(u64, Tag)>,   // (output position counted from the start of the stream, tag)
+    in_abs: u64,
+    out_abs: u64,
+}
+impl TagForwarder {
+    fn new(h: &Handle) -> Result<Self> {
+        let mut param = 1usize;
+        // SAFETY: valid handle, live out-parameter.
+        let rule = unsafe { rr_block_tag_rule(h.0, &mut param) };
+        if rule == RR_ERR { return Err(last_error()); }
+        Ok(Self { rule, param: param.max(1), pending: Vec::new(), in_abs: 0, out_abs: 0 })
+    }
+    fn step(&mut self, tags: Vec<Tag>, consumed: usize, produced: usize) -> Vec<Tag> {
+        let mut emit = Vec::new();
+        if self.rule == RR_TAGS_FORWARD {
+            for t in tags.into_iter().filter(|t| t.pos() < consumed) {
+                self.pending.push(((self.in_abs + t.pos() as u64) / self.param as u64, t));
+            }
+            let limit = self.out_abs + produced as u64;
+            let (now, keep): (Vec<_>, Vec<_>) = self.pending.drain(..).partition(|(abs, _)| *abs < limit);
+            self.pending = keep;
+            emit = now.into_iter()
+                .map(|(abs, t)| Tag::new((abs - self.out_abs) as usize, t.key(), t.val().clone()))
+                .collect();
+        } else if self.rule == RR_TAGS_FRAMES {
+            // src/fft_stream.rs:98-111 (produced is a whole number of frames)
+            let mut pos = 0usize;
+            while pos + self.param <= produced {
+                emit.push(Tag::new(pos, TAG_FRAME_SIZE, TagValue::U64(self.param as u64)));
+                emit.push(Tag::new(pos, TAG_FRAME, TagValue::Bool(true)));
+                emit.push(Tag::new(pos + self.param - 1, TAG_FRAME, TagValue::Bool(false)));
+                pos += self.param;
+            }
+        }
+        self.in_abs += consumed as u64;
+        self.out_abs += produced as u64;
+        emit
+    }
+}
+
 /// `FftFilter` on the GPU (replaces `rustradio::blocks::FftFilter`, src/fft_filter.rs:210-355).
 pub struct GpuFftFilter {
     h: Handle,
     src: ReadStream<Complex>,
     dst: WriteStream<Complex>,
-    pending_tags: Vec<(u64, Tag)>,
-    in_abs: u64,
-    out_abs: u64,
+    fwd: TagForwarder,   // tags of samples still inside the filter's block buffer wait here (fft_filter.rs:309-313)
 }
 impl GpuFftFilter {
     pub fn new<T: Into<Vec<Complex>>>(src: ReadStream<Complex>, taps: T) -> Result<(Self, ReadStream<Complex>)> {
         let taps = taps.into();
         // SAFETY: taps is a live slice of repr(C) Complex<f32>.
         let h = Handle::new(unsafe { rr_fftfilter_create(taps.as_ptr(), taps.len()) })?;
+        let fwd = TagForwarder::new(&h)?;
         let (dst, dr) = new_stream();
-        Ok((Self { h, src, dst, pending_tags: Vec::new(), in_abs: 0, out_abs: 0 }, dr))
+        Ok((Self { h, src, dst, fwd }, dr))
     }
 }
 impl BlockName for GpuFftFilter {
@@ -166,17 +219,7 @@ impl Block for GpuFftFilter {
         let mut out = self.dst.write_buf()?;
         let (st, consumed, produced, need) = self.h.work(input.slice(), out.slice())?;
         // a tag travels with its sample (fft_filter.rs:307-313,343)
-        for t in tags.into_iter().filter(|t| t.pos() < consumed) {
-            self.pending_tags.push((self.in_abs + t.pos() as u64, t));
-        }
-        let limit = self.out_abs + produced as u64;
-        let (emit, keep): (Vec<_>, Vec<_>) = self.pending_tags.drain(..).partition(|(abs, _)| *abs < limit);
-        self.pending_tags = keep;
-        let out_tags: Vec<Tag> = emit.into_iter()
-            .map(|(abs, t)| Tag::new((abs - self.out_abs) as usize, t.key(), t.val().clone()))
-            .collect();
-        self.in_abs += consumed as u64;
-        self.out_abs += produced as u64;
+        let out_tags = self.fwd.step(tags, consumed, produced);
         input.consume(consumed);
         out.produce(produced, &out_tags);
         Ok(match st {
@@ -370,30 +413,33 @@ impl Block for GpuHilbert {
     }
 }
 
-/// `FftFilterFloat::new(src, taps)` (src/fft_filter.rs:365-491).  The reference drops tags at the f32 -> Complex lift
-/// of its inner stream (fft_filter.rs:431-445); so does this block.
+/// `FftFilterFloat::new(src, taps)` (src/fft_filter.rs:365-491).  The reference carries tags into its inner Complex
+/// stream, through the inner FftFilter and out again (fft_filter.rs:441-445,467-472): a tag travels with its sample.
 pub struct GpuFftFilterFloat {
     h: Handle,
     src: ReadStream<Float>,
     dst: WriteStream<Float>,
+    fwd: TagForwarder,
 }
 impl GpuFftFilterFloat {
     pub fn new(src: ReadStream<Float>, taps: &[Float]) -> Result<(Self, ReadStream<Float>)> {
         // SAFETY: taps is a live slice.
         let h = Handle::new(unsafe { rr_fftfilter_float_create(taps.as_ptr(), taps.len()) })?;
+        let fwd = TagForwarder::new(&h)?;
         let (dst, dr) = new_stream();
-        Ok((Self { h, src, dst }, dr))
+        Ok((Self { h, src, dst, fwd }, dr))
     }
 }
 impl BlockName for GpuFftFilterFloat { fn block_name(&self) -> &str { "GpuFftFilterFloat" } }
 impl BlockEOF for GpuFftFilterFloat { fn eof(&mut self) -> bool { self.src.eof() } }
 impl Block for GpuFftFilterFloat {
     fn work(&mut self) -> Result<BlockRet<'_>> {
-        let (input, _tags) = self.src.read_buf()?;
+        let (input, tags) = self.src.read_buf()?;
         let mut out = self.dst.write_buf()?;
         let (st, consumed, produced, need) = self.h.work(input.slice(), out.slice())?;
+        let out_tags = self.fwd.step(tags, consumed, produced);
         input.consume(consumed);
-        out.produce(produced, &[]);
+        out.produce(produced, &out_tags);
         Ok(match st {
             RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need),
             RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
@@ -405,7 +451,7 @@ impl Block for GpuFftFilterFloat {
 /// `FftStream::new(src, size)` (src/fft_stream.rs:40-117): frame tags are rebuilt from `produced` exactly as
 /// fft_stream.rs:98-111 (input tags are dropped there too).
 pub const TAG_FRAME: &str = "FftStream::frame";
-pub const TAG_FRAME_SIZE: &str = "FftStream::frame_size";
+pub const TAG_FRAME_SIZE: &str = "FftStream::size";
 pub struct GpuFftStream {
     h: Handle,
     size: usize,
@@ -475,23 +521,27 @@ impl Block for GpuFft {
     }
 }
 
-/// Blocks whose tags are all dropped and that map one Complex / f32 input stream to one output stream through a fused
-/// kernel: `GpuFused::fm_chain` = FftFilter -> RationalResampler -> QuadratureDemod (rr_fm_chain_create,
+/// Several reference blocks behind one handle and one fused kernel, one Complex / f32 input stream to one output stream:
+/// `GpuFused::fm_chain` = FftFilter -> RationalResampler -> QuadratureDemod (rr_fm_chain_create,
 /// examples/rtl_fm.rs:381-419), `fir_fm_chain` = FirFilter -> FftFilter -> RationalResampler -> QuadratureDemod
-/// (rr_fir_fm_chain_create), `fir_fftfilter` = FirFilter -> FftFilter (rr_fir_fftfilter_create; tags travel with their
-/// sample as in GpuFftFilter when only those two blocks are fused — dropped here for simplicity, both reference blocks
-/// forward them), `hilbert_fir` = Hilbert -> FirFilter (rr_hilbert_fir_create, examples/ax25-1200-rx.rs:238-247).
+/// (rr_fir_fm_chain_create), `fir_fftfilter` = FirFilter -> FftFilter (rr_fir_fftfilter_create), `hilbert_fir` =
+/// Hilbert -> FirFilter (rr_hilbert_fir_create, examples/ax25-1200-rx.rs:238-247).
+/// Tags: what the reference blocks in sequence deliver (`rr_block_tag_rule`): a chain holding a RationalResampler or a
+/// QuadratureDemod drops them (rational_resampler.rs:156), `fir_fftfilter` keeps a tag on its sample (fir.rs:536-545 with
+/// deci 1, fft_filter.rs:307-313,343), `hilbert_fir` re-emits it at `pos / deci` (hilbert.rs:119-123, fir.rs:536-545).
 pub struct GpuFused<I: Sample, O: Sample> {
     h: Handle,
     name: &'static str,
     src: ReadStream<I>,
     dst: WriteStream<O>,
+    fwd: TagForwarder,
 }
 impl<I: Sample, O: Sample> GpuFused<I, O> {
     fn wrap(h: *mut RrBlock, name: &'static str, src: ReadStream<I>) -> Result<(Self, ReadStream<O>)> {
         let h = Handle::new(h)?;
+        let fwd = TagForwarder::new(&h)?;
         let (dst, dr) = new_stream();
-        Ok((Self { h, name, src, dst }, dr))
+        Ok((Self { h, name, src, dst, fwd }, dr))
     }
 }
 impl GpuFused<Complex, Float> {
@@ -555,11 +605,12 @@ impl<I: Sample, O: Sample> BlockName for GpuFused<I, O> { fn block_name(&self) -
 impl<I: Sample, O: Sample> BlockEOF for GpuFused<I, O> { fn eof(&mut self) -> bool { self.src.eof() } }
 impl<I: Sample, O: Sample> Block for GpuFused<I, O> {
     fn work(&mut self) -> Result<BlockRet<'_>> {
-        let (input, _tags) = self.src.read_buf()?;
+        let (input, tags) = self.src.read_buf()?;
         let mut out = self.dst.write_buf()?;
         let (st, consumed, produced, need) = self.h.work(input.slice(), out.slice())?;
+        let out_tags = self.fwd.step(tags, consumed, produced);
         input.consume(consumed);
-        out.produce(produced, &[]);
+        out.produce(produced, &out_tags);
         Ok(match st {
             RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need),
             RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
@@ -627,10 +678,52 @@ impl Block for GpuFmMulti {
 // dropping one calls `rr_dstream_close(side)`, and both implement `StreamWait`.  The ring's counters live in the library
 // under the ring's own lock, so the two handles may sit in blocks on different threads (MTGraph).
 
+/// Tags of an HBM ring: the host-side side-band the reference's `Buffer` keeps next to its samples
+/// (src/nowasm/circular_buffer.rs:518-557: `produce()` files the tags of the samples it publishes, `consume()` drops those
+/// of the samples it retires).  Positions are counted from the start of the stream with the side-band's OWN totals.
+#[derive(Default)]
+struct TagBand {
+    posted: u64,             // samples whose tags are filed (writer side)
+    taken: u64,              // samples whose tags have been handed on (reader side)
+    writer_gone: bool,
+    tags: Vec<(u64, Tag)>,
+}
 /// The ring both ends share (the reference's `Arc<Buffer<T>>`); destroyed with the last handle.
 struct GpuRing<T: Sample> {
     s: *mut RrDStream,
+    band: Mutex<TagBand>,    // tags only: the ring's counters and their lock live in the library
+    band_cv: Condvar,
     _t: std::marker::PhantomData<T>,
+}
+impl<T: Sample> GpuRing<T> {
+    /// Writer side: the next `n` samples of the stream carry `tags` (positions relative to the first of them).
+    fn post(&self, n: usize, tags: &[Tag]) {
+        if n == 0 { return; }
+        let mut b = self.band.lock().unwrap();
+        let base = b.posted;
+        for t in tags.iter().filter(|t| t.pos() < n) { b.tags.push((base + t.pos() as u64, t.clone())); }
+        b.posted += n as u64;
+        drop(b);
+        self.band_cv.notify_all();
+    }
+    /// Reader side: the tags of the next `n` samples, relative to the first of them; the samples are retired.
+    /// `rr_block_work_streams` publishes a block's output inside the library BEFORE the block can post the tags, so a
+    /// reader may hold samples whose tags are a moment away: wait until the side-band covers what was consumed (the
+    /// writer posts right after its call returns, or is gone).
+    fn take(&self, n: usize) -> Vec<Tag> {
+        if n == 0 { return Vec::new(); }
+        let mut b = self.band.lock().unwrap();
+        while b.posted < b.taken + n as u64 && !b.writer_gone { b = self.band_cv.wait(b).unwrap(); }
+        let (taken, limit) = (b.taken, b.taken + n as u64);
+        let (now, keep): (Vec<_>, Vec<_>) = b.tags.drain(..).partition(|(abs, _)| *abs < limit);
+        b.tags = keep;
+        b.taken = limit;
+        now.into_iter().map(|(abs, t)| Tag::new((abs - taken) as usize, t.key(), t.val().clone())).collect()
+    }
+    fn writer_dropped(&self) {
+        self.band.lock().unwrap().writer_gone = true;
+        self.band_cv.notify_all();
+    }
 }
 // SAFETY: every rr_dstream_* entry point and rr_block_work_streams lock the ring inside the library.
 unsafe impl<T: Sample> Send for GpuRing<T> {}
@@ -654,12 +747,12 @@ pub fn new_gpu_stream<T: Sample>(capacity_bytes: usize) -> Result<(GpuWriteStrea
     // SAFETY: plain values.
     let s = unsafe { rr_dstream_create(std::mem::size_of::<T>(), capacity_bytes) };
     if s.is_null() { return Err(last_error()); }
-    let ring = Arc::new(GpuRing { s, _t: std::marker::PhantomData });
+    let ring = Arc::new(GpuRing { s, band: Mutex::new(TagBand::default()), band_cv: Condvar::new(), _t: std::marker::PhantomData });
     Ok((GpuWriteStream { ring: ring.clone() }, GpuReadStream { ring }))
 }
 impl<T: Sample> Drop for GpuWriteStream<T> {
     // SAFETY (both drops): the ring outlives the handle (Arc); the flag is what `closed()` / `eof()` / `wait()` of the other end read.
-    fn drop(&mut self) { unsafe { rr_dstream_close(self.ring.s, RR_SIDE_WRITER); } }
+    fn drop(&mut self) { unsafe { rr_dstream_close(self.ring.s, RR_SIDE_WRITER); } self.ring.writer_dropped(); }
 }
 impl<T: Sample> Drop for GpuReadStream<T> {
     fn drop(&mut self) { unsafe { rr_dstream_close(self.ring.s, RR_SIDE_READER); } }
@@ -719,7 +812,7 @@ impl<T: Sample> BlockName for GpuUpload<T> { fn block_name(&self) -> &str { "Gpu
 impl<T: Sample> BlockEOF for GpuUpload<T> { fn eof(&mut self) -> bool { self.src.eof() } }
 impl<T: Sample + Sync + Send + 'static> Block for GpuUpload<T> {
     fn work(&mut self) -> Result<BlockRet<'_>> {
-        let (input, _tags) = self.src.read_buf()?;
+        let (input, tags) = self.src.read_buf()?;
         let have = input.slice().len();
         let n = have.min(self.dst.free());
         if n == 0 {
@@ -728,6 +821,7 @@ impl<T: Sample + Sync + Send + 'static> Block for GpuUpload<T> {
         }
         // SAFETY: input is a live window of n elements; the ring has room for n (only this block writes it).
         check(unsafe { rr_dstream_copy_in(self.dst.ring.s, 0, input.slice().as_ptr().cast(), n, std::ptr::null_mut()) })?;
+        self.dst.ring.post(n, &tags);   // tags move with their samples (pos < n; the rest stay in the host ring)
         check(unsafe { rr_dstream_produce(self.dst.ring.s, n) })?;
         input.consume(n);
         Ok(BlockRet::Again)
@@ -757,18 +851,22 @@ impl<T: Sample + Sync + Send + 'static> Block for GpuDownload<T> {
         // SAFETY: out is a live window with room for n elements; the ring holds n readable elements (only this block reads it).
         check(unsafe { rr_dstream_copy_out(self.src.ring.s, 0, out.slice().as_mut_ptr().cast(), n, std::ptr::null_mut()) })?;
         check(unsafe { rr_dstream_consume(self.src.ring.s, n) })?;
-        out.produce(n, &[]);
+        out.produce(n, &self.src.ring.take(n));
         Ok(BlockRet::Again)
     }
 }
 /// One GPU block between two HBM rings: `Block::work()` without a PCIe hop (rr_block_work_streams).  The status is the
 /// block's own — `WaitForStream(src, need)` when starved, `WaitForStream(dst, need)` when the output ring is full — so
 /// both runners end it the reference's way: upstream dropped ∧ ring drained ∧ (resampler) no pending sample.
+/// Tags are re-based from `consumed` / `produced` by the reference rule of the block behind the handle
+/// (`rr_block_tag_rule`): FirFilter `pos / deci` (fir.rs:536-545), FftFilter's waiting list (fft_filter.rs:307-313,343),
+/// Hilbert `pos < n` (hilbert.rs:119-123), FftStream's frame tags; RationalResampler / QuadratureDemod drop them.
 pub struct GpuResident<I: Sample, O: Sample> {
     h: Handle,
     name: &'static str,
     src: GpuReadStream<I>,
     dst: GpuWriteStream<O>,
+    fwd: TagForwarder,
 }
 impl<I: Sample, O: Sample> GpuResident<I, O> {
     /// `create` = any `rr_*_create` call, e.g. `|| unsafe { rr_fftfilter_create(taps.as_ptr(), taps.len()) }`.
@@ -776,8 +874,9 @@ impl<I: Sample, O: Sample> GpuResident<I, O> {
     pub fn new(create: impl FnOnce() -> *mut RrBlock, name: &'static str, src: GpuReadStream<I>,
                out_capacity_bytes: usize) -> Result<(Self, GpuReadStream<O>)> {
         let h = Handle::new(create())?;
+        let fwd = TagForwarder::new(&h)?;
         let (dst, dr) = new_gpu_stream(out_capacity_bytes)?;
-        Ok((Self { h, name, src, dst }, dr))
+        Ok((Self { h, name, src, dst, fwd }, dr))
     }
 }
 impl<I: Sample, O: Sample> BlockName for GpuResident<I, O> { fn block_name(&self) -> &str { self.name } }
@@ -795,6 +894,8 @@ impl<I: Sample + Sync + Send + 'static, O: Sample + Sync + Send + 'static> Block
             rr_block_work_streams(self.h.0, self.src.ring.s, self.dst.ring.s, &mut c, &mut p, &mut need, std::ptr::null_mut())
         };
         check(st)?;
+        let out_tags = self.fwd.step(self.src.ring.take(c), c, p);
+        self.dst.ring.post(p, &out_tags);
         Ok(match st {
             RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need),
             RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need),
@@ -870,7 +971,10 @@ impl GpuFanout {
 }
 
 /// Page-lock a host ring the blocks will be handed windows of (rr_host_register): once per stream, at creation.
+/// Zero-copy windows need a page-aligned range of whole pages — the reference's ring is one (circular_buffer.rs:98-128).
 pub fn register_ring(base: *mut u8, bytes: usize) -> Result<()> { check(unsafe { rr_host_register(base.cast(), bytes) }) }
+/// Whether `rr_block_work` lets kernels work in place on this host window (else it is staged through device memory).
+pub fn window_in_place(ptr: *const u8, bytes: usize) -> bool { unsafe { rr_host_window_in_place(ptr.cast(), bytes) != 0 } }
 pub fn unregister_ring(base: *mut u8) -> Result<()> { check(unsafe { rr_host_unregister(base.cast()) }) }
 /// Wait for everything a handle enqueued (device-pointer work is asynchronous).
 pub fn sync_block(h: *mut RrBlock) -> Result<()> { check(unsafe { rr_block_sync(h) }) }

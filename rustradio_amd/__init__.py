@@ -252,10 +252,24 @@ class Block:
         return ms.value, n.value
 
 
+def host_ring(nbytes: int) -> np.ndarray:
+    """a page-aligned, whole-pages host buffer (one private anonymous mapping, like the reference's ring:
+    src/nowasm/circular_buffer.rs:98-128) as a uint8 array of at least `nbytes` — the only kind of range rr_host_register
+    grants zero-copy windows on (include/rustradio_amd.h)"""
+    import mmap
+    size = -(-max(int(nbytes), 1) // mmap.PAGESIZE) * mmap.PAGESIZE
+    return np.frombuffer(mmap.mmap(-1, size), dtype=np.uint8)
+
+
 def host_register(a: np.ndarray) -> None:
     """page-lock a host array that will be handed to work()/push()/pop() (rr_host_register)"""
     if lib().rr_host_register(_ptr(a), a.nbytes) != 0:
         raise RuntimeError(last_error())
+
+
+def host_window_in_place(a: np.ndarray) -> bool:
+    """whether work_into() lets the kernels read / write this host window in place (rr_host_window_in_place)"""
+    return bool(lib().rr_host_window_in_place(_ptr(a), a.nbytes))
 
 
 def host_unregister(a: np.ndarray) -> None:

@@ -20,10 +20,10 @@ SYMBOLS = [
     "rr_hilbert_taps", "rr_multiband",
     "rr_fir_c32_create", "rr_fir_f32_create", "rr_fftfilter_create", "rr_fftfilter_float_create",
     "rr_resampler_create", "rr_quaddemod_create", "rr_rtlsdr_decode_create", "rr_fftstream_create", "rr_fft_process", "rr_multiply_const_f32_create", "rr_multiply_const_c32_create", "rr_fastfm_create", "rr_hilbert_create", "rr_fm_chain_create", "rr_fm_chain_u8_create", "rr_fir_fftfilter_create", "rr_fir_fm_chain_create", "rr_audio_chain_create", "rr_hilbert_fir_create", "rr_fm_multi_create", "rr_fm_multi_u8_create", "rr_block_out_windows", "rr_block_destroy",
-    "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_in_elem_size",
+    "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_tag_rule", "rr_block_in_elem_size",
     "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_fft_tile", "rr_fir_set_rotator_mode",
     "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps",
-    "rr_host_register", "rr_host_unregister",
+    "rr_host_register", "rr_host_unregister", "rr_host_window_in_place",
     "rr_dstream_create", "rr_dstream_destroy", "rr_dstream_capacity", "rr_dstream_is_double_mapped", "rr_dstream_read_buf", "rr_dstream_write_buf",
     "rr_dstream_consume", "rr_dstream_produce", "rr_dstream_close", "rr_dstream_closed", "rr_dstream_wait", "rr_dstream_id", "rr_dstream_copy_in", "rr_dstream_copy_out", "rr_dstream_copy", "rr_block_work_streams",
     "rr_fanout_unique_id", "rr_fanout_create", "rr_fanout_destroy", "rr_fanout_produce_buf", "rr_fanout_submit",
@@ -98,6 +98,7 @@ def lib():
     L.rr_block_work_dev.argtypes = [vp, vp, sz, vp, sz, psz, psz, psz, vp]; L.rr_block_work_dev.restype = i32
     L.rr_block_eof.argtypes = [vp, i32]; L.rr_block_eof.restype = i32
     L.rr_block_name.argtypes = [vp]; L.rr_block_name.restype = C.c_char_p
+    L.rr_block_tag_rule.argtypes = [vp, psz]; L.rr_block_tag_rule.restype = i32
     L.rr_block_in_elem_size.argtypes = [vp]; L.rr_block_in_elem_size.restype = sz
     L.rr_block_out_elem_size.argtypes = [vp]; L.rr_block_out_elem_size.restype = sz
     L.rr_block_sync.argtypes = [vp]; L.rr_block_sync.restype = i32
@@ -107,6 +108,7 @@ def lib():
     L.rr_debug_fft_stamps.argtypes = [vp]; L.rr_debug_fft_stamps.restype = i32
     pvp = C.POINTER(vp)
     L.rr_host_register.argtypes = [vp, sz]; L.rr_host_register.restype = i32
+    L.rr_host_window_in_place.argtypes = [vp, sz]; L.rr_host_window_in_place.restype = i32
     L.rr_host_unregister.argtypes = [vp]; L.rr_host_unregister.restype = i32
     L.rr_dstream_create.argtypes = [sz, sz]; L.rr_dstream_create.restype = vp
     L.rr_dstream_destroy.argtypes = [vp]; L.rr_dstream_destroy.restype = None

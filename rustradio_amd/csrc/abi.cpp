@@ -13,6 +13,8 @@
 
 struct rr_block {
     std::unique_ptr<rr::Block> b;
+    int tag_rule = RR_TAGS_DROP;      // rr_block_tag_rule: what the reference block(s) behind the handle do with tags
+    size_t tag_param = 1;
 };
 // One ring + what makes it a two-ended stream between threads: every entry point takes `m` (two rings: both, deadlock-free),
 // produce / consume / close wake `cv`.  closed[side] is the reference's Arc strong count dropping to 1
@@ -35,12 +37,14 @@ void set_build_opts(const BuildOpts* o) { g_opts = o ? *o : BuildOpts(); }
 struct OptsScope { ~OptsScope() { set_build_opts(nullptr); } };
 }  // namespace rr
 
-template <class F> static rr_block* make_block(F&& f) {
+template <class F> static rr_block* make_block(F&& f, int tag_rule = RR_TAGS_DROP, size_t tag_param = 1) {
     rr::OptsScope scope;
     try {
         std::unique_ptr<rr::Block> b(f());         // a throwing constructor leaks nothing
         auto* h = new rr_block;
         h->b = std::move(b);
+        h->tag_rule = tag_rule;
+        h->tag_param = tag_param;
         return h;
     } catch (const std::exception& e) {
         rr::set_last_error(e.what());
@@ -125,16 +129,16 @@ int rr_hilbert_taps(const float* window, size_t ntaps, float* out) {
 }
 
 rr_block* rr_fir_c32_create(const rr_c32* taps, size_t ntaps, size_t deci, int translate, float samp_rate, float freq) {
-    return make_block([&] { return new rr::FirC32(taps, ntaps, deci, translate != 0, samp_rate, freq); });
+    return make_block([&] { return new rr::FirC32(taps, ntaps, deci, translate != 0, samp_rate, freq); }, RR_TAGS_FORWARD, deci);
 }
 rr_block* rr_fir_f32_create(const float* taps, size_t ntaps, size_t deci) {
-    return make_block([&] { return new rr::FirF32(taps, ntaps, deci); });
+    return make_block([&] { return new rr::FirF32(taps, ntaps, deci); }, RR_TAGS_FORWARD, deci);
 }
 rr_block* rr_fftfilter_create(const rr_c32* taps, size_t ntaps) {
-    return make_block([&] { return new rr::FftFilter(taps, ntaps); });
+    return make_block([&] { return new rr::FftFilter(taps, ntaps); }, RR_TAGS_FORWARD, 1);
 }
 rr_block* rr_fftfilter_float_create(const float* taps, size_t ntaps) {
-    return make_block([&] { return new rr::FftFilterFloat(taps, ntaps); });
+    return make_block([&] { return new rr::FftFilterFloat(taps, ntaps); }, RR_TAGS_FORWARD, 1);
 }
 rr_block* rr_resampler_create(size_t interp, size_t deci, size_t elem_size) {
     return make_block([&] { return new rr::Resampler(interp, deci, elem_size); });
@@ -147,10 +151,10 @@ rr_block* rr_hilbert_fir_create(size_t hilbert_ntaps, int window, float window_p
                                 size_t deci, int translate, float samp_rate, float freq) {
     return make_block([&] {
         return new rr::HilbertFir(hilbert_ntaps, window, window_parm, taps, ntaps, deci, translate != 0, samp_rate, freq);
-    });
+    }, RR_TAGS_FORWARD, deci);
 }
 rr_block* rr_fftstream_create(size_t size) {
-    return make_block([&] { return new rr::FftStream(size); });
+    return make_block([&] { return new rr::FftStream(size); }, RR_TAGS_FRAMES, size);
 }
 int rr_fft_process(rr_block* b, const rr_c32* msg, size_t n, rr_c32* out) {
     auto* f = b ? dynamic_cast<rr::FftStream*>(b->b.get()) : nullptr;
@@ -164,13 +168,13 @@ int rr_fft_process(rr_block* b, const rr_c32* msg, size_t n, rr_c32* out) {
     return st == RR_ERR ? RR_ERR : (p == n ? 0 : RR_ERR);
 }
 rr_block* rr_multiply_const_f32_create(float val) {
-    return make_block([&] { return new rr::MultiplyConst(4, val, 0.0f); });
+    return make_block([&] { return new rr::MultiplyConst(4, val, 0.0f); }, RR_TAGS_FORWARD, 1);
 }
 rr_block* rr_multiply_const_c32_create(float re, float im) {
-    return make_block([&] { return new rr::MultiplyConst(8, re, im); });
+    return make_block([&] { return new rr::MultiplyConst(8, re, im); }, RR_TAGS_FORWARD, 1);
 }
 rr_block* rr_fastfm_create(void) {
-    return make_block([&] { return new rr::FastFM(); });
+    return make_block([&] { return new rr::FastFM(); }, RR_TAGS_FORWARD, 1);
 }
 rr_block* rr_rtlsdr_decode_create(void) {
     return make_block([&] { return new rr::RtlSdrDecode(); });
@@ -179,7 +183,7 @@ rr_block* rr_quaddemod_create(float gain, int atan2_mode) {
     return make_block([&] { return new rr::QuadDemod(gain, atan2_mode); });
 }
 rr_block* rr_hilbert_create(size_t ntaps, int window, float window_parm) {
-    return make_block([&] { return new rr::Hilbert(ntaps, window, window_parm); });
+    return make_block([&] { return new rr::Hilbert(ntaps, window, window_parm); }, RR_TAGS_FORWARD, 1);
 }
 rr_block* rr_fm_chain_create(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int atan2_mode) {
     return make_block([&] { return rr::make_fm_chain(taps, ntaps, interp, deci, gain, atan2_mode, false, nullptr, 0); });
@@ -190,7 +194,7 @@ rr_block* rr_fir_fftfilter_create(const rr_c32* fir_taps, size_t fir_ntaps, cons
         std::unique_ptr<rr::FftFilter> f(new rr::FftFilter(g.data(), g.size(), false, 14, false, fir_ntaps - 1));
         f->set_stage_taps(fir_taps, fir_ntaps, fft_taps, fft_ntaps);
         return f.release();
-    });
+    }, RR_TAGS_FORWARD, 1);
 }
 rr_block* rr_fir_fm_chain_create(const rr_c32* fir_taps, size_t fir_ntaps, const rr_c32* fft_taps, size_t fft_ntaps,
                                  size_t interp, size_t deci, float gain, int atan2_mode) {
@@ -245,6 +249,11 @@ int rr_block_work_dev(rr_block* b, const void* d_in, size_t in_len, void* d_out,
 }
 int rr_block_eof(rr_block* b, int src_eof) { return b && b->b->eof(src_eof != 0) ? 1 : 0; }
 const char* rr_block_name(const rr_block* b) { return b ? b->b->name : ""; }
+int rr_block_tag_rule(const rr_block* b, size_t* param) {
+    if (!b) { rr::set_last_error("rr_block_tag_rule: null handle"); return RR_ERR; }
+    if (param) *param = b->tag_param;
+    return b->tag_rule;
+}
 size_t rr_block_in_elem_size(const rr_block* b) { return b ? b->b->in_es : 0; }
 size_t rr_block_out_elem_size(const rr_block* b) { return b ? b->b->out_es : 0; }
 int rr_block_sync(rr_block* b) {
@@ -293,6 +302,7 @@ int rr_host_register(void* ptr, size_t bytes) {
     if (!ptr || !bytes) { rr::set_last_error("rr_host_register: null / empty range"); return RR_ERR; }
     return guarded([&] { RR_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault)); rr::host_range_add(ptr, bytes); });
 }
+int rr_host_window_in_place(const void* ptr, size_t bytes) { return ptr && bytes && rr::device_view_of_host(ptr, bytes) ? 1 : 0; }
 int rr_host_unregister(void* ptr) {
     if (!ptr) { rr::set_last_error("rr_host_unregister: null"); return RR_ERR; }
     return guarded([&] { rr::host_range_remove(ptr); RR_HIP(hipHostUnregister(ptr)); });

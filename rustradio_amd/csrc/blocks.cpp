@@ -90,34 +90,45 @@ bool Block::eof(bool src_eof) { return src_eof; }   // rustradio_macros_code/src
 // page-locked behind its back (hipHostMalloc by the caller) can be freed behind its back too, and an answer remembered for
 // such a pointer would outlive the mapping — it takes the staged path, whose copies are DMA from page-locked memory anyway.
 //
-// RETIRED addresses.  tools/zerocopy_churn.py (round 4): register fresh arrays, run kernels on them in place, unregister,
-// free, again — the allocator hands the same virtual addresses out with new pages behind them, and on this pool a kernel
-// that reads or writes such a RE-registered range in place now and then misses (runs of outputs never written, or computed
-// from the previous contents: 24 of 4,500 calls in a bad pass, none in others; never on a range registered once — 12,000
-// calls — and never through DMA copies or pageable windows in the same churn).  So an address range that has been
-// unregistered once is retired for the life of the process: registering it again still page-locks it (the staged copies are
-// direct DMA), but its windows are no longer handed to kernels in place.  The reference registers a ring once, at stream
-// creation: it never meets this; a process that builds and drops graphs all day keeps its throughput on fresh addresses
-// and its correctness on recycled ones.
+// WHICH ranges run zero-copy (round 5).  Round 4's churn probe (tools/zerocopy_churn.py: register fresh heap arrays, run
+// kernels on them in place, unregister, free, again) showed kernels that work in place on a RE-registered range now and
+// then missing — runs of outputs never written, or computed from the previous contents: 24 of 4,500 calls in a bad pass —
+// and only on ranges that shared their first or last PAGE with a neighbour of an earlier registration; page-aligned private
+// mappings never missed, nor did a range registered once (12,000 calls), DMA copies or pageable windows.  The root cause
+// (a stale device translation for a page that was page-locked, released and page-locked again) is the platform's and is not
+// closed; the library therefore hands a range to kernels in place only when NO page of it can have such a history:
+//   * base and size are multiples of the page size (a page-lock covers whole pages: nothing is shared with a neighbour) —
+//     what the reference's ring is (circular_buffer.rs:98-128, one mmap of 2 x len) and what the shims register;
+//   * no page of it overlaps a range that is registered now or was EVER registered and released in this process.
+// Every rr_host_register call is tracked, admitted or not, so releasing a refused range retires its pages too.  Everything
+// else is still page-locked (the staged copies are direct DMA) but goes through device memory.  RR_ZERO_COPY=0 in the
+// environment turns the in-place path off altogether.
 namespace {
-struct HostRange { const unsigned char* base; size_t bytes; unsigned char* dev; };
+struct HostRange { const unsigned char* base; size_t bytes; unsigned char* dev; };   // dev == nullptr: tracked, not admitted
 std::mutex g_host_m;
 std::vector<HostRange> g_host_ranges;
-std::vector<std::pair<const unsigned char*, const unsigned char*>> g_retired;    // [lo, hi) of ranges unregistered before
+std::vector<std::pair<const unsigned char*, const unsigned char*>> g_retired;    // page-rounded [lo, hi) of released ranges
+constexpr uintptr_t PAGE = 4096;
+bool zero_copy_enabled() {
+    static const bool on = [] { const char* e = getenv("RR_ZERO_COPY"); return !(e && e[0] == '0'); }();
+    return on;
+}
 }  // namespace
-// (retirement is by PAGE: a page-lock covers whole pages, and the ranges that missed were heap arrays sharing pages with
-//  their neighbours — a range whose first or last page was part of an earlier registration counts as re-registered)
-static const unsigned char* page_floor(const unsigned char* p) { return reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)4095); }
-static const unsigned char* page_ceil(const unsigned char* p) { return page_floor(p + 4095); }
+static const unsigned char* page_floor(const unsigned char* p) { return reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(p) & ~(PAGE - 1)); }
+static const unsigned char* page_ceil(const unsigned char* p) { return page_floor(p + (PAGE - 1)); }
 void host_range_add(void* base, size_t bytes) {
-    const unsigned char* lo = page_floor(static_cast<const unsigned char*>(base));
-    const unsigned char* hi = page_ceil(static_cast<const unsigned char*>(base) + bytes);
+    const unsigned char* b = static_cast<const unsigned char*>(base);
+    const unsigned char* lo = page_floor(b);
+    const unsigned char* hi = page_ceil(b + bytes);
     void* dev = nullptr;
-    if (hipHostGetDevicePointer(&dev, base, 0) != hipSuccess || !dev) { (void)hipGetLastError(); return; }
+    bool admit = zero_copy_enabled() && lo == b && hi == b + bytes;
+    if (admit && (hipHostGetDevicePointer(&dev, base, 0) != hipSuccess || !dev)) { (void)hipGetLastError(); admit = false; }
     std::lock_guard<std::mutex> g(g_host_m);
     for (auto& r : g_retired)
-        if (lo < r.second && r.first < hi) return;            // overlaps a retired range: page-locked, but never zero-copy again
-    g_host_ranges.push_back({static_cast<const unsigned char*>(base), bytes, static_cast<unsigned char*>(dev)});
+        if (lo < r.second && r.first < hi) admit = false;     // a page of it was registered and released before
+    for (auto& r : g_host_ranges)
+        if (lo < page_ceil(r.base + r.bytes) && page_floor(r.base) < hi) admit = false;   // shares a page with a live registration
+    g_host_ranges.push_back({b, bytes, admit ? static_cast<unsigned char*>(dev) : nullptr});
 }
 void host_range_remove(void* base) {
     std::lock_guard<std::mutex> g(g_host_m);
@@ -142,7 +153,7 @@ void* device_view_of_host(const void* host, size_t bytes) {
     const unsigned char* h = static_cast<const unsigned char*>(host);
     std::lock_guard<std::mutex> g(g_host_m);
     for (auto& r : g_host_ranges)
-        if (h >= r.base && bytes <= r.bytes && (size_t)(h - r.base) <= r.bytes - bytes) return r.dev + (h - r.base);
+        if (r.dev && h >= r.base && bytes <= r.bytes && (size_t)(h - r.base) <= r.bytes - bytes) return r.dev + (h - r.base);
     return nullptr;
 }
 

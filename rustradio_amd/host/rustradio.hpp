@@ -231,9 +231,10 @@ public:
             if (!s_->ds) {
                 s_->rb = (s_->rb + n * sizeof(T)) % s_->ring->phys;
                 s_->used_ -= n;
+            } else if (rr_dstream_consume(s_->ds, n) != 0) {   // under m, like produce: tags and the ring's counters move together
+                throw Error(rr_last_error());
             }
         }
-        if (s_->ds && rr_dstream_consume(s_->ds, n) != 0) throw Error(rr_last_error());
         ptr_ += n; len_ -= n;
         if (n) s_->cv.notify_all();
     }
@@ -428,6 +429,48 @@ template <class I, class O> inline WorkOut work(rr_block* h, const BufferReader<
     return w;
 }
 static_assert(sizeof(Complex) == sizeof(rr_c32), "Complex<f32> must be interleaved re, im");
+
+// Tags through a block that is known only by its handle (Fused, GpuResident): the reference rule of the block(s) behind the
+// handle, as rr_block_tag_rule states it in whole-stream positions.  step() takes the tags of the read window (positions
+// relative to it; only those on consumed samples travel, the rest stay in the stream) and returns the tags of the
+// `produced` outputs of this call (positions relative to them).  A tag whose output sample does not exist yet waits here,
+// as it does in FftFilter's `self.tags` (fft_filter.rs:309-313).
+class TagForwarder {
+    int rule_ = RR_TAGS_DROP;
+    size_t param_ = 1;
+    std::vector<std::pair<uint64_t, Tag>> pending_;   // (output position counted from the start of the stream, tag)
+    uint64_t in_abs_ = 0, out_abs_ = 0;
+public:
+    explicit TagForwarder(const rr_block* h) {
+        size_t p = 1;
+        rule_ = rr_block_tag_rule(h, &p);
+        if (rule_ == RR_ERR) throw Error(rr_last_error());
+        param_ = p ? p : 1;
+    }
+    bool drops() const { return rule_ == RR_TAGS_DROP; }
+    std::vector<Tag> step(const std::vector<Tag>& tags, size_t consumed, size_t produced) {
+        std::vector<Tag> emit;
+        if (rule_ == RR_TAGS_FORWARD) {
+            for (auto& t : tags)
+                if (t.pos() < consumed) pending_.emplace_back((in_abs_ + t.pos()) / param_, t);
+            std::vector<std::pair<uint64_t, Tag>> keep;
+            for (auto& pt : pending_) {
+                if (pt.first < out_abs_ + produced) emit.emplace_back((size_t)(pt.first - out_abs_), pt.second.key(), pt.second.val());
+                else keep.push_back(std::move(pt));
+            }
+            pending_.swap(keep);
+        } else if (rule_ == RR_TAGS_FRAMES) {             // fft_stream.rs:98-111 (produced is a whole number of frames)
+            for (size_t pos = 0; pos + param_ <= produced; pos += param_) {
+                emit.emplace_back(pos, "FftStream::size", (uint64_t)param_);
+                emit.emplace_back(pos, "FftStream::frame", true);
+                emit.emplace_back(pos + param_ - 1, "FftStream::frame", false);
+            }
+        }
+        in_abs_ += consumed;
+        out_abs_ += produced;
+        return emit;
+    }
+};
 }  // namespace detail
 
 // ---- FirFilter (src/fir.rs) ---------------------------------------------------------------------------------
@@ -533,10 +576,9 @@ protected:
     detail::Handle h_;
     ReadStream<T> src_;
     WriteStream<T> dst_;
-    std::vector<std::pair<uint64_t, Tag>> pending_;   // tags of samples still inside `buf` (:309-313), absolute position
-    uint64_t in_abs_ = 0, out_abs_ = 0;
+    detail::TagForwarder fwd_;                        // tags of samples still inside `buf` wait here (:309-313)
 public:
-    FftFilterBase(rr_block* h, ReadStream<T> src, WriteStream<T> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)) {}
+    FftFilterBase(rr_block* h, ReadStream<T> src, WriteStream<T> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)), fwd_(h_.h) {}
     const char* block_name() const override { return rr_block_name(h_.h); }
     bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
     BlockRet work() override {                    // fft_filter.rs:290-354 / 429-490
@@ -544,16 +586,7 @@ public:
         auto out = dst_.write_buf();
         auto w = detail::work(h_.h, input, out);
         // a tag travels with its sample: output sample i is input sample i of the stream
-        for (auto& t : tags)
-            if (t.pos() < w.consumed) pending_.emplace_back(in_abs_ + t.pos(), t);
-        std::vector<Tag> emit;
-        std::vector<std::pair<uint64_t, Tag>> keep;
-        for (auto& pt : pending_) {
-            if (pt.first < out_abs_ + w.produced) emit.emplace_back((size_t)(pt.first - out_abs_), pt.second.key(), pt.second.val());
-            else keep.push_back(pt);
-        }
-        pending_.swap(keep);
-        in_abs_ += w.consumed; out_abs_ += w.produced;
+        const std::vector<Tag> emit = fwd_.step(tags, w.consumed, w.produced);
         input.consume(w.consumed);
         out.produce(w.produced, emit);
         if (w.st == RR_WAIT_SRC) return BlockRet::wait(src_.wait_handle(), w.need);
@@ -767,22 +800,24 @@ public:
 };
 
 // ---- graph-level fusions (one block, one kernel; whole-stream output = the reference blocks in sequence) ------------------
-// All of them drop tags (as RationalResampler / QuadratureDemod / FftFilterFloat's inner lift do in the reference).
+// Tags: what the reference blocks in sequence would deliver (rr_block_tag_rule) — a chain holding a RationalResampler or a
+// QuadratureDemod drops them, FirFilter -> FftFilter and Hilbert -> FirFilter forward them.
 template <class In, class Out> class Fused : public Block {
     detail::Handle h_;
     ReadStream<In> src_;
     WriteStream<Out> dst_;
+    detail::TagForwarder fwd_;
 public:
-    Fused(rr_block* h, ReadStream<In> src, WriteStream<Out> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)) {}
+    Fused(rr_block* h, ReadStream<In> src, WriteStream<Out> dst) : h_(h), src_(std::move(src)), dst_(std::move(dst)), fwd_(h_.h) {}
     const char* block_name() const override { return rr_block_name(h_.h); }
     bool eof() override { return rr_block_eof(h_.h, src_.eof()) != 0; }
     BlockRet work() override {
         auto [input, tags] = src_.read_buf();
-        (void)tags;
         auto out = dst_.write_buf();
         auto w = detail::work(h_.h, input, out);
+        const std::vector<Tag> emit = fwd_.step(tags, w.consumed, w.produced);
         input.consume(w.consumed);
-        out.produce(w.produced, {});
+        out.produce(w.produced, emit);
         if (w.st == RR_AGAIN) return BlockRet::again();
         return w.st == RR_WAIT_DST ? BlockRet::wait(dst_.wait_handle(), w.need) : BlockRet::wait(src_.wait_handle(), w.need);
     }
@@ -806,6 +841,13 @@ inline auto FirFmChain(ReadStream<Complex> src, const std::vector<Complex>& fir_
     return Fused<Complex, Float>::make(std::move(src), [&] {
         return rr_fir_fm_chain_create(c32(fir_taps), fir_taps.size(), c32(fft_taps), fft_taps.size(), interp, deci, gain,
                                       exact_atan2 ? RR_ATAN2_EXACT : RR_ATAN2_FAST);
+    });
+}
+// Hilbert -> FirFilter(deci)[.translate(samp_rate, freq)] (BASELINE configs[4]; hilbert.rs:38-129 + fir.rs:303-551)
+inline auto HilbertFir(ReadStream<Float> src, size_t hilbert_ntaps, const window::WindowType& w, const std::vector<Complex>& taps,
+                       size_t deci, bool translate = false, Float samp_rate = 0, Float freq = 0) {
+    return Fused<Float, Complex>::make(std::move(src), [&] {
+        return rr_hilbert_fir_create(hilbert_ntaps, w.kind, w.parm, c32(taps), taps.size(), deci, translate, samp_rate, freq);
     });
 }
 // FftFilterFloat -> RationalResampler -> MultiplyConst (examples/rtl_fm.rs:398-418)

@@ -143,19 +143,17 @@ _ARENAS = {}
 
 def _arena(rr, which, nbytes):
     """Two page-locked arenas per process, registered ONCE (rr_host_register) and never unregistered — what the shim does
-    with a stream's ring.  (Round 4: registering fresh arrays per block, as this driver first did, recycles virtual addresses
-    with new pages behind them, and on this pool kernels working in place on a re-registered range now and then miss:
-    tools/zerocopy_churn.py.  The library retires such addresses from zero-copy; the tests keep to addresses that stay.)"""
+    with a stream's ring: a page-aligned mapping of whole pages (rr.host_ring), the only kind of range the library runs
+    zero-copy on (csrc/blocks.cpp "WHICH ranges run zero-copy")."""
     a = _ARENAS.get(which)
     if a is None or a.nbytes < nbytes:
         if a is not None:
             rr.host_unregister(a)
-        a = np.zeros(max(nbytes, (48 << 20) if which == "out" else (16 << 20)) + 64, np.uint8)
+        a = rr.host_ring(max(nbytes, (160 << 20) if which == "out" else (32 << 20)))     # never grown in practice: a second mapping could land on retired pages
         a[:] = 0
         rr.host_register(a)
         _ARENAS[which] = a
-    off = (-a.ctypes.data) % 64                                   # element-aligned views from a 64-byte boundary
-    return a[off:off + nbytes]
+    return a[:nbytes]
 
 
 def drive_registered(rr, blk, x, in_cap, out_cap):
@@ -173,6 +171,8 @@ def drive_registered(rr, blk, x, in_cap, out_cap):
         take = min(in_cap - have, len(x) - pos)
         ring_in[rpos + have:rpos + have + take] = x[pos:pos + take]; have += take; pos += take
         wo = (7 * k + 1) % 13
+        if k == 0:                                                # the path under test IS the in-place one
+            assert rr.host_window_in_place(ring_in[rpos:rpos + max(have, 1)]) and rr.host_window_in_place(ring_out[wo:wo + nw * out_cap])
         st, c, p, need = blk.work_into(ring_in[rpos:rpos + have], ring_out[wo:], out_cap)
         log.append((st, c, p, need))
         rpos += c; have -= c

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"{s} declared in include/rustradio_amd.h but not exported"
     from rustradio_amd._lib import SYMBOLS
     assert sorted(SYMBOLS) == syms
-    assert rr.lib().rr_abi_version() == 2
+    assert rr.lib().rr_abi_version() == 3
 
 
 def test_no_cpu_fallback():

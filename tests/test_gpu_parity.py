@@ -1030,16 +1030,22 @@ def test_device_stream_ring_contract(rr, monkeypatch, no_vmm):
         rr.DeviceStream(np.uint32, 2)                      # smaller than one element
 
 
-def test_reregistered_addresses_keep_working(rr):
-    """csrc/blocks.cpp "RETIRED addresses": an address range that has been unregistered is page-locked again by a second
-    rr_host_register but never handed to kernels in place again (tools/zerocopy_churn.py: on this pool kernels working in
-    place on re-registered addresses now and then miss).  Whatever path a window takes, the samples are the same."""
+@pytest.mark.parametrize("aligned", [True, False])
+def test_reregistered_addresses_keep_working(rr, aligned):
+    """csrc/blocks.cpp "WHICH ranges run zero-copy": kernels work in place only on page-aligned whole-page ranges none of whose
+    pages was registered before (aligned=True, first cycle); a range that was released and registered again, and any range
+    that is not page-aligned (aligned=False: a heap array shares its first and last page with its neighbours), is page-locked
+    but staged through DMA.  Whatever path a window takes, the samples are the same."""
     n = 200_000
     x = rnd_f(n, 8)
-    a, b = np.zeros(n + 32, np.float32), np.zeros(n + 32, np.float32)
+    if aligned:
+        a, b = rr.host_ring(4 * (n + 32)).view(np.float32), rr.host_ring(4 * (n + 32)).view(np.float32)
+        assert a.ctypes.data % 4096 == 0 and a.nbytes % 4096 == 0
+    else:
+        a, b = np.zeros(n + 32, np.float32), np.zeros(n + 32, np.float32)
     want = x * np.float32(0.25)
     blk = rr.MultiplyConst(0.25)
-    for cycle in range(4):                                 # first cycle: zero copy; later ones: retired, staged through DMA
+    for cycle in range(4):
         rr.host_register(a); rr.host_register(b)
         try:
             for k in range(3):

@@ -67,3 +67,13 @@ def test_resident_graph_terminates_with_the_oracle_stream(exe, tmp_path, runner,
     assert len(got) == len(want) and len(want) > 1000, (len(got), len(want))
     par = harness.angle_parity(got, want, ro)
     assert par["used"] <= 1.0, par
+
+
+@pytest.mark.parametrize("runner", ["graph", "mt"])
+def test_tags_cross_the_device_resident_boundary(exe, runner):
+    """The reference's tag tests (fft_filter.rs:551-574 tag_propagation, fir.rs:691-741 test_identity) through GpuUpload ->
+    GpuResident -> GpuDownload; FirFilter / FftFilter / FftFilterFloat / Hilbert / FftStream and the fused FirFilter -> FftFilter
+    and Hilbert -> FirFilter forms deliver the tags the reference blocks on host windows deliver; chains holding a
+    RationalResampler drop them.  (tests/cpp/test_resident_graph.cpp tag_tests)"""
+    out = subprocess.run([exe, runner, "tags"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK tags" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]

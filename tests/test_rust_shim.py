@@ -106,7 +106,9 @@ def test_resident_streams_are_two_handles_that_implement_streamwait():
     res = re.search(r"Block for GpuResident<I, O>\s*\{(.*?)\n\}", src, flags=re.S).group(1)
     assert "RR_WAIT_SRC => BlockRet::WaitForStream(&self.src, need)" in res
     assert "RR_WAIT_DST => BlockRet::WaitForStream(&self.dst, need)" in res
-    assert "Mutex" not in re.sub(r"//[^\n]*", "", src)          # the ring's lock lives in the library
+    # the ring's counters and their lock live in the library; the only lock in the shim guards the tag side-band
+    code = re.sub(r"//[^\n]*", "", src)
+    assert code.count("Mutex<") == 1 and "band: Mutex<TagBand>" in code
 
 
 def test_cpp_twin_mirrors_the_rust_resident_design():
@@ -120,3 +122,41 @@ def test_cpp_twin_mirrors_the_rust_resident_design():
         assert call in twin and call in rust, call
     assert "case RR_WAIT_SRC: return BlockRet::wait(src_, need);" in twin
     assert "case RR_WAIT_DST: return BlockRet::wait(dst_, need);" in twin
+
+
+def _block_impl(src, name):
+    m = re.search(r"impl(?:<[^>]*>)?\s+Block\s+for\s+" + name + r"(?:<[^>]*>)?\s*\{(.*?)\n\}", src, flags=re.S)
+    assert m, name
+    return m.group(1)
+
+
+def test_no_block_whose_reference_forwards_tags_drops_them():
+    """VERDICT r4 item 1.  The reference forwards tags in FirFilter (src/fir.rs:536-545), FftFilter (src/fft_filter.rs:307-313,343),
+    FftFilterFloat (:441-445,467-472), Hilbert (src/hilbert.rs:119-123) and the sync-macro blocks; the shim's blocks for them —
+    and the generic ones that may hold them (GpuFused, GpuResident) and the graph edges (GpuUpload, GpuDownload) — must not
+    read the input tags into `_tags` or produce with `&[]`."""
+    src = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    for name in ("GpuFftFilter", "GpuFirFilter", "GpuHilbert", "GpuFftFilterFloat", "GpuMap", "GpuFused", "GpuUpload", "GpuDownload",
+                 "GpuResident"):
+        body = re.sub(r"//[^\n]*", "", _block_impl(src, name))
+        assert not re.search(r"\b_tags\b", body) and "&[]" not in body, name
+    # the generic blocks ask the library for the rule of the handle they hold
+    for name in ("GpuFused", "GpuResident"):
+        assert "self.fwd.step(" in _block_impl(src, name), name
+    res = _block_impl(src, "GpuResident")
+    assert "self.src.ring.take(c)" in res and "self.dst.ring.post(p, &out_tags)" in res
+    assert "self.dst.ring.post(n, &tags)" in _block_impl(src, "GpuUpload")
+    assert "self.src.ring.take(n)" in _block_impl(src, "GpuDownload")
+    # blocks whose reference drops tags may: RationalResampler / QuadratureDemod chains, FftStream's input tags
+    assert 'TAG_FRAME_SIZE: &str = "FftStream::size"' in src          # src/fft_stream.rs:21
+
+
+def test_cpp_twin_forwards_tags_the_same_way():
+    twin = open(os.path.join(ROOT, "rustradio_amd", "host", "resident.hpp")).read()
+    host = open(os.path.join(ROOT, "rustradio_amd", "host", "rustradio.hpp")).read()
+    rust = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    assert "class TagForwarder" in host and "struct TagForwarder" in rust
+    for word in ("rr_block_tag_rule", "RR_TAGS_FORWARD", "RR_TAGS_FRAMES"):
+        assert word in host and word in rust, word
+    assert "dst_.post_tags(p, fwd_.step(src_.take_tags(c), c, p));" in twin
+    assert "dst_.post_tags(n, tags);" in twin and "out.produce(n, src_.take_tags(n));" in twin
