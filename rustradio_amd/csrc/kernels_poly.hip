@@ -104,6 +104,12 @@ typedef creg2 creg2u __attribute__((aligned(8)));                        // two 
 #endif
 
 __device__ __forceinline__ void wave_fence() { asm volatile("" ::: "memory"); }   // a wave's LDS operations execute in order
+// phase markers for tools/isa_phase_table.py (a comment line in the assembly; measurement builds only: -DRR_ISA_MARKS)
+#ifdef RR_ISA_MARKS
+#define RR_MARK(name) asm volatile("; RRMARK " name ::: "memory")
+#else
+#define RR_MARK(name) do { } while (0)
+#endif
 
 // acc + a * w (complex): the product's two halves as packed FMAs (see cmul in fft_core.hpp)
 __device__ __forceinline__ creg cmac(creg acc, creg a, creg w) {
@@ -113,6 +119,22 @@ __device__ __forceinline__ creg cmac(creg acc, creg a, creg w) {
     return r;
 #else
     return cadd(acc, cmul(a, w));
+#endif
+}
+
+// two of them issued interleaved (fma, fma, fma, fma): the second half of a product reads what the first half wrote right
+// before it, which costs a wait state (an s_nop per product: 96 of a channel-tile's ~1400 issue slots); with the partner's
+// first half in between there is nothing to wait for (cmul2 in fft_core.hpp does the same inside the transforms)
+__device__ __forceinline__ void cmac2(creg& acc0, creg a0, creg w0, creg& acc1, creg a1, creg w1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    creg t0 = a0 * __builtin_shufflevector(w0, w0, 0, 0) + acc0;
+    creg t1 = a1 * __builtin_shufflevector(w1, w1, 0, 0) + acc1;
+    creg r0, r1;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r0) : "v"(a0), "v"(w0), "v"(t0));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r1) : "v"(a1), "v"(w1), "v"(t1));
+    acc0 = r0; acc1 = r1;
+#else
+    acc0 = cadd(acc0, cmul(a0, w0)); acc1 = cadd(acc1, cmul(a1, w1));
 #endif
 }
 
@@ -308,7 +330,7 @@ __device__ __forceinline__ void poly_phases(creg* z, const SRC& src, long vbase,
 #endif
                 fwd_pass<PLG, 2>(v[i], nullptr);         // (P == 1: no twiddles)
 #pragma unroll
-                for (int j = 0; j < 16; j++) z[j] = cmac(z[j], v[i][j], h[j]);
+                for (int j = 0; j < 16; j += 2) cmac2(z[j], v[i][j], h[j], z[j + 1], v[i][j + 1], h[j + 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -353,6 +375,8 @@ __device__ __forceinline__ void poly_issue_raw(creg2* raw, const creg* lane_base
     }
 }
 // forward transform of one phase (pass-0 twiddles from the LDS table tw0tab), z += H_phase X
+// (PAIR: products issued two by two, cmac2 — its two temporaries spill in the FirFilter instantiations, which sit at 168 VGPRs)
+template <bool PAIR = true>
 __device__ __forceinline__ void poly_xform_mac(creg* z, creg* vi, int t, creg* ex, const creg* tw0tab, const creg* tab1,
                                                const creg* __restrict__ hreg, int phase) {
     __builtin_amdgcn_sched_barrier(0);
@@ -382,7 +406,10 @@ __device__ __forceinline__ void poly_xform_mac(creg* z, creg* vi, int t, creg* e
     }
     fwd_pass<PLG, 2>(vi, nullptr);                   // (P == 1: no twiddles)
 #pragma unroll
-    for (int j = 0; j < 16; j++) z[j] = cmac(z[j], vi[j], h[j]);
+    for (int j = 0; j < 16; j += 2) {
+        if constexpr (PAIR) cmac2(z[j], vi[j], h[j], z[j + 1], vi[j + 1], h[j + 1]);
+        else { z[j] = cmac(z[j], vi[j], h[j]); z[j + 1] = cmac(z[j + 1], vi[j + 1], h[j + 1]); }
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -402,13 +429,32 @@ __device__ __forceinline__ void nat_store(const creg* z, int t, creg* area) {
 // first / last tile of a call only and are handled under wave-uniform tests outside the steady-state loop.
 // (conj(rl) * ru here is ru * conj(rl) with FMA contraction: within 1 ulp of the reference's un-fused form,
 //  quadrature_demod.rs:72; zeros stay exact zeros, so atan2(0, 0) * gain == 0 still holds.)
-template <int MODE>
+template <int MODE, bool TAME = false>
 __device__ __forceinline__ float poly_angle(creg rl, creg ru, float gain) {
     const creg zz = cmulc(ru, rl);
     if constexpr ((RR_POLY_ABLATE & 2) != 0) return gain * (zz.x + zz.y);
-    return gain * (MODE == 0 ? atan2_poly(zz.y, zz.x) : fmc_atan2(zz.y, zz.x));
+    return gain * (MODE == 0 ? atan2_poly<TAME>(zz.y, zz.x) : fmc_atan2(zz.y, zz.x));
 }
-template <int MODE>
+// Whether a finished tile (the 16 values of every lane of the wave that ran its inverse transform) is TAME: every value
+// finite and below 1e18 in magnitude, so that conj(a) * b of any two of them is finite too and the demodulation may leave
+// the inf / NaN fix-ups of atan2 out (4 of its ~31 instructions per output; the demodulation is 47 % of the multi-channel
+// kernel's VALU instructions: profiles/r05_fm_multi_phase_table.txt).  Sum of squares through packed FMAs: a NaN or an inf
+// anywhere propagates into the sum (a maximum would drop NaNs), and a square overflows where the products could.  16 packed
+// FMAs + a ballot per tile against 4 instructions x 15 outputs per lane.  Wave-uniform result.
+__device__ __forceinline__ bool tile_tame(const creg* z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    creg a0 = z[0] * z[0], a1 = z[1] * z[1];
+#pragma unroll
+    for (int n = 2; n < 16; n += 2) { a0 = z[n] * z[n] + a0; a1 = z[n + 1] * z[n + 1] + a1; }
+    const creg a = a0 + a1;
+    const float q = a.x + a.y;
+    return __builtin_amdgcn_ballot_w64(!(q < 1e36f)) == 0;
+#else
+    (void)z;
+    return false;
+#endif
+}
+template <int MODE, bool TAME = false>
 __device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int stride, long u0, int Sa, const PolyArgs& a,
                                                 float* __restrict__ out, const cf* __restrict__ last_r_in, cf* __restrict__ last_r_out) {
     const long left = a.r_hi - u0;
@@ -421,7 +467,7 @@ __device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int
     if (u0 == a.r_lo) {                                                  // (wave-uniform) first tile of the call
         if (i < nv) {
             const creg ru = *pu;
-            const creg rl = i == 0 ? to_reg(last_r_in[0]) : *pl;       // lower sample from the previous call
+            const creg rl = i == 0 ? to_reg(last_r_in[0]) : *pl;       // lower sample from the previous call (any value: full atan2)
             if (!(i == 0 && u0 == 0)) *o = poly_angle<MODE>(rl, ru, a.gain);   // r[0] has no lower partner
         }
         i += stride; pu += inc; pl += inc; o += stride;
@@ -435,12 +481,12 @@ __device__ __forceinline__ void poly_demod_tile(const creg* ldsR, int lane0, int
         //  measured 0.0770 against 0.0765 ms: a v_pk_fma_f32 holds the SIMD 4.5 clocks against 2.6 for a v_fma_f32
         //  (tools/micro/valubench.hip), so packing two independent scalar chains buys 13 % of their issue time and the
         //  dependent packed chain pays it back in wait states.  Removed.)
-        const float y0 = poly_angle<MODE>(l0, u0v, a.gain);
-        const float y1 = poly_angle<MODE>(l1, u1v, a.gain);
+        const float y0 = poly_angle<MODE, TAME>(l0, u0v, a.gain);
+        const float y1 = poly_angle<MODE, TAME>(l1, u1v, a.gain);
         if constexpr ((RR_POLY_ABLATE & 4) != 0) { if (y0 == 1234.5678f) { o[0] = y0; o[stride] = y1; } } else { o[0] = y0; o[stride] = y1; }
     }
     for (; i < nv; i += stride, pu += inc, pl += inc, o += stride) {
-        const float y = poly_angle<MODE>(*pl, *pu, a.gain);
+        const float y = poly_angle<MODE, TAME>(*pl, *pu, a.gain);
         if constexpr ((RR_POLY_ABLATE & 4) != 0) { if (y == 1234.5678f) *o = y; } else { *o = y; }
     }
     if (left <= Sa) {                                                    // (wave-uniform) last tile: carry r[r_hi - 1]
@@ -481,6 +527,7 @@ void k_fm_chain_poly(NanFixCtx nfx, SRC src, float* __restrict__ out, long ntile
     // pass-0 twiddles of lane t in an LDS table [15][64] (read right before the passes that use them) instead of 30 VGPRs
     // held for the whole kernel: the registers go to the 16-byte response loads
     creg* tw0 = tab1 + 64;
+    int* tame_flag = reinterpret_cast<int*>(tw0 + 15 * PT);     // wave 0's tile_tame() verdict for the tile being demodulated
     if (w == 0) {
         creg twr[15];
         load_twiddles<PLG, 0>(twr, t_, tw);
@@ -490,6 +537,7 @@ void k_fm_chain_poly(NanFixCtx nfx, SRC src, float* __restrict__ out, long ntile
 #else
     creg tw0[15];
     load_twiddles<PLG, 0>(tw0, t_, tw);
+    int* tame_flag = reinterpret_cast<int*>(tab1 + 64);
 #endif
     if (w == 0) tab1[t_] = to_reg(tw[t_ * (PF / 64)]);
     tile_sync<128>();
@@ -532,12 +580,17 @@ void k_fm_chain_poly(NanFixCtx nfx, SRC src, float* __restrict__ out, long ntile
 #endif
             if constexpr (FIR) nf_mark(nf_bad(z[15].x));
             nat_store(z, t, ldsR);
+            if constexpr (!FIR) { const bool tame = tile_tame(z); if (t == 0) tame_flag[0] = tame; }
         }
         PSTAMP(3);
         tile_sync<128>();
         PSTAMP(4);
-        if (a.mode == 0) poly_demod_tile<0>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
-        else if (a.mode == 1) poly_demod_tile<1>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        if constexpr (FIR) {                                 // (launch_fir_poly: mode 2 only)
+            poly_store_tile(ldsR, w * PT + t, 2 * PT, u0, Sa, a, reinterpret_cast<creg*>(out));
+        } else if (a.mode == 0) {
+            if (__builtin_amdgcn_readfirstlane(tame_flag[0])) poly_demod_tile<0, true>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
+            else poly_demod_tile<0>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        } else if (a.mode == 1) poly_demod_tile<1>(ldsR, w * PT + t, 2 * PT, u0, Sa, a, out, last_r_in, last_r_out);
         else poly_store_tile(ldsR, w * PT + t, 2 * PT, u0, Sa, a, reinterpret_cast<creg*>(out));
         PSTAMP(5);
         // (the next tile rewrites exB / ldsR only after its first barrier, which both waves reach after these reads)
@@ -565,6 +618,7 @@ void k_fm_chain_polyw(NanFixCtx nfx, SRC src, float* __restrict__ out, long ntil
     creg* ldsR = lds;                                    // the tile's resampled samples, natural order (= wave 0's area)
     creg* tab1 = lds + NW * PLE;                         // w_64^j
     creg* tw0 = tab1 + 64;                               // pass-0 twiddles of lane t, [15][64]
+    int* tame_flag = reinterpret_cast<int*>(tw0 + 15 * PT);   // wave 0's tile_tame() verdict for the tile being demodulated
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t_ = threadIdx.x & 63;
     creg* ex = lds + w * PLE;
     if (w == 0) {
@@ -631,7 +685,7 @@ void k_fm_chain_polyw(NanFixCtx nfx, SRC src, float* __restrict__ out, long ntil
         }
 #pragma unroll
         for (int i = 0; i < PPW; i++)
-            if (D % PPW == 0 || w * PPW + i < D) poly_xform_mac(z, v[i], t, ex, tw0, tab1, hr, w * PPW + i);
+            if (D % PPW == 0 || w * PPW + i < D) poly_xform_mac<!FIR>(z, v[i], t, ex, tw0, tab1, hr, w * PPW + i);
         long vbn = 0; bool intn = false;
         if constexpr (PIPE) {
             if (it.tile + it.step < it.end) { long u0n; tile_geom(it.tile + it.step, u0n, vbn, intn); }
@@ -654,11 +708,16 @@ void k_fm_chain_polyw(NanFixCtx nfx, SRC src, float* __restrict__ out, long ntil
             poly_inverse_tab(z, t, ex, tw0, tab1);
             if constexpr (FIR) nf_mark(nf_bad(z[15].x));
             nat_store(z, t, ldsR);
+            if constexpr (!FIR) { const bool tame = tile_tame(z); if (t == 0) tame_flag[0] = tame; }
         }
         if constexpr (PIPE) poly_issue_raw<D, RR_POLY_PIPE_SPLIT, 16>(raw, nb, t);
         tile_sync<64 * NW>();
-        if (a.mode == 0) poly_demod_tile<0>(ldsR, w * PT + t, NW * PT, u0, Sa, a, out, last_r_in, last_r_out);
-        else if (a.mode == 1) poly_demod_tile<1>(ldsR, w * PT + t, NW * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        if constexpr (FIR) {                                 // (launch_fir_poly: mode 2 only)
+            poly_store_tile(ldsR, w * PT + t, NW * PT, u0, Sa, a, reinterpret_cast<creg*>(out));
+        } else if (a.mode == 0) {
+            if (__builtin_amdgcn_readfirstlane(tame_flag[0])) poly_demod_tile<0, true>(ldsR, w * PT + t, NW * PT, u0, Sa, a, out, last_r_in, last_r_out);
+            else poly_demod_tile<0>(ldsR, w * PT + t, NW * PT, u0, Sa, a, out, last_r_in, last_r_out);
+        } else if (a.mode == 1) poly_demod_tile<1>(ldsR, w * PT + t, NW * PT, u0, Sa, a, out, last_r_in, last_r_out);
         else poly_store_tile(ldsR, w * PT + t, NW * PT, u0, Sa, a, reinterpret_cast<creg*>(out));
         tile_sync<64 * NW>();                            // wave 0's next transforms rewrite the area the others read here
     }
@@ -769,7 +828,7 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 16; j++) z[j] = cmac(z[j], x[j], h[p % NB][j]);
+                for (int j = 0; j < 16; j += 2) cmac2(z[j], x[j], h[p % NB][j], z[j + 1], x[j + 1], h[p % NB][j + 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (c == 8 * r0 + w) PSTAMP(3);
@@ -779,8 +838,10 @@ void k_fm_multi_poly(SRC src, float* __restrict__ out, long out_stride, long nti
             wave_fence();
             if (c == 8 * r0 + w) PSTAMP(4);
             float* oc = out + (long)c * out_stride;
-            if (a.mode == 0) poly_demod_tile<0>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
-            else poly_demod_tile<1>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+            if (a.mode == 0) {
+                if (tile_tame(z)) poly_demod_tile<0, true>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+                else poly_demod_tile<0>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+            } else poly_demod_tile<1>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
             wave_fence();
             if (c == 8 * r0 + w) PSTAMP(5);
         }
@@ -831,6 +892,7 @@ void k_fm_multi_poly12(SRC src, float* __restrict__ out, long out_stride, long n
         const bool interior = vbase - (D - 1) >= src.plen && vbase + (long)D * (PF - 1) - src.plen < src.in_len;
         // (requesting the NEXT run's tile before the demodulation of a wave's last channel — the k_fm_chain_polyw scheme, two
         //  instances of the channel body — puts the kernel over its 168 registers: 7-14 spilled, 0.0588 against 0.0562 ms)
+        RR_MARK("forward");
         if (w < D) {
             creg v[16];
             poly_load<D>(v, src, vbase, w, t, interior, ex);
@@ -839,8 +901,10 @@ void k_fm_multi_poly12(SRC src, float* __restrict__ out, long out_stride, long n
             for (int j = 0; j < 16; j++) park[(w * 16 + j) * PT + t] = v[j];
         }
         tile_sync<64 * MW>();
+        RR_MARK("channels");
 #pragma unroll 1
         for (int c = MW * r0 + w; c < nchan && c < MW * r1; c += MW) {
+            RR_MARK("products");
             creg z[16], h[2][8], x[8];
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const gptr<f32x4> hq = as_global(reinterpret_cast<const f32x4*>(hr + (long)c * D * 16 * PT) + t);
@@ -861,18 +925,25 @@ void k_fm_multi_poly12(SRC src, float* __restrict__ out, long out_stride, long n
                 for (int j = 0; j < 8; j++) x[j] = park[(k * 8 + j) * PT + t];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 8; j++) z[8 * (k & 1) + j] = cmac(z[8 * (k & 1) + j], x[j], h[k & 1][j]);
+                for (int j = 0; j < 8; j += 2)
+                    cmac2(z[8 * (k & 1) + j], x[j], h[k & 1][j], z[8 * (k & 1) + j + 1], x[j + 1], h[k & 1][j + 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            RR_MARK("inverse");
             poly_inverse_tab(z, t, ex, tw0tab, tab1);
             wave_fence();
             nat_store(z, t, ex);
             wave_fence();
+            RR_MARK("demod");
             float* oc = out + (long)c * out_stride;
-            if (a.mode == 0) poly_demod_tile<0>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
-            else poly_demod_tile<1>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+            if (a.mode == 0) {
+                if (tile_tame(z)) poly_demod_tile<0, true>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+                else poly_demod_tile<0>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
+            } else poly_demod_tile<1>(ex, t, PT, u0, Sa, a, oc, last_r_in + c, last_r_out + c);
             wave_fence();
+            RR_MARK("channel_end");
         }
+        RR_MARK("tile_end");
         tile_sync<64 * MW>();                            // every wave is done with the parked spectra
     }
 }
@@ -919,7 +990,7 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
     constexpr int NWsel = (std::is_same<SRC, VSrcIQ8>::value && (D % 2 == 1) && D >= 5) ? 0 : ChainWaves<D>::NW;
     if constexpr (NWsel != 0) {
         constexpr int NW = NWsel;
-        const size_t smemw = sizeof(cf) * (NW * PLE + 64 + 15 * PT);
+        const size_t smemw = sizeof(cf) * (NW * PLE + 64 + 15 * PT + 1);
         long gridw = grid_for_tiles(k_fm_chain_polyw<D, NW, SRC>, 64 * NW, smemw, ntiles);
         if (ntiles > gridw && ntiles < 12 * gridw) gridw = std::min(ntiles, (long)RR_POLY_OVERSUB * gridw);
         if constexpr (std::is_same<SRC, VSrc<cf>>::value) {
@@ -936,7 +1007,7 @@ static void launch_chain_poly_d(SRC src, float* out, int L, const cf* tw, const 
         return;
     }
 #endif
-    const size_t smem = sizeof(cf) * (3 * PLE + 64 + (RR_POLY_CHAIN_TWLDS ? 15 * PT : 0));
+    const size_t smem = sizeof(cf) * (3 * PLE + 64 + (RR_POLY_CHAIN_TWLDS ? 15 * PT : 0) + 1);
     long grid = grid_for_tiles(k_fm_chain_poly<D, SRC>, 128, smem, ntiles);
     // A few tiles per resident workgroup (configs[2]: 4228 tiles on 1024 slots = 4.1) end in a round where most of the
     // chip waits for the workgroups with one tile more.  Launching 3x the resident workgroups lets the hardware dispatcher

@@ -56,10 +56,27 @@ __device__ __forceinline__ float fmc_atan2(float y, float x) {
 }
 
 // f32::atan2 (quadrature_demod.rs:106-108) for the fused epilogues: |y| / |x| folded into [0, 1] with one v_rcp_f32
-// (1 ulp), an odd polynomial atan(t) = t P(t^2) (degree 8 in t^2, Chebyshev fit; 1.1e-7 rad worst case evaluated in f32),
-// then the octant fix-ups.  Worst case 3e-7 rad against libm (test_quaddemod_exact_atan2_accuracy asks for 1e-6);
+// (1 ulp), an odd polynomial atan(t) = t P(t^2), P(0) = 1 (degree 7 in t^2, minimax fit with the constant term pinned so
+// that tiny angles stay exact to rounding; 1.2e-7 rad worst case evaluated in f32 — round 5: one term fewer than the
+// degree-8 fit it replaces, 9e-8, both at the level of f32 rounding), then the octant fix-ups.  Worst case 3e-7 rad against
+// libm (test_quaddemod_exact_atan2_accuracy asks for 1e-6);
 // atan2(+-0, +x) = +-0 and atan2(+-0, -x) = +-pi exactly (quad_nulls), inf / inf = pi/4 multiples, NaN propagates.
-// ~24 VALU instructions; the library atan2f is 2-3x that, and the epilogue is the largest part of a decimated chain's work.
+// ~23 VALU instructions; the library atan2f is 2-3x that, and the epilogue is the largest part of a decimated chain's work.
+__device__ __forceinline__ float atan_poly01(float t) {
+    const float s = t * t;
+    float p = -0.004355404991656542f;
+    p = fmaf(p, s, 0.023040134459733963f);
+    p = fmaf(p, s, -0.05777358636260033f);
+    p = fmaf(p, s, 0.09794234484434128f);
+    p = fmaf(p, s, -0.13976581394672394f);
+    p = fmaf(p, s, 0.19962704181671143f);
+    p = fmaf(p, s, -0.3333165943622589f);
+    p = fmaf(p, s, 1.0f);
+    return t * p;
+}
+// TAME = the caller has established that x and y are finite (see tile_tame in kernels_poly.hip): the inf / inf and NaN
+// fix-ups — two compares and two selects per value — are left out; everything else is the same instruction for instruction.
+template <bool TAME = false>
 __device__ __forceinline__ float atan2_poly(float y, float x) {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(fmaxf(ax, ay), 1.17549435e-38f);
@@ -72,21 +89,11 @@ __device__ __forceinline__ float atan2_poly(float y, float x) {
     const float mn = fminf(ax, ay);
 #endif
     float t = mn * __builtin_amdgcn_rcpf(mx);
-    if (mn == __builtin_inff()) t = 1.0f;                 // inf / inf
-    const float s = t * t;
-    float p = 0.0028340641874819994f;
-    p = fmaf(p, s, -0.016005029901862144f);
-    p = fmaf(p, s, 0.042587608098983765f);
-    p = fmaf(p, s, -0.07495445758104324f);
-    p = fmaf(p, s, 0.10636754333972931f);
-    p = fmaf(p, s, -0.14202570915222168f);
-    p = fmaf(p, s, 0.19992484152317047f);
-    p = fmaf(p, s, -0.3333306610584259f);
-    p = fmaf(p, s, 1.0f);
-    float r = t * p;
+    if constexpr (!TAME) { if (mn == __builtin_inff()) t = 1.0f; }   // inf / inf
+    float r = atan_poly01(t);
     if (ay > ax) r = 1.57079632679489661923f - r;
     if (__float_as_uint(x) >> 31) r = 3.14159265358979323846f - r;
-    if (__builtin_isunordered(x, y)) r = __builtin_nanf("");   // (fmaxf / fminf drop a NaN operand)
+    if constexpr (!TAME) { if (__builtin_isunordered(x, y)) r = __builtin_nanf(""); }   // (fmaxf / fminf drop a NaN operand)
     return __uint_as_float(__float_as_uint(r) | (__float_as_uint(y) & 0x80000000u));
 }
 

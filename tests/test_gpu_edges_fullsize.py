@@ -453,3 +453,54 @@ def test_nonfinite_samples_hilbert_pair_kernel(rr):
         assert not np.any(bg & ~bo) and bg.sum() >= bo.sum() // 2 - L
         ok = ~_nonfinite_mask(yo)
         assert max_norm_err(yg[ok], yo[ok]) <= TOL
+
+
+@pytest.mark.parametrize("kind", ["chain-1:6", "chain-1:10-two-wave-kernel", "multi-12", "multi-8", "chain-full-rate-2:3"])
+def test_nonfinite_samples_in_the_fused_fm_chains(rr, kind):
+    """Round 5: the decimate-first chains demodulate a tile without atan2's inf / NaN fix-ups when tile_tame() finds every value
+    of the tile finite (csrc/kernels_poly.hip), and with them otherwise.  A poisoned input (NaN / +-Inf, whole samples and
+    single components) must leave every output the reference keeps finite within tolerance unless it shares a GPU tile with a
+    poisoned one (FftFilter's known tile-sized smear, DESIGN "known deviations"), and every output the reference poisons
+    non-finite."""
+    from tests.harness import angle_parity
+    taps = orc.low_pass_complex(2.4e6, 100e3, 12.5e3)
+    n = 400_000
+    # an FM-ish carrier (|r| stays away from 0: the plain bound applies almost everywhere)
+    ph = np.cumsum(0.3 * np.sin(2 * np.pi * 1e-3 * np.arange(n)))
+    clean = (np.exp(1j * ph) + 0.02 * rnd_c(n, 3)).astype(np.complex64)
+    x = _poisoned(clean, 13)
+    I, D = (2, 3) if kind.endswith("2:3") else (1, 10) if "1:10" in kind else (1, 6)
+    if kind.startswith("multi"):
+        t3 = np.stack([taps, np.conj(taps), (taps * np.exp(1j * 0.1 * np.arange(len(taps)))).astype(np.complex64)])
+        with rr.build_options(fm_poly=12 if kind == "multi-12" else 8):
+            blk = rr.FmMulti(t3, I, D, 1.0)
+        st, c_, p_, need, yg = blk.work(x, 1_024_000)                 # one window holds the whole stream (N outputs: (N, produced))
+        assert yg.shape == (3, p_) and p_ > 60_000
+        chans = [(t3[c], yg[c]) for c in range(3)]
+    else:
+        with rr.build_options(**({"fm_poly": 1} if "1:10" in kind else {})):      # (1:10 at 463 taps: decimate-first tiles forced)
+            blk = rr.FmChain(taps, I, D, 1.0)
+        chans = [(taps, run_chain([blk], x))]
+    for tc, got in chans:
+        want = run_chain([orc.FftFilter(tc), orc.RationalResampler(I, D), orc.QuadratureDemod(1.0)], x)
+        ro = run_chain([orc.FftFilter(tc), orc.RationalResampler(I, D)], x)
+        assert len(want) >= len(got) > 1000 and (len(got) == len(want) or kind.startswith("multi"))
+        want, ro = want[:len(got)], ro[:len(got) + 1]                  # (one work() call: the block's last partial tile is not out yet)
+        bo, bg = ~np.isfinite(want), ~np.isfinite(got)
+        # every output whose filter window holds a poisoned sample is poisoned (the data dependence itself: y[n] sees
+        # x[n - L + 1 .. n], r[m] = y[floor(m D / I)], the angle m sees r[m] and r[m + 1]); the reference's FFT blocks and the
+        # GPU's tiles both smear further, each over its own block
+        xm = _nonfinite_mask(x).astype(np.float64)
+        dep_y = np.convolve(xm, np.ones(len(tc)))[:len(x)] > 0
+        idx = (np.arange(len(want) + 1) * D) // I
+        dep_r = dep_y[np.minimum(idx, len(dep_y) - 1)]
+        must = dep_r[:-1] | dep_r[1:]
+        assert bo.sum() > 20 and must.sum() > 20 and not np.any(must & ~bg) and not np.any(must & ~bo)
+        # outputs farther than a GPU tile (1024 outputs on the decimate-first tiles, <= 8192 input samples on the others) from
+        # every poisoned output of the reference: untouched
+        near = np.convolve(bo.astype(np.float64), np.ones(2 * (max(1024, 8192 * I // D) + 2) + 1), mode="same") > 0
+        assert not np.any(bg & ~near), int(np.sum(bg & ~near))
+        ok = ~near
+        ro_ok = np.where(np.isfinite(ro.real) & np.isfinite(ro.imag), ro, 1.0)
+        par = angle_parity(np.where(ok, got, 0.0), np.where(ok, np.nan_to_num(want), 0.0), ro_ok)
+        assert par["used"] <= 1.0, (kind, par)
