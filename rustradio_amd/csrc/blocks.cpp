@@ -1242,7 +1242,7 @@ int FmChain::work_blocks(const void* in, size_t in_len, float* out, size_t, size
         // (and below ~1.2 M samples the plain 2048-point tiles — more, smaller workgroups — beat the half-size inverse,
         //  which finishes two tiles per workgroup: 512 k samples 15.4 against 18.8 us)
         const bool use_half = half_ok && (!window_aware || n_y >= chip_units(1200000));
-        const bool use_alt = f->nsub && f->alt_log2f && window_aware && f->alt_wins((long)n_y) &&
+        const bool use_alt = f->nsub && f->alt_log2f && window_aware && f->alt_wins((long)n_y, true) &&
                              (int64_t)((D + I - 1) / I) < (int64_t)(((size_t)1 << f->alt_log2f) - f->L + 1);
         prof_begin(s);
         if (use_poly && packed)

@@ -194,17 +194,21 @@ struct FftFilter : Block {
     // plain 4096-point tile beside the split tables, for windows of too few split tiles to fill the chip
     int alt_log2f = 0;
     DevBuf<cf> d_tw_alt, d_hpos_alt;
-    // below ~520 split tiles (two resident workgroups per CU) the alternate tile wins
-    // Does the plain 4096-point tile beat the split tile on a window of n_out filtered samples?  Fitted costs in us on the
-    // 256 CUs they were measured on (tools/call_overhead.py, 2467 taps, 512 k / 2 M / 8 M samples: plain 16.8 / 25.3 / 64.3,
-    // split 26.2 / 30.3 / 57.4): plain 13 + 0.0104 per tile, split max(25 + 0.015, 0.041) per tile — so the answer depends
-    // on how many MORE tiles the plain form needs (3.5x at 2467 taps, 6.3x at 3330: round 3 compared tile counts of the
-    // split form only, and a 3330-tap chain on a 2.4 M-sample window ran 1.8x slower on the plain tile it was handed).
-    bool alt_wins(long n_out) const {
+    // Does the plain 4096-point tile beat the split tile on a window of n_out filtered samples?  Costs in us on the 256 CUs
+    // they were measured on (tools/chain_tile_probe.py, round 5: 1500 / 2467 / 3330 taps, 512 k ... 64 M samples, the FftFilter
+    // block and the fused FM chain, Complex and RTL-SDR byte sources; profiles/r05_rtl_fm_tiles.txt):
+    //   plain  13 + c na,  c = 0.0105 (FftFilter), 0.0112 -> 0.0127 beyond 2500 tiles (chain: the epilogue's share grows)
+    //   split  max(25 + 0.022 ns, 12 + per-tile cost x ns): FftFilter 0.0207 per tile + 2.6e-6 per output sample (stores);
+    //          chain 0.032 per tile, with a 200-tile tail (a window of 2-3 rounds of the 512 resident workgroups ends uneven)
+    // na / ns = the tiles each form needs (3.5x more plain tiles at 2467 taps, 6.3x at 3330).  Round 4's fit stopped at 8 M
+    // samples and handed the reference's own rtl_fm shape (2467 taps, 24 M samples) to the plain tile: 0.191 ms against 0.138.
+    bool alt_wins(long n_out, bool chain = false) const {
         const double cu = (double)device_cu_count() / 256.0;
         const double na = (double)n_out / (double)(((size_t)1 << alt_log2f) - L + 1) / cu;
         const double ns = (double)n_out / (double)(((size_t)1 << log2f) - L + 1) / cu;
-        return 13.0 + 0.0104 * na < std::max(25.0 + 0.015 * ns, 0.041 * ns);
+        const double plain = 13.0 + na * (chain ? (na < 2500.0 ? 0.0112 : 0.0127) : 0.0105);
+        const double split = std::max(25.0 + 0.022 * ns, chain ? 12.0 + 0.032 * (ns + 200.0) : 12.0 + 0.0207 * ns + 2.6e-6 * (double)n_out / cu);
+        return plain < split;
     }
     // more than 16383 taps: overlap-save frames of M = 2^m >= 2 L points through the any-size transform (AnyFft)
     NanFix nanfix;                    // set by a FirFilter that runs on these tiles (default: none — FftFilter's own reference is a transform)
