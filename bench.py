@@ -467,13 +467,16 @@ def make_fm_multi_u8(dev, rank, world, shared_src):
     return make_fm_multi(dev, rank, world, shared_src, u8=True)
 
 
-def make_channelizer(dev, rank, world, shared_src, fused=True, rotator=None):
+def make_channelizer(dev, rank, world, shared_src, fused=True, rotator=None, as_rank=None):
     """BASELINE configs[4]; on N > 1 GPUs rank g runs channel offset f_g through FirFilter::translate(100e6, f_g)
     (src/fir.rs:476-486, SURVEY §8d cfg5: multi.cfg5_translate_hz) — with the library's DEFAULT rotator, the reference's own
     f32 recurrence replayed bit for bit (RR_ROT_REPLAY: on parity for any stream length, one sequential chain per block,
-    walked ahead of the filter by a host thread at ~2.6 ns per output and copied into the device ring, round 4); `channelizer_model` is the same with the opt-in f64 closed form (parallel, but outside the 1e-5
-    parity bar beyond ~1e5 outputs of a stream)."""
+    walked ahead of the filter — by one device lane at 14 ns per output while the block's calls leave it time, by a host
+    thread at ~2.6 ns per output once they do not (round 5; back-to-back bench steps do not)); `channelizer_model` is the same with
+    the opt-in f64 closed form (parallel, but outside the 1e-5 parity bar beyond ~1e5 outputs of a stream)."""
     w = Workload()
+    if as_rank is not None:                      # (N = 1 line: the workload ONE rank of the 8-GPU variant runs)
+        rank, world = as_rank
     f_g = multi.cfg5_translate_hz(rank, world)
     rotator = rr.ROT_REPLAY if rotator is None else rotator
     rot_txt = ("rotator=replay: the reference's f32 recurrence bit for bit, the library default, ON parity; back-to-back steps are "
@@ -514,6 +517,17 @@ def make_channelizer_unfused(dev, rank, world, shared_src):
     return make_channelizer(dev, rank, world, shared_src, fused=False)
 
 
+def make_channelizer_translate(dev, rank, world, shared_src):
+    """what ONE rank of configs[4]'s 8-GPU variant runs (rank 1 of 8: .translate(100e6, f_1), default on-parity rotator), on
+    the N = 1 line so that the driver sees it: bound by the sequential rotator chain, not by a roofline"""
+    w = make_channelizer(dev, rank, world, shared_src, as_rank=(1, 8))
+    w.bound = "sequential_rotator"
+    w.bound_note = ("FirFilter::translate's rotator (src/fir.rs:464-473) is an un-renormalised f32 recurrence, one dependent chain of 12.5 M "
+                    "steps per step here; replayed bit for bit it runs at 2.6 ns per output on a host core (14 ns on a device lane), "
+                    "whatever the filter kernel does (0.14 ms).  rotator_ns_per_output is this step's time per output")
+    return w
+
+
 def make_channelizer_model(dev, rank, world, shared_src):
     """configs[4]'s N > 1 variant with the OPT-IN model rotator (labelled off-parity; see make_channelizer)"""
     return make_channelizer(dev, rank, world, shared_src, rotator=rr.ROT_MODEL)
@@ -522,6 +536,7 @@ def make_channelizer_model(dev, rank, world, shared_src):
 WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
              "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "fm_multi_u8": make_fm_multi_u8,
              "channelizer": make_channelizer, "channelizer_model": make_channelizer_model,
+             "channelizer_translate": make_channelizer_translate,
              "rtl_fm_chain": make_rtl_fm_chain, "channelizer_unfused": make_channelizer_unfused,
              "fir_fft_chain": make_fir_fft_chain, "fir_fft_chain_unfused": make_fir_fft_chain_unfused,
              "full_chain": make_full_chain, "full_chain_fused": make_full_chain_fused,
@@ -1209,6 +1224,9 @@ def main():
                             "dominant_kernel_nominal_reference_fp32_frac": None if fl is None else round(fl / FP32_PEAK_TFLOPS, 4)}
             if getattr(wo, "rotator", None):
                 others[name]["rotator"] = wo.rotator
+            if wo.bound == "sequential_rotator":
+                others[name]["outputs_per_s"] = round(ua / 8 / ta, 1)
+                others[name]["rotator_ns_per_output"] = round(ta / (ua / 8) * 1e9, 2)
             if wo.bound_note:
                 others[name]["bound_note"] = wo.bound_note
             if world == 1 and not args.no_cpu and name in ("full_chain_fused", "fir_fft_chain"):

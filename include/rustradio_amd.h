@@ -57,19 +57,24 @@ enum rr_atan2 { RR_ATAN2_EXACT = 0, RR_ATAN2_FAST = 1,
 /* Rotator evaluation for FirFilter::translate (src/fir.rs:464-473: `sample *= phase; phase *= step` in f32, never
  * renormalised):
  * RR_ROT_REPLAY = DEFAULT.  The reference's sequential f32 recurrence replayed bit for bit, for any stream length.  The
- *                 chain is data-independent, so it is generated AHEAD of the filter: one host thread per translating
- *                 block walks it in strict f32 (an x86 core does a step in its multiply + add latency, 2-3 ns) into a
- *                 pinned ring, and the block copies the phases of the next window into its device ring on a side
- *                 stream (8 B per output over PCIe) while the filter kernels of this one run; a call waits only for
- *                 what the chain has not reached.  Back-to-back calls are bounded by the chain.
- * RR_ROT_REPLAY_DEVICE = the same chain walked by one device lane from the phase carried in device memory (no host
- *                 thread, no PCIe traffic; 14 ns per output: a lone wave issues every 5-6 clocks).  Bit-identical.
+ *                 chain is data-independent, so it is generated AHEAD of the filter on a side stream while the filter
+ *                 kernels of the current window run; a call waits only for what the chain has not reached.  It starts
+ *                 on the device: one lane walks it from the phase carried in device memory (three packed f32
+ *                 instructions per step, 14 ns per output = 70 M outputs/s; no host thread, no PCIe traffic) — enough
+ *                 for any graph paced by its source (BASELINE configs[4]: 12.5 M outputs/s).  A block whose calls keep
+ *                 arriving before the look-ahead has finished (three in a row: back-to-back batch calls) is given a host
+ *                 generator instead: one thread walks the same chain in strict f32 at an x86 core's multiply + add
+ *                 latency (2.6 ns per output) from the device chain's current phase into a pinned ring, copied ahead
+ *                 into the device ring (8 B per output over PCIe).  The sequential chain bounds such a block either
+ *                 way ("sequential_rotator" in bench.py).
+ * RR_ROT_REPLAY_DEVICE = the device chain only (never a thread).  RR_ROT_REPLAY_HOST = the host generator from the first
+ *                 call.  Bit-identical to each other and to the reference in every case.
  * RR_ROT_MODEL  = opt-in: closed form phase0 * step^m evaluated in f64 from the SAME f32-rounded phase0 / step
  *                 (parallel, as fast as the filter).  NOT parity-faithful for long streams: it differs from the
  *                 recurrence by its accumulated rounding, <= 1e-7 * n after n outputs (measured 1.5e-8 * n:
  *                 tests/test_gpu_edges_fullsize.py::test_rotator_drift_vs_length), i.e. inside the 1e-5 bar only for
  *                 the first ~1e2 (bound) .. 1e5 (measured) outputs of a stream. */
-enum rr_rotator { RR_ROT_MODEL = 0, RR_ROT_REPLAY = 1, RR_ROT_REPLAY_DEVICE = 2 };
+enum rr_rotator { RR_ROT_MODEL = 0, RR_ROT_REPLAY = 1, RR_ROT_REPLAY_DEVICE = 2, RR_ROT_REPLAY_HOST = 3 };
 
 /* ---- library / device ------------------------------------------------------ */
 int         rr_abi_version(void);

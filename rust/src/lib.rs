@@ -586,7 +586,8 @@ impl GpuFused<Complex, Complex> {
 }
 impl GpuFused<Float, Complex> {
     /// `translate` = `Some((samp_rate, freq))` for `.translate()`; `replay_rotator` = true keeps the library default, the
-    /// reference's own f32 rotator recurrence replayed bit for bit (RR_ROT_REPLAY, generated ahead on a side stream);
+    /// reference's own f32 rotator recurrence replayed bit for bit (RR_ROT_REPLAY, generated ahead on a side stream: by a
+    /// device lane, or by a host thread for a block whose calls outrun that lane — include/rustradio_amd.h);
     /// false opts into the parallel closed-form model (RR_ROT_MODEL), which is outside 1e-5 parity beyond ~1e5 outputs.
     pub fn hilbert_fir(src: ReadStream<Float>, hilbert_ntaps: usize, window_type: &WindowType, taps: &[Complex], deci: usize,
                        translate: Option<(Float, Float)>, replay_rotator: bool) -> Result<(Self, ReadStream<Complex>)> {

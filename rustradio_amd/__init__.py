@@ -33,7 +33,7 @@ AGAIN, WAIT_SRC, WAIT_DST, EOF, PENDING, ERR = 0, 1, 2, 3, 4, -1
 # WindowType (src/window.rs:42-60)
 WIN_HAMMING, WIN_BLACKMAN, WIN_BLACKMAN_HARRIS, WIN_HAMMING_PARM = 0, 1, 2, 3
 ATAN2_EXACT, ATAN2_FAST = 0, 1
-ROT_MODEL, ROT_REPLAY, ROT_REPLAY_DEVICE = 0, 1, 2
+ROT_MODEL, ROT_REPLAY, ROT_REPLAY_DEVICE, ROT_REPLAY_HOST = 0, 1, 2, 3
 DEMOD_FASTFM = 2        # fused-chain constructors: FastFM in the demodulator's place (RR_DEMOD_FASTFM)
 DEFAULT_STREAM_SIZE = 4_096_000  # bytes, src/stream.rs:105
 

@@ -480,7 +480,7 @@ int rr_block_work_streams(rr_block* b, rr_dstream* src, rr_dstream* dst, size_t*
 int rr_fir_set_rotator_mode(rr_block* b, int mode) {
     auto* f = b ? dynamic_cast<rr::FirC32*>(b->b.get()) : nullptr;
     if (!f && b) if (auto* hf = dynamic_cast<rr::HilbertFir*>(b->b.get())) f = hf->fir.get();
-    if (!f || (mode != RR_ROT_MODEL && mode != RR_ROT_REPLAY && mode != RR_ROT_REPLAY_DEVICE)) { rr::set_last_error("rr_fir_set_rotator_mode: bad argument"); return RR_ERR; }
+    if (!f || (mode != RR_ROT_MODEL && mode != RR_ROT_REPLAY && mode != RR_ROT_REPLAY_DEVICE && mode != RR_ROT_REPLAY_HOST)) { rr::set_last_error("rr_fir_set_rotator_mode: bad argument"); return RR_ERR; }
     f->rot_mode = mode;
     return 0;
 }

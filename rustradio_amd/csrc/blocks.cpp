@@ -422,12 +422,13 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
 }
 
 // The reference's rotator (fir.rs:464-473): out[m] *= phase; phase *= step, in f32, never renormalised.
-//   RR_ROT_REPLAY (default): that recurrence, bit for bit, for any stream length.  It is inherently serial (~5 ns per
-//     output on one lane) but data-independent, so it is generated AHEAD: after every call the side stream walks the chain
-//     on into a ring of phases for the next window while this window's filter kernels (and whatever the graph runs next)
-//     execute; a call waits only for the part of its range the chain has not reached.  Sustained back-to-back calls are
-//     bounded by the chain (~200 M outputs/s); a graph paced by its source (100 Msps / 8 = 12.5 M outputs/s in
-//     BASELINE configs[4]) never waits.
+//   RR_ROT_REPLAY (default): that recurrence, bit for bit, for any stream length.  It is inherently serial (14 ns per
+//     output on one device lane, 2.6 ns on a host core) but data-independent, so it is generated AHEAD: after every call the
+//     side stream walks the chain on into a ring of phases for the next window while this window's filter kernels (and
+//     whatever the graph runs next) execute; a call waits only for the part of its range the chain has not reached.  A
+//     graph paced by its source (100 Msps / 8 = 12.5 M outputs/s in BASELINE configs[4]) never waits for the device
+//     chain (70 M outputs/s); a block that does (back-to-back batch calls) is moved onto a host generator thread
+//     (rotate_output: `starving`, rotor_start_host).
 //   RR_ROT_MODEL (opt-in): phase0 * step^m in f64, parallel; NOT within 1e-5 of the reference beyond ~1e5 outputs
 //     (it does not reproduce the recurrence's accumulated rounding; tests/test_gpu_edges_fullsize.py).
 void FirC32::rotor_generate(size_t upto) {
@@ -450,7 +451,7 @@ void FirC32::rotor_reap(bool wait_oldest) {
         wait_oldest = false;
         if (e == hipErrorNotReady) break;
         if (e != hipSuccess) throw Error(std::string("rotator: copy event: ") + hipGetErrorString(e));
-        hrot->release(copies.front().upto);
+        hrot->release(copies.front().upto - hrot_base);
         free_events.push_back(copies.front().ev);
         copies.erase(copies.begin());
     }
@@ -462,14 +463,14 @@ bool FirC32::rotor_fetch(size_t upto, bool block) {
     if (upto <= rot_gen) return true;
     if (upto - rot_gen > ring_cap) throw Error("rotator: look-ahead request beyond the phase ring");
     rotor_reap(false);
-    while (hrot->wait_for(upto, block ? 20 : 0) < upto) {
+    while (hrot->wait_for(upto - hrot_base, block ? 20 : 0) < upto - hrot_base) {
         if (!block) return false;
         // the generator stalls on a full ring only while copies of its oldest phases are still in flight
         if (hrot->gen.load() >= hrot->tail.load() + hrot->cap) rotor_reap(true);
     }
     if (used_pending) { RR_HIP(hipStreamWaitEvent(rot_stream, ev_used, 0)); used_pending = false; }
     for (size_t i = rot_gen; i < upto;) {
-        const size_t hs = i & hrot->mask, ds = i & (ring_cap - 1);
+        const size_t hs = (i - hrot_base) & hrot->mask, ds = i & (ring_cap - 1);
         const size_t n = std::min({upto - i, hrot->cap - hs, ring_cap - ds});
         RR_HIP(hipMemcpyAsync(d_ring.p + ds, hrot->ring + hs, n * sizeof(cf), hipMemcpyHostToDevice, rot_stream));
         i += n;
@@ -491,7 +492,6 @@ void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
         n_rot += out_n;
         return;
     }
-    const bool host = rot_mode == RR_ROT_REPLAY;
     if (!rot_stream) {
         RR_HIP(hipStreamCreateWithFlags(&rot_stream, hipStreamNonBlocking));
         RR_HIP(hipEventCreateWithFlags(&ev_gen, hipEventDisableTiming));
@@ -507,15 +507,28 @@ void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
         dphase_at = 0;
         rot_gen = n_rot;                                             // (outputs rotated by the model so far are skipped below)
     }
-    if (host && !hrot) hrot.reset(new HostRotor(ph0x, ph0y, stx, sty, 2 * ring_cap));   // (starts walking from phase 0 at once)
     if (rot_gen < n_rot) rot_gen = n_rot;
     // REPLAY -> MODEL -> REPLAY, or REPLAY chosen after outputs were produced: nothing below n_rot is needed any more — the
-    // host generator walks through those phases on its own (they are overwritten in its ring), the device chain skips to
-    // rot_gen without storing (rotor_generate); neither ever spans more than a chunk of the ring.
+    // device chain skips to rot_gen without storing (rotor_generate), a host generator is started AT the device chain's phase.
+    if (hrot && rot_mode == RR_ROT_REPLAY_DEVICE) {                  // (forced back: drop the thread; the device chain catches up)
+        RR_HIP(hipStreamSynchronize(rot_stream));
+        for (auto& c : copies) free_events.push_back(c.ev);
+        copies.clear();
+        hrot.reset();
+    }
+    if (!hrot && rot_mode == RR_ROT_REPLAY) {
+        // the starvation test: the look-ahead enqueued at the end of the previous call is what this call's phases come from
+        if (lookahead_pending && hipEventQuery(ev_gen) == hipErrorNotReady) starving++;
+        else starving = 0;
+        (void)hipGetLastError();
+        if (starving >= 3) rotor_start_host();
+    }
+    if (!hrot && rot_mode == RR_ROT_REPLAY_HOST) rotor_start_host();
+    const bool host = hrot != nullptr;
     if (host) {
         // (only once no copy out of the host ring is in flight: a slot handed back early could be overwritten under a copy)
         rotor_reap(false);
-        if (copies.empty()) hrot->release(rot_gen);
+        if (copies.empty() && rot_gen > hrot_base) hrot->release(rot_gen - hrot_base);
     }
     // one event remembers the ring's readers: a call on another HIP stream first waits for the previous stream's rotate
     // kernels, so that the record below still covers every reader enqueued so far
@@ -534,13 +547,32 @@ void FirC32::rotate_output(cf* out, size_t out_n, hipStream_t s) {
     }
     n_rot += out_n;
     // look-ahead: the next window of the same size (host mode: as far as the generator has got, without waiting)
+    lookahead_pending = false;
     if (host) {
         const size_t want = n_rot + std::min(out_n, half);
-        const size_t got = (size_t)std::min<uint64_t>(want, hrot->gen.load(std::memory_order_acquire));
+        const size_t got = (size_t)std::min<uint64_t>(want, hrot->gen.load(std::memory_order_acquire) + hrot_base);
         if (got > rot_gen) rotor_fetch(got, false);
     } else {
+        const size_t before = rot_gen;
         rotor_generate(n_rot + std::min(out_n, half));
+        lookahead_pending = rot_gen > before;
     }
+}
+
+// The host generator takes over where the device chain stands: everything enqueued on rot_stream is waited for (once per
+// block), the carried phase comes back over PCIe (8 bytes) and the thread walks on from there.
+void FirC32::rotor_start_host() {
+    RR_HIP(hipStreamSynchronize(rot_stream));
+    if (dphase_at < rot_gen) {                                       // (a model interlude: bring the device chain up to rot_gen first)
+        launch_rotor_replay(d_phase.p, stx, sty, d_ring.p, 0, (long)(ring_cap - 1), (long)(rot_gen - dphase_at), 0, rot_stream);
+        dphase_at = rot_gen;
+        RR_HIP(hipStreamSynchronize(rot_stream));
+    }
+    cf p{};
+    RR_HIP(hipMemcpy(&p, d_phase.p, sizeof(cf), hipMemcpyDeviceToHost));
+    hrot_base = dphase_at;                                           // == rot_gen: phases below it are in d_ring already
+    hrot.reset(new HostRotor(p.x, p.y, stx, sty, 2 * ring_cap));
+    starving = 0;
 }
 
 // ---- Hilbert -> FirFilter<Complex> as one composite decimating FIR ------------------------------------------

@@ -119,9 +119,17 @@ struct FirC32 : Block {
     bool used_pending = false;
     hipStream_t used_stream = nullptr;            // stream of the last ev_used record
     void rotor_generate(size_t upto);             // enqueue the chain up to phase index `upto` (exclusive) on rot_stream
-    // RR_ROT_REPLAY (default since round 4): the same chain walked by a HOST thread of this block (rotor_host.cpp) into a
-    // pinned ring and copied ahead into d_ring on rot_stream; RR_ROT_REPLAY_DEVICE keeps the one-lane kernel.
+    // RR_ROT_REPLAY (default), round 5: the chain starts on the device (one lane, no host thread, no PCIe traffic) and only a
+    // block whose calls keep ARRIVING BEFORE the chain's look-ahead has finished (`starving` calls in a row: the rotator, not
+    // the filter, paces the block — back-to-back batch calls, never a graph paced by a 12.5 M outputs/s source) gets a host
+    // generator: a HOST thread of this block (rotor_host.cpp) walks the same chain at 2.6 ns per output from the device
+    // chain's current phase into a pinned ring, copied ahead into d_ring on rot_stream.  RR_ROT_REPLAY_DEVICE never
+    // switches; RR_ROT_REPLAY_HOST starts on the host thread.  The same bits in every case.
     std::unique_ptr<struct HostRotor> hrot;
+    size_t hrot_base = 0;                         // phase index of the host generator's phase 0
+    int starving = 0;                             // consecutive calls that found the look-ahead still running
+    bool lookahead_pending = false;               // ev_gen was last recorded by a look-ahead (not by a demand generation)
+    void rotor_start_host();                      // spawn the host generator at the device chain's position
     size_t dphase_at = 0;                         // phase index d_phase holds (the device chain's position)
     struct CopyDone { hipEvent_t ev; size_t upto; };
     std::vector<CopyDone> copies;                 // host-ring ranges in flight to the device, oldest first

@@ -1,6 +1,8 @@
 """GPU: (1) edge cases of every block's work() protocol — empty / ragged / zero-capacity windows —
 against the oracle; (2) BASELINE full-size runs checked through size-independent properties:
 random segments against the oracle, linearity, DC gain, resampler index identity."""
+import os
+
 import numpy as np
 import pytest
 
@@ -281,18 +283,53 @@ def test_device_replay_mode_is_the_same_chain(rr):
     yo = run_chain([orc.FirFilter(one, translate=(fs, f))], x)
     yd = run_chain([rr.FirFilter(one, translate=(fs, f), rotator=rr.ROT_REPLAY_DEVICE)], x)
     assert np.array_equal(yd.view(np.uint32), yo.view(np.uint32))
+    yh = run_chain([rr.FirFilter(one, translate=(fs, f), rotator=rr.ROT_REPLAY_HOST)], x)
+    assert np.array_equal(yh.view(np.uint32), yo.view(np.uint32))
     b = rr.FirFilter(one, translate=(fs, f))
     outs, step = [], 100_000
     for i, a in enumerate(range(0, n, step)):
         if i % 7 == 3:
             b.set_rotator_mode(rr.ROT_REPLAY_DEVICE)
         if i % 7 == 5:
-            b.set_rotator_mode(rr.ROT_REPLAY)
+            b.set_rotator_mode(rr.ROT_REPLAY_HOST if i % 2 else rr.ROT_REPLAY)
         st, c, p, need, out = b.work(x[a:a + step], step)
         assert c == p == step
         outs.append(out)
     y = np.concatenate(outs)
     assert np.array_equal(y.view(np.uint32), yo.view(np.uint32)), int(np.flatnonzero(y != yo)[0])
+
+
+def test_default_rotator_takes_a_host_thread_only_when_the_chain_paces_the_block(rr):
+    """Round 5: RR_ROT_REPLAY starts on the device chain (no thread per translating block) and moves to a
+    host generator thread only when three calls in a row arrive before the chain's look-ahead has finished — the same bits
+    before, across and after the switch."""
+    import threading, time
+    fs, f = 1.0e6, 123_456.7
+    one = np.ones(1, np.complex64)
+    nthreads = lambda: len(os.listdir("/proc/self/task"))
+    # paced: 50 k outputs per call (0.7 ms of chain), 10 ms apart — the look-ahead is always done: no thread
+    step, calls = 50_000, 12
+    x = rnd_c(step * calls, 5)
+    yo = run_chain([orc.FirFilter(one, translate=(fs, f))], x)
+    b = rr.FirFilter(one, translate=(fs, f))
+    st, c, p, need, out0 = b.work(x[:step], step)                 # (the first call creates the side stream)
+    t0 = nthreads()
+    outs = [out0]
+    for a in range(step, len(x), step):
+        time.sleep(0.010)
+        outs.append(b.work(x[a:a + step], step)[4])
+    assert nthreads() == t0, (t0, nthreads())
+    assert np.array_equal(np.concatenate(outs).view(np.uint32), yo.view(np.uint32))
+    # back to back: 500 k outputs per call (7 ms of chain each) with nothing in between — the block is handed a generator
+    step, calls = 500_000, 10
+    x = rnd_c(step * calls, 6)
+    yo = run_chain([orc.FirFilter(one, translate=(fs, f))], x, stream_bytes=8 * step)
+    b = rr.FirFilter(one, translate=(fs, f))
+    st, c, p, need, out0 = b.work(x[:step], step)
+    t0 = nthreads()
+    outs = [out0] + [b.work(x[a:a + step], step)[4] for a in range(step, len(x), step)]
+    assert nthreads() == t0 + 1, (t0, nthreads())
+    assert np.array_equal(np.concatenate(outs).view(np.uint32), yo.view(np.uint32))
 
 
 def test_rotator_drift_vs_length(rr):
