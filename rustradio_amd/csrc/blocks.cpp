@@ -1878,6 +1878,8 @@ Hilbert::Hilbert(size_t ntaps, int window, float parm) : Block("Hilbert", 4, 8) 
     par = (int)((((ntaps - 1) / 2) + 1) % 2);
     skip_ok = true;
     for (size_t j = 0; j < ntaps; j++) if ((int)(j % 2) != par && rev[j] != 0.0f) skip_ok = false;
+    d_nf_flags.reserve(HILBERT_MAX_GRID);
+    RR_HIP(hipMemsetAsync(d_nf_flags.p, 0, HILBERT_MAX_GRID * sizeof(int), stream));
     if (skip_ok) {
         const size_t q = (ntaps - par + 1) / 2;
         Q = (int)((q + 7) / 8 * 8);

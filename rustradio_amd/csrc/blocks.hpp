@@ -473,7 +473,8 @@ Block* make_audio_chain(const float* taps, size_t ntaps, size_t interp, size_t d
 struct Hilbert : Block {
     FirPlan pl;
     DevBuf<float> d_tp, d_rev;
-    NanFix nanfix() const { NanFix f; f.rev = d_rev.p; f.L = pl.L; f.d = 1; f.kind = NANFIX_HILBERT; return f; }
+    DevBuf<int> d_nf_flags;           // one word per workgroup of k_hilbert (zeroed once; the repair launch clears what it consumed)
+    NanFix nanfix() const { NanFix f; f.rev = d_rev.p; f.L = pl.L; f.d = 1; f.kind = NANFIX_HILBERT; f.wgflags = d_nf_flags.p; return f; }
     DevBuf<float> hist[2];
     int cur = 0;
     // zero-tap skipping (kernels_fir.hip k_hilbert): taps of one parity only

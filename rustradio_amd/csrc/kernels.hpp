@@ -169,6 +169,7 @@ void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<f
                     long n_out, hipStream_t s, NanFix fx = {});
 // Hilbert with the zero taps skipped: hq[q] = rev[2q + par] (Q entries, padded to a multiple of 8).
 // Returns false if the shape is not covered (use launch_hilbert).
+constexpr int HILBERT_MAX_GRID = 8192;        // workgroups k_hilbert is launched with at most (NanFix::wgflags has one word each)
 bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src, cf* out, long n_out, hipStream_t s, NanFix fx = {});
 // y[m] *= phase0 * step^(m0 + m) evaluated in f64 (RR_ROT_MODEL)
 void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, double sy, long m0,

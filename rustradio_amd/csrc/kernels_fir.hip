@@ -456,18 +456,41 @@ void launch_hilbert(const FirPlan& pl, const float* tp, const float* rev, VSrc<f
 // the same tile: L/2 - par is odd, so Re a[2m] is the .y of pair m + (L/2-par-1)/2 and Re a[2m+1] the
 // .x of the pair after it.
 constexpr int HIL_PRE = 10;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) float* hil_sptr;      // constant address space: s_load_dword, a scalar register
+__device__ __forceinline__ hil_sptr hil_scalar(const float* p) { return (hil_sptr)p; }
+#else
+inline const float* hil_scalar(const float* p) { return p; }
+#endif
+// acc |= lanes whose x is NaN or +-Inf: v_cmp_class_f32 into VCC and s_or_b64 at once (class bits: signalling NaN, quiet
+// NaN, -Inf, +Inf) — written as one asm block so that no compare's mask waits in a scalar register pair of its own: sixteen
+// of them in the unrolled store loop exhausted the kernel's scalar registers, and the overflow went into vector registers.
+// acc is a WAVE mask: only ever updated under wave-uniform control flow.
+__device__ __forceinline__ void hil_acc(unsigned long long& acc, float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_cmp_class_f32 vcc, %1, %2\n\ts_or_b64 %0, %0, vcc" : "+s"(acc) : "v"(x), "s"(0x207) : "vcc", "scc");   // (s_or_b64 writes SCC)
+#else
+    acc |= !(x - x == 0.0f);
+#endif
+}
 // A pair = two consecutive input floats, the first of any parity, read with ONE 8-byte load (as a cf)
 // although it is only 4-byte aligned: gfx9+ global memory instructions take dword-aligned addresses
 // (compute queues run in unaligned access mode); with the honest alignment the compiler splits every
 // load in two.  Covered by the Hilbert tests with even and odd L/2 and odd window offsets.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict__ out, long n_out, int L, int par,
-                                                   int Q, int np, int rstride, const float* __restrict__ hq) {
+                                                   int Q, int np, int rstride, const float* __restrict__ hq, int* __restrict__ wgflags) {
     constexpr int R = 8, NP = NT * R;                   // pairs per tile (2*NP outputs)
-    // (Non-finite samples, nan_fix.hpp: NOT repaired here.  The taps this kernel skips are zero and the reference multiplies
-    //  them all the same — 0 * NaN = NaN — so a bad sample reaches every output of its window there and only every other one
-    //  here (plus the one real part); testing the staged input for it cost this kernel 21 % (a spilled register pair or a
-    //  wave per SIMD: tools/hilbert_probe.py 0.230 -> 0.279 / 0.41 ms per 1e8 samples).  DESIGN.md "known deviations".)
+    // Non-finite samples (nan_fix.hpp), round 5.  The taps this kernel skips are zero and the reference multiplies them all
+    // the same — 0 * NaN = NaN — so a bad sample reaches every output of its window there and only every other one here.
+    // The tile's INPUT is tested where that costs no vector register (the kernel sits at 126 of the 128 that four waves per
+    // SIMD allow; a packed accumulator in the staging code, a branch there, or nan_fix.hpp's in-kernel hook with its LDS
+    // flags each tipped it to three waves: 0.23 -> 0.40 ms per 1e8 samples): the real part of every output IS an input
+    // sample and is tested as it is stored (hil_acc: a compare into VCC and a scalar OR), the few dozen samples around them
+    // by one wave from LDS, the zero-tap position in front of the first pair through a scalar load.  The verdict leaves the
+    // kernel as one word per workgroup (wgflags), and a second, tiny launch (k_hilbert_repair, same grid) recomputes ALL
+    // outputs of the tiles of a flagged workgroup with the reference's own fold — exactly the reference's set — and exits at
+    // once where the flag is clear.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* lds = reinterpret_cast<cf*>(smem_raw);          // pair n at (n % R)*rstride + n / R
     cf* lds_o = reinterpret_cast<cf*>(smem_raw);
@@ -475,14 +498,19 @@ __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict_
     const long ntiles = (n_out + 2 * NP - 1) / (2 * NP);
     const int cnt_k = (np + NT - 1) / NT;               // <= HIL_PRE (host checks)
 
+    unsigned long long bad_any = 0;                     // lanes that met a non-finite input sample in any tile (a wave mask: scalar registers)
     cf pre[HIL_PRE];
+    float pre_edge = 0.0f;                              // xp[tile start] when par == 1: a zero-tap position of the tile's FIRST
+                                                        // output that the pairs do not cover (the reference multiplies it: 0 * NaN)
     auto interior = [&](long tile) {
         const long g0 = tile * 2 * NP + par;
-        return g0 >= src.plen && g0 - src.plen + 2L * np <= src.in_len;
+        return g0 - par >= src.plen && g0 - src.plen + 2L * np <= src.in_len;     // (- par: pre_edge)
     };
     auto fetch = [&](long tile) {                       // (see k_fir for the two asm barriers)
         if (!interior(tile)) return;
         const cf* gp = reinterpret_cast<const cf*>(src.in + (tile * 2 * NP + par - src.plen));
+        // (a scalar load into a scalar register — the index is workgroup-uniform; interior: g0 - 1 >= plen)
+        if (par) pre_edge = *hil_scalar(src.in + (tile * 2 * NP - src.plen));
         unsigned tt = t;
         asm volatile("" : "+v"(tt));
         int cnt = cnt_k;
@@ -503,6 +531,7 @@ __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict_
         int cnt = cnt_k;
         asm volatile("" : "+s"(cnt));
         cf* slot = lds + (tt % R) * rstride + tt / R;   // R divides NT: round c lands NT/R columns further
+        hil_acc(bad_any, pre_edge);
 #pragma unroll
         for (int c = 0; c < HIL_PRE; c++) {
             if (c < cnt - 1) slot[c * (NT / R)] = pre[c];
@@ -511,6 +540,7 @@ __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict_
     };
     auto stage_direct = [&](long tile) {                // tiles touching the carried history / window end
         const long g0 = tile * 2 * NP + par;
+        if (par) hil_acc(bad_any, src.load(g0 - 1));
         for (int i = t; i < np; i += NT)
             lds[(i % R) * rstride + i / R] = mkcf(src.load(g0 + 2L * i), src.load(g0 + 2L * i + 1));
     };
@@ -522,6 +552,22 @@ __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict_
         __syncthreads();
         if (interior(tile)) commit(); else stage_direct(tile);
         __syncthreads();
+        // The input samples of this tile that do NOT come by as the real part of one of its outputs (tested where they are
+        // stored, below): the pairs in front of the first real part and behind the last one — a few dozen, one wave, here,
+        // where next to nothing is live in registers.  (Scalar branch, uniform trip counts: bad_any stays a wave mask.)
+        if (__builtin_amdgcn_readfirstlane(t >> 6) == 0) {
+            const int hh = (L / 2 - par - 1) / 2;        // real parts come from the pairs [hh, NP + hh]
+            for (int b = 0; b <= hh; b += 64) {
+                const int n = b + t < hh ? b + t : hh;   // (clamped lanes re-test pair hh)
+                const cf v = lds[(n % R) * rstride + n / R];
+                hil_acc(bad_any, v.x); hil_acc(bad_any, v.y);
+            }
+            for (int b = NP + hh; b < np; b += 64) {
+                const int n = b + t < np ? b + t : np - 1;
+                const cf v = lds[(n % R) * rstride + n / R];
+                hil_acc(bad_any, v.x); hil_acc(bad_any, v.y);
+            }
+        }
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
 
         cf acc[R], w[R];
@@ -553,12 +599,29 @@ __global__ __launch_bounds__(NT) void k_hilbert(VSrc<float> src, cf* __restrict_
 #pragma unroll
         for (int c = 0; c < 2 * R; c++) lds_o[t * (2 * R + 1) + c] = res[c];
         __syncthreads();
+        cf vo[2 * R];
 #pragma unroll
         for (int c = 0; c < 2 * R; c++) {
             const int i = c * NT + t;
-            if (m0 + i < n_out) out[m0 + i] = lds_o[(i / (2 * R)) * (2 * R + 1) + i % (2 * R)];
+            vo[c] = lds_o[(i / (2 * R)) * (2 * R + 1) + i % (2 * R)];
+        }
+#pragma unroll
+        for (int c = 0; c < 2 * R; c++) {
+            hil_acc(bad_any, vo[c].x);                   // the real part IS an input sample (hilbert.rs:115)
+            if (m0 + c * NT + t < n_out) out[m0 + c * NT + t] = vo[c];
         }
     }
+    if (wgflags && bad_any != 0 && (threadIdx.x & 63) == 0) wgflags[blockIdx.x] = 1;
+}
+// (force: outputs k_hilbert left finite are the reference's NaN too — 0 * NaN on the transformer's zero taps)
+__global__ __launch_bounds__(256) void k_hilbert_repair(NanFixCtx nfx, int* __restrict__ wgflags) {
+    (void)nfx;
+    if (__hip_atomic_load(wgflags + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // (workgroup-uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+    nf_repair<float, cf>((nf_ctx_ptr)__builtin_amdgcn_kernarg_segment_ptr(), true);
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) wgflags[blockIdx.x] = 0;
 }
 
 // hq = device [Q] (Q = taps per phase padded to a multiple of 8); returns false when the shape is
@@ -576,11 +639,17 @@ bool launch_hilbert_skip(int L, int par, int Q, const float* hq, VSrc<float> src
     long per_cu = (long)(160 * 1024) / (long)smem;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
-    const long cap = (long)device_cu_count() * per_cu;
+    const long cap = std::min<long>((long)device_cu_count() * per_cu, HILBERT_MAX_GRID);
     const long grid = ntiles < cap ? ntiles : cap;
-    (void)fx;                                           // (see k_hilbert)
-    hipLaunchKernelGGL((k_hilbert<NT>), dim3((unsigned)grid), dim3(NT), smem, s, src, out, n_out, L, par, Q, np, rs, hq);
+    int* flags = fx.rev ? fx.wgflags : nullptr;
+    hipLaunchKernelGGL((k_hilbert<NT>), dim3((unsigned)grid), dim3(NT), smem, s, src, out, n_out, L, par, Q, np, rs, hq, flags);
     RR_HIP(hipGetLastError());
+    if (flags) {
+        // (nan_fix.hpp: tile k = blockIdx.x + j gridDim.x owns the outputs [k 2 NT R, (k + 1) 2 NT R); same grid as above)
+        const NanFixCtx nfx = nanfix_ctx(fx, src, out, (long)NT * 2 * R, 1, n_out, ntiles, 1);
+        hipLaunchKernelGGL(k_hilbert_repair, dim3((unsigned)grid), dim3(256), 0, s, nfx, flags);
+        RR_HIP(hipGetLastError());
+    }
     return true;
 }
 

@@ -25,6 +25,7 @@ struct NanFix {                    // what a block hands a launcher
     const void* rev = nullptr;     // reversed taps (cf for CC / FC, float for FF / HILBERT); nullptr: no repair (FftFilter)
     int L = 0, d = 1;
     int kind = NANFIX_CC;
+    int* wgflags = nullptr;        // k_hilbert only: one zeroed word per workgroup (the verdict leaves the kernel; k_hilbert_repair reads it)
 };
 // What the repair needs, built by the launcher and passed as the kernel's FIRST argument.  The kernel body never touches it:
 // these kernels run at their register limits, and a value kept alive for the repair (or merely copied somewhere at kernel
