@@ -865,7 +865,12 @@ def dropin_host_windows(kind, registered, seconds=1.5):
     read_buf()/write_buf() windows of the reference's rings; `registered` = the ring mappings page-locked once with
     rr_host_register.  -> Msamples/s (input samples of the first block, wall clock incl. PCIe)"""
     rng = np.random.default_rng(7)
-    if kind == "fftfilter":
+    if kind == "copy":          # the path's own ceiling: a block that only moves the window (x * 1.0), same bytes each way
+        blk = rr.MultiplyConst(1.0)
+        n_in = 4_096_000 // 4
+        x = rng.uniform(-1, 1, n_in).astype(np.float32)
+        mult = 1
+    elif kind == "fftfilter":
         taps = rr.low_pass_complex(10e6, 1e6, 60e3)
         blk = rr.FftFilter(taps)
         n_in = 4_096_000 // 8
@@ -936,6 +941,13 @@ def devgraph_ref_rings(fused, seconds=1.5):
 
 def dropin_report():
     out = {}
+    # the ceiling of the path itself: 4,096,000 bytes down and 4,096,000 up per call through a kernel that does nothing else
+    cps = dropin_host_windows("copy", True) * 1e6 / (4_096_000 // 4)           # calls per second
+    out["dropin_ceiling"] = {
+        "what": "rr_block_work on a block that only copies (MultiplyConst(1.0), f32): 4,096,000-byte registered HOST windows, "
+                "in place over PCIe both ways, one call at a time (launch + completion wait included)",
+        "us_per_call": round(1e6 / cps, 1), "gbs_each_way": round(4_096_000 * cps / 1e9, 2),
+        "pcie_gen5_x16_gbs_each_way_spec": 63.0}
     for kind in ("fftfilter", "rtl_fm"):
         out[f"dropin_{kind}"] = {
             "what": ("rr_block_work, FftFilter 401 taps" if kind == "fftfilter" else

@@ -179,6 +179,8 @@ int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, s
         if (out_windows() == 1) RR_HIP(hipMemcpyAsync(out, st_out.p, *produced * out_es, hipMemcpyDeviceToHost, stream));
         else RR_HIP(hipMemcpy2DAsync(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, out_windows(), hipMemcpyDeviceToHost, stream));
     }
+    // (polling an event from the calling thread instead was measured and changes nothing: 154 -> 158 us per reference-sized
+    //  window; the call sits on the link — tools/micro/pcie_inplace.hip: a kernel moves 4,096,000 bytes each way in 128-145 us)
     RR_HIP(hipStreamSynchronize(stream));
     return st;
 }
@@ -351,7 +353,7 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     } else if (allow_fft && fits && !force_direct && (force_fft || wins || poly || prune)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
-        fftk.reset(new FftFilter(ct.data(), ntaps));
+        fftk.reset(new FftFilter(ct.data(), ntaps, false, 14, false, 0, deci > 1));
         if (deci > 1 && fftk->log2f >= 13 && !fftk->nsub) fftk.reset();   // (RR_FFT_NO_SPLIT measurement runs)
         if (fftk) { fftk->nanfix = nanfix(); fftk->nanfix.d = 1; }        // (fftk->filter is the full-rate form)
     }
@@ -661,8 +663,10 @@ int HilbertFir::work_dev(const void* in, size_t in_len, void* out, size_t out_ca
         // stays at 128 MB whatever the window.
         const size_t CH = (size_t)1 << 24;
         // (the FirFilter stage produces floor((len - L + 1) / d) outputs, fir.rs:503-510: k outputs take k d + L - 1 samples)
-        const size_t per = std::max<size_t>(1, (CH - L) / d);
-        analytic.reserve(std::min(CH, out_n * d + L - 1) + 8);
+        // (CH <= L, or d > CH - L: one output per chunk; the buffer holds what a chunk really takes — ADVICE r4: `CH - L`
+        //  wrapped around and a chunk of per d + L - 1 > CH samples overran a buffer of CH)
+        const size_t per = CH > L ? std::max<size_t>(1, (CH - L) / d) : 1;
+        analytic.reserve(std::min(per, out_n) * d + L - 1 + 8);
         for (size_t m0 = 0; m0 < out_n; m0 += per) {
             const size_t m1 = std::min(out_n, m0 + per), k0 = m0 * d, na = (m1 - m0) * d + L - 1;
             VSrc<float> sa = src;
@@ -749,8 +753,8 @@ int FirF32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     const bool small_direct = prune && !use_prune && (!fftk || (L <= 320 && fir_direct_has_tile(pl, sizeof(float), sizeof(float))));
     if (wide) {
         // outputs [m0, m1) take samples [m0 d, m1 d + L - 1) (fir.rs:503-510); chunks keep the work buffers at 128 + 128 / d MB
-        const size_t out_n = n / d, CH = (size_t)1 << 24, per = std::max<size_t>(1, (CH - L) / d);
-        wide_in.reserve(std::min(CH, out_n * d + L - 1) + 8);
+        const size_t out_n = n / d, CH = (size_t)1 << 24, per = CH > L ? std::max<size_t>(1, (CH - L) / d) : 1;   // (see HilbertFir)
+        wide_in.reserve(std::min(per, out_n) * d + L - 1 + 8);
         wide_out.reserve(std::min(per, out_n) + 8);
         for (size_t m0 = 0; m0 < out_n; m0 += per) {
             const size_t m1 = std::min(out_n, m0 + per), na = (m1 - m0) * d + L - 1;
@@ -911,7 +915,7 @@ bool PolyTables::build(const rr_c32* taps, size_t C, size_t L, size_t D, bool mu
     return true;
 }
 
-FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int max_log2f, bool real, size_t front_)
+FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int max_log2f, bool real, size_t front_, bool tiles_only)
     : Block(front_ ? "FirFilter>FftFilter" : "FftFilter", real ? 4 : 8, real ? 4 : 8), real_stream(real), front(front_) {
     if (ntaps == 0) throw Error("FftFilter: empty taps");            // fft_filter.rs:146
     if (front >= ntaps || (front && real)) throw Error("FftFilter: bad front-filter length");
@@ -948,7 +952,7 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
     // Towards 16383 taps the largest tile is all overlap (16385 - L samples per 16384-point tile: 16383 taps = 2 samples,
     // tools/misc_cliff_probe.py: 1795 ms per 5e7 samples against 3.7 ms for 16385 taps on the any-size frames).  The frames
     // cost ~7.4 units of the tile model: from 15293 taps on they are cheaper.
-    if (log2f == 14 && !real && !for_chain && max_log2f >= 14 && 7900.0 / (double)(16385 - L) + 0.17 > 7.4) log2f = 15;
+    if (log2f == 14 && !real && !for_chain && !tiles_only && max_log2f >= 14 && 7900.0 / (double)(16385 - L) + 0.17 > 7.4) log2f = 15;
     if (const int v = build_opts().fft_log2f) {            // rr_build_opts: force a tile size
         if (v >= 10 && v <= max_log2f && ((size_t)1 << v) >= L + 1) log2f = v;
     }

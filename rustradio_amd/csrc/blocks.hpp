@@ -239,8 +239,10 @@ struct FftFilter : Block {
     size_t front = 0, hist = 0;       // hist = L - 1 - front: history samples carried in `prefix`
     DevBuf<cf> d_t1, d_t2, d_zhead;   // front > 0: caller-order taps of the two stages, z[0 .. L2 - 1 + G]
     size_t emitted = 0;               // outputs emitted so far (the head fix applies while it is 0)
+    // tiles_only: never the any-size frames below 16384 taps (a decimating FirFilter stores every d-th sample of the TILES;
+    // the frames have no such store, and the block would fall to the one-thread-per-output direct form: ADVICE r4)
     FftFilter(const rr_c32* taps, size_t ntaps, bool for_chain = false, int max_log2f = 14, bool real_stream = false,
-              size_t front = 0);
+              size_t front = 0, bool tiles_only = false);
     // t1 (*) t2 in f64, rounded once
     static std::vector<rr_c32> composite(const rr_c32* t1, size_t n1, const rr_c32* t2, size_t n2);
     void set_stage_taps(const rr_c32* t1, size_t n1, const rr_c32* t2, size_t n2);

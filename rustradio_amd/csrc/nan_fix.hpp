@@ -69,7 +69,10 @@ __device__ __forceinline__ void nf_mark(bool bad) {
 }
 #endif
 
-// out[m] in the reference's order (see the header): T = stream element (cf / float), OUT = cf / float
+// out[m] in the reference's order (see the header): T = stream element (cf / float), OUT = cf / float.
+// A fold that has become NaN stays NaN whatever follows (NaN + x = NaN in every component it has reached), so it stops
+// there: a window of NaNs costs one step per output instead of L (a long run of NaNs through a 16383-tap filter
+// made the repair — one thread per output, L dependent global loads each — orders of magnitude slower than the filter).
 template <class T, class OUT>
 __device__ __forceinline__ OUT nf_direct(const VSrc<T>& src, const void* revp, int L, int d, int kind, long m) {
     const long v0 = m * d;
@@ -77,7 +80,7 @@ __device__ __forceinline__ OUT nf_direct(const VSrc<T>& src, const void* revp, i
         const float* rev = static_cast<const float*>(revp);
         float s = 0.0f;
 #pragma unroll 1
-        for (int j = 0; j < L; j++) s = add_rn(s, mul_rn(rev[j], src.load(v0 + j)));
+        for (int j = 0; j < L; j++) { s = add_rn(s, mul_rn(rev[j], src.load(v0 + j))); if (__builtin_expect(s != s, 0)) break; }
         return s;
     } else if constexpr (std::is_same<T, cf>::value) {         // num-complex: (ar xr - ai xi, ar xi + ai xr)
         const cf* rev = static_cast<const cf*>(revp);
@@ -87,13 +90,14 @@ __device__ __forceinline__ OUT nf_direct(const VSrc<T>& src, const void* revp, i
             const cf a = rev[j], x = src.load(v0 + j);
             acc.x = add_rn(acc.x, sub_rn(mul_rn(a.x, x.x), mul_rn(a.y, x.y)));
             acc.y = add_rn(acc.y, add_rn(mul_rn(a.x, x.y), mul_rn(a.y, x.x)));
+            if (__builtin_expect(acc.x != acc.x && acc.y != acc.y, 0)) break;
         }
         return acc;
     } else if (kind == NANFIX_HILBERT) {                       // hilbert.rs:113-116
         const float* rev = static_cast<const float*>(revp);
         float s = 0.0f;
 #pragma unroll 1
-        for (int j = 0; j < L; j++) s = add_rn(s, mul_rn(rev[j], src.load(v0 + j)));
+        for (int j = 0; j < L; j++) { s = add_rn(s, mul_rn(rev[j], src.load(v0 + j))); if (__builtin_expect(s != s, 0)) break; }
         return mkcf(src.load(v0 + L / 2), s);
     } else {                                                   // Float stream, Complex taps (Hilbert -> FirFilter composite)
         const cf* rev = static_cast<const cf*>(revp);
@@ -103,6 +107,7 @@ __device__ __forceinline__ OUT nf_direct(const VSrc<T>& src, const void* revp, i
             const cf a = rev[j]; const float x = src.load(v0 + j);
             acc.x = add_rn(acc.x, mul_rn(a.x, x));
             acc.y = add_rn(acc.y, mul_rn(a.y, x));
+            if (__builtin_expect(acc.x != acc.x && acc.y != acc.y, 0)) break;
         }
         return acc;
     }

@@ -541,3 +541,20 @@ def test_nonfinite_samples_in_the_fused_fm_chains(rr, kind):
         ro_ok = np.where(np.isfinite(ro.real) & np.isfinite(ro.imag), ro, 1.0)
         par = angle_parity(np.where(ok, got, 0.0), np.where(ok, np.nan_to_num(want), 0.0), ro_ok)
         assert par["used"] <= 1.0, (kind, par)
+
+
+def test_a_window_of_nans_through_a_long_filter_is_not_a_throughput_collapse(rr):
+    """the non-finite repair (csrc/nan_fix.hpp) recomputes every non-finite output with the reference's own fold, one
+    thread per output; a fold that has become NaN stops (it stays NaN), so a window of NaNs through a 16383-tap FirFilter costs
+    about what a clean window does — not L dependent loads per output."""
+    import time
+    taps = (rnd_c(16383, 3) / 4000).astype(np.complex64)
+    n = 400_000
+    clean = rnd_c(n, 4)
+    bad = np.full(n, np.nan + 0j, np.complex64)
+    blk = rr.FirFilter(taps)
+    blk.work(clean, n)                                       # (first call: tables, allocations)
+    t0 = time.perf_counter(); st, c, p, need, y0 = blk.work(clean, n); t_clean = time.perf_counter() - t0
+    t0 = time.perf_counter(); st, c, p, need, y1 = blk.work(bad, n); t_bad = time.perf_counter() - t0
+    assert p == len(y1) > 300_000 and np.all(np.isnan(y1.real)) and np.all(np.isnan(y1.imag))
+    assert t_bad < 20 * t_clean + 0.05, (t_clean, t_bad)
