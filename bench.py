@@ -845,6 +845,28 @@ def measured_traffic(workload):
     return e.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE (separate passes), kernel sources {e['sources_sha16']}"
 
 
+def parity_report():
+    """the line's `parity` object: the tolerance the parity tests hold the chains to, and how much of it is used — from
+    profiles/parity_allowance.json (tests/parity_allowance.py on the GPU box, against the oracle), valid for the kernel
+    sources it was measured on"""
+    base = {"tol": 1e-5, "per_block": "max|y - y_ref| / max|y_ref| <= tol for every block alone (tests/test_gpu_parity.py)",
+            "chain_bound": "propagated"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "parity_allowance.json")) as f:
+            d = json.load(f)
+    except Exception:
+        return dict(base, above_plain_share=None, note="profiles/parity_allowance.json missing")
+    if d.get("kernel_sources") != _sources_hash():
+        return dict(base, above_plain_share=None,
+                    note=f"stale: measured at kernel sources {d.get('kernel_sources')}, tree is {_sources_hash()} (python -m tests.parity_allowance)")
+    sm = d["summary"]
+    return dict(base, chain_bound_formula=d["chain_bound"], used_max=sm["used_max"],
+                above_plain_share={"cfg3_centred_station": sm["above_plain_share_cfg3_centred"],
+                                   "cfg3_station_150kHz_off_centre": sm["above_plain_share_cfg3_off_centre"],
+                                   "cfg4_worst_of_32_channels": sm["above_plain_share_cfg4_worst_channel"]},
+                kernel_sources=d["kernel_sources"], source="profiles/parity_allowance.json")
+
+
 # ---- the drop-in path (others.dropin_*): rr_block_work on HOST windows, as the Rust shim calls it -------------------
 _RINGS = {}
 
@@ -947,13 +969,26 @@ def dropin_report():
         "what": "rr_block_work on a block that only copies (MultiplyConst(1.0), f32): 4,096,000-byte registered HOST windows, "
                 "in place over PCIe both ways, one call at a time (launch + completion wait included)",
         "us_per_call": round(1e6 / cps, 1), "gbs_each_way": round(4_096_000 * cps / 1e9, 2),
-        "pcie_gen5_x16_gbs_each_way_spec": 63.0}
+        "pcie_gen5_x16_gbs_each_way_spec": 63.0,
+        "link_note": "a bare copy kernel moves such a window at 55 GB/s one way and at 32 GB/s EACH way when both directions run at "
+                     "once (64 GB/s combined: profiles/r05_pcie_inplace.txt, tools/micro/pcie_inplace.hip) — 128 us per window pair "
+                     "before any launch or wait"}
+    LINK_COMBINED_GBS = 64.2                       # profiles/r05_pcie_inplace.txt: host -> host, both ways at once
     for kind in ("fftfilter", "rtl_fm"):
+        ms_reg = dropin_host_windows(kind, True)
+        n_in = 4_096_000 // 8 if kind == "fftfilter" else 4_096_000 // 2          # input samples per call
+        b_in, b_out = 4_096_000, (4_096_000 if kind == "fftfilter" else 4_096_000 // 2 // 6 * 4)
+        us_call = n_in / ms_reg
         out[f"dropin_{kind}"] = {
             "what": ("rr_block_work, FftFilter 401 taps" if kind == "fftfilter" else
                      "rr_block_work, RtlSdrDecode>FftFilter(463)>RationalResampler(1:6)>QuadratureDemod fused, u8 in")
                     + ", 4,096,000-byte HOST windows in and out, wall clock incl. PCIe",
-            "msamples_per_s_registered_rings": dropin_host_windows(kind, True),
+            "msamples_per_s_registered_rings": ms_reg,
+            "us_per_call": round(us_call, 1),
+            "bytes_per_call_in_out": [b_in, b_out],
+            "link_floor_us": round((b_in + b_out) / LINK_COMBINED_GBS / 1e3, 1),
+            "frac_of_link_floor": round((b_in + b_out) / LINK_COMBINED_GBS / 1e3 / us_call, 3),
+            "frac_of_copy_block": round((1e6 / cps) * (b_in + b_out) / 8_192_000 / us_call, 3),
             "msamples_per_s_pageable": dropin_host_windows(kind, False)}
     out["devgraph_ref_rings"] = {
         "what": "configs[2] graph over 4,096,000-byte HBM rings (rr_dstream), registered host source -> NullSink, Python driver",
@@ -1216,7 +1251,9 @@ def main():
                 k = 5                              # (a step is 1.25e7 sequential rotator phases: ~33 ms on the host generator)
             fo = make_fan(wo) if streamed else None
             # (a replay-rotator step is bound by one sequential chain, not by clocks: no settle phase for it)
-            u, t, km, ln, du, sm = run_timed(wo, k, 2, dist, stream, fo,
+            # (warm-up 6 for a replay rotator: the default starts on the device chain and hands a block whose calls outrun it —
+            #  these back-to-back steps do — to the host generator after three such calls; the timed steps are the sustained state)
+            u, t, km, ln, du, sm = run_timed(wo, k, 6 if getattr(wo, "rotator", None) == "replay" else 2, dist, stream, fo,
                                              settle_ms=0.0 if getattr(wo, "rotator", None) == "replay" else args.settle_ms / 2)
             ua, ta = multi.aggregate(dist, u, t, dev)
             avg_s = km / max(ln, 1) * 1e-3
@@ -1312,6 +1349,7 @@ def main():
                                              "BASELINE.json configs[3], the multi-GPU configuration (32 channels per GPU)"
                                              if wname == "fm_multi" else "--workload")},
             "roofline": roof,
+            "parity": parity_report(),
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),
         }
         if world > 1:

@@ -37,6 +37,8 @@ def test_single_gpu_line():
     assert "ALGORITHMIC bytes" in r["frac_counts"]
     assert "configs[1]" in d["config"]["workload"]
     assert d["config"]["settle_steps"] >= 40 and d["ms_per_step_from_idle"] > 0 and d["value_from_idle"] > 0
+    # the tolerance the parity tests hold the chains to travels with the line
+    assert d["parity"]["tol"] == 1e-5 and d["parity"]["chain_bound"] == "propagated" and "above_plain_share" in d["parity"]
 
 
 def test_default_line_carries_the_metric_chain_and_the_north_star_target():
