@@ -147,7 +147,7 @@ class Workload:
 chan_taps = multi.channel_taps
 CHAIN_BOUND_NOTE = ("neither roofline binds this kernel: fed RTL-SDR bytes (a third of the input traffic) it is only 12 % faster, its VALU is 37 % "
                     "busy and the package draws 1182 W of 1400 at full clock; three waves per SIMD are bound by instruction ISSUE (giving its "
-                    "waiting waves redundant work made it 11 % slower, DESIGN.md 4.1d round 4).  Both fractions are reported: "
+                    "waiting waves redundant work made it 11 % slower, profiles/TUNING_LOG.md 4.1d round 4).  Both fractions are reported: "
                     "dominant_kernel_hbm_frac and dominant_kernel_executed_fp32_frac")
 
 
@@ -1369,7 +1369,7 @@ def main():
         # pair; `value` stays configs[1] (the configuration the metric is quoted on).  Both chains, with their own roofline
         # and their own CPU leg, as first-class objects of the line:
         # The 1 -> 8 curve has never been measured (no node with more than one GPU has run this code): what stands in for it is
-        # a PREDICTION, regenerated on every run from THIS run's measured configs[3] step (DESIGN.md §6 prints it
+        # a PREDICTION, regenerated on every run from THIS run's measured configs[3] step (DESIGN.md §7 prints it
         # through tools/fanout_table.py).  No scaling claim is made anywhere.
         fm = others.get("fm_multi")
         if world == 1 and fm:

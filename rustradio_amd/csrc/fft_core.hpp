@@ -122,7 +122,7 @@ RR_HD cf from_reg(creg a) { return a; }
 #endif
 
 // RR_LDS_Q = volatile keeps hipcc from fusing neighbouring 8-byte LDS accesses into
-// ds_read2_b64 / ds_write2_b64 (a tuning experiment).
+// ds_read2_b64 / ds_write2_b64 (a tuning experiment; see profiles/TUNING_LOG.md).
 #ifndef RR_LDS_Q
 #define RR_LDS_Q
 #endif
@@ -269,7 +269,7 @@ template <int LOG2F> RR_HD int bin_of_pos(int pos) {
 }
 
 // LDS padding: one 8-byte slot per 16 elements (keeps stride-P and stride-R accesses
-// conflict-free for ds_read_b64/ds_write_b64).
+// conflict-free for ds_read_b64/ds_write_b64; see profiles/TUNING_LOG.md).
 RR_HD int lds_pad(int a) { return a + (a >> 4); }
 constexpr int lds_elems(int F) { return F + (F >> 4); }
 
@@ -313,7 +313,7 @@ template <int LOG2F, int I> RR_HD void inv_pass(creg* v, const creg* twl) {
 // offsets so that every ds_read/ds_write uses base VGPR + immediate:
 //   lds_pad(pos(t + T u, n)) == lds_base<I>(t) + lds_off<I>(u, n)
 // (holds because every twiddled pass has U == 1 and every multi-group pass has P == 1,
-//  and n*P never carries into bit 4 together with the group's low part).
+//  and n*P never carries into bit 4 together with the group's low part; see profiles/TUNING_LOG.md).
 template <int LOG2F, int I> RR_HD int lds_base(int t) {
     using G = PassGeom<LOG2F, I>;
     static_assert(G::U == 1 || G::P == 1, "plan shape");

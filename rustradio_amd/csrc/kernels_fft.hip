@@ -50,7 +50,7 @@ namespace rr {
 //          thread's 16 H values stay in VGPRs for the whole kernel; 2 waves/SIMD.
 //   VAR 3 (F >= 8192, 512/1024 threads, <= 128 VGPRs): twiddles and H are re-read per tile
 //          from the L1/L2-resident tables.
-// Measured alternatives that lost and were removed (DESIGN.md "FftFilter tuning log"):
+// Measured alternatives that lost and were removed (profiles/TUNING_LOG.md "FftFilter tuning log"):
 // H/twiddles re-read from L1 at 3 waves/SIMD (2.1x slower: TA-bound), H in LDS shared by
 // several tiles per workgroup at 3-4 waves/SIMD (1.3-1.7x slower: LDS-bound), register
 // prefetch of the next tile (no gain), next tile fetched by LDS-DMA (global_load_lds_dwordx4,

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NT, 4) void k_fir(NanFixCtx nfx, VSrc<T> src, OutT*
     // The outputs of a tile are held in registers across the loop back-edge and stored only AFTER the next
     // tile's input has been committed: vmcnt counts loads and stores in one in-order queue, so a store
     // issued between a tile's fetch and its commit makes the commit wait for the store's completion as
-    // well (the compiler emits vmcnt(0)) — measured 0.88 -> see DESIGN.md for the 127-tap d = 1 filter.
+    // well (the compiler emits vmcnt(0)) — measured 0.88 -> see profiles/TUNING_LOG.md for the 127-tap d = 1 filter.
     OutT hold[R / S];
     long hold_m0 = -1;
     auto flush = [&]() {
@@ -336,7 +336,7 @@ static void launch_fir_any(const FirPlan& pl, const TapT* tp, const TapT* rev, V
             const long staged_c = ((long)gc.np * pl.d + cfgs[c].NT - 1) / cfgs[c].NT;
             if (staged_c > FIR_MAXPRE) cst *= 2.0;                          // staging not pipelined
             // the R = 8, S = 1 builds with the long register pipeline spill ~50 B for Complex data x Complex taps, and
-            // every scratch access waits for the prefetched tile: prefer a split shape there (measured
+            // every scratch access waits for the prefetched tile (profiles/TUNING_LOG.md): prefer a split shape there (measured
             // at 127 taps /2: 0.78 vs 0.81 ms; with real taps the 12 B spill still wins, 0.46 vs 0.56 ms)
             if (cfgs[c].R == 8 && cfgs[c].S == 1 && staged_c > 10 && sizeof(T) == 8 && sizeof(TapT) == 8) cst *= 1.5;
             if (pick < 0 || cst < best) { pick = c; g = gc; best = cst; }

@@ -58,7 +58,7 @@ struct PolyPart {
     int start[POLY_PART_MAX + 1];
 };
 
-// tuning: phases loaded per batch and waves per SIMD of the single-chain kernel (measured on MI355X)
+// tuning: phases loaded per batch and waves per SIMD of the single-chain kernel (measured on MI355X, profiles/TUNING_LOG.md)
 #ifndef RR_POLY_NB
 #define RR_POLY_NB 3
 #endif

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""DESIGN.md §6's fan-out prediction table, regenerated from a bench.py line (its `multi_gpu_prediction` object, which
+"""DESIGN.md §7's fan-out prediction table, regenerated from a bench.py line (its `multi_gpu_prediction` object, which
 bench.py computes from that run's MEASURED configs[3] step through multi.predict_fanout).
 
     python bench.py > line.json ; python tools/fanout_table.py line.json        (or a BENCH_rNN.json of the driver)"""

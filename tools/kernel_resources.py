@@ -8,7 +8,7 @@
 --diff OLD  : print only the kernels whose figures differ from OLD/<name>.s (a build of another revision)
 
 A tile kernel that starts to spill is 1.5-2x slower (every scratch access waits on the whole in-order vmcnt queue,
-DESIGN.md §4.1), so every change to a kernel is checked with this before it goes to the GPU.
+profiles/TUNING_LOG.md §4.1), so every change to a kernel is checked with this before it goes to the GPU.
 """
 from __future__ import annotations
 
