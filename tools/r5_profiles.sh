@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the round's profile set -> gpurun_out/prof_<tag>/ (copied into profiles/ by tools/r2_collect.py <tag> afterwards).
+# GPU box: the round's profile set -> gpurun_out/prof_<tag>/ (copied into profiles/ by tools/r5_collect.py <tag> afterwards).
 #   per workload: rocprofv3 --kernel-trace --stats summary + the bench line of the same run + the per-launch durations of the
 #                 dominant kernel in bench.py's last three passes (tools/prof_launches.py: roofline.frac from profiles/ alone),
 #                 FETCH_SIZE / WRITE_SIZE in separate --pmc passes (-> profiles/traffic.json, stamped with the source hash);
