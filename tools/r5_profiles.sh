@@ -12,11 +12,7 @@ PAIRS=${@:-"fftfilter:k_fftfilt_os fm_chain:k_fm_chain_poly fm_multi:k_fm_multi_
 K=20
 for pair in $PAIRS; do
   w=${pair%%:*}; k=${pair##*:}
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w" -o p -- python3 bench.py --workload $w --steps $K --warmup 3 --no-others --no-cpu --no-dropin > "$OUT/bench_$w.json" 2> "$OUT/$w.log"
-  f=$(ls $OUT/$w/*kernel_stats.csv 2>/dev/null | head -1); t=$(ls $OUT/$w/*kernel_trace.csv 2>/dev/null | head -1)
-  alg=$(python3 -c "import json,sys; print(json.loads(open('$OUT/bench_$w.json').read().strip().splitlines()[-1])['roofline']['alg_bytes_per_launch'])" 2>/dev/null)
-  { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $w --steps $K --warmup 3 --no-others --no-cpu --no-dropin"; python3 tools/prof_summary.py "$f" 8; echo; python3 tools/prof_launches.py "$t" "$k" $K $alg; echo; echo "# bench line of the same run:"; tail -1 "$OUT/bench_$w.json"; } > "$OUT/${w}_kernel_stats.txt"
-  rm -rf "$OUT/$w"
+  # (counter passes first: the traced run below then reports roofline.traffic from the fresh profiles/traffic.json)
   T=$OUT/traffic_$w; mkdir -p $T; i=0
   for c in FETCH_SIZE WRITE_SIZE; do
     i=$((i+1))
@@ -25,6 +21,11 @@ for pair in $PAIRS; do
   python3 tools/pmc_summary.py "$T" rr:: > "$OUT/${w}_traffic_pmc.txt"
   python3 tools/pmc_traffic.py "$OUT/${w}_traffic_pmc.txt" $w "$k"
   rm -rf $T
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w" -o p -- python3 bench.py --workload $w --steps $K --warmup 3 --no-others --no-cpu --no-dropin > "$OUT/bench_$w.json" 2> "$OUT/$w.log"
+  f=$(ls $OUT/$w/*kernel_stats.csv 2>/dev/null | head -1); t=$(ls $OUT/$w/*kernel_trace.csv 2>/dev/null | head -1)
+  alg=$(python3 -c "import json,sys; print(json.loads(open('$OUT/bench_$w.json').read().strip().splitlines()[-1])['roofline']['alg_bytes_per_launch'])" 2>/dev/null)
+  { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $w --steps $K --warmup 3 --no-others --no-cpu --no-dropin"; python3 tools/prof_summary.py "$f" 8; echo; python3 tools/prof_launches.py "$t" "$k" $K $alg; echo; echo "# bench line of the same run:"; tail -1 "$OUT/bench_$w.json"; } > "$OUT/${w}_kernel_stats.txt"
+  rm -rf "$OUT/$w"
   head -3 "$OUT/${w}_kernel_stats.txt" | tail -1
 done
 cp profiles/traffic.json $OUT/traffic.json
