@@ -935,7 +935,8 @@ def devgraph_ref_rings(fused, seconds=1.5):
     fs = 2.4e6
     taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
     rng = np.random.default_rng(9)
-    x = (rng.uniform(-1, 1, 512_000) + 1j * rng.uniform(-1, 1, 512_000)).astype(np.complex64)
+    x = rr.host_ring(4_096_000).view(np.complex64)         # a page-aligned source ring, as the shims' (copy_in reads it in place)
+    x[:] = (rng.uniform(-1, 1, 512_000) + 1j * rng.uniform(-1, 1, 512_000)).astype(np.complex64)
     rr.host_register(x)
     try:
         blocks = ([rr.FmChain(taps, 1, 6, 1.0, rr.ATAN2_EXACT)] if fused else

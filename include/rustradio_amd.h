@@ -308,7 +308,8 @@ int         rr_block_sync(rr_block *b);
  * (round 4): the kernels read the input window and write the output window over PCIe themselves, so the
  * window going down overlaps the one coming up on the full-duplex link — two DMA copies do not on this
  * pool (4,096,000-byte windows: FftFilter 193 -> 148 us per call, the fused RTL-SDR chain 175 -> 109);
- * rr_dstream_copy_in/out run as direct DMA instead of staged pageable copies (35 -> 40 GB/s).  Windows
+ * rr_dstream_copy_in/out on such windows run as copy KERNELS on the range's device view (55 GB/s either way; hipMemcpyAsync
+ * gets 16-18 GB/s up and 50 down out of a registered range here: profiles/r05_pcie_inplace.txt).  Windows
  * that are not WHOLLY inside a range registered here (pageable memory, memory the caller page-locked by
  * other means) are staged through device memory as before.  Optional; unregister before the memory is
  * unmapped, and not while a work call on one of its windows is running.

@@ -201,6 +201,7 @@ void launch_carry(VSrc<cf> src, const CarryOut& c, hipStream_t s);
 void launch_carry(VSrcIQ8 src, const CarryOut& c, hipStream_t s);
 void launch_carry(VSrc<float> src, const CarryOut& c, hipStream_t s);
 void launch_f32_to_c32(const float* in, cf* out, long n, hipStream_t s);
+void launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t s);   // device <-> device view of registered host memory
 void launch_c32_re(const cf* in, float* out, long n, hipStream_t s);
 
 // ---- head fix of the fused FirFilter -> FftFilter blocks (stream start only, a few hundred samples) ----------------

@@ -201,6 +201,31 @@ void launch_carry(VSrc<float> src, const CarryOut& c, hipStream_t s) {
     if (c.n > 0) launch_vcopy_f32(src, c.v0, static_cast<float*>(c.dst), c.n, s);
 }
 
+// Plain byte copy between a device range and a page-locked host range seen through its device address (rr_dstream_copy_in /
+// _copy_out on windows of a ring registered with rr_host_register): a KERNEL moves a reference-sized window over PCIe at
+// 55 GB/s either way, hipMemcpyAsync from / to the same registered range at 16 / 50 (tools/micro/pcie_inplace.hip).  8 bytes
+// per lane where the alignment allows (16-byte reads of host memory measured slower: 41 GB/s), any alignment and length.
+template <class V>
+__global__ __launch_bounds__(256) void k_copy_v(const V* __restrict__ src, V* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)bytes;
+    if ((a & 7) == 0) {
+        const long n = (long)(bytes / 8);
+        hipLaunchKernelGGL(k_copy_v<unsigned long long>, dim3(grid_for(n, 256)), dim3(256), 0, s, static_cast<const unsigned long long*>(src),
+                           static_cast<unsigned long long*>(dst), n);
+    } else if ((a & 3) == 0) {
+        const long n = (long)(bytes / 4);
+        hipLaunchKernelGGL(k_copy_v<unsigned>, dim3(grid_for(n, 256)), dim3(256), 0, s, static_cast<const unsigned*>(src), static_cast<unsigned*>(dst), n);
+    } else {
+        hipLaunchKernelGGL(k_copy_v<unsigned char>, dim3(grid_for((long)bytes, 256)), dim3(256), 0, s, static_cast<const unsigned char*>(src),
+                           static_cast<unsigned char*>(dst), (long)bytes);
+    }
+    RR_HIP(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void k_f32_to_c32(const float* __restrict__ in, cf* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         out[i] = mkcf(in[i], 0.0f);

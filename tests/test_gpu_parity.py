@@ -1057,14 +1057,22 @@ def test_reregistered_addresses_keep_working(rr, aligned):
             rr.host_unregister(a); rr.host_unregister(b)
 
 
-def test_push_from_a_page_locked_window_is_done_on_return(rr):
+@pytest.mark.parametrize("aligned", [False, True])
+def test_push_from_a_page_locked_window_is_done_on_return(rr, aligned):
     """A source ring's window is consumed right after GpuUpload's copy_in and its writer overwrites it: out of a
-    page-locked (rr_host_register'd) ring the DMA is really asynchronous, so the call has to wait for it (round 4: the
-    thread-per-block runner saw the overwritten samples)."""
-    n = 64 << 20                                           # 256 MB: the DMA takes several ms, the overwrite microseconds
+    page-locked (rr_host_register'd) ring the copy is really asynchronous, so the call has to wait for it (round 4: the
+    thread-per-block runner saw the overwritten samples).  aligned = a page-aligned ring (rr.host_ring, what the shims
+    register): copy_in / copy_out run as copy KERNELS on the ring's device view (round 5); otherwise as DMA."""
+    from harness import _arena
+    n = (32 << 20) if aligned else (64 << 20)              # 128 / 256 MB: the copy takes ms, the overwrite microseconds
     s = rr.DeviceStream(np.uint32, 4 * n)
-    x = np.arange(n, dtype=np.uint32)
-    rr.host_register(x)
+    # (aligned: the process-wide arena of tests/harness.py, registered once and never released — a fresh mapping registered
+    #  here could land on addresses an earlier test retired, and would then be staged like any other range)
+    x = _arena(rr, "out", 4 * n).view(np.uint32) if aligned else np.empty(n, np.uint32)
+    x[:] = np.arange(n, dtype=np.uint32)
+    if not aligned:
+        rr.host_register(x)
+    assert rr.host_window_in_place(x) == aligned
     try:
         for k in range(3):
             assert s.push(x) == n
@@ -1072,8 +1080,26 @@ def test_push_from_a_page_locked_window_is_done_on_return(rr):
             got = s.pop()
             assert np.array_equal(got, np.arange(n, dtype=np.uint32)), k
             x[:] = np.arange(n, dtype=np.uint32)
+        if aligned:                                        # copy_out INTO the registered ring, odd offsets and lengths (byte-wise path too)
+            y8 = x.view(np.uint8)
+            s8 = rr.DeviceStream(np.uint8, 1 << 20)
+            src = np.random.default_rng(1).integers(0, 256, 300_001, dtype=np.uint8)
+            assert s8.push(src) == len(src)
+            h = lib_pop_into(rr, s8, y8[3:3 + len(src)])
+            assert h == len(src) and np.array_equal(y8[3:3 + len(src)], src)
     finally:
-        rr.host_unregister(x)
+        if not aligned:
+            rr.host_unregister(x)
+
+
+def lib_pop_into(rr, stream, dst):
+    """rr_dstream_copy_out into a caller-owned host window + consume -> elements moved"""
+    import ctypes as C
+    n = min(stream.readable(), len(dst))
+    L = rr.lib()
+    assert L.rr_dstream_copy_out(stream._h, 0, dst.ctypes.data_as(C.c_void_p), n, C.c_void_p(0)) == 0
+    assert L.rr_dstream_consume(stream._h, n) == 0
+    return n
 
 
 # ---- FirFilter -> FftFilter fused into one convolution (the north star's "127-tap FIR + 1024-pt FftFilter chain") ----
