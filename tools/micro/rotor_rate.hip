@@ -23,6 +23,16 @@ __device__ __forceinline__ creg step6(creg z, creg st) {          // scalar form
     asm volatile("v_add_f32 %0, %1, %2" : "=v"(y) : "v"(c), "v"(d));
     creg r; r.x = x; r.y = y; return r;
 }
+// the three instructions of a step as ONE asm statement: the compiler puts no s_nop between them (it guards every
+// separately written packed instruction that reads the previous one's result with a wait state)
+__device__ __forceinline__ creg step3_fused(creg z, creg st) {
+    creg r, p, q;
+    asm volatile("v_pk_mul_f32 %1, %3, %4 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 %2, %3, %4 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+                 "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]"
+                 : "=v"(r), "=&v"(p), "=&v"(q) : "v"(z), "s"(st));
+    return r;
+}
 template <int MODE> __global__ void k(float2* out, float sx, float sy, long n) {
     if (MODE == 1) __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x != 0 && MODE != 3) return;                    // MODE 3: all 64 lanes walk (the same chain)
@@ -30,7 +40,7 @@ template <int MODE> __global__ void k(float2* out, float sx, float sy, long n) {
     creg z; z.x = 1.0f; z.y = 0.0f;
     for (long i = 0; i < n; i += 16) {
 #pragma unroll
-        for (int k2 = 0; k2 < 16; k2++) z = MODE == 2 ? step6(z, st) : step3(z, st);
+        for (int k2 = 0; k2 < 16; k2++) z = MODE == 2 ? step6(z, st) : MODE == 4 ? step3_fused(z, st) : step3(z, st);
     }
     if (threadIdx.x == 0) out[blockIdx.x] = make_float2(z.x, z.y);
 }
@@ -43,7 +53,8 @@ template <int MODE> static void run(const char* name, int blocks) {
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 0.99f, 0.1f, n);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
-    printf("%-52s %6.2f ns per step\n", name, ms * 1e6 / n);
+    float2 h; CK(hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost));
+    printf("%-52s %6.2f ns per step   (end phase %.9g %.9g)\n", name, ms * 1e6 / n, h.x, h.y);
     CK(hipFree(d));
 }
 int main() {
@@ -52,5 +63,6 @@ int main() {
     run<2>("6 scalar instructions", 1);
     run<3>("3 packed, all 64 lanes active", 1);
     run<0>("3 packed, 8 such waves on 8 CUs (independent chains)", 8);
+    run<4>("3 packed as ONE asm statement (no s_nop in between)", 1);
     return 0;
 }
