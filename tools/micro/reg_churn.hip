@@ -4,6 +4,10 @@
 //   mode 0: fresh mmap per round (addresses recycled)      mode 1: one mapping, registered / unregistered per round
 //   mode 2: one mapping, registered once                   mode 3: fresh mmap per round, never unmapped (addresses never recycled)
 //   mode 4: malloc from the HEAP per round (unaligned, the two arrays and their neighbours share pages), freed after each round
+//   mode 5: like 4 with glibc's default trimming AND malloc_trim(0) after the frees: the freed heap pages go back to the kernel
+//           (brk shrinks / MADV_DONTNEED), so the next round's arrays sit at the SAME virtual addresses on NEW physical pages —
+//           the page-locked -> released -> page-locked-again history the library's zero-copy admission rule excludes (round 5)
+//   mode 6: like 5, and a neighbour array that shares the first / last page stays allocated and is written by the host
 //   flags : hipHostRegister flags (0 default, 1 portable, 2 mapped, ...)
 //   [temps]   : 1 = like a numpy caller, every call builds its input in two large temporaries (calloc'ed f64 + f32 arrays,
 //               mmap'ed and unmapped again by the allocator) before copying it into the window with memcpy
@@ -32,6 +36,8 @@ int main(int argc, char** argv) {
     const unsigned pause_us = argc > 4 ? (unsigned)atoi(argv[4]) : 0;
     const int temps = argc > 5 ? atoi(argv[5]) : 0;
     if (mode == 4) { mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); }
+    if (mode >= 5) mallopt(M_MMAP_THRESHOLD, 1 << 30);          // heap (brk) arrays, default trim threshold
+    char* neighbour = nullptr;
     hipStream_t s; CK(hipStreamCreate(&s));
     unsigned lcg = 12345;
     auto rnd = [&] { lcg = lcg * 1664525u + 1013904223u; return lcg; };
@@ -44,8 +50,10 @@ int main(int argc, char** argv) {
     for (int r = 0; r < rounds; r++) {
         const size_t n = 50000 + rnd() % 550000, bytes = (n + 64) * 4;
         if (mode == 0 || mode == 3) { xin = map_fresh(bytes); yout = map_fresh(bytes); }
-        if (mode == 4) { xin = static_cast<float*>(malloc(bytes)); yout = static_cast<float*>(malloc(bytes)); memset(xin, 0, bytes); memset(yout, 0, bytes); }
+        if (mode >= 4) { xin = static_cast<float*>(malloc(bytes)); yout = static_cast<float*>(malloc(bytes)); memset(xin, 0, bytes); memset(yout, 0, bytes); }
+        if (mode == 6) { neighbour = static_cast<char*>(malloc(3000)); memset(neighbour, r, 3000); }
         if (mode != 2) { CK(hipHostRegister(xin, mode == 1 ? maxb : bytes, flags)); CK(hipHostRegister(yout, mode == 1 ? maxb : bytes, flags)); }
+        if (r < 3 && mode >= 4) printf("round %d: x at %p, y at %p\n", r, (void*)xin, (void*)yout);
         float *dx, *dy;
         CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&dx), xin, 0));
         CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&dy), yout, 0));
@@ -70,7 +78,9 @@ int main(int argc, char** argv) {
         }
         if (mode != 2) { CK(hipHostUnregister(xin)); CK(hipHostUnregister(yout)); }
         if (mode == 0) { munmap(xin, bytes); munmap(yout, bytes); }
-        if (mode == 4) { free(xin); free(yout); }
+        if (mode >= 4) { free(xin); free(yout); }
+        if (mode == 6) { neighbour[r % 3000] ^= 1; free(neighbour); }
+        if (mode >= 5) malloc_trim(0);
         if (pause_us) usleep(rnd() % pause_us);
     }
     printf("pause <= %u us, mode %d flags %u: %d rounds, %ld calls, %ld with mismatches\n", pause_us, mode, flags, rounds, calls, bad_calls);
