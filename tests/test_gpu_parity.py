@@ -1345,3 +1345,29 @@ def test_zero_copy_host_windows_equal_staged_windows(rr):
         assert la == lb, mk().name
         assert ya.shape == yb.shape and ya.shape[1] > 0, mk().name
         assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8)), mk().name
+
+
+def test_tag_rule_of_every_constructor(rr):
+    """rr_block_tag_rule: what the reference block(s) behind a handle do with tags (include/rustradio_amd.h) — FirFilter
+    `pos < n -> pos / deci` (fir.rs:536-545), FftFilter / FftFilterFloat / Hilbert / the sync blocks with their sample
+    (fft_filter.rs:307-313,441-472; hilbert.rs:119-123), FftStream frame tags (fft_stream.rs:98-111), everything that holds a
+    RationalResampler / QuadratureDemod / RtlSdrDecode drops them (rational_resampler.rs:156)."""
+    import ctypes as C
+    DROP, FORWARD, FRAMES = 0, 1, 2
+    tc = orc.low_pass_complex(2.4e6, 100e3, 50e3)
+    tf = tc.real.astype(np.float32)
+    cases = [
+        (rr.FirFilter(tc, deci=7), FORWARD, 7), (rr.FirFilter(tf, deci=3), FORWARD, 3), (rr.FirFilter(tc), FORWARD, 1),
+        (rr.FftFilter(tc), FORWARD, 1), (rr.FftFilterFloat(tf), FORWARD, 1), (rr.Hilbert(65), FORWARD, 1),
+        (rr.MultiplyConst(0.5), FORWARD, 1), (rr.FastFM(), FORWARD, 1), (rr.FirFftFilter(tc[:31], tc), FORWARD, 1),
+        (rr.HilbertFir(65, tc, 8), FORWARD, 8), (rr.FftStream(256), FRAMES, 256),
+        (rr.RationalResampler(2, 3, np.complex64), DROP, None), (rr.QuadratureDemod(1.0), DROP, None), (rr.RtlSdrDecode(), DROP, None),
+        (rr.FmChain(tc, 1, 6, 1.0), DROP, None), (rr.FmChainU8(tc, 1, 6, 1.0), DROP, None), (rr.AudioChain(tf, 6, 25, 0.5), DROP, None),
+        (rr.FirFmChain(tc[:31], tc, 1, 4, 1.0), DROP, None), (rr.FmMulti(np.stack([tc, np.conj(tc)]), 1, 6, 1.0), DROP, None),
+    ]
+    for blk, rule, param in cases:
+        p = C.c_size_t(0)
+        assert rr.lib().rr_block_tag_rule(blk._h, C.byref(p)) == rule, blk.name
+        if param is not None:
+            assert p.value == param, (blk.name, p.value)
+    assert rr.lib().rr_block_tag_rule(None, None) == -1
