@@ -471,7 +471,7 @@ def make_channelizer(dev, rank, world, shared_src, fused=True, rotator=None, as_
     """BASELINE configs[4]; on N > 1 GPUs rank g runs channel offset f_g through FirFilter::translate(100e6, f_g)
     (src/fir.rs:476-486, SURVEY §8d cfg5: multi.cfg5_translate_hz) — with the library's DEFAULT rotator, the reference's own
     f32 recurrence replayed bit for bit (RR_ROT_REPLAY: on parity for any stream length, one sequential chain per block,
-    walked ahead of the filter — by one device lane at 14 ns per output while the block's calls leave it time, by a host
+    walked ahead of the filter — by one device lane at 10 ns per output while the block's calls leave it time, by a host
     thread at ~2.6 ns per output once they do not (round 5; back-to-back bench steps do not)); `channelizer_model` is the same with
     the opt-in f64 closed form (parallel, but outside the 1e-5 parity bar beyond ~1e5 outputs of a stream)."""
     w = Workload()
@@ -523,7 +523,7 @@ def make_channelizer_translate(dev, rank, world, shared_src):
     w = make_channelizer(dev, rank, world, shared_src, as_rank=(1, 8))
     w.bound = "sequential_rotator"
     w.bound_note = ("FirFilter::translate's rotator (src/fir.rs:464-473) is an un-renormalised f32 recurrence, one dependent chain of 12.5 M "
-                    "steps per step here; replayed bit for bit it runs at 2.6 ns per output on a host core (14 ns on a device lane), "
+                    "steps per step here; replayed bit for bit it runs at 2.6 ns per output on a host core (10 ns on a device lane), "
                     "whatever the filter kernel does (0.14 ms).  rotator_ns_per_output is this step's time per output")
     return w
 

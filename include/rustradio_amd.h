@@ -60,7 +60,7 @@ enum rr_atan2 { RR_ATAN2_EXACT = 0, RR_ATAN2_FAST = 1,
  *                 chain is data-independent, so it is generated AHEAD of the filter on a side stream while the filter
  *                 kernels of the current window run; a call waits only for what the chain has not reached.  It starts
  *                 on the device: one lane walks it from the phase carried in device memory (three packed f32
- *                 instructions per step, 14 ns per output = 70 M outputs/s; no host thread, no PCIe traffic) — enough
+ *                 instructions per step, 10 ns per output = 100 M outputs/s; no host thread, no PCIe traffic) — enough
  *                 for any graph paced by its source (BASELINE configs[4]: 12.5 M outputs/s).  A block whose calls keep
  *                 arriving before the look-ahead has finished (three in a row: back-to-back batch calls) is given a host
  *                 generator instead: one thread walks the same chain in strict f32 at an x86 core's multiply + add

@@ -424,12 +424,12 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
 }
 
 // The reference's rotator (fir.rs:464-473): out[m] *= phase; phase *= step, in f32, never renormalised.
-//   RR_ROT_REPLAY (default): that recurrence, bit for bit, for any stream length.  It is inherently serial (14 ns per
+//   RR_ROT_REPLAY (default): that recurrence, bit for bit, for any stream length.  It is inherently serial (10 ns per
 //     output on one device lane, 2.6 ns on a host core) but data-independent, so it is generated AHEAD: after every call the
 //     side stream walks the chain on into a ring of phases for the next window while this window's filter kernels (and
 //     whatever the graph runs next) execute; a call waits only for the part of its range the chain has not reached.  A
 //     graph paced by its source (100 Msps / 8 = 12.5 M outputs/s in BASELINE configs[4]) never waits for the device
-//     chain (70 M outputs/s); a block that does (back-to-back batch calls) is moved onto a host generator thread
+//     chain (100 M outputs/s); a block that does (back-to-back batch calls) is moved onto a host generator thread
 //     (rotate_output: `starving`, rotor_start_host).
 //   RR_ROT_MODEL (opt-in): phase0 * step^m in f64, parallel; NOT within 1e-5 of the reference beyond ~1e5 outputs
 //     (it does not reproduce the recurrence's accumulated rounding; tests/test_gpu_edges_fullsize.py).

@@ -718,10 +718,14 @@ void launch_rotate_model(cf* y, long n, double p0x, double p0y, double sx, doubl
 // AHEAD of the filter on a side stream (blocks.cpp FirC32::rotate_output).
 __device__ __forceinline__ creg rotor_step(creg z, creg st) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // ONE asm statement: written as three, the compiler guards each packed instruction that reads its predecessor's result
+    // with an s_nop (23 per 16 steps), and a lone wave pays an issue slot for every one of them: 14 -> 11 ns per output
+    // (tools/micro/rotor_rate.hip; bit-identical — test_translate_default_mode_is_the_reference_recurrence_for_1e7_outputs)
     creg p, q, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p) : "v"(z), "s"(st));   // (x sx, x sy)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(z), "s"(st));   // (y sy, y sx)
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));                    // (x sx - y sy, x sy + y sx)
+    asm("v_pk_mul_f32 %1, %3, %4 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                              // (x sx, x sy)
+        "v_pk_mul_f32 %2, %3, %4 op_sel:[1,1] op_sel_hi:[1,0]\n\t"                              // (y sy, y sx)
+        "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]"                                                    // (x sx - y sy, x sy + y sx)
+        : "=v"(r), "=&v"(p), "=&v"(q) : "v"(z), "s"(st));
     return r;
 #else
     return mk(z.x * st.x - z.y * st.y, z.x * st.y + z.y * st.x);
@@ -737,15 +741,37 @@ __device__ __forceinline__ void rotor_run(creg& z, const creg st, creg* __restri
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef f4 f4u __attribute__((aligned(8)));
     long i = 0;
-    for (; i + 16 <= n; i += 16, p += 16) {
-        creg o[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { o[k] = z; z = rotor_step(z, st); }
+    // A block's phases are stored one block LATE, a pair after every second step of the next block: a store that follows the
+    // step that produced its data waits for that step like the next step does and costs the lone wave an issue slot on the
+    // chain's critical path; a store of finished data issues in the gap in which the next instruction of the chain waits for
+    // its operand anyway (11.3 -> 9.x ns per output; tools/replay_rate.py).
+    auto store_pair = [&](creg* q, const creg* o, int k) {
+        f4 w; w.x = o[k].x; w.y = o[k].y; w.z = o[k + 1].x; w.w = o[k + 1].y;
+        *reinterpret_cast<f4u*>(q + k) = w;
+    };
+    auto fill = [&](creg* o, creg* q, const creg* prev) {      // 16 phases into o; prev (if any) leaves for q as it goes
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
-            f4 w; w.x = o[k].x; w.y = o[k].y; w.z = o[k + 1].x; w.w = o[k + 1].y;
-            *reinterpret_cast<f4u*>(p + k) = w;
+            o[k] = z; z = rotor_step(z, st);
+            o[k + 1] = z; z = rotor_step(z, st);
+            if (prev) store_pair(q, prev, k);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto flush = [&](creg* q, const creg* o) {
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) store_pair(q, o, k);
+    };
+    if (n >= 16) {
+        creg a[16], b[16];                                     // (two register blocks in turn: no copies)
+        fill(a, nullptr, nullptr); i = 16;
+        for (; i + 32 <= n; i += 32) {
+            fill(b, p + i - 16, a);
+            fill(a, p + i, b);
+        }
+        if (i + 16 <= n) { fill(b, p + i - 16, a); flush(p + i, b); i += 16; }
+        else flush(p + i - 16, a);
+        p += i;
     }
     for (; i < n; i++, p++) { *p = z; z = rotor_step(z, st); }
 }
