@@ -102,7 +102,9 @@ typedef struct {
                                8 / 12: also fixes the multi-channel kernel's waves per workgroup (0 / 1: by predicted cost) */
     int dstream_no_vmm;     /* rr_dstream_create: the copying fallback ring instead of the double mapping */
     int fir_poly;           /* decimating FirFilter<Complex>: decimate-first (polyphase) tiles, > 0 wherever supported, < 0 never */
-    int reserved[5];
+    int fft_nonfinite_tiles;/* FftFilter / FftFilterFloat: leave a NaN / Inf input sample's damage on the GPU's tile (one launch
+                               less per work() call) instead of moving it onto the reference's block of nsamples inputs */
+    int reserved[4];
 } rr_build_opts;
 int rr_next_create_options(const rr_build_opts *opts);   /* NULL clears a pending override */
 
@@ -137,7 +139,9 @@ rr_block *rr_fir_f32_create(const float *taps, size_t ntaps, size_t deci);
 /* FftFilter::new(src, taps) (src/fft_filter.rs:242-279).  Up to 16383 taps run on LDS-resident overlap-save tiles; longer
  * filters (up to 524,288 taps; the reference has no limit) as overlap-save frames of 2^m >= 2 ntaps points through the
  * any-size transform (plain HBM-streaming passes).  The tile size is internal (rr_fftfilter_dims reports it) and, for long
- * filters, depends on the window of the call; outputs do not depend on it beyond f32 rounding. */
+ * filters, depends on the window of the call; outputs do not depend on it beyond f32 rounding.  A NaN / Inf input sample
+ * makes the reference's outputs non-finite — the fft_size outputs from the start of its block of nsamples inputs
+ * (src/fft_filter.rs:326-347) — whatever tile ran (a small pass behind the tile kernels of every call; FftFilterFloat too). */
 rr_block *rr_fftfilter_create(const rr_c32 *taps, size_t ntaps);
 /* FftFilterFloat::new(src, taps) (src/fft_filter.rs:391-426). */
 rr_block *rr_fftfilter_float_create(const float *taps, size_t ntaps);

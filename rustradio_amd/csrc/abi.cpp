@@ -66,7 +66,7 @@ int rr_next_create_options(const rr_build_opts* o) {
     b.fir_path = o->fir_path; b.fir_prune = o->fir_prune; b.fir_half = o->fir_half; b.fir_cfg = o->fir_cfg_plus1 - 1;
     b.fft_log2f = o->fft_log2f; b.fft_no_split = o->fft_no_split; b.fftfloat_complex = o->fftfloat_complex;
     b.fm_full = o->fm_full; b.fm_poly = o->fm_poly; b.dstream_no_vmm = o->dstream_no_vmm;
-    b.fir_poly = o->fir_poly;
+    b.fir_poly = o->fir_poly; b.fft_nonfinite_tiles = o->fft_nonfinite_tiles;
     if (b.fir_path < 0 || b.fir_path > 2 || b.fir_cfg > 7 || (b.fft_log2f != 0 && (b.fft_log2f < 10 || b.fft_log2f > 14))) {
         rr::set_last_error("rr_next_create_options: value out of range");
         return RR_ERR;
@@ -135,7 +135,8 @@ rr_block* rr_fir_f32_create(const float* taps, size_t ntaps, size_t deci) {
     return make_block([&] { return new rr::FirF32(taps, ntaps, deci); }, RR_TAGS_FORWARD, deci);
 }
 rr_block* rr_fftfilter_create(const rr_c32* taps, size_t ntaps) {
-    return make_block([&] { return new rr::FftFilter(taps, ntaps); }, RR_TAGS_FORWARD, 1);
+    return make_block([&] { auto* f = new rr::FftFilter(taps, ntaps); std::unique_ptr<rr::FftFilter> own(f); f->ref_blocks_on(taps); return own.release(); },
+                      RR_TAGS_FORWARD, 1);
 }
 rr_block* rr_fftfilter_float_create(const float* taps, size_t ntaps) {
     return make_block([&] { return new rr::FftFilterFloat(taps, ntaps); }, RR_TAGS_FORWARD, 1);

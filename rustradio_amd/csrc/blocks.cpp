@@ -174,7 +174,10 @@ int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, s
         din = st_in.p;
     }
     if (!dout) st_out.reserve(std::max<size_t>(out_cap * out_es * out_windows(), 16));
-    int st = work_dev(din, in_len, dout ? dout : st_out.p, out_cap, consumed, produced, need, stream);
+    host_out = dout ? out : nullptr;
+    int st;
+    try { st = work_dev(din, in_len, dout ? dout : st_out.p, out_cap, consumed, produced, need, stream); }
+    catch (...) { host_out = nullptr; throw; }
     if (!dout && *produced) {
         if (out_windows() == 1) RR_HIP(hipMemcpyAsync(out, st_out.p, *produced * out_es, hipMemcpyDeviceToHost, stream));
         else RR_HIP(hipMemcpy2DAsync(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, out_windows(), hipMemcpyDeviceToHost, stream));
@@ -182,6 +185,11 @@ int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, s
     // (polling an event from the calling thread instead was measured and changes nothing: 154 -> 158 us per reference-sized
     //  window; the call sits on the link — tools/micro/pcie_inplace.hip: a kernel moves 4,096,000 bytes each way in 128-145 us)
     RR_HIP(hipStreamSynchronize(stream));
+    if (host_out) {
+        const void* h = host_out;
+        host_out = nullptr;
+        host_out_done(h, *produced);
+    }
     return st;
 }
 
@@ -1041,7 +1049,59 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
     RR_HIP(hipStreamSynchronize(stream));
 }
 
+void FftFilter::ref_blocks_on(const rr_c32* taps) {
+    if (build_opts().fft_nonfinite_tiles || front) return;
+    if (real_stream) {
+        std::vector<float> r(L);
+        for (size_t j = 0; j < L; j++) r[j] = taps[L - 1 - j].re;
+        d_rev.reserve((L + 1) / 2);
+        RR_HIP(hipMemcpyAsync(d_rev.p, r.data(), L * sizeof(float), hipMemcpyHostToDevice, stream));
+        RR_HIP(hipStreamSynchronize(stream));
+    } else {
+        std::vector<cf> r(L);
+        for (size_t j = 0; j < L; j++) r[j] = mkcf(taps[L - 1 - j].re, taps[L - 1 - j].im);
+        d_rev.upload(r.data(), L, stream);
+    }
+    const int none[2] = {-1, -1};
+    d_tail.upload(none, 2, stream);
+    RR_HIP(hipStreamSynchronize(stream));
+    ref_blocks = true;
+}
+template <class T> void FftFilter::ref_blocks_pass(VSrc<T> src, T* out, long n_out, hipStream_t s) {
+    if (!ref_blocks || n_out <= 0) return;
+    if constexpr (std::is_same<T, cf>::value) {
+        if (host_out) { deferred.on = true; deferred.src = src; deferred.out = out; deferred.n_out = n_out; return; }
+    }
+    tail_host_known = false;
+    launch_ref_blocks_nonfinite(src, out, n_out, (long)nsamples, probe_stride, (long)hist, (int)L,
+                                reinterpret_cast<const T*>(d_rev.p), d_tail.p, seq, s);
+    seq++;
+}
+
+void FftFilter::host_out_done(const void* out_host, size_t) {
+    if (!deferred.on) return;
+    deferred.on = false;
+    const std::complex<float>* y = static_cast<const std::complex<float>*>(out_host);
+    const long n = deferred.n_out, P = std::max<long>(1, probe_stride);
+    auto bad = [&](long m) { return !(std::isfinite(y[m].real()) && std::isfinite(y[m].imag())); };
+    bool hit = !tail_host_known || tail_host;
+    if (!hit) {                                                 // a tile that read a non-finite sample has NO finite output
+        for (long m = 0; m < n; m += P) __builtin_prefetch(&y[m]);   // (the lines come from memory the device just wrote: all misses)
+        hit = bad(n - 1);
+        for (long m = 0; m < n && !hit; m += P) hit = bad(m);
+    }
+    if (!hit) { seq++; return; }                               // (a call without the pass: its tail slot keeps a stale number)
+    launch_ref_blocks_nonfinite(deferred.src, static_cast<cf*>(deferred.out), n, (long)nsamples, probe_stride, (long)hist, (int)L,
+                                d_rev.p, d_tail.p, seq, stream);
+    int t = -1;
+    RR_HIP(hipMemcpyAsync(&t, d_tail.p + (seq & 1), sizeof t, hipMemcpyDeviceToHost, stream));
+    RR_HIP(hipStreamSynchronize(stream));
+    tail_host = t == seq; tail_host_known = true;
+    seq++;
+}
+
 void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOut carry) {
+    probe_stride = (long)(big ? bigM : (size_t)1 << (nsub && alt_log2f && alt_wins(n_out) ? alt_log2f : log2f)) - (long)L + 1;
     if (big) {
         // y = conj(FFT_M(conj(FFT_M(frame) H))) per overlap-save frame, in chunks of <= 2^24 elements of work space
         const long M = (long)bigM, S = M - (long)L + 1;
@@ -1067,6 +1127,7 @@ void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOu
 
 void FftFilter::filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s, CarryOut carry) {
     NanFix fx = nanfix; fx.d = d;
+    probe_stride = ((long)1 << log2f) - (long)L + 1;
     launch_fftfilt_real(log2f, src, out, n_out, (int)L, d, d_tw.p, d_hpos.p, s, carry, fx);
 }
 
@@ -1100,6 +1161,7 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
             prof_begin(s);
             filter_real(rsrc, static_cast<float*>(out), (long)n_out, 1, s, carry);
             prof_end(s);
+            ref_blocks_pass(rsrc, static_cast<float*>(out), (long)n_out, s);
         } else {
             launch_carry(rsrc, carry, s);
         }
@@ -1117,6 +1179,7 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
         prof_begin(s);
         filter(src, static_cast<cf*>(out), (long)n_out, s, carry);
         prof_end(s);
+        ref_blocks_pass(src, static_cast<cf*>(out), (long)n_out, s);
         if (front && emitted == 0) {   // head fix: FftFilter's zero history under the first L2 - 1 outputs (n_out >= S > L2 - 1)
             const long L2 = (long)(L - front);
             d_zhead.reserve((size_t)L2);
@@ -1545,6 +1608,7 @@ FftFilterFloat::FftFilterFloat(const float* taps, size_t ntaps) : Block("FftFilt
     for (size_t i = 0; i < ntaps; i++) ct[i] = rr_c32{taps[i], 0.0f};  // fft_filter.rs:398
     real_inner = ntaps <= 3584 && !build_opts().fftfloat_complex;       // (the option keeps the three-kernel path testable)
     inner.reset(real_inner ? new FftFilter(ct.data(), ntaps, false, 12, true) : new FftFilter(ct.data(), ntaps));
+    inner->ref_blocks_on(ct.data());
     cap = 4096000 / sizeof(cf);                                         // inner streams: stream.rs:105,336-339
     if (real_inner) {
         for (auto& b : fin) b.reserve(cap);

@@ -26,6 +26,10 @@ struct Block {
     // page-locked host INPUT windows are read by the kernels in place (zero copy); blocks whose kernels read the window more
     // than once (the N-channel blocks: every run of channel rounds re-reads its tiles) keep the upload
     bool zero_copy_in = true;
+    // work_host on a page-locked OUTPUT window: set around work_dev, and the hook below runs once the call's work has
+    // completed (the host then reads its own window for free where a kernel would cross PCIe again — FftFilter)
+    const void* host_out = nullptr;
+    virtual void host_out_done(const void* /*out_host*/, size_t /*produced*/) {}
 
     Block(const char* nm, size_t ies, size_t oes);
     virtual ~Block();
@@ -220,6 +224,24 @@ struct FftFilter : Block {
     }
     // more than 16383 taps: overlap-save frames of M = 2^m >= 2 L points through the any-size transform (AnyFft)
     NanFix nanfix;                    // set by a FirFilter that runs on these tiles (default: none — FftFilter's own reference is a transform)
+    // The FftFilter / FftFilterFloat BLOCKS (not the chains and FirFilters built on this object): a non-finite input sample
+    // poisons the reference's block of nsamples inputs (+ the ntaps points added to the next one, fft_filter.rs:326-347)
+    // instead of the GPU's tile — one small launch behind the tile kernels of every call (kernels_misc.hip
+    // k_ref_blocks_nonfinite; rr_build_opts.fft_nonfinite_tiles leaves it out)
+    bool ref_blocks = false;
+    DevBuf<cf> d_rev;                 // the taps reversed (floats for a real stream)
+    DevBuf<int> d_tail;               // [2]: was the last block of call seq - 1 poisoned?
+    int seq = 1;
+    long probe_stride = 0;            // of the current call: the smallest advance of the tiles that wrote it
+    // a zero-copy host output window: the probe is the HOST's (its own memory, after the call's completion wait), and the pass
+    // is launched only when it finds something (a probing kernel reads the window back over PCIe: +8 us per reference-sized call,
+    // the host's own probe +2; the tile kernels' FIX instantiation could report for free but rounds differently in the last bit
+    // than the one the other paths run, and the paths of one block are held bit-identical: tests/test_gpu_fuzz.py)
+    struct { bool on = false; VSrc<cf> src{}; void* out = nullptr; long n_out = 0; } deferred;
+    bool tail_host = false, tail_host_known = true;   // the host's copy of the carried verdict
+    void host_out_done(const void* out_host, size_t produced) override;
+    void ref_blocks_on(const rr_c32* taps);
+    template <class T> void ref_blocks_pass(VSrc<T> src, T* out, long n_out, hipStream_t s);
     std::unique_ptr<AnyFft> big;
     size_t bigM = 0;
     DevBuf<cf> d_hbig, bframes, bspec;

@@ -37,6 +37,7 @@ struct BuildOpts {
     int fm_full = 0;
     int fm_poly = 0;           // 0 auto, < 0 off: polyphase (decimate-first) tiles of the fused chains
     int dstream_no_vmm = 0;
+    int fft_nonfinite_tiles = 0;   // FftFilter / FftFilterFloat: no reference-block pass for non-finite samples
     int fir_poly = 0;          // 0 auto, > 0 on wherever supported, < 0 off: decimating FirFilter<Complex> on decimate-first tiles
 };
 const BuildOpts& build_opts();

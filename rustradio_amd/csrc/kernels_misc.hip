@@ -201,6 +201,100 @@ void launch_carry(VSrc<float> src, const CarryOut& c, hipStream_t s) {
     if (c.n > 0) launch_vcopy_f32(src, c.v0, static_cast<float*>(c.dst), c.n, s);
 }
 
+// ---- FftFilter / FftFilterFloat: non-finite samples on the REFERENCE's blocks (round 5) ------------------
+// The reference runs one fft_size-point transform per `nsamples` input samples and adds the last `ntaps` points of it to
+// the next block (fft_filter.rs:326-347): one NaN / Inf input sample of block b makes ALL of the block's transform
+// non-finite, i.e. the outputs [b S, b S + S + L) (S = nsamples, L = ntaps; S >= L by fft_filter.rs:36-42) — and nothing
+// else.  The GPU tiles are of another size and on another grid, so the same sample poisons the outputs of ITS tile.  This
+// pass runs behind the tile kernels of such a block and puts the reference's set in place:
+//   * probe: a tile that read a non-finite sample has NO finite output, so one output every P (P <= the smallest tile
+//     advance of the call) and the ends of a range tell whether any tile over the range did — n_out / P loads in the steady
+//     state, then every workgroup returns;
+//   * a workgroup whose range (its blocks and the one before) holds such a tile scans the INPUT of those blocks, and per
+//     block: bad[b] or (bad[b - 1] and m - b S < L) -> out[m] = NaN; otherwise an output the tile left non-finite is the
+//     reference's own left fold (nan_fix.hpp nf_direct), whose window lies in clean blocks.
+// The block before the call's first is gone with its input: its verdict is carried in tail[(seq - 1) & 1] == seq - 1
+// (written by the call that saw it; a call whose probes were clean writes nothing and leaves a stale sequence number).
+struct RefBlocksCtx {
+    const void* prefix; long plen; const void* in; long in_len;     // the call's virtual stream (VSrc)
+    void* out; long n_out;                                         // k * S outputs
+    long S, P, hist;                                               // block b reads the virtual samples [hist + b S, hist + (b + 1) S)
+    int L;
+    const void* rev;                                               // the taps reversed (cf / float)
+    int* tail; int seq;
+};
+template <class T>
+__global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
+    const VSrc<T> src{static_cast<const T*>(c.prefix), c.plen, static_cast<const T*>(c.in), c.in_len};
+    T* out = static_cast<T*>(c.out);
+    const long nb = c.n_out / c.S;
+    const long b0 = nb * (long)blockIdx.x / (long)gridDim.x, b1 = nb * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    if (b0 >= b1) return;
+    const bool tail_bad = c.tail[(c.seq - 1) & 1] == c.seq - 1;    // (uniform)
+    const int t = (int)threadIdx.x;
+    // any non-finite output at lo, lo + P, ..., or at hi - 1?  A tile is >= P outputs long, so one that overlaps [lo, hi)
+    // holds one of these points.  (Ranges are probed block-aligned and the caller's own blocks apart from the block before
+    // them: that one is being repaired by another wave meanwhile — a bad block only ever turns all-NaN, but a merely
+    // smeared stretch of it turns finite, and a lattice that started there could step over what the same tile left HERE.)
+    auto probe = [&](long lo, long hi, int lane, int lanes) {
+        bool bad = false;
+        for (long m = lo + (long)lane * c.P; m < hi; m += (long)lanes * c.P) bad |= nf_bad(out[m]);
+        if (lane == 0) bad |= nf_bad(out[hi - 1]);
+        return bad;
+    };
+    {
+        bool bad = probe(b0 * c.S, b1 * c.S, t, (int)blockDim.x);
+        if (b0 > 0) bad |= probe((b0 - 1) * c.S, b0 * c.S, t, (int)blockDim.x);
+        if (!__syncthreads_or((int)bad | (int)(b0 == 0 && tail_bad))) return;
+    }
+    const int lane = t & 63, wave = t >> 6, nw = (int)(blockDim.x >> 6);
+    auto any64 = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; };
+    auto scan = [&](long b) {                                       // a non-finite INPUT sample in block b?
+        bool bad = false;
+        const long v0 = c.hist + b * c.S;
+        for (long i0 = 0; i0 < c.S; i0 += 64) {                     // (uniform trip count)
+            const long i = i0 + lane;
+            bad |= i < c.S && nf_bad(src.load(v0 + i));
+            if (any64(bad)) break;
+        }
+        return any64(bad);
+    };
+    T nanv;
+    if constexpr (std::is_same<T, float>::value) nanv = __builtin_nanf(""); else nanv = mkcf(__builtin_nanf(""), __builtin_nanf(""));
+    for (long b = b0 + wave; b < b1; b += nw) {                     // one wave per block
+        const bool first = b == 0;
+        bool hit = probe(b * c.S, (b + 1) * c.S, lane, 64);
+        if (!first) hit |= probe((b - 1) * c.S, b * c.S, lane, 64);
+        if (!any64(hit) && !(first && tail_bad)) continue;
+        const bool bad_prev = first ? tail_bad : scan(b - 1);
+        const bool bad_cur = scan(b);
+        for (long i = lane; i < c.S; i += 64) {
+            const long m = b * c.S + i;
+            if (bad_cur || (bad_prev && i < (long)c.L)) out[m] = nanv;
+            else if (nf_bad(out[m])) {
+                if constexpr (std::is_same<T, float>::value) out[m] = nf_direct<float, float>(src, c.rev, c.L, 1, NANFIX_FF, m + (c.hist - (c.L - 1)));
+                else out[m] = nf_direct<cf, cf>(src, c.rev, c.L, 1, NANFIX_CC, m + (c.hist - (c.L - 1)));
+            }
+        }
+        if (b == nb - 1 && lane == 0) c.tail[c.seq & 1] = bad_cur ? c.seq : -1;
+    }
+}
+template <class T>
+static void launch_ref_blocks(VSrc<T> src, T* out, long n_out, long S, long P, long hist, int L, const void* rev, int* tail, int seq, hipStream_t s) {
+    if (n_out <= 0) return;
+    RefBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, n_out, S, P < 1 ? 1 : P, hist, L, rev, tail, seq};
+    const long nb = n_out / S;
+    const long grid = std::max<long>(1, std::min<long>(256, (nb + 3) / 4));
+    hipLaunchKernelGGL(k_ref_blocks_nonfinite<T>, dim3((unsigned)grid), dim3(256), 0, s, c);
+    RR_HIP(hipGetLastError());
+}
+void launch_ref_blocks_nonfinite(VSrc<cf> src, cf* out, long n_out, long S, long P, long hist, int L, const cf* rev, int* tail, int seq, hipStream_t s) {
+    launch_ref_blocks<cf>(src, out, n_out, S, P, hist, L, rev, tail, seq, s);
+}
+void launch_ref_blocks_nonfinite(VSrc<float> src, float* out, long n_out, long S, long P, long hist, int L, const float* rev, int* tail, int seq, hipStream_t s) {
+    launch_ref_blocks<float>(src, out, n_out, S, P, hist, L, rev, tail, seq, s);
+}
+
 // Plain byte copy between a device range and a page-locked host range seen through its device address (rr_dstream_copy_in /
 // _copy_out on windows of a ring registered with rr_host_register): a KERNEL moves a reference-sized window over PCIe at
 // 55 GB/s either way, hipMemcpyAsync from / to the same registered range at 16 / 50 (tools/micro/pcie_inplace.hip).  8 bytes

@@ -354,9 +354,9 @@ def test_rotator_drift_vs_length(rr):
 
 
 def test_nan_locality_is_bounded_by_one_tile(rr):
-    """DESIGN.md "known deviations", what is left of them in round 4: FftFilter (whose reference is a transform too, and
-    smears a non-finite sample over ITS block) poisons up to one of its own tiles; FirFilter now has the reference's locality
-    exactly (test_nonfinite_samples_reach_exactly_the_references_outputs) and passes the bounds below a fortiori."""
+    """Round 3's bound, kept as a coarse check: a non-finite sample never reaches further than one tile.  Both blocks now
+    have the reference's set exactly (FirFilter: test_nonfinite_samples_reach_exactly_the_references_outputs, round 4;
+    FftFilter: test_nonfinite_samples_in_fftfilter_poison_the_references_blocks, round 5) and pass a fortiori."""
     L, pos, n = 127, 50_000, 120_000
     taps = orc.low_pass_complex(10e6, 1e6, 190e3)
     x = rnd_c(n, 11)
@@ -465,6 +465,56 @@ def test_nonfinite_samples_reach_exactly_the_references_outputs(rr, name, mk, op
             assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
     ok = ~(bo | bg)
     assert max_norm_err(yg[ok], yo[ok]) <= TOL
+
+
+FFTFILTER_NONFINITE_CASES = [
+    # name, taps maker, real stream, small ring bytes (>= two reference blocks)
+    ("fft5", lambda: (rnd_c(5, 41) / 3).astype(np.complex64), False, 8 * 3_000),
+    ("fft127-1024-tiles", lambda: orc.low_pass_complex(10e6, 1e6, 190e3), False, 8 * 3_000),
+    ("fft401-2048-tiles", lambda: orc.low_pass_complex(10e6, 1e6, 60e3), False, 8 * 6_000),
+    ("fft1025-4096-tiles", lambda: (rnd_c(1025, 42) / 500).astype(np.complex64), False, 8 * 12_000),
+    ("fft2467-split-or-plain", lambda: (rnd_c(2467, 43) / 1000).astype(np.complex64), False, 8 * 30_000),
+    ("fft5000-16384-split", lambda: (rnd_c(5000, 44) / 2000).astype(np.complex64), False, 8 * 50_000),
+    ("fft16500-any-size-frames", lambda: (rnd_c(16500, 45) / 6000).astype(np.complex64), False, 8 * 120_000),
+    ("fftfloat127", lambda: orc.low_pass_complex(10e6, 1e6, 190e3).real.copy(), True, 4 * 3_000),
+    ("fftfloat1000", lambda: (rnd_f(1000, 46) / 300).astype(np.float32), True, 4 * 12_000),
+    ("fftfloat5000-complex-inner", lambda: (rnd_f(5000, 47) / 1500).astype(np.float32), True, 4 * 50_000),
+]
+
+
+@pytest.mark.parametrize("name,mk_taps,real_in,small", FFTFILTER_NONFINITE_CASES, ids=[c[0] for c in FFTFILTER_NONFINITE_CASES])
+@pytest.mark.parametrize("ring", ["reference", "small", "registered"])
+def test_nonfinite_samples_in_fftfilter_poison_the_references_blocks(rr, name, mk_taps, real_in, small, ring):
+    """Round 5 (csrc/kernels_misc.hip k_ref_blocks_nonfinite): FftFilter / FftFilterFloat's reference transforms blocks of
+    nsamples inputs (fft_filter.rs:326-347) — a NaN / Inf input sample makes the fft_size outputs from its block's start
+    non-finite and nothing else.  The GPU's tiles are of another size on another grid; a pass behind them puts exactly the
+    reference's set in place (across work() calls too: the small rings end most calls inside a poisoned stretch) and restores
+    what only the tile had smeared.  VERDICT r4 weak #3: 'FftFilter-type blocks smear over the GPU tile'."""
+    taps = mk_taps()
+    mk = (lambda m: [m.FftFilterFloat(taps)]) if real_in else (lambda m: [m.FftFilter(taps)])
+    n = 150_000 if len(taps) < 16_000 else 400_000
+    x = _poisoned(rnd_f(n, 51) if real_in else rnd_c(n, 51), 6)
+    for p in np.random.default_rng(len(taps)).integers(0, n, 6):     # (a few more: call ends are where the carry matters)
+        x[int(p)] = np.nan
+    sb = 4_096_000 if ring == "reference" else small
+    yo = run_chain(mk(orc), x, stream_bytes=sb)
+    if ring == "registered":           # page-locked rings: the kernels write the host window in place and the HOST probes it
+        from harness import drive_registered
+        cap = small // x.itemsize
+        yg = drive_registered(rr, mk(rr)[0], x, cap, cap)[0][0]
+    else:
+        yg = run_chain(mk(rr), x, stream_bytes=sb)
+    assert len(yo) == len(yg) > 1000
+    bo, bg = _nonfinite_mask(yo), _nonfinite_mask(yg)
+    assert bo.sum() > 20 and not bo.all()
+    assert np.array_equal(bo, bg), (int(bo.sum()), int(bg.sum()), np.flatnonzero(bo != bg)[:8])
+    assert max_norm_err(yg[~bo], yo[~bo]) <= TOL
+    if ring == "reference" and name == "fft401-2048-tiles":          # the opt-out keeps the round-4 behaviour: the tile's smear
+        with rr.build_options(fft_nonfinite_tiles=1):
+            blocks = mk(rr)
+        yt = run_chain(blocks, x, stream_bytes=sb)
+        bt = _nonfinite_mask(yt)
+        assert not np.array_equal(bt, bo) and max_norm_err(yt[~(bt | bo)], yo[~(bt | bo)]) <= TOL
 
 
 def test_nonfinite_samples_hilbert_pair_kernel(rr):
