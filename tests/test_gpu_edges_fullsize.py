@@ -299,6 +299,26 @@ def test_device_replay_mode_is_the_same_chain(rr):
     assert np.array_equal(y.view(np.uint32), yo.view(np.uint32)), int(np.flatnonzero(y != yo)[0])
 
 
+def test_device_replay_chain_any_window_length(rr):
+    """k_rotor_replay (round 5: sixteen phases per register block, each block stored while the next is computed) over calls
+    of every length 1 ... 99 and random ones to 5000: prologue, ping-pong loop, odd block and scalar tail all produce the
+    reference's recurrence bit for bit, and the phase carried between calls is the chain's."""
+    fs, f = 1.0e6, 123_456.7
+    one = np.ones(1, np.complex64)
+    rng = np.random.default_rng(17)
+    sizes = list(range(1, 100)) + [int(v) for v in rng.integers(1, 5000, 60)] + [16, 32, 48, 64, 31, 33, 47, 49]
+    x = rnd_c(sum(sizes), 80)
+    yo = run_chain([orc.FirFilter(one, translate=(fs, f))], x)
+    b = rr.FirFilter(one, translate=(fs, f), rotator=rr.ROT_REPLAY_DEVICE)
+    outs, a = [], 0
+    for k in sizes:
+        st, c, p, need, out = b.work(x[a:a + k], k)
+        assert c == p == k
+        outs.append(out); a += k
+    y = np.concatenate(outs)
+    assert np.array_equal(y.view(np.uint32), yo.view(np.uint32)), int(np.flatnonzero(y != yo)[0])
+
+
 def test_default_rotator_takes_a_host_thread_only_when_the_chain_paces_the_block(rr):
     """Round 5: RR_ROT_REPLAY starts on the device chain (no thread per translating block) and moves to a
     host generator thread only when three calls in a row arrive before the chain's look-ahead has finished — the same bits
