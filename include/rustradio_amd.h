@@ -202,7 +202,8 @@ rr_block *rr_fm_chain_create(const rr_c32 *taps, size_t ntaps, size_t interp, si
  * work(): WAIT_DST(nsamples) when a block of the FftFilter stage does not fit (fft_filter.rs:294-303), WAIT_SRC(fir_ntaps)
  * below the FIR's minimum (fir.rs:498-501); otherwise consumes len - (fir_ntaps - 1) samples like the FIR (its history
  * stays in the caller's ring, fir.rs:537), emits whole blocks of nsamples = fft_size(fft_ntaps) - fft_ntaps and returns
- * WAIT_SRC(nsamples - pending + fir_ntaps - 1) / WAIT_DST(nsamples). */
+ * WAIT_SRC(nsamples - pending + fir_ntaps - 1) / WAIT_DST(nsamples).  Non-finite input samples: the reference's set — the
+ * FIR outputs whose fir_ntaps windows hold one, and through them the FftFilter stage's whole blocks (see rr_fftfilter_create). */
 rr_block *rr_fir_fftfilter_create(const rr_c32 *fir_taps, size_t fir_ntaps, const rr_c32 *fft_taps, size_t fft_ntaps);
 /* ... followed by RationalResampler(interp, deci) -> QuadratureDemod(gain): the metric's whole chain
  * FIR + FftFilter + Resampler + QuadDemod as one kernel (rr_fm_chain_create with the composite filter and the same

@@ -194,6 +194,7 @@ rr_block* rr_fir_fftfilter_create(const rr_c32* fir_taps, size_t fir_ntaps, cons
         const std::vector<rr_c32> g = rr::FftFilter::composite(fir_taps, fir_ntaps, fft_taps, fft_ntaps);
         std::unique_ptr<rr::FftFilter> f(new rr::FftFilter(g.data(), g.size(), false, 14, false, fir_ntaps - 1));
         f->set_stage_taps(fir_taps, fir_ntaps, fft_taps, fft_ntaps);
+        f->ref_blocks_on(g.data());
         return f.release();
     }, RR_TAGS_FORWARD, 1);
 }

@@ -1050,7 +1050,7 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
 }
 
 void FftFilter::ref_blocks_on(const rr_c32* taps) {
-    if (build_opts().fft_nonfinite_tiles || front) return;
+    if (build_opts().fft_nonfinite_tiles) return;
     if (real_stream) {
         std::vector<float> r(L);
         for (size_t j = 0; j < L; j++) r[j] = taps[L - 1 - j].re;
@@ -1067,14 +1067,14 @@ void FftFilter::ref_blocks_on(const rr_c32* taps) {
     RR_HIP(hipStreamSynchronize(stream));
     ref_blocks = true;
 }
-template <class T> void FftFilter::ref_blocks_pass(VSrc<T> src, T* out, long n_out, hipStream_t s) {
+template <class T> void FftFilter::ref_blocks_pass(VSrc<T> src, T* out, long n_out, hipStream_t s, bool force0) {
     if (!ref_blocks || n_out <= 0) return;
     if constexpr (std::is_same<T, cf>::value) {
-        if (host_out) { deferred.on = true; deferred.src = src; deferred.out = out; deferred.n_out = n_out; return; }
+        if (host_out) { deferred.on = true; deferred.force0 = force0; deferred.src = src; deferred.out = out; deferred.n_out = n_out; return; }
     }
     tail_host_known = false;
-    launch_ref_blocks_nonfinite(src, out, n_out, (long)nsamples, probe_stride, (long)hist, (int)L,
-                                reinterpret_cast<const T*>(d_rev.p), d_tail.p, seq, s);
+    launch_ref_blocks_nonfinite(src, out, n_out, (long)nsamples, probe_stride, (long)hist, (int)L, (int)front,
+                                reinterpret_cast<const T*>(d_rev.p), d_tail.p, seq, force0, s);
     seq++;
 }
 
@@ -1084,15 +1084,15 @@ void FftFilter::host_out_done(const void* out_host, size_t) {
     const std::complex<float>* y = static_cast<const std::complex<float>*>(out_host);
     const long n = deferred.n_out, P = std::max<long>(1, probe_stride);
     auto bad = [&](long m) { return !(std::isfinite(y[m].real()) && std::isfinite(y[m].imag())); };
-    bool hit = !tail_host_known || tail_host;
+    bool hit = !tail_host_known || tail_host || deferred.force0;
     if (!hit) {                                                 // a tile that read a non-finite sample has NO finite output
         for (long m = 0; m < n; m += P) __builtin_prefetch(&y[m]);   // (the lines come from memory the device just wrote: all misses)
         hit = bad(n - 1);
         for (long m = 0; m < n && !hit; m += P) hit = bad(m);
     }
     if (!hit) { seq++; return; }                               // (a call without the pass: its tail slot keeps a stale number)
-    launch_ref_blocks_nonfinite(deferred.src, static_cast<cf*>(deferred.out), n, (long)nsamples, probe_stride, (long)hist, (int)L,
-                                d_rev.p, d_tail.p, seq, stream);
+    launch_ref_blocks_nonfinite(deferred.src, static_cast<cf*>(deferred.out), n, (long)nsamples, probe_stride, (long)hist, (int)L, (int)front,
+                                d_rev.p, d_tail.p, seq, deferred.force0, stream);
     int t = -1;
     RR_HIP(hipMemcpyAsync(&t, d_tail.p + (seq & 1), sizeof t, hipMemcpyDeviceToHost, stream));
     RR_HIP(hipStreamSynchronize(stream));
@@ -1179,13 +1179,16 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
         prof_begin(s);
         filter(src, static_cast<cf*>(out), (long)n_out, s, carry);
         prof_end(s);
-        ref_blocks_pass(src, static_cast<cf*>(out), (long)n_out, s);
-        if (front && emitted == 0) {   // head fix: FftFilter's zero history under the first L2 - 1 outputs (n_out >= S > L2 - 1)
+        const bool head = front && emitted == 0;
+        if (head) {   // head fix: FftFilter's zero history under the first L2 - 1 outputs (n_out >= S > L2 - 1)
             const long L2 = (long)(L - front);
             d_zhead.reserve((size_t)L2);
             launch_head_z(src, (long)hist, d_t1.p, (int)(front + 1), d_zhead.p, L2 - 1, s);
             launch_head_y(d_zhead.p, d_t2.p, (int)L2, static_cast<cf*>(out), L2 - 1, s);
         }
+        // (after the head fix, which a poisoned first block covers — and whose finite values may hide a poisoned tile from the
+        //  probes: block 0 of that one call is looked at regardless)
+        ref_blocks_pass(src, static_cast<cf*>(out), (long)n_out, s, head);
         emitted += n_out;
     } else {
         launch_carry(src, carry, s);
@@ -1974,6 +1977,19 @@ Hilbert::Hilbert(size_t ntaps, int window, float parm) : Block("Hilbert", 4, 8) 
     }
 }
 Hilbert::~Hilbert() = default;
+void Hilbert::host_out_done(const void* out_host, size_t) {
+    if (!deferred.on) return;
+    deferred.on = false;
+    const std::complex<float>* y = static_cast<const std::complex<float>*>(out_host);
+    const long n = deferred.n, P = std::max<long>(1, deferred.P);
+    auto bad = [&](long m) { return !(std::isfinite(y[m].real()) && std::isfinite(y[m].imag())); };
+    for (long m = 0; m < n; m += P) __builtin_prefetch(&y[m]);
+    bool hit = bad(n - 1);
+    for (long m = 0; m < n && !hit; m += P) hit = bad(m);
+    if (!hit) return;
+    launch_hilbert_refold_nonfinite(deferred.src, static_cast<cf*>(deferred.out), n, deferred.P, pl.L, d_rev.p, stream);
+    RR_HIP(hipStreamSynchronize(stream));
+}
 int Hilbert::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, size_t* consumed,
                       size_t* produced, size_t* need, hipStream_t s) {
     *consumed = *produced = 0; *need = 1;
@@ -1985,6 +2001,9 @@ int Hilbert::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, 
     // (windows of a few tiles leave the chip idle: the pair-sample / direct kernels keep those, as in FirC32::work_dev)
     if (fftk && n >= 16 * (((size_t)1 << fftk->log2f) - (size_t)pl.L + 1)) {
         launch_fftfilt_real_hilbert(fftk->log2f, src, static_cast<cf*>(out), (long)n, pl.L, fftk->d_tw.p, fftk->d_hpos.p, s, CarryOut{}, nanfix());
+        const long P = ((long)1 << fftk->log2f) - (long)pl.L + 1;
+        if (host_out) { deferred.on = true; deferred.src = src; deferred.out = out; deferred.n = (long)n; deferred.P = P; }
+        else launch_hilbert_refold_nonfinite(src, static_cast<cf*>(out), (long)n, P, pl.L, d_rev.p, s);
     } else if (wide && n >= 4096) {
         // a[k] over the virtual stream xp = hist ++ window needs xp[k, k + L): Complex(xp, 0) in chunks, then the filter
         const size_t L = (size_t)pl.L, CH = (size_t)1 << 24, per = CH - L;

@@ -237,11 +237,11 @@ struct FftFilter : Block {
     // is launched only when it finds something (a probing kernel reads the window back over PCIe: +8 us per reference-sized call,
     // the host's own probe +2; the tile kernels' FIX instantiation could report for free but rounds differently in the last bit
     // than the one the other paths run, and the paths of one block are held bit-identical: tests/test_gpu_fuzz.py)
-    struct { bool on = false; VSrc<cf> src{}; void* out = nullptr; long n_out = 0; } deferred;
+    struct { bool on = false, force0 = false; VSrc<cf> src{}; void* out = nullptr; long n_out = 0; } deferred;
     bool tail_host = false, tail_host_known = true;   // the host's copy of the carried verdict
     void host_out_done(const void* out_host, size_t produced) override;
     void ref_blocks_on(const rr_c32* taps);
-    template <class T> void ref_blocks_pass(VSrc<T> src, T* out, long n_out, hipStream_t s);
+    template <class T> void ref_blocks_pass(VSrc<T> src, T* out, long n_out, hipStream_t s, bool force0 = false);
     std::unique_ptr<AnyFft> big;
     size_t bigM = 0;
     DevBuf<cf> d_hbig, bframes, bspec;
@@ -512,6 +512,10 @@ struct Hilbert : Block {
     std::unique_ptr<FftFilter> fftk;
     std::unique_ptr<FirC32> wide;
     DevBuf<cf> wide_in;
+    // the tile kernel of fftk carries no non-finite hooks: a pass behind it (kernels_misc.hip k_hilbert_refold_nonfinite); on a
+    // page-locked host output window the host probes its own memory after the completion wait and launches it only on a hit
+    struct { bool on = false; VSrc<float> src{}; void* out = nullptr; long n = 0, P = 0; } deferred;
+    void host_out_done(const void* out_host, size_t produced) override;
     Hilbert(size_t ntaps, int window, float parm);
     ~Hilbert() override;
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;

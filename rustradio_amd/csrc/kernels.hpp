@@ -196,9 +196,11 @@ void launch_rtlsdr_decode(const unsigned char* in, cf* out, long n_out, hipStrea
 void launch_vcopy_c32(VSrc<cf> src, long v0, cf* dst, long n, hipStream_t s);
 void launch_vcopy_iq8(VSrcIQ8 src, long v0, cf* dst, long n, hipStream_t s);   // decoding copy
 void launch_vcopy_f32(VSrc<float> src, long v0, float* dst, long n, hipStream_t s);
+// Hilbert on transform tiles: every non-finite output of a poisoned tile recomputed with the reference's fold (kernels_misc.hip)
+void launch_hilbert_refold_nonfinite(VSrc<float> src, cf* out, long n_out, long P, int L, const float* rev, hipStream_t s);
 // FftFilter / FftFilterFloat: non-finite samples poison the REFERENCE's blocks, not the GPU's tiles (kernels_misc.hip)
-void launch_ref_blocks_nonfinite(VSrc<cf> src, cf* out, long n_out, long S, long P, long hist, int L, const cf* rev, int* tail, int seq, hipStream_t s);
-void launch_ref_blocks_nonfinite(VSrc<float> src, float* out, long n_out, long S, long P, long hist, int L, const float* rev, int* tail, int seq, hipStream_t s);
+void launch_ref_blocks_nonfinite(VSrc<cf> src, cf* out, long n_out, long S, long P, long hist, int L, int front, const cf* rev, int* tail, int seq, bool force0, hipStream_t s);
+void launch_ref_blocks_nonfinite(VSrc<float> src, float* out, long n_out, long S, long P, long hist, int L, int front, const float* rev, int* tail, int seq, bool force0, hipStream_t s);
 // a CarryOut as its own launch (calls without a main kernel; launchers with nothing to launch)
 void launch_carry(VSrc<cf> src, const CarryOut& c, hipStream_t s);
 void launch_carry(VSrcIQ8 src, const CarryOut& c, hipStream_t s);

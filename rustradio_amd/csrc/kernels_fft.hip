@@ -432,7 +432,8 @@ void k_fftfilt_real(NanFixCtx nfx, VSrc<float> src, float* __restrict__ out, lon
     const int t = threadIdx.x;
     const long S = F - L + 1;
     // (nan_fix.hpp; not in the Hilbert form: it sits at 255 of 256 registers and anything more spills into its tile loop —
-    //  a Hilbert transformer of 200 ... 3584 taps keeps the tile-wide spread of a non-finite sample, DESIGN.md "known deviations")
+    //  a pass behind the kernel gives a Hilbert transformer on these tiles the reference's locality: kernels_misc.hip
+    //  k_hilbert_refold_nonfinite, round 5)
     if constexpr (!HILB) nf_init();
     const int first = L - 1;
     const long K = DECI ? (first + d - 1) / d : 0;

@@ -218,10 +218,14 @@ void launch_carry(VSrc<float> src, const CarryOut& c, hipStream_t s) {
 struct RefBlocksCtx {
     const void* prefix; long plen; const void* in; long in_len;     // the call's virtual stream (VSrc)
     void* out; long n_out;                                         // k * S outputs
-    long S, P, hist;                                               // block b reads the virtual samples [hist + b S, hist + (b + 1) S)
-    int L;
+    long S, P, hist;                                               // block b reads the virtual samples [hist + b S, hist + (b + 1) S + front)
+    int L, front;                                                  // front: a FirFilter of front + 1 taps fused in front (rr_fir_fftfilter_create) —
+                                                                   // L = the composite's taps, the FftFilter stage's are L - front, and the sample z1[m]
+                                                                   // the reference's FftFilter reads is not finite iff one of x[m .. m + front] is not
     const void* rev;                                               // the taps reversed (cf / float)
     int* tail; int seq;
+    int force0;                                                    // look at block 0 whatever the probes say (the fused block's head fix has
+                                                                   // overwritten the first outputs of a possibly poisoned tile with its own values)
 };
 template <class T>
 __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
@@ -245,16 +249,17 @@ __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
     {
         bool bad = probe(b0 * c.S, b1 * c.S, t, (int)blockDim.x);
         if (b0 > 0) bad |= probe((b0 - 1) * c.S, b0 * c.S, t, (int)blockDim.x);
-        if (!__syncthreads_or((int)bad | (int)(b0 == 0 && tail_bad))) return;
+        if (!__syncthreads_or((int)bad | (int)(b0 == 0 && (tail_bad || c.force0)))) return;
     }
     const int lane = t & 63, wave = t >> 6, nw = (int)(blockDim.x >> 6);
     auto any64 = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; };
     auto scan = [&](long b) {                                       // a non-finite INPUT sample in block b?
         bool bad = false;
         const long v0 = c.hist + b * c.S;
-        for (long i0 = 0; i0 < c.S; i0 += 64) {                     // (uniform trip count)
+        const long len = c.S + c.front;
+        for (long i0 = 0; i0 < len; i0 += 64) {                     // (uniform trip count)
             const long i = i0 + lane;
-            bad |= i < c.S && nf_bad(src.load(v0 + i));
+            bad |= i < len && nf_bad(src.load(v0 + i));
             if (any64(bad)) break;
         }
         return any64(bad);
@@ -265,34 +270,66 @@ __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
         const bool first = b == 0;
         bool hit = probe(b * c.S, (b + 1) * c.S, lane, 64);
         if (!first) hit |= probe((b - 1) * c.S, b * c.S, lane, 64);
-        if (!any64(hit) && !(first && tail_bad)) continue;
+        if (!any64(hit) && !(first && (tail_bad || c.force0))) continue;
         const bool bad_prev = first ? tail_bad : scan(b - 1);
         const bool bad_cur = scan(b);
         for (long i = lane; i < c.S; i += 64) {
             const long m = b * c.S + i;
-            if (bad_cur || (bad_prev && i < (long)c.L)) out[m] = nanv;
+            if (bad_cur || (bad_prev && i < (long)(c.L - c.front))) out[m] = nanv;
             else if (nf_bad(out[m])) {
-                if constexpr (std::is_same<T, float>::value) out[m] = nf_direct<float, float>(src, c.rev, c.L, 1, NANFIX_FF, m + (c.hist - (c.L - 1)));
-                else out[m] = nf_direct<cf, cf>(src, c.rev, c.L, 1, NANFIX_CC, m + (c.hist - (c.L - 1)));
+                if constexpr (std::is_same<T, float>::value) out[m] = nf_direct<float, float>(src, c.rev, c.L, 1, NANFIX_FF, m);
+                else out[m] = nf_direct<cf, cf>(src, c.rev, c.L, 1, NANFIX_CC, m);   // (y[m] reads the virtual samples [m, m + L): hist + front = L - 1)
             }
         }
         if (b == nb - 1 && lane == 0) c.tail[c.seq & 1] = bad_cur ? c.seq : -1;
     }
 }
 template <class T>
-static void launch_ref_blocks(VSrc<T> src, T* out, long n_out, long S, long P, long hist, int L, const void* rev, int* tail, int seq, hipStream_t s) {
+static void launch_ref_blocks(VSrc<T> src, T* out, long n_out, long S, long P, long hist, int L, int front, const void* rev, int* tail, int seq, bool force0, hipStream_t s) {
     if (n_out <= 0) return;
-    RefBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, n_out, S, P < 1 ? 1 : P, hist, L, rev, tail, seq};
+    RefBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, n_out, S, P < 1 ? 1 : P, hist, L, front, rev, tail, seq, force0 ? 1 : 0};
     const long nb = n_out / S;
     const long grid = std::max<long>(1, std::min<long>(256, (nb + 3) / 4));
     hipLaunchKernelGGL(k_ref_blocks_nonfinite<T>, dim3((unsigned)grid), dim3(256), 0, s, c);
     RR_HIP(hipGetLastError());
 }
-void launch_ref_blocks_nonfinite(VSrc<cf> src, cf* out, long n_out, long S, long P, long hist, int L, const cf* rev, int* tail, int seq, hipStream_t s) {
-    launch_ref_blocks<cf>(src, out, n_out, S, P, hist, L, rev, tail, seq, s);
+void launch_ref_blocks_nonfinite(VSrc<cf> src, cf* out, long n_out, long S, long P, long hist, int L, int front, const cf* rev, int* tail, int seq, bool force0, hipStream_t s) {
+    launch_ref_blocks<cf>(src, out, n_out, S, P, hist, L, front, rev, tail, seq, force0, s);
 }
-void launch_ref_blocks_nonfinite(VSrc<float> src, float* out, long n_out, long S, long P, long hist, int L, const float* rev, int* tail, int seq, hipStream_t s) {
-    launch_ref_blocks<float>(src, out, n_out, S, P, hist, L, rev, tail, seq, s);
+void launch_ref_blocks_nonfinite(VSrc<float> src, float* out, long n_out, long S, long P, long hist, int L, int front, const float* rev, int* tail, int seq, bool force0, hipStream_t s) {
+    launch_ref_blocks<float>(src, out, n_out, S, P, hist, L, front, rev, tail, seq, force0, s);
+}
+
+// ---- Hilbert on transform tiles: the reference's locality for non-finite samples (round 5) -------------------
+// k_fftfilt_real<.., HILB> runs at its register limit and carries no nan_fix.hpp hooks (a transformer of 200 ... 3584 taps
+// on large windows): one non-finite input sample makes the imaginary part of its tile's 2 S outputs non-finite, where the
+// reference's per-output fold (hilbert.rs:113-116) reaches the ntaps outputs whose window holds it.  Same scheme as above:
+// probe one output every P <= S; a workgroup whose range holds a poisoned tile replaces every non-finite output of the range
+// by the reference's own fold (nf_direct: non-finite exactly where the reference's is — its window holds the sample, zero
+// taps included; a clean tile's windows are clean, so nothing is missed).
+struct RefoldCtx {
+    const void* prefix; long plen; const void* in; long in_len;
+    void* out; long n_out, P;
+    int L; const void* rev;
+};
+__global__ __launch_bounds__(256) void k_hilbert_refold_nonfinite(RefoldCtx c) {
+    const VSrc<float> src{static_cast<const float*>(c.prefix), c.plen, static_cast<const float*>(c.in), c.in_len};
+    cf* out = static_cast<cf*>(c.out);
+    const long lo = c.n_out * (long)blockIdx.x / (long)gridDim.x, hi = c.n_out * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    if (lo >= hi) return;
+    const int t = (int)threadIdx.x;
+    bool bad = t == 0 && nf_bad(out[hi - 1]);
+    for (long m = lo + (long)t * c.P; m < hi; m += (long)blockDim.x * c.P) bad |= nf_bad(out[m]);
+    if (!__syncthreads_or((int)bad)) return;
+    for (long m = lo + t; m < hi; m += blockDim.x)
+        if (nf_bad(nf_peek(out + m))) out[m] = nf_direct<float, cf>(src, c.rev, c.L, 1, NANFIX_HILBERT, m);
+}
+void launch_hilbert_refold_nonfinite(VSrc<float> src, cf* out, long n_out, long P, int L, const float* rev, hipStream_t s) {
+    if (n_out <= 0) return;
+    RefoldCtx c{src.prefix, src.plen, src.in, src.in_len, out, n_out, P < 1 ? 1 : P, L, rev};
+    const long grid = std::max<long>(1, std::min<long>(256, n_out / (4 * c.P) + 1));
+    hipLaunchKernelGGL(k_hilbert_refold_nonfinite, dim3((unsigned)grid), dim3(256), 0, s, c);
+    RR_HIP(hipGetLastError());
 }
 
 // Plain byte copy between a device range and a page-locked host range seen through its device address (rr_dstream_copy_in /

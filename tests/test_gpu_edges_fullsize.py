@@ -496,6 +496,8 @@ FFTFILTER_NONFINITE_CASES = [
     ("fft2467-split-or-plain", lambda: (rnd_c(2467, 43) / 1000).astype(np.complex64), False, 8 * 30_000),
     ("fft5000-16384-split", lambda: (rnd_c(5000, 44) / 2000).astype(np.complex64), False, 8 * 50_000),
     ("fft16500-any-size-frames", lambda: (rnd_c(16500, 45) / 6000).astype(np.complex64), False, 8 * 120_000),
+    ("firfft127x401", lambda: (orc.low_pass_complex(10e6, 1e6, 190e3), orc.low_pass_complex(10e6, 1e6, 60e3)), False, 8 * 6_000),
+    ("firfft33x2467-complex-taps", lambda: ((rnd_c(33, 48) / 10).astype(np.complex64), (rnd_c(2467, 49) / 1000).astype(np.complex64)), False, 8 * 30_000),
     ("fftfloat127", lambda: orc.low_pass_complex(10e6, 1e6, 190e3).real.copy(), True, 4 * 3_000),
     ("fftfloat1000", lambda: (rnd_f(1000, 46) / 300).astype(np.float32), True, 4 * 12_000),
     ("fftfloat5000-complex-inner", lambda: (rnd_f(5000, 47) / 1500).astype(np.float32), True, 4 * 50_000),
@@ -512,6 +514,10 @@ def test_nonfinite_samples_in_fftfilter_poison_the_references_blocks(rr, name, m
     what only the tile had smeared.  VERDICT r4 weak #3: 'FftFilter-type blocks smear over the GPU tile'."""
     taps = mk_taps()
     mk = (lambda m: [m.FftFilterFloat(taps)]) if real_in else (lambda m: [m.FftFilter(taps)])
+    if name.startswith("firfft"):      # FirFilter(t1) -> FftFilter(t2), two blocks in the reference, one composite convolution here
+        t1, t2 = taps
+        mk = lambda m: [m.FirFftFilter(t1, t2)] if m is rr else [m.FirFilter(t1), m.FftFilter(t2)]
+        taps = t2
     n = 150_000 if len(taps) < 16_000 else 400_000
     x = _poisoned(rnd_f(n, 51) if real_in else rnd_c(n, 51), 6)
     for p in np.random.default_rng(len(taps)).integers(0, n, 6):     # (a few more: call ends are where the carry matters)
@@ -542,9 +548,11 @@ def test_nonfinite_samples_hilbert_pair_kernel(rr):
     the reference poisons — it multiplies the transformer's zero taps too (0 * NaN = NaN).  Round 5: the kernel tests its
     staged input (one packed FMA per pair it stages) and a workgroup that saw a bad tile recomputes its outputs with the
     reference's fold: the non-finite outputs are EXACTLY the reference's, real and imaginary parts, of the same class
-    (NaN / +Inf / -Inf), isolated samples, clusters, the first and last positions of a tile and of the stream."""
+    (NaN / +Inf / -Inf), isolated samples, clusters, the first and last positions of a tile and of the stream.  301 and 1001
+    taps run on the real-stream transform tiles (k_fftfilt_real<.., HILB>, no hooks: it sits at its register limit) with a
+    refold pass behind them (kernels_misc.hip k_hilbert_refold_nonfinite) — found missing by test_fuzz_nonfinite_sets."""
     n = 100_000
-    for L in (31, 65, 129):
+    for L in (31, 65, 129, 301, 1001):
         for seed, extra in ((9, []), (10, [0, 1, 4095, 4096, 4097, 8191, 8192, n - 1, n - 2])):
             x = _poisoned(rnd_f(n, 4), seed)
             for k, p in enumerate(extra):                 # tile edges of the kernel (4096 outputs per tile) and stream ends

@@ -579,3 +579,50 @@ def test_fuzz_zero_copy_windows(rr, seed):
         assert la == lb, (blk.name, seed)
         assert ya.shape == yb.shape, (blk.name, seed)
         assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8)), (blk.name, seed)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_nonfinite_sets(rr, seed):
+    """Round 5: random filters, stream lengths, ring sizes and NaN / +-Inf positions (isolated, clustered, at the very ends,
+    none at all) — the outputs that are not finite are EXACTLY the reference's for FirFilter (its ntaps windows), FftFilter /
+    FftFilterFloat / the fused FirFilter -> FftFilter (the fft_size outputs from the start of the reference's block, across
+    work() calls) and Hilbert, on
+    pageable windows and on page-locked ones, and everything else stays within tolerance."""
+    rng = np.random.default_rng(9000 + seed)
+    for _ in range(3):
+        kind = int(rng.integers(0, 6))
+        L = int(rng.choice([1, 2, 5, 17, 64, 127, 128, 129, 401, 1000, 1025, 2467, 5000]))
+        if kind == 4:
+            L = int(rng.choice([3, 33, 65, 129, 301])) | 1
+        n = int(rng.integers(3 * L + 100, 3 * L + int(rng.choice([3_000, 60_000, 300_000]))))
+        real = kind in (1, 3, 4)
+        x = rng.uniform(-1, 1, n).astype(np.float32) if real else _c(rng, n)
+        nbad = int(rng.choice([0, 1, 2, 5, 12]))
+        pos = [int(p) for p in rng.integers(0, n, nbad)]
+        if nbad and rng.integers(0, 2):
+            pos += [0, n - 1, pos[0] + 1 if pos[0] + 1 < n else 0]
+        for p in pos:
+            bad = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]
+            x[p] = bad if real else [complex(bad, 0.5), complex(0.25, bad), complex(bad, bad)][int(rng.integers(0, 3))]
+        tc = (_c(rng, L) / max(1, L // 4)).astype(np.complex64)
+        tf = (rng.uniform(-1, 1, L) / max(1, L // 4)).astype(np.float32)
+        d = int(rng.choice([1, 1, 2, 3, 5, 8]))
+        t1 = (_c(rng, int(rng.choice([1, 2, 9, 33, 127]))) / 8).astype(np.complex64)      # (kind 5: the FirFilter fused in front)
+        mk = [lambda m: [m.FirFilter(tc, deci=d)], lambda m: [m.FirFilter(tf, deci=d)], lambda m: [m.FftFilter(tc)],
+              lambda m: [m.FftFilterFloat(tf)], lambda m: [m.Hilbert(L)],
+              lambda m: [m.FirFftFilter(t1, tc)] if m is rr else [m.FirFilter(t1), m.FftFilter(tc)]][kind]
+        block = 4 * (1 << int(np.ceil(np.log2(max(L, 2)))))       # (a ring holds two of the reference's transform blocks)
+        es = 4 if real else 8
+        ring = int(rng.choice([4_096_000, es * (block + int(rng.integers(64, 20_000)))]))
+        yo = run_chain(mk(orc), x, stream_bytes=ring)
+        if rng.integers(0, 3) == 0:
+            cap = ring // es
+            yg = drive_registered(rr, mk(rr)[0], x, cap, cap)[0][0]
+        else:
+            yg = run_chain(mk(rr), x, stream_bytes=ring)
+        assert len(yo) == len(yg), (kind, L, n, ring)
+        fin = lambda y: np.isfinite(y.real) & np.isfinite(y.imag) if np.iscomplexobj(y) else np.isfinite(y)
+        go, gg = fin(yo), fin(yg)
+        assert np.array_equal(go, gg), (kind, L, n, d, ring, sorted(pos)[:6], np.flatnonzero(go != gg)[:6])
+        if go.any():
+            assert max_norm_err(yg[go], yo[go]) <= TOL, (kind, L, n, ring)

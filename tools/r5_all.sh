@@ -13,6 +13,7 @@ python3 -m tests.parity_allowance > gpurun_out/prof_$TAG/parity_allowance.log 2>
 cp gpurun_out/parity_allowance.json gpurun_out/prof_$TAG/parity_allowance.json
 cp gpurun_out/parity_allowance.json profiles/parity_allowance.json      # (the default line below carries its summary)
 timeout 120 ./tools/micro/pcie_inplace.bin > gpurun_out/prof_$TAG/pcie_inplace.txt 2>&1
+(timeout 60 ./tools/micro/rotor_rate.bin; timeout 200 python3 tools/replay_rate.py 2>/dev/null | grep -v amdgpu) > gpurun_out/prof_$TAG/rotor_rate.txt 2>&1
 python3 tools/chain_tile_probe.py 2>/dev/null | grep -v amdgpu > gpurun_out/prof_$TAG/rtl_fm_tiles.txt
 python3 tools/clock_probe.py channelizer > gpurun_out/prof_$TAG/clocks.txt 2>&1
 python3 bench.py > "gpurun_out/prof_$TAG/bench_default.json" 2> "gpurun_out/prof_$TAG/bench_default.log"
