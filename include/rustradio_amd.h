@@ -104,7 +104,9 @@ typedef struct {
     int fir_poly;           /* decimating FirFilter<Complex>: decimate-first (polyphase) tiles, > 0 wherever supported, < 0 never */
     int fft_nonfinite_tiles;/* FftFilter / FftFilterFloat: leave a NaN / Inf input sample's damage on the GPU's tile (one launch
                                less per work() call) instead of moving it onto the reference's block of nsamples inputs */
-    int reserved[4];
+    int host_in_staged;     /* rr_block_work on a page-locked INPUT window: > 0 copy it to device memory first (a copy kernel, 55 GB/s)
+                               instead of letting the block's kernels read it in place, < 0 always in place; 0 = the block's default */
+    int reserved[3];
 } rr_build_opts;
 int rr_next_create_options(const rr_build_opts *opts);   /* NULL clears a pending override */
 

@@ -36,7 +36,7 @@ _lib = None
 class BuildOpts(C.Structure):
     """rr_build_opts (include/rustradio_amd.h): path-selection overrides for the next create call"""
     _fields_ = [(n, C.c_int) for n in ("fir_path", "fir_prune", "fir_half", "fir_cfg_plus1", "fft_log2f", "fft_no_split",
-                                        "fftfloat_complex", "fm_full", "fm_poly", "dstream_no_vmm", "fir_poly", "fft_nonfinite_tiles")] + [("reserved", C.c_int * 4)]
+                                        "fftfloat_complex", "fm_full", "fm_poly", "dstream_no_vmm", "fir_poly", "fft_nonfinite_tiles", "host_in_staged")] + [("reserved", C.c_int * 3)]
 
 
 def lib():

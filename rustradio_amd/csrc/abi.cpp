@@ -41,6 +41,7 @@ template <class F> static rr_block* make_block(F&& f, int tag_rule = RR_TAGS_DRO
     rr::OptsScope scope;
     try {
         std::unique_ptr<rr::Block> b(f());         // a throwing constructor leaks nothing
+        if (const int v = rr::build_opts().host_in_staged) b->zero_copy_in = v < 0;   // (rr_build_opts: the block's default otherwise)
         auto* h = new rr_block;
         h->b = std::move(b);
         h->tag_rule = tag_rule;
@@ -66,7 +67,7 @@ int rr_next_create_options(const rr_build_opts* o) {
     b.fir_path = o->fir_path; b.fir_prune = o->fir_prune; b.fir_half = o->fir_half; b.fir_cfg = o->fir_cfg_plus1 - 1;
     b.fft_log2f = o->fft_log2f; b.fft_no_split = o->fft_no_split; b.fftfloat_complex = o->fftfloat_complex;
     b.fm_full = o->fm_full; b.fm_poly = o->fm_poly; b.dstream_no_vmm = o->dstream_no_vmm;
-    b.fir_poly = o->fir_poly; b.fft_nonfinite_tiles = o->fft_nonfinite_tiles;
+    b.fir_poly = o->fir_poly; b.fft_nonfinite_tiles = o->fft_nonfinite_tiles; b.host_in_staged = o->host_in_staged;
     if (b.fir_path < 0 || b.fir_path > 2 || b.fir_cfg > 7 || (b.fft_log2f != 0 && (b.fft_log2f < 10 || b.fft_log2f > 14))) {
         rr::set_last_error("rr_next_create_options: value out of range");
         return RR_ERR;

@@ -165,12 +165,16 @@ int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, s
                      size_t* produced, size_t* need) {
     RR_HIP(hipSetDevice(device));
     last_stream = stream;
-    void* din = zero_copy_in && in_len ? device_view_of_host(in, in_len * in_es) : nullptr;
+    // (the window seen from the device, if it lies in a registered range: read in place by the block's kernels, or — blocks that
+    //  read it more than once, or in narrow loads — copied down by a kernel first: 55 GB/s against hipMemcpyAsync's 16-18)
+    void* vin = in_len ? device_view_of_host(in, in_len * in_es) : nullptr;
+    void* din = zero_copy_in ? vin : nullptr;
     void* dout = out_cap ? device_view_of_host(out, out_cap * out_es * out_windows()) : nullptr;
     const size_t in_use = in_len;   // whole window: kernels may touch (zero-weighted) samples past the consumed range
     if (!din) {
         st_in.reserve(std::max<size_t>(in_use * in_es, 16));
-        if (in_use) RR_HIP(hipMemcpyAsync(st_in.p, in, in_use * in_es, hipMemcpyHostToDevice, stream));
+        if (in_use && vin) launch_copy_bytes(vin, st_in.p, in_use * in_es, stream);
+        else if (in_use) RR_HIP(hipMemcpyAsync(st_in.p, in, in_use * in_es, hipMemcpyHostToDevice, stream));
         din = st_in.p;
     }
     if (!dout) st_out.reserve(std::max<size_t>(out_cap * out_es * out_windows(), 16));

@@ -38,6 +38,7 @@ struct BuildOpts {
     int fm_poly = 0;           // 0 auto, < 0 off: polyphase (decimate-first) tiles of the fused chains
     int dstream_no_vmm = 0;
     int fft_nonfinite_tiles = 0;   // FftFilter / FftFilterFloat: no reference-block pass for non-finite samples
+    int host_in_staged = 0;    // page-locked input windows: > 0 staged through a copy kernel, < 0 read in place, 0 the block's default
     int fir_poly = 0;          // 0 auto, > 0 on wherever supported, < 0 off: decimating FirFilter<Complex> on decimate-first tiles
 };
 const BuildOpts& build_opts();

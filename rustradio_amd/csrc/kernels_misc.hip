@@ -201,6 +201,35 @@ void launch_carry(VSrc<float> src, const CarryOut& c, hipStream_t s) {
     if (c.n > 0) launch_vcopy_f32(src, c.v0, static_cast<float*>(c.dst), c.n, s);
 }
 
+// The reference's left fold out[m] = sum_j rev[j] V[m + j] (nan_fix.hpp nf_direct: same operations in the same order, so
+// the same bits and the same non-finite class) with the operands fetched eight at a time: the rolled form waits a memory
+// round trip per tap (190 ns: one bad sample in a 401-tap FftFilter cost 0.8 ms), and nothing here is short of registers.
+template <class T, class TAP, class ACC, class STEP>
+__device__ __forceinline__ ACC nf_fold8(const VSrc<T>& src, const TAP* rev, int L, long v0, ACC acc, STEP step) {
+    int j = 0;
+    for (; j + 8 <= L; j += 8) {
+        TAP a[8]; T x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a[k] = rev[j + k]; x[k] = src.load(v0 + j + k); }
+        bool dead = false;
+#pragma unroll
+        for (int k = 0; k < 8; k++) dead = step(acc, a[k], x[k]);
+        if (dead) return acc;                                        // (NaN in every component it can reach: it stays)
+    }
+    for (; j < L; j++) step(acc, rev[j], src.load(v0 + j));
+    return acc;
+}
+__device__ __forceinline__ cf nf_fold_cc(const VSrc<cf>& src, const cf* rev, int L, long v0) {        // num-complex: (ar xr - ai xi, ar xi + ai xr)
+    return nf_fold8(src, rev, L, v0, mkcf(0.0f, 0.0f), [](cf& acc, cf a, cf x) {
+        acc.x = add_rn(acc.x, sub_rn(mul_rn(a.x, x.x), mul_rn(a.y, x.y)));
+        acc.y = add_rn(acc.y, add_rn(mul_rn(a.x, x.y), mul_rn(a.y, x.x)));
+        return acc.x != acc.x && acc.y != acc.y;
+    });
+}
+__device__ __forceinline__ float nf_fold_ff(const VSrc<float>& src, const float* rev, int L, long v0) {  // fir.rs:146 / hilbert.rs:113-116
+    return nf_fold8(src, rev, L, v0, 0.0f, [](float& s, float a, float x) { s = add_rn(s, mul_rn(a, x)); return s != s; });
+}
+
 // ---- FftFilter / FftFilterFloat: non-finite samples on the REFERENCE's blocks (round 5) ------------------
 // The reference runs one fft_size-point transform per `nsamples` input samples and adds the last `ntaps` points of it to
 // the next block (fft_filter.rs:326-347): one NaN / Inf input sample of block b makes ALL of the block's transform
@@ -215,6 +244,7 @@ void launch_carry(VSrc<float> src, const CarryOut& c, hipStream_t s) {
 //     reference's own left fold (nan_fix.hpp nf_direct), whose window lies in clean blocks.
 // The block before the call's first is gone with its input: its verdict is carried in tail[(seq - 1) & 1] == seq - 1
 // (written by the call that saw it; a call whose probes were clean writes nothing and leaves a stale sequence number).
+__host__ __device__ inline long ref_blocks_sub(long S) { const long q = S / 256; return q < 1 ? 1 : q > 64 ? 64 : q; }
 struct RefBlocksCtx {
     const void* prefix; long plen; const void* in; long in_len;     // the call's virtual stream (VSrc)
     void* out; long n_out;                                         // k * S outputs
@@ -232,8 +262,13 @@ __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
     const VSrc<T> src{static_cast<const T*>(c.prefix), c.plen, static_cast<const T*>(c.in), c.in_len};
     T* out = static_cast<T*>(c.out);
     const long nb = c.n_out / c.S;
-    const long b0 = nb * (long)blockIdx.x / (long)gridDim.x, b1 = nb * ((long)blockIdx.x + 1) / (long)gridDim.x;
-    if (b0 >= b1) return;
+    // work items = (block, sub-range of its outputs): long blocks are cut so that the fold over what a tile smeared (up to S
+    // outputs x L taps for ONE bad sample) is shared by several waves: sub-ranges of >= 256 outputs, at most 64 per block
+    const long sub = ref_blocks_sub(c.S);
+    const long nitem = nb * sub;
+    const long w0 = nitem * (long)blockIdx.x / (long)gridDim.x, w1 = nitem * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    if (w0 >= w1) return;
+    const long b0 = w0 / sub, b1 = (w1 - 1) / sub + 1;             // the blocks this workgroup's items lie in
     const bool tail_bad = c.tail[(c.seq - 1) & 1] == c.seq - 1;    // (uniform)
     const int t = (int)threadIdx.x;
     // any non-finite output at lo, lo + P, ..., or at hi - 1?  A tile is >= P outputs long, so one that overlaps [lo, hi)
@@ -257,39 +292,48 @@ __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
         bool bad = false;
         const long v0 = c.hist + b * c.S;
         const long len = c.S + c.front;
-        for (long i0 = 0; i0 < len; i0 += 64) {                     // (uniform trip count)
-            const long i = i0 + lane;
-            bad |= i < len && nf_bad(src.load(v0 + i));
+        for (long i0 = 0; i0 < len; i0 += 512) {                    // (uniform trip count; eight loads in flight per lane)
+            T x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = src.load(v0 + i0 + 64 * k + lane);   // (past the block's end: still the stream, or its zero padding — masked below)
+#pragma unroll
+            for (int k = 0; k < 8; k++) bad |= i0 + 64 * k + lane < len && nf_bad(x[k]);
             if (any64(bad)) break;
         }
         return any64(bad);
     };
     T nanv;
     if constexpr (std::is_same<T, float>::value) nanv = __builtin_nanf(""); else nanv = mkcf(__builtin_nanf(""), __builtin_nanf(""));
-    for (long b = b0 + wave; b < b1; b += nw) {                     // one wave per block
+    for (long w = w0 + wave; w < w1; w += nw) {                     // one wave per item
+        const long b = w / sub, q = w - b * sub;
+        const long i0 = c.S * q / sub, i1 = c.S * (q + 1) / sub;    // its outputs of block b
         const bool first = b == 0;
+        // the block's own lattice (a bad sample anywhere in it poisons ALL of it: the tile that read the sample may end before
+        // this sub-range), the previous block's (its tail), and this sub-range's (what a tile smeared here; the other
+        // sub-ranges of the block are being repaired by other waves)
         bool hit = probe(b * c.S, (b + 1) * c.S, lane, 64);
+        if (sub > 1) hit |= probe(b * c.S + i0, b * c.S + i1, lane, 64);
         if (!first) hit |= probe((b - 1) * c.S, b * c.S, lane, 64);
         if (!any64(hit) && !(first && (tail_bad || c.force0))) continue;
         const bool bad_prev = first ? tail_bad : scan(b - 1);
         const bool bad_cur = scan(b);
-        for (long i = lane; i < c.S; i += 64) {
+        for (long i = i0 + lane; i < i1; i += 64) {
             const long m = b * c.S + i;
             if (bad_cur || (bad_prev && i < (long)(c.L - c.front))) out[m] = nanv;
             else if (nf_bad(out[m])) {
-                if constexpr (std::is_same<T, float>::value) out[m] = nf_direct<float, float>(src, c.rev, c.L, 1, NANFIX_FF, m);
-                else out[m] = nf_direct<cf, cf>(src, c.rev, c.L, 1, NANFIX_CC, m);   // (y[m] reads the virtual samples [m, m + L): hist + front = L - 1)
+                if constexpr (std::is_same<T, float>::value) out[m] = nf_fold_ff(src, static_cast<const float*>(c.rev), c.L, m);
+                else out[m] = nf_fold_cc(src, static_cast<const cf*>(c.rev), c.L, m);   // (y[m] reads the virtual samples [m, m + L): hist + front = L - 1)
             }
         }
-        if (b == nb - 1 && lane == 0) c.tail[c.seq & 1] = bad_cur ? c.seq : -1;
+        if (b == nb - 1 && q == sub - 1 && lane == 0) c.tail[c.seq & 1] = bad_cur ? c.seq : -1;
     }
 }
 template <class T>
 static void launch_ref_blocks(VSrc<T> src, T* out, long n_out, long S, long P, long hist, int L, int front, const void* rev, int* tail, int seq, bool force0, hipStream_t s) {
     if (n_out <= 0) return;
     RefBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, n_out, S, P < 1 ? 1 : P, hist, L, front, rev, tail, seq, force0 ? 1 : 0};
-    const long nb = n_out / S;
-    const long grid = std::max<long>(1, std::min<long>(256, (nb + 3) / 4));
+    const long nb = n_out / S, sub = ref_blocks_sub(S);
+    const long grid = std::max<long>(1, std::min<long>(256, (nb * sub + 3) / 4));
     hipLaunchKernelGGL(k_ref_blocks_nonfinite<T>, dim3((unsigned)grid), dim3(256), 0, s, c);
     RR_HIP(hipGetLastError());
 }
@@ -322,7 +366,7 @@ __global__ __launch_bounds__(256) void k_hilbert_refold_nonfinite(RefoldCtx c) {
     for (long m = lo + (long)t * c.P; m < hi; m += (long)blockDim.x * c.P) bad |= nf_bad(out[m]);
     if (!__syncthreads_or((int)bad)) return;
     for (long m = lo + t; m < hi; m += blockDim.x)
-        if (nf_bad(nf_peek(out + m))) out[m] = nf_direct<float, cf>(src, c.rev, c.L, 1, NANFIX_HILBERT, m);
+        if (nf_bad(nf_peek(out + m))) out[m] = mkcf(src.load(m + c.L / 2), nf_fold_ff(src, static_cast<const float*>(c.rev), c.L, m));   // hilbert.rs:113-116
 }
 void launch_hilbert_refold_nonfinite(VSrc<float> src, cf* out, long n_out, long P, int L, const float* rev, hipStream_t s) {
     if (n_out <= 0) return;
