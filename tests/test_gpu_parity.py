@@ -1339,12 +1339,18 @@ def test_zero_copy_host_windows_equal_staged_windows(rr):
         (lambda: rr.RtlSdrDecode(), xb, 100_001, 40_000), (lambda: rr.FftStream(1024), xc, 50_000, 50_000),
         (lambda: rr.MultiplyConst(0.5), xf, 50_000, 50_000),
     ]
-    for mk, x, in_cap, out_cap in cases:
+    for k, (mk, x, in_cap, out_cap) in enumerate(cases):
         ya, la = drive_pageable(mk(), x, in_cap, out_cap)
         yb, lb = drive_registered(rr, mk(), x, in_cap, out_cap)
         assert la == lb, mk().name
         assert ya.shape == yb.shape and ya.shape[1] > 0, mk().name
         assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8)), mk().name
+        # rr_build_opts.host_in_staged: the registered INPUT window copied down by a kernel first (+1; what the N-channel blocks do
+        # by default) or read in place (-1): the same kernels behind it, the same bits
+        with rr.build_options(host_in_staged=1 if k % 2 else -1):
+            blk = mk()
+        yc, lc = drive_registered(rr, blk, x, in_cap, out_cap)
+        assert lc == la and np.array_equal(yc.view(np.uint8), ya.view(np.uint8)), (blk.name, k % 2)
 
 
 def test_tag_rule_of_every_constructor(rr):
