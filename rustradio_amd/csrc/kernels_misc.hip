@@ -254,6 +254,7 @@ struct RefBlocksCtx {
                                                                    // the reference's FftFilter reads is not finite iff one of x[m .. m + front] is not
     const void* rev;                                               // the taps reversed (cf / float)
     int* tail; int seq;
+    long nb, bpw, sub, qpp;                                        // blocks of the call, blocks per workgroup, sub-ranges per block and per row
     int force0;                                                    // look at block 0 whatever the probes say (the fused block's head fix has
                                                                    // overwritten the first outputs of a possibly poisoned tile with its own values)
 };
@@ -261,14 +262,18 @@ template <class T>
 __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
     const VSrc<T> src{static_cast<const T*>(c.prefix), c.plen, static_cast<const T*>(c.in), c.in_len};
     T* out = static_cast<T*>(c.out);
-    const long nb = c.n_out / c.S;
+    // (no division on the way to the probes: the launcher passes the block count and the blocks per workgroup — five 64-bit
+    //  divisions were 2 us of this kernel's 5 in the steady state, where it runs behind every call)
+    const long nb = c.nb;
+    const long b0 = (long)blockIdx.x * c.bpw, b1 = b0 + c.bpw < nb ? b0 + c.bpw : nb;
+    if (b0 >= b1) return;
     // work items = (block, sub-range of its outputs): long blocks are cut so that the fold over what a tile smeared (up to S
-    // outputs x L taps for ONE bad sample) is shared by several waves: sub-ranges of >= 256 outputs, at most 64 per block
-    const long sub = ref_blocks_sub(c.S);
-    const long nitem = nb * sub;
-    const long w0 = nitem * (long)blockIdx.x / (long)gridDim.x, w1 = nitem * ((long)blockIdx.x + 1) / (long)gridDim.x;
-    if (w0 >= w1) return;
-    const long b0 = w0 / sub, b1 = (w1 - 1) / sub + 1;             // the blocks this workgroup's items lie in
+    // outputs x L taps for ONE bad sample) is shared by several waves — sub-ranges of >= 256 outputs, at most 64 per block,
+    // qpp of them per workgroup row (blockIdx.y)
+    const long sub = c.sub;
+    const long q0 = (long)blockIdx.y * c.qpp, q1 = q0 + c.qpp < sub ? q0 + c.qpp : sub, nq = q1 - q0;
+    if (nq <= 0) return;
+    const long w0 = 0, w1 = (b1 - b0) * nq;                        // this workgroup's items
     const bool tail_bad = c.tail[(c.seq - 1) & 1] == c.seq - 1;    // (uniform)
     const int t = (int)threadIdx.x;
     // any non-finite output at lo, lo + P, ..., or at hi - 1?  A tile is >= P outputs long, so one that overlaps [lo, hi)
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
     T nanv;
     if constexpr (std::is_same<T, float>::value) nanv = __builtin_nanf(""); else nanv = mkcf(__builtin_nanf(""), __builtin_nanf(""));
     for (long w = w0 + wave; w < w1; w += nw) {                     // one wave per item
-        const long b = w / sub, q = w - b * sub;
+        const long bq = w / nq, q = q0 + (w - bq * nq), b = b0 + bq;
         const long i0 = c.S * q / sub, i1 = c.S * (q + 1) / sub;    // its outputs of block b
         const bool first = b == 0;
         // the block's own lattice (a bad sample anywhere in it poisons ALL of it: the tile that read the sample may end before
@@ -331,10 +336,13 @@ __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
 template <class T>
 static void launch_ref_blocks(VSrc<T> src, T* out, long n_out, long S, long P, long hist, int L, int front, const void* rev, int* tail, int seq, bool force0, hipStream_t s) {
     if (n_out <= 0) return;
-    RefBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, n_out, S, P < 1 ? 1 : P, hist, L, front, rev, tail, seq, force0 ? 1 : 0};
-    const long nb = n_out / S, sub = ref_blocks_sub(S);
-    const long grid = std::max<long>(1, std::min<long>(256, (nb * sub + 3) / 4));
-    hipLaunchKernelGGL(k_ref_blocks_nonfinite<T>, dim3((unsigned)grid), dim3(256), 0, s, c);
+    RefBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, n_out, S, P < 1 ? 1 : P, hist, L, front, rev, tail, seq, 0, 0, 0, 0, force0 ? 1 : 0};
+    c.nb = n_out / S; c.sub = ref_blocks_sub(S);
+    const long rows = std::min<long>(16, (c.sub + 3) / 4);          // (a workgroup has four waves)
+    c.qpp = (c.sub + rows - 1) / rows;
+    c.bpw = std::max<long>(1, (c.nb * rows + 255) / 256);
+    const long gx = (c.nb + c.bpw - 1) / c.bpw;
+    hipLaunchKernelGGL(k_ref_blocks_nonfinite<T>, dim3((unsigned)gx, (unsigned)rows), dim3(256), 0, s, c);
     RR_HIP(hipGetLastError());
 }
 void launch_ref_blocks_nonfinite(VSrc<cf> src, cf* out, long n_out, long S, long P, long hist, int L, int front, const cf* rev, int* tail, int seq, bool force0, hipStream_t s) {
@@ -353,13 +361,13 @@ void launch_ref_blocks_nonfinite(VSrc<float> src, float* out, long n_out, long S
 // taps included; a clean tile's windows are clean, so nothing is missed).
 struct RefoldCtx {
     const void* prefix; long plen; const void* in; long in_len;
-    void* out; long n_out, P;
+    void* out; long n_out, P, span;                                // span: outputs per workgroup
     int L; const void* rev;
 };
 __global__ __launch_bounds__(256) void k_hilbert_refold_nonfinite(RefoldCtx c) {
     const VSrc<float> src{static_cast<const float*>(c.prefix), c.plen, static_cast<const float*>(c.in), c.in_len};
     cf* out = static_cast<cf*>(c.out);
-    const long lo = c.n_out * (long)blockIdx.x / (long)gridDim.x, hi = c.n_out * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    const long lo = (long)blockIdx.x * c.span, hi = lo + c.span < c.n_out ? lo + c.span : c.n_out;
     if (lo >= hi) return;
     const int t = (int)threadIdx.x;
     bool bad = t == 0 && nf_bad(out[hi - 1]);
@@ -370,8 +378,9 @@ __global__ __launch_bounds__(256) void k_hilbert_refold_nonfinite(RefoldCtx c) {
 }
 void launch_hilbert_refold_nonfinite(VSrc<float> src, cf* out, long n_out, long P, int L, const float* rev, hipStream_t s) {
     if (n_out <= 0) return;
-    RefoldCtx c{src.prefix, src.plen, src.in, src.in_len, out, n_out, P < 1 ? 1 : P, L, rev};
-    const long grid = std::max<long>(1, std::min<long>(256, n_out / (4 * c.P) + 1));
+    RefoldCtx c{src.prefix, src.plen, src.in, src.in_len, out, n_out, P < 1 ? 1 : P, 0, L, rev};
+    c.span = std::max<long>(4 * c.P, (n_out + 255) / 256);
+    const long grid = (n_out + c.span - 1) / c.span;
     hipLaunchKernelGGL(k_hilbert_refold_nonfinite, dim3((unsigned)grid), dim3(256), 0, s, c);
     RR_HIP(hipGetLastError());
 }
