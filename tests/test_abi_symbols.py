@@ -84,3 +84,17 @@ def test_cpu_emulation_of_fft_tile():
                     os.path.join(ROOT, "tests", "cpp", "emu_fft.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_build_opts_struct_matches_the_header():
+    """rr_build_opts (include/rustradio_amd.h) and its ctypes mirror: the same int fields in the same order, 16 ints in all —
+    a field added to one side only would shift every override behind it"""
+    from rustradio_amd._lib import BuildOpts
+    src = open(os.path.join(ROOT, "include", "rustradio_amd.h")).read()
+    body = re.search(r"typedef struct \{(.*?)\} rr_build_opts;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\bint\s+([a-z0-9_]+)(?:\[(\d+)\])?\s*;", body)
+    names = [n for n, _ in fields]
+    total = sum(int(k) if k else 1 for _, k in fields)
+    assert names == [n for n, _ in BuildOpts._fields_] and names[-1] == "reserved"
+    assert total == 16 and ctypes.sizeof(BuildOpts) == 16 * ctypes.sizeof(ctypes.c_int)
