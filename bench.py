@@ -1348,7 +1348,11 @@ def main():
                                              "metric's four-block chain is others.full_chain / others.full_chain_fused"
                                              if wname == "fftfilter" else
                                              "BASELINE.json configs[3], the multi-GPU configuration (32 channels per GPU)"
-                                             if wname == "fm_multi" else "--workload")},
+                                             if wname == "fm_multi" else "--workload"),
+                       **({"step_is": "k_fftfilt_os (roofline.avg_kernel_ms) + the 5 us pass that keeps FftFilter's outputs on non-finite input "
+                                      "the reference's (k_ref_blocks_nonfinite: one probe per tile in the steady state, DESIGN.md section 8); "
+                                      "rr_build_opts.fft_nonfinite_tiles leaves it out (bench.py --opt fft_nonfinite_tiles=1)"}
+                          if wname in ("fftfilter", "fir_fft_chain") else {})},
             "roofline": roof,
             "parity": parity_report(),
             "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),
