@@ -33,3 +33,23 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionstart(session):
+    """RR_ABORT_BT=1: a SIGABRT handler that keeps the NATIVE backtrace of an abort() (tests/cpp/abort_bt.c; the file goes to
+    gpurun_out/abort_bt_<pid>.txt and the original stderr).  pytest's per-test fd capture otherwise swallows what the HIP
+    runtime / libstdc++ printed before aborting — run the hunt with --capture=sys as well so that fd 2 stays the log."""
+    if os.environ.get("RR_ABORT_BT") != "1":
+        return
+    import ctypes
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "abort_bt.c")
+    so = os.path.join(ROOT, "tests", "cpp", "abort_bt.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", so, src], check=True)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    lib = ctypes.CDLL(so)
+    lib.abort_bt_install.argtypes = [ctypes.c_char_p]
+    assert lib.abort_bt_install(os.path.join(out, f"abort_bt_{os.getpid()}.txt").encode()) == 0
+    session.config._rr_abort_bt = lib          # keep the library loaded
