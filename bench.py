@@ -8,24 +8,8 @@ A "step" is one pass of the hot path over one batch of synthetic input that is a
 resident in HBM.  Default workload = BASELINE.json configs[1]:
     FftFilter, 401 taps (low_pass_complex(10e6, 1e6, 60e3) => reference fft_size 1024,
     nsamples 623), 10 Msps synthetic Complex<f32>, 10 s = 100,000,000 samples per step.
-Other workloads (--workload, also summarised under "others" in the JSON line):
-    fir          configs[0]: FirFilter<Complex> 127 real taps, 1,000,000 samples (deci 1 and > 40 taps: the block runs
-                 on overlap-save FFT tiles, the FftFilter kernel with no history)
-    fm_chain     configs[2]: FftFilter(463) -> RationalResampler(1:6) -> QuadratureDemod, 2.4 Msps x 10 s
-    fm_multi     configs[3]: 32 such channels per GPU on one shared IQ source (256 channels on 8 GPUs)
-    channelizer  configs[4]: Hilbert(65) -> FirFilter(255 taps, deci 8), 100 Msps x 1 s (f32 in), fused into one
-                 composite decimating FIR (rr.HilbertFir: real-stream overlap-save tiles, inverse transform pruned to 1/8);
-                 channelizer_unfused = the two blocks
-    fir_1e8      the configs[0] filter on 100,000,000 samples (steady state; 1e6 samples is a single ~15 us launch)
-    fir_float    FirFilter<Float>, the same 127 taps on 100,000,000 f32 samples (real-stream tiles, 8 B/sample)
-    fir_fft_chain  configs[0] taps -> configs[1] filter as one chain (the north star's ">= 100x CPU" pair)
-    rtl_fm_example examples/rtl_fm.rs with its own parameters (1.024 Msps, 2467 taps, 25:128), fused
-    rtl_fm_chain configs[2] fed by the RTL-SDR byte stream: RtlSdrDecode fused in front (u8 in)
-
-    full_chain   the metric's own words: FirFilter(127) -> FftFilter(401) -> RationalResampler(1:4) -> QuadratureDemod,
-                 four blocks with device-resident intermediates; full_chain_fused = the best fused form
-    dropin_*     (under "others" only) the DROP-IN path: rr_block_work on reference-sized 4,096,000-byte HOST windows
-                 exactly as the Rust shim calls it, and the device-resident graph with reference-sized rings
+Other workloads (--workload; every one also runs short in the default run): bench_workloads.py lists them; the drop-in
+path (rr_block_work on reference-sized HOST windows, PCIe-inclusive, never `value`) is bench_dropin.py.
 
 Multi-GPU (`--gpus N`, one process per GPU, weak scaling): when WORLD_SIZE is not set, this process — before it
 touches the GPU — starts N ranks of itself with torch.distributed.run and exits with their code.  The path shards
@@ -33,8 +17,14 @@ by channel: default N > 1 workload = configs[3] (fm_multi: rank r owns channels 
 bank).  The only collective is the fan-out of the shared IQ source: rank 0 produces tile t+1 and RCCL-broadcasts it on a
 communication stream while every rank runs tile t (double buffer, events) — INSIDE the timed region.
 
-Prints ONE JSON line (rank 0).  `value` counts input samples entering the first block (x channels for the
-multi-channel block), summed over ranks, per second of max-over-ranks wall time.
+Prints ONE JSON line (rank 0), strict JSON under 4 KB: the contract keys, `config`, `roofline` (dominant kernel: mean launch
+duration from HIP events on its launch stream, algorithmic bytes and executed flops per launch, both fractions, `bound` = the
+larger), `cpu_baseline`, and compact companions (`metric_chain`, `north_star_target`, `parity`, `verified`, `others_brief`).
+Everything else — every workload's full record, the drop-in path, the CPU modes, the multi-GPU prediction, the prose — goes
+to gpurun_out/bench_detail.json (--detail-out) and to stderr BEFORE the line.  After each workload's timed passes one more
+step on fresh handles is checked against a float64 evaluation of the reference's chain (bench_verify.py); a failed check
+makes the exit code 3.  `value` counts input samples entering the first block (x channels for the multi-channel block),
+summed over ranks, per second of max-over-ranks wall time.
 """
 from __future__ import annotations
 
@@ -59,489 +49,9 @@ if ROOT not in sys.path:
 
 import rustradio_amd as rr  # noqa: E402
 from rustradio_amd import multi  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP32_PEAK_TFLOPS = 157.3       # same guide: peak vector FP32 (no MFMA on this path: vector contractions)
-METRIC = "Msamples/s through FIR+FftFilter+Resampler+QuadDemod chain; % HBM roofline"
-
-
-# ---- synthetic inputs (generated on the GPU; torch is plumbing only) -----------------------
-def synth_complex(n, fs, tones_hz, seed, device, chunk=8_000_000):
-    """uniform[-1,1) noise per component + unit tones, Complex<f32> interleaved -> float32[2n]."""
-    out = torch.empty(2 * n, dtype=torch.float32, device=device)
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    for s in range(0, n, chunk):
-        m = min(chunk, n - s)
-        v = torch.rand(m, 2, generator=g, device=device, dtype=torch.float32) * 2 - 1
-        t = torch.arange(s, s + m, device=device, dtype=torch.float64)
-        for f in tones_hz:
-            ph = (2 * math.pi * f / fs) * t
-            v[:, 0] += torch.cos(ph).float() * 0.25
-            v[:, 1] += torch.sin(ph).float() * 0.25
-        out[2 * s:2 * (s + m)] = v.reshape(-1)
-    return out
-
-
-def synth_real(n, fs, tones_hz, seed, device, chunk=16_000_000):
-    out = torch.empty(n, dtype=torch.float32, device=device)
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    for s in range(0, n, chunk):
-        m = min(chunk, n - s)
-        v = torch.rand(m, generator=g, device=device, dtype=torch.float32) * 2 - 1
-        t = torch.arange(s, s + m, device=device, dtype=torch.float64)
-        for f in tones_hz:
-            v += torch.cos((2 * math.pi * f / fs) * t).float() * 0.25
-        out[s:s + m] = v
-    return out
-
-
-def synth_fm(n, fs, device, seed, chunk=4_000_000):
-    """Broadcast-FM-like station centred in the channel: 75 kHz deviation, 1 kHz tone, sigma=0.01 noise."""
-    out = torch.empty(2 * n, dtype=torch.float32, device=device)
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    for s in range(0, n, chunk):
-        m = min(chunk, n - s)
-        t = torch.arange(s, s + m, device=device, dtype=torch.float64)
-        # phase = integral of 2 pi * 75e3 * sin(2 pi 1e3 t): closed form
-        ph = -(75e3 / 1e3) * torch.cos(2 * math.pi * 1e3 * t / fs)
-        v = torch.stack([torch.cos(ph), torch.sin(ph)], dim=1).float()
-        v += 0.01 * torch.randn(m, 2, generator=g, device=device, dtype=torch.float32)
-        out[2 * s:2 * (s + m)] = v.reshape(-1)
-    return out
-
-
-# ---- workloads ------------------------------------------------------------------------------
-class Workload:
-    """blocks = device-resident chain; bufs[i] feeds blocks[i]; bufs[-1] is the sink."""
-    name = ""
-    dtype = "f32"
-    alg_bytes_per_sample = 0.0     # SURVEY §8d compulsory traffic per INPUT sample of the chain
-    dominant = 0                   # index of the block whose kernel the roofline object describes
-    dominant_bytes_per_unit = 0.0  # algorithmic bytes of that kernel per sample it consumes
-    in_mult = 1                    # stream elements of the first block per input sample (2 for u8 I/Q bytes)
-    bound = "hbm"                  # roofline that bounds the dominant kernel: "hbm" | "vector_fp32"
-    dominant_flops_per_unit = 0.0  # NOMINAL flops per sample it consumes: the REFERENCE's algorithm (5 N log2 N per N-point transform)
-    dominant_flops_exec_per_unit = None   # flops of the algorithm the GPU kernel actually EXECUTES per sample (None: the same count)
-    kernel = ""                    # name of the dominant kernel (rocprofv3 --kernel-trace shows it)
-    bound_note = None              # when neither roofline is what the kernel is short of: what is, and the evidence
-
-    def step(self, stream, src_ptr=None):
-        """one pass over the resident batch (or the broadcast tile at src_ptr); returns input samples consumed by the first block"""
-        n_in = self.n * self.in_mult
-        for i, b in enumerate(self.blocks):
-            cap = self.caps[i]
-            inp = src_ptr if (i == 0 and src_ptr is not None) else self.bufs[i].data_ptr()
-            st, c, p, need = b.work_dev(inp, n_in, self.bufs[i + 1].data_ptr(), cap, stream)
-            if i == 0:
-                c //= self.in_mult
-                consumed0 = c
-            if i == self.dominant:
-                self.dom_units += c
-            n_in = p
-        return consumed0
-
-
-chan_taps = multi.channel_taps
-CHAIN_BOUND_NOTE = ("neither roofline binds this kernel: fed RTL-SDR bytes (a third of the input traffic) it is only 12 % faster, its VALU is 37 % "
-                    "busy and the package draws 1182 W of 1400 at full clock; three waves per SIMD are bound by instruction ISSUE (giving its "
-                    "waiting waves redundant work made it 11 % slower, profiles/TUNING_LOG.md 4.1d round 4).  Both fractions are reported: "
-                    "dominant_kernel_hbm_frac and dominant_kernel_executed_fp32_frac")
-
-
-def fft_flops(n):
-    """nominal flop count of one n-point complex transform"""
-    return 5.0 * n * math.log2(n)
-
-
-def poly_exec_flops_per_sample(ntaps, deci, nch=1, demod=True):
-    """flops the decimate-first tile kernels (kernels_poly.hip) EXECUTE per input sample: per tile of 1024 - ceil(L / D)
-    outputs = D (1024 - Ls) inputs: D forward transforms of 1024 points (shared by all channels), and per channel D x 1024
-    complex multiply-adds (8 flop), one inverse transform and the demodulation (conj-multiply 6 + polynomial atan2 27 + gain 1)"""
-    ls = -(-ntaps // deci)
-    sa = 1024 - ls
-    per_ch = deci * 1024 * 8 + fft_flops(1024) + (sa * 34 if demod else 0)
-    return (deci * fft_flops(1024) + nch * per_ch) / (deci * sa)
-
-
-def make_fftfilter(dev, rank, world, shared_src):
-    w = Workload()
-    w.name = "configs[1]: FftFilter 401 taps (ref fft_size 1024, nsamples 623), 10 Msps Complex<f32>, 100,000,000 samples/step"
-    fs, n = 10e6, 100_000_000
-    taps = rr.low_pass_complex(fs, 1e6, 60e3)
-    assert len(taps) == 401
-    f_c = 0.0 if world == 1 else multi.channel_frequency(rank, world, 250e3)
-    w.blocks = [rr.FftFilter(chan_taps(taps, fs, f_c))]
-    w.n = n
-    w.bufs = [shared_src(lambda: synth_complex(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0002, dev), 2 * n, torch.float32),
-              torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev)]
-    w.caps = [n + 1024]
-    w.alg_bytes_per_sample = 16.0
-    w.dominant, w.dominant_bytes_per_unit = 0, 16.0
-    gf = rr.fftfilter_dims(w.blocks[0])[2]
-    w.dominant_flops_per_unit = (2 * fft_flops(gf) + 6 * gf) / (gf - 400)
-    w.kernel = "k_fftfilt_os"
-    w.cpu = ("FftFilter", taps)
-    return w
-
-
-def _make_fir(dev, shared_src, n, label):
-    w = Workload()
-    fs = 10e6
-    taps = rr.low_pass_complex(fs, 1e6, 190e3)
-    assert len(taps) == 127
-    w.name = f"{label}: FirFilter<Complex> 127 real taps, {n:,} samples/step (deci 1, > 40 taps: overlap-save tiles)"
-    w.blocks = [rr.FirFilter(taps)]
-    w.n = n
-    w.bufs = [shared_src(lambda: synth_complex(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0001, dev), 2 * n, torch.float32),
-              torch.empty(2 * n, dtype=torch.float32, device=dev)]
-    w.caps = [n]
-    w.alg_bytes_per_sample = 16.0
-    w.dominant, w.dominant_bytes_per_unit = 0, 16.0
-    w.dominant_flops_per_unit = (2 * fft_flops(1024) + 6 * 1024) / (1024 - 126)
-    w.kernel = "k_fftfilt_os"
-    w.cpu = ("FirFilter", taps)
-    return w
-
-
-def make_fir(dev, rank, world, shared_src):
-    return _make_fir(dev, shared_src, 1_000_000, "configs[0]")
-
-
-def make_fir_1e8(dev, rank, world, shared_src):
-    """configs[0]'s filter at a steady-state size (1e6 samples is one launch of ~15 us: launch-bound)"""
-    return _make_fir(dev, shared_src, 100_000_000, "configs[0] filter at steady-state size")
-
-
-def make_fir_direct(dev, rank, world, shared_src):
-    """configs[0]'s filter forced onto the DIRECT-FORM kernel (the north star's LDS-staged tap window + register-blocked
-    dot products): vector-FP32-bound, 4 flop per real tap and sample (31.75 flop/B > the 19.7 flop/B ridge)"""
-    with rr.build_options(fir_path="direct"):
-        w = _make_fir(dev, shared_src, 100_000_000, "configs[0] filter, direct form")
-    w.name = w.name.replace("(deci 1, > 40 taps: overlap-save tiles)", "(forced direct-form k_fir)")
-    w.bound, w.dominant_flops_per_unit, w.kernel = "vector_fp32", 4.0 * 127, "k_fir"
-    return w
-
-
-def make_fir_float(dev, rank, world, shared_src):
-    """Fir<Float> with the configs[0] taps on a real stream: two overlap-save segments per Complex tile"""
-    w = Workload()
-    w.name = "FirFilter<Float> 127 taps, 100,000,000 f32 samples/step (real-stream overlap-save tiles)"
-    fs, n = 10e6, 100_000_000
-    taps = rr.low_pass(fs, 1e6, 190e3)
-    assert len(taps) == 127
-    w.blocks = [rr.FirFilter(taps)]
-    w.n = n
-    w.bufs = [shared_src(lambda: synth_real(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0006, dev), n, torch.float32),
-              torch.empty(n, dtype=torch.float32, device=dev)]
-    w.caps = [n]
-    w.alg_bytes_per_sample = 8.0
-    w.dominant, w.dominant_bytes_per_unit = 0, 8.0
-    w.dominant_flops_per_unit = (2 * fft_flops(1024) + 6 * 1024) / (2 * (1024 - 126))
-    w.kernel = "k_fftfilt_real"
-    w.cpu = ("FirFilterFloat", taps)
-    return w
-
-
-def make_fir_fft_chain(dev, rank, world, shared_src, fused=True):
-    """the north star's ">= 100x the CPU reference" pair: 127-tap FirFilter -> FftFilter(401 taps, ref 1024-pt)
-    on the configs[1] input.  fused: ONE convolution with the composite taps t1 (*) t2 (rr.FirFftFilter); unfused: two
-    blocks with a device-resident intermediate."""
-    w = Workload()
-    fs, n = 10e6, 100_000_000
-    t1 = rr.low_pass_complex(fs, 1e6, 190e3)
-    t2 = rr.low_pass_complex(fs, 1e6, 60e3)
-    assert len(t1) == 127 and len(t2) == 401
-    src = shared_src(lambda: synth_complex(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0002, dev), 2 * n, torch.float32)
-    w.n = n
-    if fused:
-        w.name = ("FirFilter<Complex>(127 real taps) -> FftFilter(401 taps, ref fft_size 1024) fused into one 527-tap "
-                  "convolution (rr.FirFftFilter), 10 Msps Complex<f32>, 100,000,000 samples/step")
-        w.blocks = [rr.FirFftFilter(t1, t2)]
-        w.bufs = [src, torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev)]
-        w.caps = [n + 1024]
-        w.dominant = 0
-    else:
-        w.name = ("FirFilter<Complex>(127 real taps) -> FftFilter(401 taps, ref fft_size 1024), two blocks, 10 Msps "
-                  "Complex<f32>, 100,000,000 samples/step")
-        w.blocks = [rr.FirFilter(t1), rr.FftFilter(t2)]
-        w.bufs = [src, torch.empty(2 * n, dtype=torch.float32, device=dev), torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev)]
-        w.caps = [n, n + 1024]
-        w.dominant = 1
-    w.alg_bytes_per_sample = w.dominant_bytes_per_unit = 16.0
-    w.dominant_flops_per_unit = (2 * fft_flops(2048) + 6 * 2048) / (2048 - 526)
-    w.kernel = "k_fftfilt_os"
-    w.cpu = ("fir_fft_chain", (t1, t2))
-    return w
-
-
-def make_fir_fft_chain_unfused(dev, rank, world, shared_src):
-    return make_fir_fft_chain(dev, rank, world, shared_src, fused=False)
-
-
-def make_full_chain(dev, rank, world, shared_src, fused=False):
-    """BASELINE.json's metric in its own words: FIR + FftFilter + Resampler + QuadDemod as ONE chain —
-    FirFilter(127 real taps) -> FftFilter(401 taps) -> RationalResampler(1:4) -> QuadratureDemod on the configs[1] input
-    (10 Msps; 1 MHz low-pass => 2.5 Msps after 1:4).  unfused: four blocks, device-resident intermediates; fused: the
-    composite 527-tap filter, the resampler and the demodulator in one kernel (rr.FirFmChain)."""
-    w = Workload()
-    fs, n = 10e6, 100_000_000
-    t1 = rr.low_pass_complex(fs, 1e6, 190e3)
-    t2 = rr.low_pass_complex(fs, 1e6, 60e3)
-    src = shared_src(lambda: synth_complex(n, fs, (0.3e6, 1.2e6, 3.7e6), 0x5EED0002, dev), 2 * n, torch.float32)
-    w.n = n
-    w.alg_bytes_per_sample = 8.0 + 4.0 / 4.0
-    oc = n // 4 + 1024
-    if fused:
-        w.name = ("full chain FirFilter(127)->FftFilter(401)->RationalResampler(1:4)->QuadratureDemod fused into one kernel "
-                  "(rr.FirFmChain: composite 527-tap filter), 10 Msps Complex<f32>, 100,000,000 samples/step")
-        w.blocks = [rr.FirFmChain(t1, t2, 1, 4, 1.0, rr.ATAN2_EXACT)]
-        w.bufs = [src, torch.empty(oc, dtype=torch.float32, device=dev)]
-        w.caps = [oc]
-        w.dominant, w.dominant_bytes_per_unit = 0, 9.0
-        w.kernel = "k_fm_chain*"
-        w.bound_note = CHAIN_BOUND_NOTE
-    else:
-        w.name = ("full chain FirFilter(127)->FftFilter(401)->RationalResampler(1:4)->QuadratureDemod, four blocks with "
-                  "device-resident intermediates, 10 Msps Complex<f32>, 100,000,000 samples/step")
-        w.blocks = [rr.FirFilter(t1), rr.FftFilter(t2), rr.RationalResampler(1, 4, np.complex64), rr.QuadratureDemod(1.0, rr.ATAN2_EXACT)]
-        w.bufs = [src, torch.empty(2 * n, dtype=torch.float32, device=dev), torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev),
-                  torch.empty(2 * oc, dtype=torch.float32, device=dev), torch.empty(oc, dtype=torch.float32, device=dev)]
-        w.caps = [n, n + 1024, oc, oc]
-        w.dominant, w.dominant_bytes_per_unit = 1, 16.0
-        w.kernel = "k_fftfilt_os"
-    w.dominant_flops_per_unit = (2 * fft_flops(2048) + 6 * 2048) / (2048 - 526)
-    w.cpu = ("full_chain", (t1, t2))
-    return w
-
-
-def make_full_chain_fused(dev, rank, world, shared_src):
-    return make_full_chain(dev, rank, world, shared_src, fused=True)
-
-
-def make_fm_chain(dev, rank, world, shared_src, fused=True):
-    w = Workload()
-    how = "fused into one kernel (rr.FmChain)" if fused else "three blocks, device-resident intermediates"
-    w.name = ("configs[2]: FftFilter(463 taps)->RationalResampler(1:6)->QuadratureDemod(exact atan2), 2.4 Msps x 10 s = "
-              "24,000,000 samples/step, " + how)
-    fs, n = 2.4e6, 24_000_000
-    taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
-    assert len(taps) == 463
-    src = shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0003), 2 * n, torch.float32)
-    if fused:
-        w.blocks = [rr.FmChain(taps, 1, 6, 1.0, rr.ATAN2_EXACT)]
-        w.bufs = [src, torch.empty(n // 6 + 1024, dtype=torch.float32, device=dev)]
-        w.caps = [n // 6 + 1024]
-        w.dominant_bytes_per_unit = 8.0 + 4.0 / 6.0
-        w.kernel = "k_fm_chain*"
-        w.bound_note = CHAIN_BOUND_NOTE
-    else:
-        w.blocks = [rr.FftFilter(taps), rr.RationalResampler(1, 6, np.complex64), rr.QuadratureDemod(1.0, rr.ATAN2_EXACT)]
-        w.bufs = [src,
-                  torch.empty(2 * (n + 1024), dtype=torch.float32, device=dev),
-                  torch.empty(2 * (n // 6 + 1024), dtype=torch.float32, device=dev),
-                  torch.empty(n // 6 + 1024, dtype=torch.float32, device=dev)]
-        w.caps = [n + 1024, n // 6 + 1024, n // 6 + 1024]
-        w.dominant_bytes_per_unit = 16.0
-        w.kernel = "k_fftfilt_os"
-    w.n = n
-    w.alg_bytes_per_sample = 8.0 + 4.0 / 6.0
-    w.dominant = 0
-    # nominal work of the chain as the reference runs it per input sample: two 1024-point transforms + the product per
-    # 561 samples (fft_filter.rs:172-176) + conj-multiply and atan2 per output
-    w.dominant_flops_per_unit = (2 * fft_flops(1024) + 6 * 1024) / 561 + 40.0 / 6.0
-    if fused:
-        w.dominant_flops_exec_per_unit = poly_exec_flops_per_sample(463, 6)
-    w.cpu = ("fm_chain", taps)
-    return w
-
-
-def make_rtl_fm_chain(dev, rank, world, shared_src):
-    """configs[2] from the RTL-SDR wire format (examples/rtl_fm.rs:328-419): u8 I/Q pairs in, f32 out."""
-    w = Workload()
-    w.name = ("RtlSdrDecode->FftFilter(463 taps)->RationalResampler(1:6)->QuadratureDemod(exact atan2) fused into one "
-              "kernel (rr.FmChainU8), 2.4 Msps x 10 s = 24,000,000 samples/step, u8 I/Q input")
-    fs, n = 2.4e6, 24_000_000
-    taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
-    f32 = synth_fm(n, fs, dev, 0x5EED0003)
-    src = torch.clamp(torch.round(f32 / 0.008 + 127.0), 0, 255).to(torch.uint8)      # what the dongle delivers
-    w.blocks = [rr.FmChainU8(taps, 1, 6, 1.0, rr.ATAN2_EXACT)]
-    w.bufs = [src, torch.empty(n // 6 + 1024, dtype=torch.float32, device=dev)]
-    w.caps = [n // 6 + 1024]
-    w.in_mult = 2
-    w.dtype = "u8->f32"
-    w.n = n
-    w.alg_bytes_per_sample = w.dominant_bytes_per_unit = 2.0 + 4.0 / 6.0
-    w.dominant = 0
-    w.dominant_flops_per_unit = (2 * fft_flops(1024) + 6 * 1024) / 561 + 40.0 / 6.0
-    w.kernel = "k_fm_chain*"
-    w.bound_note = CHAIN_BOUND_NOTE
-    w.cpu = ("rtl_fm_chain", taps)
-    return w
-
-
-def make_rtl_fm_example(dev, rank, world, shared_src):
-    """examples/rtl_fm.rs:328-419 with its own numbers: 1.024 Msps RTL-SDR bytes, low_pass_complex(fs, 100 kHz, 1 kHz)
-    = 2467 taps (reference fft_size 8192), resampled 1,024,000 -> 200,000 (25:128), quadrature demod."""
-    w = Workload()
-    fs, n = 1.024e6, 24_000_000
-    taps = rr.low_pass_complex(fs, 100e3, 1e3)
-    w.name = (f"examples/rtl_fm.rs front end: RtlSdrDecode->FftFilter({len(taps)} taps)->RationalResampler(25:128)->QuadratureDemod "
-              "fused (rr.FmChainU8), 1.024 Msps u8 I/Q, 24,000,000 samples/step")
-    f32 = synth_fm(n, fs, dev, 0x5EED0006)
-    src = torch.clamp(torch.round(f32 / 0.008 + 127.0), 0, 255).to(torch.uint8)
-    w.blocks = [rr.FmChainU8(taps, 200000, 1024000, 1.0, rr.ATAN2_EXACT)]
-    cap = n * 25 // 128 + 4096
-    w.bufs = [src, torch.empty(cap, dtype=torch.float32, device=dev)]
-    w.caps = [cap]
-    w.in_mult = 2
-    w.dtype = "u8->f32"
-    w.n = n
-    w.alg_bytes_per_sample = w.dominant_bytes_per_unit = 2.0 + 4.0 * 25 / 128
-    w.dominant = 0
-    w.dominant_flops_per_unit = (2 * fft_flops(8192) + 6 * 8192) / 5725 + 40.0 * 25 / 128
-    w.kernel = "k_fm_chain_split"
-    w.cpu = ("rtl_fm_example", taps)
-    return w
-
-
-def make_fm_chain_unfused(dev, rank, world, shared_src):
-    return make_fm_chain(dev, rank, world, shared_src, fused=False)
-
-
-def make_fm_multi(dev, rank, world, shared_src, per_gpu=32, u8=False):
-    """BASELINE configs[3]: 256 FM channels of configs[2] on one shared IQ source, 32 per GPU (weak scaling: N GPUs run
-    the first 32 N channels of the bank; 8 GPUs = all 256).  Channel c uses the configs[2] low-pass shifted to
-    f_c = (c - 128) * 8 kHz (complex band-pass, multi.cfg4_taps); rank r owns channels r*32 .. r*32+31
-    (multi.shard_channels).  `value` counts channel-samples: input samples x channels processed."""
-    w = Workload()
-    fs, n = 2.4e6, 2_400_000
-    taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
-    total = multi.CFG4_CHANNELS
-    chans = list(multi.shard_channels(per_gpu * world, world, rank))
-    w.name = (f"configs[3]: {len(chans)} FM channels/GPU (FftFilter 463 taps->RationalResampler 1:6->QuadratureDemod, fused, "
-              f"rr.FmMulti) on one shared 2.4 Msps IQ source, {n:,} samples/step/channel"
-              + (f"; this rank: channels {chans[0]}..{chans[-1]} of the {total}-channel bank, {per_gpu * world} in the job" if world > 1 else ""))
-    if u8:      # the RTL-SDR wire format as the fan-out format: 2 B instead of 8 B per sample over xGMI, decoded in the kernel
-        src = shared_src(lambda: torch.clamp(torch.round(synth_fm(n, fs, dev, 0x5EED0004) / 0.008 + 127.0), 0, 255).to(torch.uint8),
-                         2 * n, torch.uint8)
-        w.in_mult, w.dtype = 2, "u8->f32"
-        w.name = w.name.replace("one shared 2.4 Msps IQ source", "one shared 2.4 Msps RTL-SDR byte stream (rr.FmMultiU8)")
-    else:
-        src = shared_src(lambda: synth_fm(n, fs, dev, 0x5EED0004), 2 * n, torch.float32)
-    taps_all = multi.cfg4_taps(taps, chans, total)
-    blk = (rr.FmMultiU8 if u8 else rr.FmMulti)(taps_all, 1, 6, 1.0, rr.ATAN2_EXACT)     # one kernel: forward FFT shared by all channels
-    w.blocks = [blk]
-    w.n = n
-    cap = n // 6 + 1024
-    w.outs = torch.empty(len(chans) * cap, dtype=torch.float32, device=dev)
-    nch = len(chans)
-    w.units_per_sample = nch
-    bin_ = 2.0 if u8 else 8.0
-    w.alg_bytes_per_sample = bin_ / nch + 4.0 / 6.0       # shared read: 8/N (2/N) B in + 0.67 B out per channel-sample
-    w.dominant, w.dominant_bytes_per_unit = 0, (bin_ / nch + 4.0 / 6.0) * nch
-    # vector-FP32-bound: per channel and input sample the reference's filter work (two 1024-point transforms + product
-    # per 561 samples) + demod, the forward transform shared by the channels of one GPU
-    w.bound = "vector_fp32"
-    w.dominant_flops_per_unit = fft_flops(1024) / 561 + nch * ((fft_flops(1024) + 6 * 1024) / 561 + 40.0 / 6.0)
-    # ... and what k_fm_multi_poly<6> executes: 6 shared phase transforms + per channel 6 x 1024 multiply-adds, ONE inverse
-    # transform and the demodulation per 946 outputs = 5676 inputs (VERDICT r2 weak #4: ~4x less than the nominal count)
-    w.dominant_flops_exec_per_unit = poly_exec_flops_per_sample(463, 6, nch)
-    w.kernel = "k_fm_multi*"
-    w.cpu = ("fm_chain", taps)
-    w.bufs = [src]
-
-    def step(stream, src_ptr=None):
-        st, c, p, need = blk.work_dev(src.data_ptr() if src_ptr is None else src_ptr, n * w.in_mult, w.outs.data_ptr(), cap, stream)
-        c //= w.in_mult
-        w.dom_units += c
-        return c * nch
-    w.step = step
-    return w
-
-
-def make_fm_multi_u8(dev, rank, world, shared_src):
-    """configs[3] with the fan-out in the RTL-SDR wire format: the broadcast moves 2 B per sample"""
-    return make_fm_multi(dev, rank, world, shared_src, u8=True)
-
-
-def make_channelizer(dev, rank, world, shared_src, fused=True, rotator=None, as_rank=None):
-    """BASELINE configs[4]; on N > 1 GPUs rank g runs channel offset f_g through FirFilter::translate(100e6, f_g)
-    (src/fir.rs:476-486, SURVEY §8d cfg5: multi.cfg5_translate_hz) — with the library's DEFAULT rotator, the reference's own
-    f32 recurrence replayed bit for bit (RR_ROT_REPLAY: on parity for any stream length, one sequential chain per block,
-    walked ahead of the filter — by one device lane at 10 ns per output while the block's calls leave it time, by a host
-    thread at ~2.6 ns per output once they do not (round 5; back-to-back bench steps do not)); `channelizer_model` is the same with
-    the opt-in f64 closed form (parallel, but outside the 1e-5 parity bar beyond ~1e5 outputs of a stream)."""
-    w = Workload()
-    if as_rank is not None:                      # (N = 1 line: the workload ONE rank of the 8-GPU variant runs)
-        rank, world = as_rank
-    f_g = multi.cfg5_translate_hz(rank, world)
-    rotator = rr.ROT_REPLAY if rotator is None else rotator
-    rot_txt = ("rotator=replay: the reference's f32 recurrence bit for bit, the library default, ON parity; back-to-back steps are "
-               "bound by that sequential chain, not by the filter" if rotator == rr.ROT_REPLAY else
-               "rotator=model: opt-in f64 closed form, parallel, OFF parity beyond ~1e5 outputs of a stream")
-    how = ("fused into one composite decimating FIR (rr.HilbertFir)" if fused
-           else "two blocks, device-resident analytic stream")
-    w.name = ("configs[4]: Hilbert(65)->FirFilter<Complex>(255 real taps, deci 8), 100 Msps f32 x 1 s = 100,000,000 samples/step, "
-              + how + (f", .translate(100e6, {f_g / 1e6:.3f} MHz) on this rank ({rot_txt})" if world > 1 else ""))
-    w.rotator = None if world == 1 else ("replay" if rotator == rr.ROT_REPLAY else "model")
-    fs, n = 100e6, 100_000_000
-    taps = rr.low_pass_complex(fs, 5e6, 943e3)
-    assert len(taps) == 255
-    src = shared_src(lambda: synth_real(n, fs, (3e6, 12e6, 37e6), 0x5EED0005, dev), n, torch.float32)
-    tr = (fs, f_g) if world > 1 else None
-    w.n = n
-    w.alg_bytes_per_sample = 5.0
-    if fused:
-        w.blocks = [rr.HilbertFir(65, taps, 8, translate=tr, rotator=rotator)]
-        w.bufs = [src, torch.empty(2 * (n // 8 + 8), dtype=torch.float32, device=dev)]
-        w.caps = [n // 8 + 8]
-        w.dominant, w.dominant_bytes_per_unit = 0, 5.0
-        w.kernel = "k_fftfilt_prune"
-        w.dominant_flops_per_unit = (fft_flops(2048) + 2 * 6 * 2048 + 2 * fft_flops(256)) / (2 * (2048 - 318))
-    else:
-        w.blocks = [rr.Hilbert(65), rr.FirFilter(taps, deci=8, translate=tr, rotator=rotator)]
-        w.bufs = [src, torch.empty(2 * n, dtype=torch.float32, device=dev),
-                  torch.empty(2 * (n // 8 + 8), dtype=torch.float32, device=dev)]
-        w.caps = [n, n // 8 + 8]
-        w.dominant, w.dominant_bytes_per_unit = 0, 12.0
-        w.kernel = "k_hilbert"
-        w.dominant_flops_per_unit = 2.0 * 33 + 2
-    w.cpu = ("channelizer", taps)
-    return w
-
-
-def make_channelizer_unfused(dev, rank, world, shared_src):
-    return make_channelizer(dev, rank, world, shared_src, fused=False)
-
-
-def make_channelizer_translate(dev, rank, world, shared_src):
-    """what ONE rank of configs[4]'s 8-GPU variant runs (rank 1 of 8: .translate(100e6, f_1), default on-parity rotator), on
-    the N = 1 line so that the driver sees it: bound by the sequential rotator chain, not by a roofline"""
-    w = make_channelizer(dev, rank, world, shared_src, as_rank=(1, 8))
-    w.bound = "sequential_rotator"
-    w.bound_note = ("FirFilter::translate's rotator (src/fir.rs:464-473) is an un-renormalised f32 recurrence, one dependent chain of 12.5 M "
-                    "steps per step here; replayed bit for bit it runs at 2.6 ns per output on a host core (10 ns on a device lane), "
-                    "whatever the filter kernel does (0.14 ms).  rotator_ns_per_output is this step's time per output")
-    return w
-
-
-def make_channelizer_model(dev, rank, world, shared_src):
-    """configs[4]'s N > 1 variant with the OPT-IN model rotator (labelled off-parity; see make_channelizer)"""
-    return make_channelizer(dev, rank, world, shared_src, rotator=rr.ROT_MODEL)
-
-
-WORKLOADS = {"fftfilter": make_fftfilter, "fir": make_fir, "fm_chain": make_fm_chain,
-             "fm_chain_unfused": make_fm_chain_unfused, "fm_multi": make_fm_multi, "fm_multi_u8": make_fm_multi_u8,
-             "channelizer": make_channelizer, "channelizer_model": make_channelizer_model,
-             "channelizer_translate": make_channelizer_translate,
-             "rtl_fm_chain": make_rtl_fm_chain, "channelizer_unfused": make_channelizer_unfused,
-             "fir_fft_chain": make_fir_fft_chain, "fir_fft_chain_unfused": make_fir_fft_chain_unfused,
-             "full_chain": make_full_chain, "full_chain_fused": make_full_chain_fused,
-             "rtl_fm_example": make_rtl_fm_example,
-             "fir_1e8": make_fir_1e8, "fir_direct": make_fir_direct, "fir_float": make_fir_float}
+import bench_dropin  # noqa: E402
+import bench_verify  # noqa: E402
+from bench_workloads import HBM_PEAK_GBS, FP32_PEAK_TFLOPS, METRIC, WORKLOADS, make as make_workload  # noqa: E402
 
 
 # ---- measurement ------------------------------------------------------------------------------
@@ -801,6 +311,7 @@ def cpu_baseline(w, seconds=8.0):
     return {"value": round(base, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
             "sample": f"{fed} input samples of the same synthetic stream in {win}-sample work() windows, {dt:.1f} s, 1 thread, "
                       f"{flags} built on this host at bench time, strict f32 (own scalar radix-4 FFT, not rustfft's SIMD kernels)",
+            "sample_short": f"{fed} samples of the same stream, {win}-sample work() windows, {dt:.1f} s, 1 thread, gcc -O3 -march=native, strict f32",
             "build": flags, "host_cores": cores, "modes": modes}
 
 
@@ -867,137 +378,6 @@ def parity_report():
                 kernel_sources=d["kernel_sources"], source="profiles/parity_allowance.json")
 
 
-# ---- the drop-in path (others.dropin_*): rr_block_work on HOST windows, as the Rust shim calls it -------------------
-_RINGS = {}
-
-
-def _registered_ring(which, like):
-    """a 4,096,000-byte page-locked ring per direction, registered once; returned as a view of `like`'s dtype and length"""
-    a = _RINGS.get(which)
-    if a is None:
-        a = rr.host_ring(4_096_000)             # page-aligned whole pages: what the library grants zero-copy windows on
-        rr.host_register(a)
-        _RINGS[which] = a
-    return a[:like.nbytes].view(like.dtype)
-
-
-
-def dropin_host_windows(kind, registered, seconds=1.5):
-    """`rr_block_work` on reference-sized 4,096,000-byte host windows (src/stream.rs:105,208-217,301-310): the shim hands
-    read_buf()/write_buf() windows of the reference's rings; `registered` = the ring mappings page-locked once with
-    rr_host_register.  -> Msamples/s (input samples of the first block, wall clock incl. PCIe)"""
-    rng = np.random.default_rng(7)
-    if kind == "copy":          # the path's own ceiling: a block that only moves the window (x * 1.0), same bytes each way
-        blk = rr.MultiplyConst(1.0)
-        n_in = 4_096_000 // 4
-        x = rng.uniform(-1, 1, n_in).astype(np.float32)
-        mult = 1
-    elif kind == "fftfilter":
-        taps = rr.low_pass_complex(10e6, 1e6, 60e3)
-        blk = rr.FftFilter(taps)
-        n_in = 4_096_000 // 8
-        x = (rng.uniform(-1, 1, n_in) + 1j * rng.uniform(-1, 1, n_in)).astype(np.complex64)
-        mult = 1
-    else:                       # examples/rtl_fm.rs front end from the RTL-SDR byte ring, fused
-        taps = rr.low_pass_complex(2.4e6, 100e3, 12.5e3)
-        blk = rr.FmChainU8(taps, 1, 6, 1.0, rr.ATAN2_EXACT)
-        n_in = 4_096_000
-        x = rng.integers(0, 256, n_in, dtype=np.uint8)
-        mult = 2
-    out_cap = 4_096_000 // blk.out_dtype.itemsize
-    out = np.zeros(out_cap, blk.out_dtype)
-    if registered:
-        # the two rings of a stream pair, page-locked ONCE per process like the shim's (an address range registered a
-        # second time is retired from zero-copy by the library: csrc/blocks.cpp "RETIRED addresses")
-        xin, out = _registered_ring("in", x), _registered_ring("out", out)
-        xin[:] = x
-        x = xin
-    try:
-        fed, t0 = 0, None
-        i = 0
-        while True:
-            st, c, p, need = blk.work_into(x, out, out_cap)
-            if i == 3:
-                t0, fed = time.perf_counter(), 0
-            fed += c // mult
-            i += 1
-            if t0 is not None and time.perf_counter() - t0 > seconds:
-                break
-        dt = time.perf_counter() - t0
-    finally:
-        pass
-    return round(fed / dt / 1e6, 1)
-
-
-def devgraph_ref_rings(fused, seconds=1.5):
-    """the configs[2] graph device-resident with reference-sized 4,096,000-byte HBM rings (rr_dstream): a host source
-    pushes windows in, blocks run ring to ring (rr_block_work_streams), a NullSink consumes.  Python drives it (ctypes)."""
-    fs = 2.4e6
-    taps = rr.low_pass_complex(fs, 100e3, 12.5e3)
-    rng = np.random.default_rng(9)
-    x = rr.host_ring(4_096_000).view(np.complex64)         # a page-aligned source ring, as the shims' (copy_in reads it in place)
-    x[:] = (rng.uniform(-1, 1, 512_000) + 1j * rng.uniform(-1, 1, 512_000)).astype(np.complex64)
-    rr.host_register(x)
-    try:
-        blocks = ([rr.FmChain(taps, 1, 6, 1.0, rr.ATAN2_EXACT)] if fused else
-                  [rr.FftFilter(taps), rr.RationalResampler(1, 6, np.complex64), rr.QuadratureDemod(1.0, rr.ATAN2_EXACT)])
-        rings = [rr.DeviceStream(blocks[0].in_dtype)] + [rr.DeviceStream(b.out_dtype) for b in blocks]
-        fed, t0, rounds = 0, None, 0
-        while True:
-            fed += rings[0].push(x)
-            for i, b in enumerate(blocks):
-                b.work_streams(rings[i], rings[i + 1])
-            rings[-1].discard()                      # NullSink: consume without copying (null_sink.rs:15-25)
-            rounds += 1
-            if rounds == 20:
-                torch.cuda.synchronize(); t0, fed = time.perf_counter(), 0
-            if t0 is not None and rounds % 50 == 0:
-                torch.cuda.synchronize()
-                if time.perf_counter() - t0 > seconds:
-                    break
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    finally:
-        rr.host_unregister(x)
-    return round(fed / dt / 1e6, 1)
-
-
-def dropin_report():
-    out = {}
-    # the ceiling of the path itself: 4,096,000 bytes down and 4,096,000 up per call through a kernel that does nothing else
-    cps = dropin_host_windows("copy", True) * 1e6 / (4_096_000 // 4)           # calls per second
-    out["dropin_ceiling"] = {
-        "what": "rr_block_work on a block that only copies (MultiplyConst(1.0), f32): 4,096,000-byte registered HOST windows, "
-                "in place over PCIe both ways, one call at a time (launch + completion wait included)",
-        "us_per_call": round(1e6 / cps, 1), "gbs_each_way": round(4_096_000 * cps / 1e9, 2),
-        "pcie_gen5_x16_gbs_each_way_spec": 63.0,
-        "link_note": "a bare copy kernel moves such a window at 55 GB/s one way and at 32 GB/s EACH way when both directions run at "
-                     "once (64 GB/s combined: profiles/r05_pcie_inplace.txt, tools/micro/pcie_inplace.hip) — 128 us per window pair "
-                     "before any launch or wait"}
-    LINK_COMBINED_GBS = 64.2                       # profiles/r05_pcie_inplace.txt: host -> host, both ways at once
-    for kind in ("fftfilter", "rtl_fm"):
-        ms_reg = dropin_host_windows(kind, True)
-        n_in = 4_096_000 // 8 if kind == "fftfilter" else 4_096_000 // 2          # input samples per call
-        b_in, b_out = 4_096_000, (4_096_000 if kind == "fftfilter" else 4_096_000 // 2 // 6 * 4)
-        us_call = n_in / ms_reg
-        out[f"dropin_{kind}"] = {
-            "what": ("rr_block_work, FftFilter 401 taps" if kind == "fftfilter" else
-                     "rr_block_work, RtlSdrDecode>FftFilter(463)>RationalResampler(1:6)>QuadratureDemod fused, u8 in")
-                    + ", 4,096,000-byte HOST windows in and out, wall clock incl. PCIe",
-            "msamples_per_s_registered_rings": ms_reg,
-            "us_per_call": round(us_call, 1),
-            "bytes_per_call_in_out": [b_in, b_out],
-            "link_floor_us": round((b_in + b_out) / LINK_COMBINED_GBS / 1e3, 1),
-            "frac_of_link_floor": round((b_in + b_out) / LINK_COMBINED_GBS / 1e3 / us_call, 3),
-            "frac_of_copy_block": round((1e6 / cps) * (b_in + b_out) / 8_192_000 / us_call, 3),
-            "msamples_per_s_pageable": dropin_host_windows(kind, False)}
-    out["devgraph_ref_rings"] = {
-        "what": "configs[2] graph over 4,096,000-byte HBM rings (rr_dstream), registered host source -> NullSink, Python driver",
-        "msamples_per_s_three_blocks": devgraph_ref_rings(False),
-        "msamples_per_s_fused": devgraph_ref_rings(True)}
-    return out
-
-
 # ---- launch ----------------------------------------------------------------------------------------------------
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
@@ -1040,6 +420,87 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def _r(x, n=4):
+    return None if x is None else round(float(x), n)
+
+
+def summarize(w, units_all, wall_s, steps, kms, launches, dom_units, step_ms):
+    """one workload's figures: rate, the dominant kernel's mean launch duration against BOTH rooflines (algorithmic bytes /
+    8 TB/s; executed flops / 157.3 TFLOP/s), `bound` = the larger fraction unless the workload names another bound"""
+    avg_s = kms / max(launches, 1) * 1e-3
+    per_launch = dom_units / max(launches, 1)
+    have = kms > 0 and launches > 0
+    gbs = w.dominant_bytes_per_unit * per_launch / avg_s / 1e9 if have else None
+    tfx = w.exec_flops_per_unit() * per_launch / avg_s / 1e12 if have else None
+    tfl = w.dominant_flops_per_unit * per_launch / avg_s / 1e12 if have else None
+    hbm_frac = None if gbs is None else gbs / HBM_PEAK_GBS
+    fp_frac = None if tfx is None else tfx / FP32_PEAK_TFLOPS
+    bound = w.bound or ("hbm" if (hbm_frac or 0) >= (fp_frac or 0) else "vector_fp32")
+    rate = units_all / wall_s / 1e6
+    d = {"workload": w.desc or w.name, "msamples_per_s": _r(rate, 1), "ms_per_step": _r(wall_s / steps * 1e3),
+         "ms_per_step_median": _r(statistics.median(step_ms)) if step_ms else None,
+         "chain_alg_gbs": _r(w.alg_bytes_per_sample * rate * 1e6 / 1e9, 1),
+         "bound": bound, "dominant_kernel": w.kernel, "dominant_kernel_ms": _r(avg_s * 1e3) if have else None,
+         "launches": launches, "alg_bytes_per_launch": w.dominant_bytes_per_unit * per_launch,
+         "executed_flops_per_launch": w.exec_flops_per_unit() * per_launch,
+         "nominal_reference_flops_per_launch": w.dominant_flops_per_unit * per_launch,
+         "dominant_kernel_alg_gbs": _r(gbs, 1), "dominant_kernel_hbm_frac": _r(hbm_frac),
+         "dominant_kernel_executed_tflops": _r(tfx, 2), "dominant_kernel_executed_fp32_frac": _r(fp_frac),
+         "dominant_kernel_nominal_reference_tflops": _r(tfl, 2),
+         "dominant_kernel_nominal_reference_fp32_frac": None if tfl is None else _r(tfl / FP32_PEAK_TFLOPS)}
+    if w.rotator:
+        d["rotator"] = w.rotator
+    if w.bound == "sequential_rotator":
+        d["outputs_per_s"] = _r(units_all / 8 / wall_s, 1)
+        d["rotator_ns_per_output"] = _r(wall_s / (units_all / 8) * 1e9, 2)
+    if w.bound_note:
+        d["bound_note"] = w.bound_note
+    return d
+
+
+def roofline_object(w, s, wname):
+    """the line's `roofline` (contract: bound, achieved, peak, unit, frac, traffic) from a summarize() record"""
+    traffic, tnote = measured_traffic(wname)
+    r = {"bound": s["bound"], "kernel": s["dominant_kernel"],
+         "avg_kernel_ms": s["dominant_kernel_ms"], "launches": s["launches"], "alg_bytes_per_launch": s["alg_bytes_per_launch"],
+         "traffic": traffic}
+    if s["bound"] == "vector_fp32":
+        r.update({"achieved": s["dominant_kernel_executed_tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": s["dominant_kernel_executed_fp32_frac"]})
+    else:
+        r.update({"achieved": s["dominant_kernel_alg_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s["dominant_kernel_hbm_frac"]})
+    r.update({"hbm_frac": s["dominant_kernel_hbm_frac"], "executed_fp32_frac": s["dominant_kernel_executed_fp32_frac"],
+              "executed_flops_per_launch": s["executed_flops_per_launch"]})
+    return r, tnote
+
+
+LINE_LIMIT = 4000          # bytes: the driver's record of round 5 could not take a 22 KB line (VERDICT r5 item 1)
+
+
+def compact_line(line):
+    """strict JSON under LINE_LIMIT bytes: the optional tables go first if it does not fit (they are all in the detail file)"""
+    for drop in (None, "others_brief", "verified_worst", "parity", "north_star_target", "metric_chain"):
+        if drop:
+            line.pop(drop, None)
+        s = json.dumps(line, allow_nan=False, separators=(",", ":"))
+        if len(s) <= LINE_LIMIT:
+            return s
+    raise SystemExit(f"bench.py: the result line is {len(s)} bytes, over {LINE_LIMIT}")
+
+
+def _clean(o):
+    """NaN / Inf -> None so that the detail file is strict JSON too"""
+    if isinstance(o, float):
+        return o if math.isfinite(o) else None
+    if isinstance(o, dict):
+        return {k: _clean(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_clean(v) for v in o]
+    if isinstance(o, (np.floating, np.integer)):
+        return _clean(o.item())
+    return o
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1050,7 +511,11 @@ def main():
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-window (drop-in path) measurements")
+    ap.add_argument("--no-verify", action="store_true", help="skip the f64 check of what was timed (bench_verify.py)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the full record goes (every workload, the drop-in path, the CPU modes, the multi-GPU prediction, "
+                         "prose); the stdout line stays under 4 KB")
     ap.add_argument("--fanout", choices=("torch", "abi"), default=None,
                     help="N > 1: the source fan-out through the library's own rr_fanout_* entry points (RCCL bound by the C ABI, what "
                          "a Rust graph would call: the default whenever every rank has its own GPU) or through torch.distributed "
@@ -1118,7 +583,7 @@ def main():
     stream = torch.cuda.current_stream()
     stage("build workload")
     with rr.build_options(**opts):
-        w = WORKLOADS[wname](dev, rank, world, shared_src)
+        w = make_workload(wname, dev, rank, world, shared_src)
     abi_check = {}
 
     def make_fan(wl):
@@ -1169,7 +634,7 @@ def main():
     def src_fmt(wl):
         return "u8 I/Q bytes (2 B per sample, the RTL-SDR wire format)" if wl.in_mult == 2 else "Complex<f32> (8 B per sample)"
 
-    def collective_report(fan_, kms_, steps_, wall_ms, kernel_ms, fmt):
+    def collective_report(fan_, steps_, wall_ms, kernel_ms, fmt):
         bms_sum, bn = fan_.broadcast_ms()
         bms = bms_sum / max(bn, 1)
         kstep = kernel_ms
@@ -1192,17 +657,27 @@ def main():
                 "source_broadcast_gbs": round(fan_.bytes_per_tile / (bms * 1e-3) / 1e9, 1) if bms > 0 else None,
                 "kernel_ms_per_step": round(kstep, 4),
                 "overlap": round(max(0.0, min(1.0, (bstep + kstep - wall_ms) / max(min(bstep, kstep), 1e-9))), 3),
-                # written down BEFORE any run on more than one GPU (none has happened: DESIGN §6): per algorithm the fan-out
+                # written down BEFORE any run on more than one GPU (none has happened: DESIGN §7): per algorithm the fan-out
                 # time of one tile over ~153 GB/s xGMI links and the efficiency it allows, at this job's size and at 2 / 4 / 8
                 "predicted": {"assumptions": {"xgmi_link_gbs": multi.XGMI_LINK_GBS, "collective_latency_ms": multi.COLLECTIVE_LATENCY_MS,
                                               "compute_ms_per_tile": round(kstep * ks, 4), "tile_bytes": fan_.bytes_per_tile},
                               "this_job": multi.predict_fanout(dist.get_world_size(), fan_.bytes_per_tile, kstep * ks),
                               "at_2_4_8_gpus": {str(n): multi.predict_fanout(n, fan_.bytes_per_tile, kstep * ks) for n in (2, 4, 8)}}}
 
+    def check(wl):
+        """bench_verify on this rank's copy of the workload (needs the source resident: rank 0 of an N > 1 job, any rank at N = 1)"""
+        if args.no_verify or rank != 0 or (wl.ref is None and not hasattr(wl, "ref_of")):
+            return None
+        with rr.build_options(**opts):
+            try:
+                return bench_verify.verify(wl, stream)
+            except Exception as e:            # a check that cannot run is a failed check, not a skipped one
+                return {"ok": False, "segments": 0, "why": f"{type(e).__name__}: {e}"}
+
     # N > 1: the SAME workload on one rank with its source resident, measured by rank 0 alone before the collective run (the
     # other ranks wait at the barrier): the N = 1 anchor of this line's scaling curve.  (The driver's own N = 1 run is a
     # different workload, configs[1]: value(N) / value(1) across those two lines would compare FftFilter samples with
-    # channel-samples — VERDICT r2 weak #9.)
+    # channel-samples.)
     anchor = None
     if world > 1:
         stage("N = 1 anchor on rank 0 (the other ranks wait at the barrier)")
@@ -1222,10 +697,10 @@ def main():
 
     # max over ranks of the wall time, sum over ranks of the units
     units_all, dt = multi.aggregate(dist, units, dt, dev)
+    main_sum = summarize(w, units_all, dt, args.steps, kms, launches, dom_units, step_ms)
 
     # N > 1: the same step on every rank at once with the tile ALREADY on the rank (no fan-out) — what channel sharding
-    # alone scales to; value / this = what the fan-out costs.  (N = 1 of the driver's scaling run is a different
-    # workload, configs[1]: this is the same-workload reference for the N > 1 lines.)
+    # alone scales to; value / this = what the fan-out costs.
     resident = None
     if fan is not None:
         stage("resident reference run (no fan-out)")
@@ -1236,6 +711,8 @@ def main():
         resident = {"value": round(u1a / t1a / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(t1a / args.steps * 1e3, 4),
                     "ms_per_step_median": round(statistics.median(sm1), 4),
                     "what": "the same N-rank step with the source tile already resident on every rank (no fan-out in the step)"}
+    stage("verify the headline workload")
+    verified = {wname: check(w)}
 
     others = {}
     cpu_legs = {}
@@ -1246,177 +723,182 @@ def main():
             streamed = world > 1 and name.startswith("fm_multi")
             stage(f"others: {name}")
             with rr.build_options(**opts):
-                wo = WORKLOADS[name](dev, rank, world, shared_src if streamed else (lambda gen, numel, dtype: gen()))
+                wo = make_workload(name, dev, rank, world, shared_src if streamed else (lambda gen, numel, dtype: gen()))
             k = max(3, min(args.steps, 10)) if name != "fir" else 200
-            if getattr(wo, "rotator", None) == "replay":
+            replay = wo.rotator == "replay"
+            if replay:
                 k = 5                              # (a step is 1.25e7 sequential rotator phases: ~33 ms on the host generator)
             fo = make_fan(wo) if streamed else None
-            # (a replay-rotator step is bound by one sequential chain, not by clocks: no settle phase for it)
-            # (warm-up 6 for a replay rotator: the default starts on the device chain and hands a block whose calls outrun it —
-            #  these back-to-back steps do — to the host generator after three such calls; the timed steps are the sustained state)
-            u, t, km, ln, du, sm = run_timed(wo, k, 6 if getattr(wo, "rotator", None) == "replay" else 2, dist, stream, fo,
-                                             settle_ms=0.0 if getattr(wo, "rotator", None) == "replay" else args.settle_ms / 2)
+            # (a replay-rotator step is bound by one sequential chain, not by clocks: no settle phase for it; warm-up 6: the
+            #  default starts on the device chain and hands a block whose calls outrun it — these back-to-back steps do — to the
+            #  host generator after three such calls; the timed steps are the sustained state)
+            u, t, km, ln, du, sm = run_timed(wo, k, 6 if replay else 2, dist, stream, fo, settle_ms=0.0 if replay else args.settle_ms / 2)
             ua, ta = multi.aggregate(dist, u, t, dev)
-            avg_s = km / max(ln, 1) * 1e-3
-            ach = (wo.dominant_bytes_per_unit * du / max(ln, 1)) / avg_s / 1e9 if km > 0 else None
-            fl = (wo.dominant_flops_per_unit * du / max(ln, 1)) / avg_s / 1e12 if km > 0 else None
-            fx = None if (km <= 0 or wo.dominant_flops_exec_per_unit is None) else (wo.dominant_flops_exec_per_unit * du / max(ln, 1)) / avg_s / 1e12
-            others[name] = {"workload": wo.name, "msamples_per_s": round(ua / ta / 1e6, 1),
-                            "ms_per_step": round(ta / k * 1e3, 4), "ms_per_step_median": round(statistics.median(sm), 4),
-                            "chain_alg_gbs": round(wo.alg_bytes_per_sample * ua / ta / 1e9, 1),
-                            "bound": wo.bound, "dominant_kernel": wo.kernel,
-                            "dominant_kernel_alg_gbs": None if ach is None else round(ach, 1),
-                            "dominant_kernel_hbm_frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
-                            "dominant_kernel_ms": round(avg_s * 1e3, 4) if km > 0 else None,
-                            "dominant_kernel_executed_tflops": None if fx is None else round(fx, 2),
-                            "dominant_kernel_executed_fp32_frac": None if fx is None else round(fx / FP32_PEAK_TFLOPS, 4),
-                            "dominant_kernel_nominal_reference_tflops": None if fl is None else round(fl, 2),
-                            "dominant_kernel_nominal_reference_fp32_frac": None if fl is None else round(fl / FP32_PEAK_TFLOPS, 4)}
-            if getattr(wo, "rotator", None):
-                others[name]["rotator"] = wo.rotator
-            if wo.bound == "sequential_rotator":
-                others[name]["outputs_per_s"] = round(ua / 8 / ta, 1)
-                others[name]["rotator_ns_per_output"] = round(ta / (ua / 8) * 1e9, 2)
-            if wo.bound_note:
-                others[name]["bound_note"] = wo.bound_note
+            others[name] = summarize(wo, ua, ta, k, km, ln, du, sm)
+            if not streamed:
+                verified[name] = check(wo)
+                others[name]["verified"] = verified[name]
             if world == 1 and not args.no_cpu and name in ("full_chain_fused", "fir_fft_chain"):
                 cpu_legs[name] = cpu_1thread(wo, max(2.0, args.cpu_seconds / 2))
             if world > 1 and streamed:
                 others[name]["source"] = "streamed: rank 0 broadcasts every step's tile (double-buffered) inside the timed region"
-                others[name]["collective"] = collective_report(fo, km, k, ta / k * 1e3, avg_s * 1e3, src_fmt(wo))
+                others[name]["collective"] = collective_report(fo, k, ta / k * 1e3, others[name]["dominant_kernel_ms"] or 0.0, src_fmt(wo))
             elif world > 1:
                 others[name]["source"] = "resident on every rank (a 400 MB f32 tile per 0.14 ms step cannot stream over xGMI)"
             del fo
             del wo
             torch.cuda.empty_cache()
         if world == 1 and not args.no_dropin:
-            others.update(dropin_report())
+            stage("drop-in path (host windows, reference-sized rings)")
+            others.update(bench_dropin.dropin_report())
 
+    rc = 0
     if rank == 0:
         value = units_all / dt / 1e6
-        avg_kernel_s = (kms / max(launches, 1)) * 1e-3
-        alg_bytes_per_launch = w.dominant_bytes_per_unit * dom_units / max(launches, 1)
-        alg_flops_per_launch = w.dominant_flops_per_unit * dom_units / max(launches, 1)
-        exec_per_unit = w.dominant_flops_per_unit if w.dominant_flops_exec_per_unit is None else w.dominant_flops_exec_per_unit
-        exec_flops_per_launch = exec_per_unit * dom_units / max(launches, 1)
-        gbs = alg_bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-        tfl = alg_flops_per_launch / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
-        tfx = exec_flops_per_launch / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
-        traffic, tnote = measured_traffic(wname)
-        roof = {"bound": w.bound, "kernel": w.kernel, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
-                "measured_in": "a pass of `steps` steps right after the timed region (the library's HIP-event brackets around the "
-                               "dominant kernel on its launch stream); the timed region itself carries no instrumentation",
-                "alg_bytes_per_launch": alg_bytes_per_launch,
-                "executed_flops_per_launch": exec_flops_per_launch, "nominal_reference_flops_per_launch": alg_flops_per_launch,
-                "traffic": traffic, "traffic_note": tnote}
-        if w.bound_note:
-            roof["bound_note"] = w.bound_note
-        if w.bound == "hbm":
-            roof.update({"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                         "frac_counts": "ALGORITHMIC bytes (SURVEY §8d: compulsory input + output of the chain) per launch / mean kernel duration / 8 TB/s",
-                         "executed_vector_fp32_tflops": round(tfx, 2)})
-        else:
-            roof.update({"achieved": round(tfx, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tfx / FP32_PEAK_TFLOPS, 4),
-                         "frac_counts": "EXECUTED flops: the transforms (5 N log2 N), multiply-adds and demodulation the GPU kernel actually "
-                                        "runs per launch / mean kernel duration / 157.3 TFLOP/s (not the reference algorithm's count)",
-                         "nominal_reference_tflops": round(tfl, 2),
-                         "nominal_reference_frac": round(tfl / FP32_PEAK_TFLOPS, 4),
-                         "nominal_reference_note": "the REFERENCE's algorithm for the same samples (two 1024-point transforms + product per 561 "
-                                                   "samples and channel) priced at this kernel's duration: a speed-up-at-peak figure, not a utilisation",
-                         "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
-        par = ("1 GPU" if world == 1 else
-               f"{world} ranks, channel-sharded (no data-path collective); shared IQ source produced on rank 0 and broadcast "
-               f"tile by tile on a communication stream, double-buffered against the compute stream, inside the timed region")
-        line = {
-            "metric": METRIC, "value": round(value, 2), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            # the same W + K steps straight from an idle GPU, measured first (no settle phase): what `value` would be without
-            # the sustained-clock protocol, comparable with the round-1 figures
-            "ms_per_step_from_idle": None if getattr(w, "cold_ms_per_step", None) is None else round(w.cold_ms_per_step, 4),
-            "value_from_idle": None if getattr(w, "cold_ms_per_step", None) is None else round(units_all / (w.cold_ms_per_step * 1e-3 * args.steps) / 1e6, 2),
-            "ms_per_step_median": round(statistics.median(step_ms), 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": w.dtype, "data": "synthetic",
-            "config": {"workload": w.name, "workload_key": wname, "samples_per_step_per_gpu": w.n, "parallelism": par,
+        roof, tnote = roofline_object(w, main_sum, wname)
+        par = "1 GPU" if world == 1 else f"{world} ranks, channel-sharded; shared IQ source fanned out per tile inside the timed region"
+        cold = getattr(w, "cold_ms_per_step", None)
+        parity_full = parity_report()
+        checks = {k: v for k, v in verified.items() if v is not None}
+        bad = [k for k, v in checks.items() if not v["ok"]]
+        worst = max(checks.items(), key=lambda kv: (kv[1].get("max_err", float("inf")) / kv[1].get("tol", 1.0)) if kv[1]["ok"] else float("inf"),
+                    default=(None, None))
+        # ---- the full record (detail file + stderr) ----
+        detail = {
+            "metric": METRIC, "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_step_median": round(statistics.median(step_ms), 4),
+            "ms_per_step_from_idle": _r(cold), "value_from_idle": None if cold is None else round(units_all / (cold * 1e-3 * args.steps) / 1e6, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": w.dtype, "data": "synthetic",
+            "config": {"workload": w.desc, "workload_key": wname, "samples_per_step_per_gpu": w.n, "parallelism": par,
                        "settle_steps": settle_main,
                        "protocol": (f"{settle_main} untimed settle steps (~{args.settle_ms:g} ms of back-to-back passes: the power controller's "
                                     f"start-up transient), then the driver's {args.warmup} warm-up and {args.steps} timed steps; the timed "
-                                    "region carries no events or profiling"),
+                                    "region carries no events or profiling; a pass with the library's HIP-event brackets around the dominant "
+                                    "kernel on its launch stream follows (roofline.avg_kernel_ms), then one with an event pair per step (median)"),
                        "why_this_workload": ("BASELINE.json configs[1] is the single-GPU configuration the metric is quoted on; the "
-                                             "metric's four-block chain is others.full_chain / others.full_chain_fused"
+                                             "metric's four-block chain is metric_chain (others.full_chain_fused / others.full_chain)"
                                              if wname == "fftfilter" else
                                              "BASELINE.json configs[3], the multi-GPU configuration (32 channels per GPU)"
-                                             if wname == "fm_multi" else "--workload"),
-                       **({"step_is": "k_fftfilt_os (roofline.avg_kernel_ms) + the 5 us pass that keeps FftFilter's outputs on non-finite input "
-                                      "the reference's (k_ref_blocks_nonfinite: one probe per tile in the steady state, DESIGN.md section 8); "
-                                      "rr_build_opts.fft_nonfinite_tiles leaves it out (bench.py --opt fft_nonfinite_tiles=1)"}
-                          if wname in ("fftfilter", "fir_fft_chain") else {})},
-            "roofline": roof,
-            "parity": parity_report(),
-            "chain_alg_gbs": round(w.alg_bytes_per_sample * value * 1e6 / 1e9, 1),
+                                             if wname == "fm_multi" else "--workload")},
+            "headline": main_sum,
+            "roofline": dict(roof, traffic_note=tnote,
+                             frac_counts="hbm: ALGORITHMIC bytes (SURVEY §8d: compulsory input + output) per launch / mean kernel duration / "
+                                         "8 TB/s; vector_fp32: EXECUTED flops per launch / mean kernel duration / 157.3 TFLOP/s; `bound` = "
+                                         "the larger of the two fractions"),
+            "parity": parity_full, "verified": checks, "others": others,
         }
         if world > 1:
-            line["scale_anchor"] = anchor
-            line["scaling_efficiency_vs_anchor"] = (round(value / (world * anchor["n1_value"]), 4)
-                                                    if anchor and anchor["n1_value"] > 0 else None)
-            line["collective"] = collective_report(fan, kms, args.steps, dt / args.steps * 1e3, avg_kernel_s * 1e3, src_fmt(w))
-            line["source_broadcast_gbs"] = line["collective"]["source_broadcast_gbs"]
-            line["resident_source"] = resident
-            line["fanout_efficiency"] = round(value / resident["value"], 4) if resident and resident["value"] > 0 else None
-        if others:
-            line["others"] = others
+            detail["scale_anchor"] = anchor
+            detail["scaling_efficiency_vs_anchor"] = (round(value / (world * anchor["n1_value"]), 4) if anchor and anchor["n1_value"] > 0 else None)
+            detail["collective"] = collective_report(fan, args.steps, dt / args.steps * 1e3, main_sum["dominant_kernel_ms"] or 0.0, src_fmt(w))
+            detail["resident_source"] = resident
+            detail["fanout_efficiency"] = round(value / resident["value"], 4) if resident and resident["value"] > 0 else None
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
-            line["gpu_over_cpu_1thread_port"] = round(value / line["cpu_baseline"]["value"], 1)
-        # The metric string names the FOUR-block chain and the north star states its ">= 100x" target on the FIR + FftFilter
-        # pair; `value` stays configs[1] (the configuration the metric is quoted on).  Both chains, with their own roofline
-        # and their own CPU leg, as first-class objects of the line:
+            detail["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+            detail["gpu_over_cpu_1thread_port"] = round(value / detail["cpu_baseline"]["value"], 1)
         # The 1 -> 8 curve has never been measured (no node with more than one GPU has run this code): what stands in for it is
-        # a PREDICTION, regenerated on every run from THIS run's measured configs[3] step (DESIGN.md §7 prints it
-        # through tools/fanout_table.py).  No scaling claim is made anywhere.
+        # a PREDICTION, regenerated on every run from THIS run's measured configs[3] step (tools/fanout_table.py prints it).
         fm = others.get("fm_multi")
         if world == 1 and fm:
             ks = max(1, args.tile_steps)
             comp = fm["ms_per_step"] * ks
             tile_f32, tile_u8 = ks * 19_200_000, ks * 4_800_000
-            line["multi_gpu_prediction"] = {
+            detail["multi_gpu_prediction"] = {
                 "what": "PREDICTED weak-scaling efficiency of configs[3] (32 channels per GPU, shared source fanned out per tile of "
                         f"{ks} steps, overlapped with the compute on the previous tile) from this run's measured step; never measured",
                 "measured_fm_multi_ms_per_step": fm["ms_per_step"], "tile_steps": ks,
                 "assumptions": {"xgmi_link_gbs": multi.XGMI_LINK_GBS, "collective_latency_ms": multi.COLLECTIVE_LATENCY_MS},
                 "complex_f32_source": {"tile_bytes": tile_f32, **{str(n): multi.predict_fanout(n, tile_f32, comp) for n in (2, 4, 8)}},
                 "u8_source": {"tile_bytes": tile_u8, **{str(n): multi.predict_fanout(n, tile_u8, comp) for n in (2, 4, 8)}}}
+        # The metric string names the FOUR-block chain and the north star states its ">= 100x" target on the FIR + FftFilter
+        # pair; `value` stays configs[1] (the configuration the metric is quoted on).  Both chains with their own roofline
+        # fractions and their own CPU leg:
         fc = others.get("full_chain_fused")
         if fc and "full_chain_fused" in cpu_legs:
             cb = cpu_legs["full_chain_fused"]
-            line["metric_chain"] = {
+            detail["metric_chain"] = {
                 "workload": fc["workload"], "workload_key": "full_chain_fused", "value": fc["msamples_per_s"], "unit": "Msamples/s",
-                "ms_per_step": fc["ms_per_step"],
-                "roofline": {"kernel": fc["dominant_kernel"], "avg_kernel_ms": fc["dominant_kernel_ms"],
-                             "bound": fc["bound"], "bound_note": fc.get("bound_note"), "achieved": fc["dominant_kernel_alg_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": fc["dominant_kernel_hbm_frac"],
-                             "alg_bytes_per_sample": 9.0,
-                             "executed_vector_fp32_tflops": fc["dominant_kernel_executed_tflops"],
-                             "executed_fp32_frac": fc["dominant_kernel_executed_fp32_frac"]},
+                "ms_per_step": fc["ms_per_step"], "kernel": fc["dominant_kernel"], "avg_kernel_ms": fc["dominant_kernel_ms"],
+                "bound": fc["bound"], "hbm_frac": fc["dominant_kernel_hbm_frac"], "executed_fp32_frac": fc["dominant_kernel_executed_fp32_frac"],
+                "alg_bytes_per_sample": 9.0, "bound_note": fc.get("bound_note"),
                 "cpu_baseline": dict(cb, chain="FirFilter(127) -> FftFilter(401) -> RationalResampler(1:4) -> QuadratureDemod, "
                                                 "four oracle blocks under the reference's single-threaded Graph loop"),
                 "gpu_over_cpu_1thread_port": round(fc["msamples_per_s"] / cb["value"], 1) if cb["value"] > 0 else None}
         pr = others.get("fir_fft_chain")
         if pr and "fir_fft_chain" in cpu_legs:
             cb = cpu_legs["fir_fft_chain"]
-            line["north_star_target"] = {
+            detail["north_star_target"] = {
                 "workload": pr["workload"], "workload_key": "fir_fft_chain",
                 "target": ">= 100x the CPU-reference Msamples/s on the 127-tap FIR + 1024-pt FftFilter chain at 1 GPU (BASELINE.json north_star)",
                 "gpu_msamples": pr["msamples_per_s"], "cpu_msamples_1thread": cb["value"], "cpu_kind": cb["kind"], "cpu_sample": cb["sample"],
                 "ratio": round(pr["msamples_per_s"] / cb["value"], 1) if cb["value"] > 0 else None,
                 "met": bool(cb["value"] > 0 and pr["msamples_per_s"] / cb["value"] >= 100.0),
-                "roofline_frac": pr["dominant_kernel_hbm_frac"]}
-        print(json.dumps(line), flush=True)
+                "hbm_frac": pr["dominant_kernel_hbm_frac"]}
+        detail = _clean(detail)
+        dtext = json.dumps(detail, allow_nan=False)
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail_out)), exist_ok=True)
+            with open(args.detail_out, "w") as f:
+                f.write(json.dumps(detail, allow_nan=False, indent=1) + "\n")
+            detail_where = os.path.relpath(args.detail_out, ROOT)
+        except OSError as e:
+            detail_where = f"stderr only ({e})"
+        print("bench.py detail: " + dtext, file=sys.stderr, flush=True)
+
+        # ---- the line: contract keys + config + roofline + cpu_baseline + compact companions, < 4 KB, strict JSON ----
+        line = {
+            "metric": METRIC, "value": detail["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": detail["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": w.dtype, "data": "synthetic",
+            "config": {"workload": w.name[:118], "workload_key": wname, "samples_per_step_per_gpu": w.n, "parallelism": par[:118],
+                       "settle_steps": settle_main},
+            "roofline": _clean(roof),
+            "ms_per_step_median": detail["ms_per_step_median"], "value_from_idle": detail["value_from_idle"],
+        }
+        if "cpu_baseline" in detail:
+            cb = detail["cpu_baseline"]
+            allc = cb["modes"].get("one_chain_per_core_all_cores", {})
+            line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": 1, "kind": cb["kind"], "sample": cb["sample_short"],
+                                    "host_cores": cb["host_cores"], "all_cores_value": allc.get("msamples_per_s"),
+                                    "all_cores_processes": allc.get("processes")}
+        if world > 1:
+            c = detail["collective"]
+            line["collective"] = {k: c[k] for k in ("backend", "fanout", "algorithm", "ranks", "tile_bytes", "tile_steps", "broadcasts_timed",
+                                                    "broadcast_ms_per_tile", "source_broadcast_gbs", "kernel_ms_per_step", "overlap")}
+            line["scale_anchor_n1_value"] = anchor["n1_value"] if anchor else None
+            line["scaling_efficiency_vs_anchor"] = detail["scaling_efficiency_vs_anchor"]
+            line["resident_source_value"] = resident["value"] if resident else None
+            line["fanout_efficiency"] = detail["fanout_efficiency"]
+        if "metric_chain" in detail:
+            m = detail["metric_chain"]
+            line["metric_chain"] = {"workload_key": m["workload_key"], "value": m["value"], "ms_per_step": m["ms_per_step"], "kernel": m["kernel"],
+                                    "avg_kernel_ms": m["avg_kernel_ms"], "bound": m["bound"], "hbm_frac": m["hbm_frac"],
+                                    "executed_fp32_frac": m["executed_fp32_frac"], "cpu_1thread": m["cpu_baseline"]["value"],
+                                    "x_cpu_1thread": m["gpu_over_cpu_1thread_port"]}
+        if "north_star_target" in detail:
+            t = detail["north_star_target"]
+            line["north_star_target"] = {k: t[k] for k in ("workload_key", "gpu_msamples", "cpu_msamples_1thread", "ratio", "met", "hbm_frac")}
+        aps = parity_full.get("above_plain_share")
+        line["parity"] = {"tol": parity_full["tol"], "chain_bound": parity_full["chain_bound"], "used_max": parity_full.get("used_max"),
+                          "above_plain_share_max": max(aps.values()) if isinstance(aps, dict) else None}
+        line["verified"] = None if args.no_verify else {"ok": not bad, "workloads": len(checks), "segments_each": 16, "failed": bad}
+        if worst[0] is not None and not bad:
+            line["verified_worst"] = {"workload": worst[0], "max_err": _r(worst[1]["max_err"], 9), "tol": worst[1]["tol"]}
+        if others:
+            line["others_brief"] = {"cols": ["msamples_per_s", "ms_per_step", "hbm_frac", "executed_fp32_frac"],
+                                    **{k: [v["msamples_per_s"], v["ms_per_step"], v["dominant_kernel_hbm_frac"], v["dominant_kernel_executed_fp32_frac"]]
+                                       for k, v in others.items() if "msamples_per_s" in v}}
+        line["detail"] = detail_where
+        sys.stderr.flush()
+        print(compact_line(_clean(line)), flush=True)
+        if bad:
+            print(f"bench.py: the f64 check of what was timed FAILED for {bad}: {[checks[k] for k in bad]}", file=sys.stderr, flush=True)
+            rc = 3
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -334,6 +334,13 @@ class DeviceStream:
             raise RuntimeError(last_error())
         return n
 
+    def produce_resident(self, stream: int = 0) -> int:
+        """a device-resident source: everything free becomes readable as it stands in the ring (write_buf + produce, no copy) -> n"""
+        n = self.free(stream)
+        if n and lib().rr_dstream_produce(self._h, n) != 0:
+            raise RuntimeError(last_error())
+        return n
+
     def discard(self) -> int:
         """consume everything readable without copying it anywhere (NullSink, src/null_sink.rs:15-25)"""
         n = self.readable()
