@@ -320,7 +320,7 @@ int         rr_block_sync(rr_block *b);
  * that are not WHOLLY inside a range registered here (pageable memory, memory the caller page-locked by
  * other means) are staged through device memory as before.  Optional; unregister before the memory is
  * unmapped, and not while a work call on one of its windows is running.
- * Zero-copy is granted only to a range whose base and size are multiples of the page size (4096) and none of
+ * Zero-copy is granted only to a range whose base and size are multiples of the SYSTEM page size (sysconf(_SC_PAGESIZE)) and none of
  * whose pages is, or ever was, part of another registration in this process — the reference's ring qualifies
  * (one page-aligned mmap, registered once).  Any other range is still page-locked (its staged copies run as
  * direct DMA) but is never handed to kernels in place: kernels working in place on pages that had been

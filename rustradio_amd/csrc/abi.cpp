@@ -50,12 +50,15 @@ template <class F> static rr_block* make_block(F&& f, int tag_rule = RR_TAGS_DRO
     } catch (const std::exception& e) {
         rr::set_last_error(e.what());
         return nullptr;
+    } catch (...) {
+        rr::set_last_error("non-standard exception");
+        return nullptr;
     }
 }
 
 template <class F> static int guarded(F&& f) {
     try { f(); return 0; }
-    catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
+    catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; } catch (...) { rr::set_last_error("non-standard exception"); return RR_ERR; }
 }
 
 extern "C" {
@@ -218,7 +221,7 @@ rr_block* rr_fm_multi_u8_create(const rr_c32* taps, size_t nchan, size_t ntaps, 
     return make_block([&] { return rr::make_fm_multi(taps, nchan, ntaps, interp, deci, gain, atan2_mode, true); });
 }
 size_t rr_block_out_windows(const rr_block* b) { return b ? b->b->out_windows() : 0; }
-void rr_block_destroy(rr_block* b) { delete b; }
+void rr_block_destroy(rr_block* b) { try { delete b; } catch (...) {} }
 
 static int guarded(rr_block* b, size_t* consumed, size_t* produced, size_t* need, const char* what,
                    const std::function<int()>& f) {
@@ -229,6 +232,10 @@ static int guarded(rr_block* b, size_t* consumed, size_t* produced, size_t* need
         return f();
     } catch (const std::exception& e) {
         rr::set_last_error(std::string(what) + ": " + e.what());
+        *consumed = *produced = *need = 0;
+        return RR_ERR;
+    } catch (...) {
+        rr::set_last_error("non-standard exception");
         *consumed = *produced = *need = 0;
         return RR_ERR;
     }
@@ -261,7 +268,7 @@ size_t rr_block_in_elem_size(const rr_block* b) { return b ? b->b->in_es : 0; }
 size_t rr_block_out_elem_size(const rr_block* b) { return b ? b->b->out_es : 0; }
 int rr_block_sync(rr_block* b) {
     if (!b) return RR_ERR;
-    try { b->b->sync(); return 0; } catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
+    try { b->b->sync(); return 0; } catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; } catch (...) { rr::set_last_error("non-standard exception"); return RR_ERR; }
 }
 
 int rr_block_set_profiling(rr_block* b, int on) {
@@ -272,12 +279,12 @@ int rr_block_set_profiling(rr_block* b, int on) {
 int rr_block_profile(rr_block* b, double* total_ms, size_t* launches, int reset) {
     if (!b) return RR_ERR;
     try { RR_HIP(hipSetDevice(b->b->device)); b->b->prof_read(total_ms, launches, reset != 0); return 0; }
-    catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
+    catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; } catch (...) { rr::set_last_error("non-standard exception"); return RR_ERR; }
 }
 
 /* measurement builds (make ABLATE=1): phase time stamps of one FftFilter tile; 0 in product builds */
 int rr_debug_fft_stamps(unsigned long long* out16) {
-    try { return rr::fft_read_stamps(out16); } catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
+    try { return rr::fft_read_stamps(out16); } catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; } catch (...) { rr::set_last_error("non-standard exception"); return RR_ERR; }
 }
 
 int rr_fftfilter_dims(const rr_block* b, size_t* fft_size, size_t* nsamples, size_t* gpu_fft_size) {
@@ -324,9 +331,12 @@ rr_dstream* rr_dstream_create(size_t elem_size, size_t capacity_bytes) {
     } catch (const std::exception& e) {
         rr::set_last_error(e.what());
         return nullptr;
+    } catch (...) {
+        rr::set_last_error("non-standard exception");
+        return nullptr;
     }
 }
-void rr_dstream_destroy(rr_dstream* s) { delete s; }
+void rr_dstream_destroy(rr_dstream* s) { try { delete s; } catch (...) {} }
 size_t rr_dstream_capacity(const rr_dstream* s) { return s ? s->s->cap : 0; }
 int rr_dstream_is_double_mapped(const rr_dstream* s) { return s && s->s->vmm ? 1 : 0; }
 size_t rr_dstream_id(const rr_dstream* s) { return s ? s->id : 0; }
@@ -347,6 +357,9 @@ size_t rr_dstream_write_buf(rr_dstream* s, void** dev_ptr, void* hip_stream) {
         return s->s->free();
     } catch (const std::exception& e) {
         rr::set_last_error(e.what());
+        return 0;
+    } catch (...) {
+        rr::set_last_error("non-standard exception");
         return 0;
     }
 }

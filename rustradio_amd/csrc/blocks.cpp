@@ -14,6 +14,7 @@
 #include <complex>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 
 #include "taps.hpp"
 
@@ -108,7 +109,9 @@ struct HostRange { const unsigned char* base; size_t bytes; unsigned char* dev; 
 std::mutex g_host_m;
 std::vector<HostRange> g_host_ranges;
 std::vector<std::pair<const unsigned char*, const unsigned char*>> g_retired;    // page-rounded [lo, hi) of released ranges
-constexpr uintptr_t PAGE = 4096;
+// the SYSTEM page size (a page-lock covers whole pages of it: on a 64K-page kernel a 4K-aligned range still shares its first
+// and last page with its neighbours, the very condition this policy excludes)
+const uintptr_t PAGE = [] { const long p = sysconf(_SC_PAGESIZE); return (uintptr_t)(p > 0 ? p : 4096); }();
 bool zero_copy_enabled() {
     static const bool on = [] { const char* e = getenv("RR_ZERO_COPY"); return !(e && e[0] == '0'); }();
     return on;
@@ -179,9 +182,10 @@ int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, s
     }
     if (!dout) st_out.reserve(std::max<size_t>(out_cap * out_es * out_windows(), 16));
     host_out = dout ? out : nullptr;
+    host_out_reset();       // (a pass an earlier call deferred and then failed to run — a throw between work_dev and the wait — is stale)
     int st;
     try { st = work_dev(din, in_len, dout ? dout : st_out.p, out_cap, consumed, produced, need, stream); }
-    catch (...) { host_out = nullptr; throw; }
+    catch (...) { host_out = nullptr; host_out_reset(); throw; }
     if (!dout && *produced) {
         if (out_windows() == 1) RR_HIP(hipMemcpyAsync(out, st_out.p, *produced * out_es, hipMemcpyDeviceToHost, stream));
         else RR_HIP(hipMemcpy2DAsync(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, out_windows(), hipMemcpyDeviceToHost, stream));
@@ -365,8 +369,11 @@ FirC32::FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, fl
     } else if (allow_fft && fits && !force_direct && (force_fft || wins || poly || prune)) {
         std::vector<rr_c32> ct(ntaps);
         for (size_t i = 0; i < ntaps; i++) ct[i] = {t[i].real(), t[i].imag()};
-        fftk.reset(new FftFilter(ct.data(), ntaps, false, 14, false, 0, deci > 1));
-        if (deci > 1 && fftk->log2f >= 13 && !fftk->nsub) fftk.reset();   // (RR_FFT_NO_SPLIT measurement runs)
+        // deci > 1 near the top of the tile range: a 16384-point tile keeps 16385 - L samples (16383 taps: 2), so — like the
+        // plain filter — from where the any-size frames are cheaper (15293 taps on) the block runs THEM at the full rate
+        // and keeps every deci-th output with a strided copy (work_dev: `big`); the tiles with a decimating store below that.
+        fftk.reset(new FftFilter(ct.data(), ntaps, false, 14, false, 0, false));
+        if (deci > 1 && !fftk->big && fftk->log2f >= 13 && !fftk->nsub) fftk.reset();   // (RR_FFT_NO_SPLIT measurement runs)
         if (fftk) { fftk->nanfix = nanfix(); fftk->nanfix.d = 1; }        // (fftk->filter is the full-rate form)
     }
 }
@@ -425,6 +432,18 @@ int FirC32::work_dev(const void* in, size_t in_len, void* out, size_t out_cap, s
     else if (small_direct) launch_fir_c32(pl, d_tp.p, d_rev.p, src, static_cast<cf*>(out), (long)out_n, s, nanfix());
     else if (half_ok) launch_fftfilt_half(src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, d_htw.p, d_htw_half.p, d_hhpos.p, s, nanfix());
     else if (use_prune) launch_fftfilt_prune_c32(prune->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, prune->d_tw.p, prune->d_h2.p, prune->d_twb.p, s, (int)prune_sub, nanfix());
+    else if (fftk && d > 1 && fftk->big) {
+        // full-rate overlap-save frames into a scratch buffer, chunk by chunk, then out[m] = y[m d] (the resampler's index
+        // pick with I = 1: a strided copy).  A window position o0 d of the input starts chunk o0.
+        const size_t chunk = std::max<size_t>(1, ((size_t)1 << 22) / d);
+        for (size_t o0 = 0; o0 < out_n; o0 += chunk) {
+            const size_t m = std::min(chunk, out_n - o0), nfull = (m - 1) * d + 1;
+            VSrc<cf> sc{nullptr, 0, static_cast<const cf*>(in) + o0 * d, (long)(in_len - o0 * d)};
+            dec_tmp.reserve(nfull);
+            fftk->filter(sc, dec_tmp.p, (long)nfull, s);
+            launch_resample(dec_tmp.p, static_cast<cf*>(out) + o0, sizeof(cf), 0, nullptr, (long)m, 1, (long)d, 0, s);
+        }
+    }
     else if (fftk && d > 1 && fftk->nsub) launch_fftfilt_split_deci(fftk->nsub, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw4096.p, fftk->d_hs.p, fftk->d_wk.p, s, nanfix());
     else if (fftk && d > 1) launch_fftfilt_deci(fftk->log2f, src, static_cast<cf*>(out), (long)out_n, (int)L, (int)d, fftk->d_tw.p, fftk->d_hpos.p, s, nanfix());
     else if (fftk) fftk->filter(src, static_cast<cf*>(out), (long)out_n, s);

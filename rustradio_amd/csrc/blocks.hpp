@@ -30,6 +30,7 @@ struct Block {
     // completed (the host then reads its own window for free where a kernel would cross PCIe again — FftFilter)
     const void* host_out = nullptr;
     virtual void host_out_done(const void* /*out_host*/, size_t /*produced*/) {}
+    virtual void host_out_reset() {}      // drop a pass deferred by an earlier host-window call that never reached host_out_done
 
     Block(const char* nm, size_t ies, size_t oes);
     virtual ~Block();
@@ -143,6 +144,7 @@ struct FirC32 : Block {
     std::vector<std::complex<float>> h_taps;      // caller-order taps after the translate pre-rotation
     // allow_fft = false: bookkeeping / direct form only (HilbertFir's inner object)
     FirC32(const rr_c32* taps, size_t ntaps, size_t deci, bool translate, float samp_rate, float freq, bool allow_fft = true);
+    DevBuf<cf> dec_tmp;               // full-rate scratch of the any-size + strided-copy path (deci > 1, 15293..16383 taps)
     ~FirC32() override;
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
     void rotate_output(cf* out, size_t out_n, hipStream_t s);   // fir.rs:464-473 (no-op without translate)
@@ -240,6 +242,7 @@ struct FftFilter : Block {
     struct { bool on = false, force0 = false; VSrc<cf> src{}; void* out = nullptr; long n_out = 0; } deferred;
     bool tail_host = false, tail_host_known = true;   // the host's copy of the carried verdict
     void host_out_done(const void* out_host, size_t produced) override;
+    void host_out_reset() override { deferred.on = false; }
     void ref_blocks_on(const rr_c32* taps);
     template <class T> void ref_blocks_pass(VSrc<T> src, T* out, long n_out, hipStream_t s, bool force0 = false);
     std::unique_ptr<AnyFft> big;
@@ -516,6 +519,7 @@ struct Hilbert : Block {
     // page-locked host output window the host probes its own memory after the completion wait and launches it only on a hit
     struct { bool on = false; VSrc<float> src{}; void* out = nullptr; long n = 0, P = 0; } deferred;
     void host_out_done(const void* out_host, size_t produced) override;
+    void host_out_reset() override { deferred.on = false; }
     Hilbert(size_t ntaps, int window, float parm);
     ~Hilbert() override;
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;

@@ -132,9 +132,24 @@ int Parallel::work_dev(const void* in, size_t in_len, void* out, size_t out_cap,
         RR_HIP(hipEventCreateWithFlags(&forked, hipEventDisableTiming));
     }
     prof_begin(s);
+    // Whatever happens below — a channel's work_dev throwing, the channels disagreeing — the pool streams are joined back into
+    // the caller's stream before this call returns: work the channels already enqueued must not run on past the caller's next
+    // step (its copy of the output windows, its next window, the destruction of this block) un-ordered.
+    struct Join {
+        Parallel& p; hipStream_t s; size_t np; bool armed = false;
+        void run() {
+            if (!armed) return;
+            armed = false;
+            for (size_t i = 0; i < np; i++)
+                if (hipEventRecord(p.joined[i], p.pool[i]) != hipSuccess || hipStreamWaitEvent(s, p.joined[i], 0) != hipSuccess)
+                    (void)hipStreamSynchronize(p.pool[i]);             // (the event path failed: wait here instead)
+        }
+        ~Join() { run(); }
+    } join{*this, s, NP};
     if (NP > 1) {
         RR_HIP(hipEventRecord(forked, s));
         for (size_t i = 0; i < NP; i++) RR_HIP(hipStreamWaitEvent(pool[i], forked, 0));
+        join.armed = true;
     }
     for (size_t c = 0; c < ch.size(); c++) {
         size_t cc = 0, pp = 0, nn = 0;
@@ -144,12 +159,7 @@ int Parallel::work_dev(const void* in, size_t in_len, void* out, size_t out_cap,
         else if (st != st0 || cc != *consumed || pp != *produced || nn != *need)
             throw Error("Parallel: channels of one shape disagree on the window protocol");
     }
-    if (NP > 1) {
-        for (size_t i = 0; i < NP; i++) {
-            RR_HIP(hipEventRecord(joined[i], pool[i]));
-            RR_HIP(hipStreamWaitEvent(s, joined[i], 0));
-        }
-    }
+    join.run();
     prof_end(s);
     return st0;
 }

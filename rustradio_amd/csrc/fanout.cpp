@@ -214,7 +214,7 @@ struct rr_fanout { std::unique_ptr<rr::Fanout> f; };
 
 template <class F> static int fan_guard(F&& f) {
     try { f(); return 0; }
-    catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; }
+    catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; } catch (...) { rr::set_last_error("non-standard exception"); return RR_ERR; }
 }
 
 extern "C" {
@@ -235,9 +235,12 @@ rr_fanout* rr_fanout_create(const void* id128, int rank, int world, int src_rank
     } catch (const std::exception& e) {
         rr::set_last_error(e.what());
         return nullptr;
+    } catch (...) {
+        rr::set_last_error("non-standard exception");
+        return nullptr;
     }
 }
-void rr_fanout_destroy(rr_fanout* f) { delete f; }
+void rr_fanout_destroy(rr_fanout* f) { try { delete f; } catch (...) {} }
 void* rr_fanout_produce_buf(rr_fanout* f, unsigned long long t, void* producer_stream) {
     void* p = nullptr;
     if (!f) return nullptr;

@@ -636,3 +636,38 @@ def test_a_window_of_nans_through_a_long_filter_is_not_a_throughput_collapse(rr)
     t0 = time.perf_counter(); st, c, p, need, y1 = blk.work(bad, n); t_bad = time.perf_counter() - t0
     assert p == len(y1) > 300_000 and np.all(np.isnan(y1.real)) and np.all(np.isnan(y1.imag))
     assert t_bad < 20 * t_clean + 0.05, (t_clean, t_bad)
+
+
+@pytest.mark.parametrize("L,deci", [(16380, 2), (15400, 3), (16383, 8)])
+def test_decimating_fir_near_the_top_of_the_tile_range(rr, L, deci):
+    """a decimating FirFilter of 15293..16383 taps used to stay on 16384-point tiles, which keep 16385 - L samples each
+    (16380 taps: 5 — seconds per 1e7 samples).  It now runs the any-size overlap-save frames at the full rate and keeps every
+    deci-th output with a strided copy: parity with the oracle, the reference's protocol, and a throughput bound."""
+    import time
+    import torch
+    taps = (rnd_c(L, L) / 4000).astype(np.complex64)
+    x = rnd_c(60_000, L + deci)
+    yo = run_chain([orc.FirFilter(taps, deci)], x)
+    logs = []
+    yg = run_chain([rr.FirFilter(taps, deci=deci)], x, log=logs)
+    logo = []
+    run_chain([orc.FirFilter(taps, deci)], x, log=logo)
+    assert logs == logo and len(yg) == len(yo) > 0
+    assert max_norm_err(yg, yo) <= TOL
+    n = 10_000_000
+    dx = torch.rand(2 * n, device="cuda") * 2 - 1
+    dy = torch.empty(2 * (n // deci + 8), device="cuda")
+    blk = rr.FirFilter(taps, deci=deci)
+    s = torch.cuda.current_stream().cuda_stream
+    blk.work_dev(dx.data_ptr(), n, dy.data_ptr(), n // deci + 8, s); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st, c, p, need = blk.work_dev(dx.data_ptr(), n, dy.data_ptr(), n // deci + 8, s); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert p == (n - L + 1) // deci and c == p * deci
+    assert dt < 0.05, dt          # (any-size frames: a few ms per 1e7 samples; the 16384-point tiles took 0.3 s at 16380 taps)
+    # spot check at full size against f64
+    k0 = 1_234_567
+    seg = dx[2 * k0 * deci:2 * (k0 * deci + 63 * deci + L)].cpu().numpy().view(np.complex64).astype(np.complex128)
+    ref = np.convolve(seg, taps.astype(np.complex128))[L - 1::deci][:64]
+    got = dy[2 * k0:2 * (k0 + 64)].cpu().numpy().view(np.complex64)
+    assert max_norm_err(got, ref) <= TOL
