@@ -433,6 +433,11 @@ int rr_block_profile(rr_block *b, double *total_ms, size_t *launches, int reset)
 /* Measurement builds only (make TIMING=1): 32 s_memtime stamps taken at the phase boundaries of one tile of the
  * last stamped kernel (out must hold 32 values); returns 0 in product builds. */
 int rr_debug_fft_stamps(unsigned long long *out32);
+/* Kernel launches the library has made in this process so far (every hipLaunchKernelGGL of a block's work(), incl. carry
+ * copies and repair passes; not the copies of host windows).  Tests use the difference around one call: a clean
+ * FftFilter work() on a device window is ONE launch (round 6; the reference's one work() = one pass over the window,
+ * src/fft_filter.rs:289-355). */
+unsigned long long rr_debug_kernel_launches(void);
 
 /* ---- per-block knobs / introspection ------------------------------------------- */
 /* FftFilter: reference fft_size and nsamples (src/fft_filter.rs:261-262) and the

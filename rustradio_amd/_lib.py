@@ -22,7 +22,7 @@ SYMBOLS = [
     "rr_resampler_create", "rr_quaddemod_create", "rr_rtlsdr_decode_create", "rr_fftstream_create", "rr_fft_process", "rr_multiply_const_f32_create", "rr_multiply_const_c32_create", "rr_fastfm_create", "rr_hilbert_create", "rr_fm_chain_create", "rr_fm_chain_u8_create", "rr_fir_fftfilter_create", "rr_fir_fm_chain_create", "rr_audio_chain_create", "rr_hilbert_fir_create", "rr_fm_multi_create", "rr_fm_multi_u8_create", "rr_block_out_windows", "rr_block_destroy",
     "rr_block_work", "rr_block_work_dev", "rr_block_eof", "rr_block_name", "rr_block_tag_rule", "rr_block_in_elem_size",
     "rr_block_out_elem_size", "rr_block_sync", "rr_fftfilter_dims", "rr_fir_fft_tile", "rr_fir_set_rotator_mode",
-    "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps",
+    "rr_block_set_profiling", "rr_block_profile", "rr_debug_fft_stamps", "rr_debug_kernel_launches",
     "rr_host_register", "rr_host_unregister", "rr_host_window_in_place",
     "rr_dstream_create", "rr_dstream_destroy", "rr_dstream_capacity", "rr_dstream_is_double_mapped", "rr_dstream_read_buf", "rr_dstream_write_buf",
     "rr_dstream_consume", "rr_dstream_produce", "rr_dstream_close", "rr_dstream_closed", "rr_dstream_wait", "rr_dstream_id", "rr_dstream_copy_in", "rr_dstream_copy_out", "rr_dstream_copy", "rr_block_work_streams",
@@ -106,6 +106,7 @@ def lib():
     L.rr_fir_fft_tile.argtypes = [vp]; L.rr_fir_fft_tile.restype = sz
     L.rr_fir_set_rotator_mode.argtypes = [vp, i32]; L.rr_fir_set_rotator_mode.restype = i32
     L.rr_debug_fft_stamps.argtypes = [vp]; L.rr_debug_fft_stamps.restype = i32
+    L.rr_debug_kernel_launches.argtypes = []; L.rr_debug_kernel_launches.restype = C.c_ulonglong
     pvp = C.POINTER(vp)
     L.rr_host_register.argtypes = [vp, sz]; L.rr_host_register.restype = i32
     L.rr_host_window_in_place.argtypes = [vp, sz]; L.rr_host_window_in_place.restype = i32

@@ -28,6 +28,7 @@ struct rr_dstream {
 };
 
 namespace rr {
+std::atomic<unsigned long long> g_kernel_launches{0};
 static thread_local std::string g_err;
 void set_last_error(const std::string& m) { g_err = m; }
 static thread_local BuildOpts g_opts;
@@ -281,6 +282,8 @@ int rr_block_profile(rr_block* b, double* total_ms, size_t* launches, int reset)
     try { RR_HIP(hipSetDevice(b->b->device)); b->b->prof_read(total_ms, launches, reset != 0); return 0; }
     catch (const std::exception& e) { rr::set_last_error(e.what()); return RR_ERR; } catch (...) { rr::set_last_error("non-standard exception"); return RR_ERR; }
 }
+
+unsigned long long rr_debug_kernel_launches(void) { return rr::g_kernel_launches.load(std::memory_order_relaxed); }
 
 /* measurement builds (make ABLATE=1): phase time stamps of one FftFilter tile; 0 in product builds */
 int rr_debug_fft_stamps(unsigned long long* out16) {

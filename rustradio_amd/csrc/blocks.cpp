@@ -1087,6 +1087,8 @@ void FftFilter::ref_blocks_on(const rr_c32* taps) {
     }
     const int none[2] = {-1, -1};
     d_tail.upload(none, 2, stream);
+    const int zero[4] = {0, 0, 0, 0};
+    d_rb_work.upload(zero, 4, stream);
     RR_HIP(hipStreamSynchronize(stream));
     ref_blocks = true;
 }
@@ -1123,7 +1125,9 @@ void FftFilter::host_out_done(const void* out_host, size_t) {
     seq++;
 }
 
-void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOut carry) {
+// rb_ok: this call may put the reference's blocks in place inside the tile kernel (nan_fix.hpp rb_finish) -> whether it did
+// (the split tiles and the any-size frames have no such tail: the caller runs the pass behind them)
+bool FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOut carry, bool rb_ok) {
     probe_stride = (long)(big ? bigM : (size_t)1 << (nsub && alt_log2f && alt_wins(n_out) ? alt_log2f : log2f)) - (long)L + 1;
     if (big) {
         // y = conj(FFT_M(conj(FFT_M(frame) H))) per overlap-save frame, in chunks of <= 2^24 elements of work space
@@ -1141,11 +1145,24 @@ void FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOu
             launch_ols_scatter(bframes.p, out, S, M, (long)L, f0, nf, n_out, s);
         }
         launch_carry(src, carry, s);
-        return;
+        return false;
     }
-    if (nsub && alt_log2f && alt_wins(n_out)) launch_fftfilt_os(alt_log2f, src, out, n_out, (int)L, d_tw_alt.p, d_hpos_alt.p, s, carry, nanfix);
-    else if (nsub) launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s, carry, nanfix);
-    else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s, carry, nanfix);
+    const bool use_alt = nsub && alt_log2f && alt_wins(n_out);
+    if (nsub && !use_alt) { launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s, carry, nanfix); return false; }
+    NanFix fx = nanfix;
+    const bool rb = rb_ok && ref_blocks && n_out > 0;
+    if (rb) {
+        const long P = probe_stride, ntiles = (n_out + P - 1) / P;
+        const long cap = 4 * ntiles + 8;                             // (a flagged tile writes at most four records)
+        d_rb_recs.reserve((size_t)(2 * cap));
+        fx = NanFix{};
+        fx.rev = d_rev.p; fx.L = (int)L; fx.d = 1; fx.kind = NANFIX_CC;
+        fx.rb_work = d_rb_work.p; fx.rb_recs = d_rb_recs.p; fx.rb_cap = cap; fx.rb_S = (long)nsamples; fx.rb_hist = (long)hist;
+        fx.rb_front = (int)front; fx.rb_seq = seq; fx.rb_tail = d_tail.p;
+    }
+    if (use_alt) launch_fftfilt_os(alt_log2f, src, out, n_out, (int)L, d_tw_alt.p, d_hpos_alt.p, s, carry, fx);
+    else launch_fftfilt_os(log2f, src, out, n_out, (int)L, d_tw.p, d_hpos.p, s, carry, fx);
+    return rb;
 }
 
 void FftFilter::filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s, CarryOut carry) {
@@ -1199,10 +1216,12 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
     CarryOut carry;      // (as above)
     if (*consumed) carry = CarryOut{prefix[cur ^ 1].p, (long)n_out, (long)(hist + new_pend)};
     if (k) {
-        prof_begin(s);
-        filter(src, static_cast<cf*>(out), (long)n_out, s, carry);
-        prof_end(s);
         const bool head = front && emitted == 0;
+        prof_begin(s);
+        // (the head fix below overwrites the first outputs of a possibly poisoned tile AFTER the tile kernel: that one call keeps the
+        //  pass behind it)
+        const bool in_kernel = filter(src, static_cast<cf*>(out), (long)n_out, s, carry, !head);
+        prof_end(s);
         if (head) {   // head fix: FftFilter's zero history under the first L2 - 1 outputs (n_out >= S > L2 - 1)
             const long L2 = (long)(L - front);
             d_zhead.reserve((size_t)L2);
@@ -1211,7 +1230,8 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
         }
         // (after the head fix, which a poisoned first block covers — and whose finite values may hide a poisoned tile from the
         //  probes: block 0 of that one call is looked at regardless)
-        ref_blocks_pass(src, static_cast<cf*>(out), (long)n_out, s, head);
+        if (in_kernel) { tail_host_known = false; seq++; }      // (the verdict on this call's last block is in d_tail, not on the host)
+        else ref_blocks_pass(src, static_cast<cf*>(out), (long)n_out, s, head);
         emitted += n_out;
     } else {
         launch_carry(src, carry, s);

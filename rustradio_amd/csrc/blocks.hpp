@@ -233,6 +233,8 @@ struct FftFilter : Block {
     bool ref_blocks = false;
     DevBuf<cf> d_rev;                 // the taps reversed (floats for a real stream)
     DevBuf<int> d_tail;               // [2]: was the last block of call seq - 1 poisoned?
+    DevBuf<int> d_rb_work;            // the in-kernel form (nan_fix.hpp rb_finish): ticket, records, flagged tiles — zero between launches
+    DevBuf<long> d_rb_recs;
     int seq = 1;
     long probe_stride = 0;            // of the current call: the smallest advance of the tiles that wrote it
     // a zero-copy host output window: the probe is the HOST's (its own memory, after the call's completion wait), and the pass
@@ -276,7 +278,7 @@ struct FftFilter : Block {
     int work_dev(const void*, size_t, void*, size_t, size_t*, size_t*, size_t*, hipStream_t) override;
     // out[n] = sum_k t[k] src[n + L - 1 - k], n < n_out (the tile kernel of the chosen size)
     // (carry: the caller's carry-state update, written by the same launch — common.hpp CarryOut)
-    void filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOut carry = {});
+    bool filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOut carry = {}, bool rb_ok = false);
     void filter_real(VSrc<float> src, float* out, long n_out, int d, hipStream_t s, CarryOut carry = {});   // out[m] = y[m d]
 };
 

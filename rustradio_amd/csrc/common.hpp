@@ -2,12 +2,25 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
 
 #include "fft_core.hpp"
+
+namespace rr {
+// every kernel launch of the library goes through hipLaunchKernelGGL: counted for rr_debug_kernel_launches (a test asserts
+// that a clean FftFilter work() is ONE launch)
+extern std::atomic<unsigned long long> g_kernel_launches;
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                                     \
+    do {                                                                                        \
+        ::rr::g_kernel_launches.fetch_add(1, std::memory_order_relaxed);                        \
+        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                                  \
+    } while (0)
 
 namespace rr {
 

@@ -270,8 +270,9 @@ __device__ __forceinline__ void store_stream(creg* p, creg v) {
 }
 
 // ---- FftFilter -----------------------------------------------------------------------------------
-// (FIX: FirFilter on these tiles — nan_fix.hpp; FftFilter's own instantiation carries none of it)
-template <int LOG2F, int VAR, bool FIX = false>
+// (FIX 1: FirFilter on these tiles — nan_fix.hpp nf_finish; FIX 2: the FftFilter BLOCK — the reference's blocks, rb_finish;
+//  FIX 0: the chains and measurement builds carry none of it)
+template <int LOG2F, int VAR, int FIX = 0>
 __global__ __launch_bounds__((KCfg<LOG2F, VAR>::T), (KCfg<LOG2F, VAR>::WAVES_PER_SIMD))
 void k_fftfilt_os(NanFixCtx nfx, VSrc<cf> src, cf* __restrict__ out, long n_out, int L, long ntiles,
                   const cf* __restrict__ tw, const cf* __restrict__ hpos, int ablate,
@@ -339,7 +340,8 @@ void k_fftfilt_os(NanFixCtx nfx, VSrc<cf> src, cf* __restrict__ out, long n_out,
         RR_PHASE(); RR_STAMP(12);
         // next tile's first lds_store touches exactly the slots this thread just read
     }
-    if constexpr (FIX) nf_finish<cf, cf>();       // FirFilter on these tiles: the reference's locality for non-finite samples
+    if constexpr (FIX == 1) nf_finish<cf, cf>();  // FirFilter on these tiles: the reference's locality for non-finite samples
+    if constexpr (FIX == 2) rb_finish<cf>();      // FftFilter: the reference's blocks
 }
 
 // ---- decimating FirFilter on the same tiles ----------------------------------------------------------
@@ -1974,13 +1976,17 @@ static void launch_one(VSrc<cf> src, cf* out, long n_out, int L, const cf* tw, c
     const size_t smem = sizeof(cf) * lds_elems(F);
     const int ablate = 0;
     const NanFixCtx nfx = nanfix_ctx(fx, src, out, S, 1, n_out, ntiles, 0, tile_lo);
-    if (fx.rev) {
-        const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR, true>, T, smem, ntiles);
-        hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR, true>), dim3((unsigned)grid), dim3(T), smem, s, nfx, src, out, n_out, L,
+    if (fx.rb_work) {
+        const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR, 2>, T, smem, ntiles);
+        hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR, 2>), dim3((unsigned)grid), dim3(T), smem, s, nfx, src, out, n_out, L,
+                           ntiles, tw, hpos, ablate, fft_stamp_buffer(), tile_lo, carry);
+    } else if (fx.rev) {
+        const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR, 1>, T, smem, ntiles);
+        hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR, 1>), dim3((unsigned)grid), dim3(T), smem, s, nfx, src, out, n_out, L,
                            ntiles, tw, hpos, ablate, fft_stamp_buffer(), tile_lo, carry);
     } else {
-        const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR, false>, T, smem, ntiles);
-        hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR, false>), dim3((unsigned)grid), dim3(T), smem, s, nfx, src, out, n_out, L,
+        const long grid = grid_for_tiles(k_fftfilt_os<LOG2F, VAR, 0>, T, smem, ntiles);
+        hipLaunchKernelGGL((k_fftfilt_os<LOG2F, VAR, 0>), dim3((unsigned)grid), dim3(T), smem, s, nfx, src, out, n_out, L,
                            ntiles, tw, hpos, ablate, fft_stamp_buffer(), tile_lo, carry);
     }
     RR_HIP(hipGetLastError());

@@ -201,35 +201,6 @@ void launch_carry(VSrc<float> src, const CarryOut& c, hipStream_t s) {
     if (c.n > 0) launch_vcopy_f32(src, c.v0, static_cast<float*>(c.dst), c.n, s);
 }
 
-// The reference's left fold out[m] = sum_j rev[j] V[m + j] (nan_fix.hpp nf_direct: same operations in the same order, so
-// the same bits and the same non-finite class) with the operands fetched eight at a time: the rolled form waits a memory
-// round trip per tap (190 ns: one bad sample in a 401-tap FftFilter cost 0.8 ms), and nothing here is short of registers.
-template <class T, class TAP, class ACC, class STEP>
-__device__ __forceinline__ ACC nf_fold8(const VSrc<T>& src, const TAP* rev, int L, long v0, ACC acc, STEP step) {
-    int j = 0;
-    for (; j + 8 <= L; j += 8) {
-        TAP a[8]; T x[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { a[k] = rev[j + k]; x[k] = src.load(v0 + j + k); }
-        bool dead = false;
-#pragma unroll
-        for (int k = 0; k < 8; k++) dead = step(acc, a[k], x[k]);
-        if (dead) return acc;                                        // (NaN in every component it can reach: it stays)
-    }
-    for (; j < L; j++) step(acc, rev[j], src.load(v0 + j));
-    return acc;
-}
-__device__ __forceinline__ cf nf_fold_cc(const VSrc<cf>& src, const cf* rev, int L, long v0) {        // num-complex: (ar xr - ai xi, ar xi + ai xr)
-    return nf_fold8(src, rev, L, v0, mkcf(0.0f, 0.0f), [](cf& acc, cf a, cf x) {
-        acc.x = add_rn(acc.x, sub_rn(mul_rn(a.x, x.x), mul_rn(a.y, x.y)));
-        acc.y = add_rn(acc.y, add_rn(mul_rn(a.x, x.y), mul_rn(a.y, x.x)));
-        return acc.x != acc.x && acc.y != acc.y;
-    });
-}
-__device__ __forceinline__ float nf_fold_ff(const VSrc<float>& src, const float* rev, int L, long v0) {  // fir.rs:146 / hilbert.rs:113-116
-    return nf_fold8(src, rev, L, v0, 0.0f, [](float& s, float a, float x) { s = add_rn(s, mul_rn(a, x)); return s != s; });
-}
-
 // ---- FftFilter / FftFilterFloat: non-finite samples on the REFERENCE's blocks (round 5) ------------------
 // The reference runs one fft_size-point transform per `nsamples` input samples and adds the last `ntaps` points of it to
 // the next block (fft_filter.rs:326-347): one NaN / Inf input sample of block b makes ALL of the block's transform

@@ -26,6 +26,12 @@ struct NanFix {                    // what a block hands a launcher
     int L = 0, d = 1;
     int kind = NANFIX_CC;
     int* wgflags = nullptr;        // k_hilbert only: one zeroed word per workgroup (the verdict leaves the kernel; k_hilbert_repair reads it)
+    // FftFilter's own blocks (round 6, "ref blocks in the tile kernel", see rb_finish below): rb_work != nullptr turns it on
+    int* rb_work = nullptr;        // [0] finished workgroups, [1] records written, [2] flagged tiles (zero between launches)
+    long* rb_recs = nullptr;       // (start, length) pairs: outputs OUTSIDE the writer's tiles that the reference poisons
+    long rb_cap = 0, rb_S = 0, rb_hist = 0;
+    int rb_front = 0, rb_seq = 0;
+    int* rb_tail = nullptr;        // [2]: tail[(q) & 1] == q <=> the last block of call q was poisoned
 };
 // What the repair needs, built by the launcher and passed as the kernel's FIRST argument.  The kernel body never touches it:
 // these kernels run at their register limits, and a value kept alive for the repair (or merely copied somewhere at kernel
@@ -38,6 +44,7 @@ struct NanFixCtx {
     const void* rev; int L, d, kind, iter;
     const void* prefix; long plen; const void* in; long in_len;
     void* out; long A, C, nfin, niter, kbase;
+    int* rb_work; long* rb_recs; long rb_cap, rb_S, rb_hist; int rb_front, rb_seq; int* rb_tail;
 };
 template <class SRC>
 inline NanFixCtx nanfix_ctx(const NanFix& fx, const SRC& src, void* out, long A, long C, long nfin, long niter, int iter = 0, long kbase = 0) {
@@ -45,6 +52,8 @@ inline NanFixCtx nanfix_ctx(const NanFix& fx, const SRC& src, void* out, long A,
     c.rev = fx.rev; c.L = fx.L; c.d = fx.d; c.kind = fx.kind; c.iter = iter;
     c.prefix = src.prefix; c.plen = src.plen; c.in = src.in; c.in_len = src.in_len;
     c.out = out; c.A = A; c.C = C; c.nfin = nfin; c.niter = niter; c.kbase = kbase;
+    c.rb_work = fx.rb_work; c.rb_recs = fx.rb_recs; c.rb_cap = fx.rb_cap; c.rb_S = fx.rb_S; c.rb_hist = fx.rb_hist;
+    c.rb_front = fx.rb_front; c.rb_seq = fx.rb_seq; c.rb_tail = fx.rb_tail;
     return c;
 }
 
@@ -166,6 +175,187 @@ __device__ __forceinline__ void nf_finish(bool force = false) {
     __threadfence();
     __syncthreads();
     nf_repair<T, OUT>(cp, force);
+}
+// The reference's left fold out[m] = sum_j rev[j] V[m + j] (nan_fix.hpp nf_direct: same operations in the same order, so
+// the same bits and the same non-finite class) with the operands fetched eight at a time: the rolled form waits a memory
+// round trip per tap (190 ns: one bad sample in a 401-tap FftFilter cost 0.8 ms), and nothing here is short of registers.
+template <class T, class TAP, class ACC, class STEP>
+__device__ __forceinline__ ACC nf_fold8(const VSrc<T>& src, const TAP* rev, int L, long v0, ACC acc, STEP step) {
+    int j = 0;
+    for (; j + 8 <= L; j += 8) {
+        TAP a[8]; T x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a[k] = rev[j + k]; x[k] = src.load(v0 + j + k); }
+        bool dead = false;
+#pragma unroll
+        for (int k = 0; k < 8; k++) dead = step(acc, a[k], x[k]);
+        if (dead) return acc;                                        // (NaN in every component it can reach: it stays)
+    }
+    for (; j < L; j++) step(acc, rev[j], src.load(v0 + j));
+    return acc;
+}
+__device__ __forceinline__ cf nf_fold_cc(const VSrc<cf>& src, const cf* rev, int L, long v0) {        // num-complex: (ar xr - ai xi, ar xi + ai xr)
+    return nf_fold8(src, rev, L, v0, mkcf(0.0f, 0.0f), [](cf& acc, cf a, cf x) {
+        acc.x = add_rn(acc.x, sub_rn(mul_rn(a.x, x.x), mul_rn(a.y, x.y)));
+        acc.y = add_rn(acc.y, add_rn(mul_rn(a.x, x.y), mul_rn(a.y, x.x)));
+        return acc.x != acc.x && acc.y != acc.y;
+    });
+}
+__device__ __forceinline__ float nf_fold_ff(const VSrc<float>& src, const float* rev, int L, long v0) {  // fir.rs:146 / hilbert.rs:113-116
+    return nf_fold8(src, rev, L, v0, 0.0f, [](float& s, float a, float x) { s = add_rn(s, mul_rn(a, x)); return s != s; });
+}
+
+
+// ---- FftFilter / FftFilterFloat: the REFERENCE's blocks, inside the tile kernel (round 6) ------------------------------
+// The reference's FftFilter transforms blocks of S = nsamples inputs and adds each block's last ntaps points to the next
+// (fft_filter.rs:326-347): a non-finite input sample of block b makes the outputs [b S, (b + 1) S + Lf) non-finite
+// (Lf = ntaps of the FftFilter stage) and nothing else; the GPU's tiles are of another size on another grid, and a tile that
+// read such a sample has NO finite output.  Round 5 put the reference's set in place with a second launch behind every
+// call (kernels_misc.hip k_ref_blocks_nonfinite: 3-5.5 us of a 14.5 us call at the reference's window size).  Here the same
+// happens in the tile kernel's tail, and a clean call is ONE launch that ends with one atomic per workgroup:
+//   * the tile loop tests "this tile's output is not finite" (nf_mark: one compare per tile);
+//   * a workgroup that saw such a tile walks its own tiles once more: for a flagged tile it scans the INPUT of the blocks
+//     its outputs lie in (and the one before), writes NaN over the reference's set and the reference-order fold over
+//     everything else of the tile (all of which the tile had smeared) — it only ever writes outputs of its own tiles.  What
+//     the reference poisons OUTSIDE the tile (a block that straddles the tile's edge, a block's tail) goes into a record;
+//   * every workgroup takes a ticket when it is done; the LAST one — all outputs of the call are written and visible by then —
+//     writes NaN over the records and over the previous call's tail, leaves the verdict on this call's last block for the
+//     next call and zeroes the counters.  No workgroup ever waits for another.
+// The fold is the one of the separate pass (nf_fold_cc / nf_fold_ff: same operations, same order).
+template <class T> __device__ __forceinline__ T rb_nan();
+template <> __device__ __forceinline__ float rb_nan<float>() { return __builtin_nanf(""); }
+template <> __device__ __forceinline__ cf rb_nan<cf>() { return mkcf(__builtin_nanf(""), __builtin_nanf("")); }
+__device__ __forceinline__ cf rb_fold(const VSrc<cf>& src, const void* rev, int L, long m) { return nf_fold_cc(src, static_cast<const cf*>(rev), L, m); }
+__device__ __forceinline__ float rb_fold(const VSrc<float>& src, const void* rev, int L, long m) { return nf_fold_ff(src, static_cast<const float*>(rev), L, m); }
+
+// a non-finite INPUT sample in block b (workgroup-cooperative; uniform result)?  b == -1: the last block of the previous call
+template <class T> __device__ __forceinline__ bool rb_scan(const VSrc<T>& src, long hist, long S, long front, long b, bool tail_bad) {
+    if (b < 0) return tail_bad;
+    bool bad = false;
+    const long v0 = hist + b * S, len = S + front;
+    for (long i = (long)threadIdx.x; i < len && !bad; i += (long)blockDim.x) bad = nf_bad(src.load(v0 + i));
+    return __syncthreads_or((int)bad) != 0;
+}
+// [a, b) of the call's outputs, outside the writer's tiles: for the last workgroup to fill (thread 0 only)
+__device__ __forceinline__ void rb_record(int* work, long* recs, long cap, long nfin, long a, long b) {
+    if (a < 0) a = 0;
+    if (b > nfin) b = nfin;
+    if (b <= a || threadIdx.x != 0) return;
+    const int i = atomicAdd(&work[1], 1);
+    if ((long)i < cap) { recs[2 * i] = a; recs[2 * i + 1] = b - a; }
+}
+// (the context is read field by field where it lies — a by-value copy of the struct would live in scratch memory, and a
+//  kernel that owns scratch pays for it at every wave launch)
+template <class T>
+__device__ __forceinline__ void rb_own_tiles(nf_ctx_ptr cp) {
+    const VSrc<T> src{static_cast<const T*>(cp->prefix), cp->plen, static_cast<const T*>(cp->in), cp->in_len};
+    T* out = static_cast<T*>(cp->out);
+    const void* rev = cp->rev;
+    const int L = cp->L;
+    const long A = cp->A, nfin = cp->nfin, niter = cp->niter, kbase = cp->kbase;
+    int* work = cp->rb_work;
+    long* recs = cp->rb_recs;
+    const long cap = cp->rb_cap, S = cp->rb_S, hist = cp->rb_hist, front = cp->rb_front, Lf = (long)L - front;
+    const int seq = cp->rb_seq;
+    const bool tail_bad = cp->rb_tail[(seq - 1) & 1] == seq - 1;
+    const int t = (int)threadIdx.x, nt = (int)blockDim.x;
+    const T nanv = rb_nan<T>();
+    const int bx = (int)blockIdx.x, g = (int)gridDim.x;         // (TileIter, tile_common.hpp)
+    const int nx = g < 8 ? g : 8, xcd = bx % nx, slot = bx / nx, gx = (g - xcd + nx - 1) / nx;
+    const long lo = niter * xcd / nx, hi = niter * (xcd + 1) / nx;
+    for (long kk = lo + slot; kk < hi; kk += gx) {
+        const long k = kbase + kk;
+        const long o0 = k * A;
+        long o1 = o0 + A;
+        if (o1 > nfin) o1 = nfin;
+        if (o0 >= o1) continue;
+        if (!nf_bad(nf_peek(out + o0))) continue;               // (uniform: every thread reads the same output)
+        if (t == 0) atomicAdd(&work[2], 1);
+        const long b_first = o0 / S, b_last = (o1 - 1) / S;
+        bool bad_prev = rb_scan<T>(src, hist, S, front, b_first - 1, tail_bad);
+        if (bad_prev && b_first >= 1) rb_record(work, recs, cap, nfin, (b_first - 1) * S, o0);   // (its own outputs lie in the tile(s) before)
+        if (bad_prev) rb_record(work, recs, cap, nfin, o1, b_first * S + Lf);                    // (its tail, should the tile end inside it)
+        for (long b = b_first; b <= b_last; b++) {
+            const bool bad_cur = rb_scan<T>(src, hist, S, front, b, tail_bad);
+            long m0 = b * S, m1 = m0 + S;
+            if (m0 < o0) m0 = o0;
+            if (m1 > o1) m1 = o1;
+            for (long m = m0 + t; m < m1; m += nt)
+                out[m] = (bad_cur || (bad_prev && m - b * S < Lf)) ? nanv : rb_fold(src, rev, L, m);
+            if (bad_cur) {
+                rb_record(work, recs, cap, nfin, b * S, o0);
+                rb_record(work, recs, cap, nfin, o1, (b + 1) * S + Lf);
+            }
+            bad_prev = bad_cur;
+        }
+    }
+}
+template <class T>
+__device__ __forceinline__ void rb_last(nf_ctx_ptr cp) {
+    int* work = cp->rb_work;
+    int* tail = cp->rb_tail;
+    const int seq = cp->rb_seq;
+    const int t = (int)threadIdx.x, nt = (int)blockDim.x;
+    const int nflag = __hip_atomic_load(&work[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool tail_bad = tail[(seq - 1) & 1] == seq - 1;
+    if (nflag || tail_bad) {                                    // (uniform)
+        T* out = static_cast<T*>(cp->out);
+        const long nfin = cp->nfin;
+        const T nanv = rb_nan<T>();
+        const long* recs = cp->rb_recs;
+        long nrec = (long)__hip_atomic_load(&work[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nrec > cp->rb_cap) nrec = cp->rb_cap;               // (four records per tile at most: the launcher sizes for it)
+        for (long r = 0; r < nrec; r++) {
+            const long a = recs[2 * r], n = recs[2 * r + 1];
+            for (long m = t; m < n; m += nt) out[a + m] = nanv;
+        }
+        if (tail_bad) {                                         // the previous call's last block: its tail lies at the head of this call
+            long n = (long)cp->L - (long)cp->rb_front;
+            if (n > nfin) n = nfin;
+            for (long m = t; m < n; m += nt) out[m] = nanv;
+        }
+        if (nflag) {                                            // (no flagged tile: every input of the call is finite, the slot stays stale)
+            const VSrc<T> src{static_cast<const T*>(cp->prefix), cp->plen, static_cast<const T*>(cp->in), cp->in_len};
+            const long S = cp->rb_S;
+            const bool bad = rb_scan<T>(src, cp->rb_hist, S, (long)cp->rb_front, nfin / S - 1, false);
+            if (t == 0) tail[seq & 1] = bad ? seq : -1;
+        }
+    }
+    __syncthreads();
+    if (t == 0) { work[1] = 0; work[2] = 0; __threadfence(); work[0] = 0; }
+}
+// the tile kernel's tail in this mode (after its tile loop; nf_init / nf_mark as for the FirFilter repair)
+template <class T>
+__device__ __forceinline__ void rb_finish() {
+    __syncthreads();
+    int any = 0;
+    const int nw = (int)((blockDim.x + 63) >> 6);
+    for (int w = 0; w < nw; w++) any |= nf_flags[w];
+#if defined(__HIP_DEVICE_COMPILE__)
+    nf_ctx_ptr cp = (nf_ctx_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    nf_ctx_ptr cp = nullptr;
+#endif
+    // (inlined, not called: a callee that folds eight operands at a time needs more vector registers than the calling convention
+    //  leaves it without saving some to scratch memory, and a kernel that owns scratch pays for it at every wave launch.  The
+    //  pointer goes through an opaque asm so that none of the context's loads can move up into the tile loop.)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(cp));
+#endif
+    int* work = cp->rb_work;
+    if (work == nullptr) return;                               // (uniform: the mode is off for this launch)
+    if (any) {
+        __threadfence();                                        // this workgroup's stores, before it reads them back
+        __syncthreads();
+        rb_own_tiles<T>(cp);
+    }
+    __threadfence();                                            // outputs, repairs and records before the ticket
+    __syncthreads();
+    if (threadIdx.x == 0) nf_flags[0] = atomicAdd(&work[0], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!nf_flags[0]) return;
+    __threadfence();
+    rb_last<T>(cp);
 }
 #endif
 

@@ -671,3 +671,43 @@ def test_decimating_fir_near_the_top_of_the_tile_range(rr, L, deci):
     ref = np.convolve(seg, taps.astype(np.complex128))[L - 1::deci][:64]
     got = dy[2 * k0:2 * (k0 + 64)].cpu().numpy().view(np.complex64)
     assert max_norm_err(got, ref) <= TOL
+
+
+def test_a_clean_fftfilter_work_is_one_kernel_launch(rr):
+    """Round 6: the pass that keeps FftFilter's outputs on non-finite input the reference's
+    (fft_filter.rs:326-347) lives in the tile kernel's tail — a work() on a device window is ONE launch, clean or not, at the
+    reference's window size (stream.rs:105) and at 1e7 samples; and the non-finite call still gives the reference's set."""
+    import torch
+    taps = orc.low_pass_complex(10e6, 1e6, 60e3)
+    s = torch.cuda.current_stream().cuda_stream
+    launches = rr.lib().rr_debug_kernel_launches
+    for n in (512_000, 10_000_000):
+        x = rnd_c(n, 77)
+        dx = torch.from_numpy(x.view(np.float32)).cuda()
+        dy = torch.empty(2 * (n + 1024), device="cuda")
+        blk = rr.FftFilter(taps)
+        blk.work_dev(dx.data_ptr(), n, dy.data_ptr(), n + 1024, s); torch.cuda.synchronize()
+        for _ in range(3):
+            c0 = launches()
+            st, c, p, need = blk.work_dev(dx.data_ptr(), n, dy.data_ptr(), n + 1024, s)
+            assert launches() - c0 == 1 and p > 0
+        torch.cuda.synchronize()
+    # a NaN in the window: still one launch, and exactly the reference's outputs are NaN
+    n = 512_000
+    x = rnd_c(n, 78)
+    x[123_456] = np.nan
+    dx = torch.from_numpy(x.view(np.float32)).cuda()
+    dy = torch.empty(2 * (n + 1024), device="cuda")
+    blk, ob = rr.FftFilter(taps), orc.FftFilter(taps)
+    c0 = launches()
+    st, c, p, need = blk.work_dev(dx.data_ptr(), n, dy.data_ptr(), n + 1024, s); torch.cuda.synchronize()
+    assert launches() - c0 == 1
+    st2, c2, p2, need2, yo = ob.work(x, n + 1024)
+    yg = dy[:2 * p].cpu().numpy().view(np.complex64)
+    assert (st, c, p, need) == (st2, c2, p2, need2)
+    bad_o = ~(np.isfinite(yo.real) & np.isfinite(yo.imag))
+    bad_g = ~(np.isfinite(yg.real) & np.isfinite(yg.imag))
+    assert bad_o.sum() == 1023 + 0 or bad_o.sum() > 600                     # (the block of 623 + the 400 carried points)
+    assert np.array_equal(bad_o, bad_g)
+    ok = ~bad_o
+    assert max_norm_err(yg[ok], yo[ok]) <= TOL
