@@ -421,7 +421,8 @@ int rr_dstream_copy_in(rr_dstream* s, size_t offset, const void* host, size_t n,
             // rate hipMemcpyAsync gets out of such a range on this platform (kernels_misc.hip launch_copy_bytes)
             void* hv = n ? rr::device_view_of_host(host, n * d.es) : nullptr;
             if (hv) rr::launch_copy_bytes(hv, w + offset * d.es, n * d.es, st);
-            else if (n) RR_HIP(hipMemcpyAsync(w + offset * d.es, host, n * d.es, hipMemcpyHostToDevice, st));
+            else if (n && rr::host_range_registered(host, n * d.es)) RR_HIP(hipMemcpyAsync(w + offset * d.es, host, n * d.es, hipMemcpyHostToDevice, st));
+            else if (n) rr::stage_upload_sync(w + offset * d.es, host, n * d.es, st);     // pageable: stage.hpp
         });
     }
     if (rc != 0 || n == 0) return rc;
@@ -444,7 +445,8 @@ int rr_dstream_copy_out(rr_dstream* s, size_t offset, void* host, size_t n, void
             void* hv = n ? rr::device_view_of_host(host, n * d.es) : nullptr;
             const unsigned char* rp = static_cast<const unsigned char*>(d.read_ptr()) + offset * d.es;
             if (hv) rr::launch_copy_bytes(rp, hv, n * d.es, st);              // (see copy_in)
-            else if (n) RR_HIP(hipMemcpyAsync(host, rp, n * d.es, hipMemcpyDeviceToHost, st));
+            else if (n && rr::host_range_registered(host, n * d.es)) RR_HIP(hipMemcpyAsync(host, rp, n * d.es, hipMemcpyDeviceToHost, st));
+            else if (n) rr::stage_download_sync(host, rp, n * d.es, st);                   // pageable: stage.hpp
         });
     }
     if (rc != 0) return rc;

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <unistd.h>
 
+#include "stage.hpp"
 #include "taps.hpp"
 
 namespace rr {
@@ -151,6 +152,17 @@ void host_range_remove(void* base) {
             break;
         }
 }
+// whether [host, host + bytes) lies wholly inside a range that IS page-locked through rr_host_register right now (admitted to
+// zero-copy or not): such memory may be handed to hipMemcpyAsync — the runtime finds the caller's registration.  Anything else
+// goes through stage.hpp.
+bool host_range_registered(const void* host, size_t bytes) {
+    if (!host) return false;
+    const unsigned char* h = static_cast<const unsigned char*>(host);
+    std::lock_guard<std::mutex> g(g_host_m);
+    for (auto& r : g_host_ranges)
+        if (h >= r.base && bytes <= r.bytes && (size_t)(h - r.base) <= r.bytes - bytes) return true;
+    return false;
+}
 void* device_view_of_host(const void* host, size_t bytes) {
     if (!host) return nullptr;
     const unsigned char* h = static_cast<const unsigned char*>(host);
@@ -177,7 +189,8 @@ int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, s
     if (!din) {
         st_in.reserve(std::max<size_t>(in_use * in_es, 16));
         if (in_use && vin) launch_copy_bytes(vin, st_in.p, in_use * in_es, stream);
-        else if (in_use) RR_HIP(hipMemcpyAsync(st_in.p, in, in_use * in_es, hipMemcpyHostToDevice, stream));
+        else if (in_use && host_range_registered(in, in_use * in_es)) RR_HIP(hipMemcpyAsync(st_in.p, in, in_use * in_es, hipMemcpyHostToDevice, stream));
+        else if (in_use) hstage().h2d(st_in.p, in, in_use * in_es, stream);     // pageable: never a DMA out of the caller's memory (stage.hpp)
         din = st_in.p;
     }
     if (!dout) st_out.reserve(std::max<size_t>(out_cap * out_es * out_windows(), 16));
@@ -187,8 +200,12 @@ int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, s
     try { st = work_dev(din, in_len, dout ? dout : st_out.p, out_cap, consumed, produced, need, stream); }
     catch (...) { host_out = nullptr; host_out_reset(); throw; }
     if (!dout && *produced) {
-        if (out_windows() == 1) RR_HIP(hipMemcpyAsync(out, st_out.p, *produced * out_es, hipMemcpyDeviceToHost, stream));
-        else RR_HIP(hipMemcpy2DAsync(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, out_windows(), hipMemcpyDeviceToHost, stream));
+        if (host_range_registered(out, out_cap * out_es * out_windows())) {
+            if (out_windows() == 1) RR_HIP(hipMemcpyAsync(out, st_out.p, *produced * out_es, hipMemcpyDeviceToHost, stream));
+            else RR_HIP(hipMemcpy2DAsync(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, out_windows(), hipMemcpyDeviceToHost, stream));
+        } else {
+            hstage().d2h_2d(out, out_cap * out_es, st_out.p, out_cap * out_es, *produced * out_es, out_windows(), stream);
+        }
     }
     // (polling an event from the calling thread instead was measured and changes nothing: 154 -> 158 us per reference-sized
     //  window; the call sits on the link — tools/micro/pcie_inplace.hip: a kernel moves 4,096,000 bytes each way in 128-145 us)
@@ -1078,8 +1095,7 @@ void FftFilter::ref_blocks_on(const rr_c32* taps) {
         std::vector<float> r(L);
         for (size_t j = 0; j < L; j++) r[j] = taps[L - 1 - j].re;
         d_rev.reserve((L + 1) / 2);
-        RR_HIP(hipMemcpyAsync(d_rev.p, r.data(), L * sizeof(float), hipMemcpyHostToDevice, stream));
-        RR_HIP(hipStreamSynchronize(stream));
+        stage_upload_sync(d_rev.p, r.data(), L * sizeof(float), stream);
     } else {
         std::vector<cf> r(L);
         for (size_t j = 0; j < L; j++) r[j] = mkcf(taps[L - 1 - j].re, taps[L - 1 - j].im);

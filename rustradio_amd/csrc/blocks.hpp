@@ -6,6 +6,7 @@
 
 #include "../../include/rustradio_amd.h"
 #include "kernels.hpp"
+#include "stage.hpp"
 
 namespace rr {
 
@@ -14,6 +15,7 @@ int thread_device();
 // page-locked host ranges the library was told about (rr_host_register): their device view, for zero-copy host windows
 void host_range_add(void* base, size_t bytes);
 void host_range_remove(void* base);
+bool host_range_registered(const void* host, size_t bytes);     // inside a live rr_host_register'd range (admitted to zero-copy or not)
 void* device_view_of_host(const void* host, size_t bytes);      // nullptr: not wholly inside an rr_host_register'd range (staged copies)
 
 struct Block {
@@ -23,6 +25,8 @@ struct Block {
     hipStream_t stream = nullptr;         // private stream: host-window work() and setup copies
     hipStream_t last_stream = nullptr;    // stream of the most recent work call (what sync() waits for)
     DevBuf<unsigned char> st_in, st_out;   // staging for host-window work() (pageable windows)
+    std::unique_ptr<HostStage> hstage_;    // ... and the pinned chunks their bytes cross the bus in (stage.hpp), made on first use
+    HostStage& hstage() { if (!hstage_) hstage_.reset(new HostStage()); return *hstage_; }
     // page-locked host INPUT windows are read by the kernels in place (zero copy); blocks whose kernels read the window more
     // than once (the N-channel blocks: every run of channel rounds re-reads its tiles) keep the upload
     bool zero_copy_in = true;

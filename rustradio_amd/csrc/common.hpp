@@ -64,6 +64,9 @@ void set_build_opts(const BuildOpts* o);   // nullptr = reset
             throw ::rr::Error(std::string(#expr) + ": " + hipGetErrorString(_e));             \
     } while (0)
 
+void stage_upload_sync(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);      // stage.cpp
+void stage_download_sync(void* dst_host, const void* src_dev, size_t bytes, hipStream_t s);
+
 // Device buffer that only grows.
 template <class T> struct DevBuf {
     T* p = nullptr;
@@ -82,10 +85,7 @@ template <class T> struct DevBuf {
     // one-time setup tables: blocking, so the host vector may go out of scope right after the call
     void upload(const T* h, size_t n, hipStream_t s) {
         reserve(n);
-        if (n) {
-            RR_HIP(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, s));
-            RR_HIP(hipStreamSynchronize(s));
-        }
+        if (n) stage_upload_sync(p, h, n * sizeof(T), s);   // (stage.hpp: through the library's own pinned chunks, never a DMA out of `h`)
     }
 };
 
