@@ -102,8 +102,10 @@ typedef struct {
                                8 / 12: also fixes the multi-channel kernel's waves per workgroup (0 / 1: by predicted cost) */
     int dstream_no_vmm;     /* rr_dstream_create: the copying fallback ring instead of the double mapping */
     int fir_poly;           /* decimating FirFilter<Complex>: decimate-first (polyphase) tiles, > 0 wherever supported, < 0 never */
-    int fft_nonfinite_tiles;/* FftFilter / FftFilterFloat: leave a NaN / Inf input sample's damage on the GPU's tile (one launch
-                               less per work() call) instead of moving it onto the reference's block of nsamples inputs */
+    int fft_nonfinite_tiles;/* FftFilter / FftFilterFloat: 1 = leave a NaN / Inf input sample's damage on the GPU's tile instead of
+                               moving it onto the reference's block of nsamples inputs (no pass behind the tile kernels);
+                               3 = do the pass inside the tile kernel's tail (one launch per work(), slower: csrc/blocks.cpp
+                               ref_blocks_on); 0 / 2 = the default, a small launch of its own behind every call */
     int host_in_staged;     /* rr_block_work on a page-locked INPUT window: > 0 copy it to device memory first (a copy kernel, 55 GB/s)
                                instead of letting the block's kernels read it in place, < 0 always in place; 0 = the block's default */
     int reserved[3];

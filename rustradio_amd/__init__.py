@@ -59,7 +59,7 @@ def _effective_opts() -> dict:
 def build_options(**kw):
     """fir_path='direct'|'fft', fir_prune=+-1, fir_half=-1, fir_cfg=0..7, fft_log2f=10..14, fft_no_split=1,
     fftfloat_complex=1, fm_full=1, fm_poly=-1 (8 / 12: the multi-channel kernel variant), dstream_no_vmm=1, fir_poly=+-1,
-    fft_nonfinite_tiles=1, host_in_staged=+-1"""
+    fft_nonfinite_tiles=1 (none) | 3 (in the tile kernel's tail), host_in_staged=+-1"""
     prev = getattr(_tls, "opts", None)
     _tls.opts = dict(_effective_opts(), **kw)
     try:

@@ -1090,7 +1090,13 @@ FftFilter::FftFilter(const rr_c32* taps_in, size_t ntaps, bool for_chain, int ma
 }
 
 void FftFilter::ref_blocks_on(const rr_c32* taps) {
-    if (build_opts().fft_nonfinite_tiles) return;
+    if (build_opts().fft_nonfinite_tiles == 1) return;
+    // 3: the pass inside the tile kernel's tail (nan_fix.hpp rb_finish, round 6): ONE launch per work(), but every workgroup
+    // must release its outputs to the device before the last one may overwrite some of them — on this part that is a write-back
+    // of the XCD's L2 per workgroup.  Measured on one box, FftFilter 401 taps (tools/r6_gpu3.sh): 1e8 samples 0.360 ms against
+    // 0.332 with the pass as its own launch (0.325 without any pass); a 512,000-sample call 22.2 us against 17.1 (12.9).  The
+    // launch it saves costs less than the releases it needs: opt-in, for the record.
+    rb_in_kernel = build_opts().fft_nonfinite_tiles == 3;
     if (real_stream) {
         std::vector<float> r(L);
         for (size_t j = 0; j < L; j++) r[j] = taps[L - 1 - j].re;
@@ -1166,7 +1172,7 @@ bool FftFilter::filter(VSrc<cf> src, cf* out, long n_out, hipStream_t s, CarryOu
     const bool use_alt = nsub && alt_log2f && alt_wins(n_out);
     if (nsub && !use_alt) { launch_fftfilt_split(nsub, src, out, n_out, (int)L, d_tw4096.p, d_hs.p, d_wk.p, s, carry, nanfix); return false; }
     NanFix fx = nanfix;
-    const bool rb = rb_ok && ref_blocks && n_out > 0;
+    const bool rb = rb_ok && ref_blocks && rb_in_kernel && n_out > 0;
     if (rb) {
         const long P = probe_stride, ntiles = (n_out + P - 1) / P;
         const long cap = 4 * ntiles + 8;                             // (a flagged tile writes at most four records)

@@ -235,6 +235,7 @@ struct FftFilter : Block {
     // instead of the GPU's tile — one small launch behind the tile kernels of every call (kernels_misc.hip
     // k_ref_blocks_nonfinite; rr_build_opts.fft_nonfinite_tiles leaves it out)
     bool ref_blocks = false;
+    bool rb_in_kernel = true;         // ... inside the tile kernel's tail where the kernel has one (round 6, nan_fix.hpp rb_finish)
     DevBuf<cf> d_rev;                 // the taps reversed (floats for a real stream)
     DevBuf<int> d_tail;               // [2]: was the last block of call seq - 1 poisoned?
     DevBuf<int> d_rb_work;            // the in-kernel form (nan_fix.hpp rb_finish): ticket, records, flagged tiles — zero between launches
