@@ -1268,6 +1268,29 @@ int FftFilter::work_dev(const void* in, size_t in_len, void* out, size_t out_cap
 
 // ---- fused FM chain ------------------------------------------------------------------------------------
 static int64_t gcd64(int64_t a, int64_t b);
+void ChainNf::init(hipStream_t s) {
+    const int none[6] = {-1, -1, -1, -1, -1, -1};
+    slots.upload(none, 6, s);
+    on = true;
+}
+// whether a chain of this shape gets the pass: not with rr_build_opts.fft_nonfinite_tiles = 1, not from RTL-SDR bytes (always
+// finite), and only while an output's two filtered samples lie in one reference block or two neighbours (ceil(D / I) <= S)
+static bool chain_nf_wanted(bool u8, int64_t I, int64_t D, size_t S) {
+    return !u8 && build_opts().fft_nonfinite_tiles != 1 && (D + I - 1) / I <= (int64_t)S;
+}
+static void reversed_taps(const rr_c32* t, size_t L, cf* dst) {
+    for (size_t j = 0; j < L; j++) dst[j] = mkcf(t[L - 1 - j].re, t[L - 1 - j].im);
+}
+// outputs (r positions) of the smallest tile a chain kernel of this call may have run on: P_y filtered samples hold at least
+// floor(P_y I / D) of them
+// (the chain kernels advance by fm_advance((F - L + 1) - ceil(D / I)), which rounds down to whole epilogue rounds but never
+//  below 9/10 of it — kernels_fft.hip; the half-size inverse takes two more off: a stride of 0.85 of the nominal count, less two,
+//  is below every variant's, and a lattice finer than the tiles only costs a few more loads)
+static long chain_probe_stride(long P_y, int64_t I, int64_t D) {
+    const long G = (long)((D + I - 1) / I);
+    const __int128 q = (__int128)(P_y - G) * I * 85 / (D * 100) - 2;
+    return q < 1 ? 1 : (long)q;
+}
 FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float g, int m, bool u8, int max_log2f,
                  const rr_c32* fir_taps, size_t fir_ntaps)
     : Block(fir_taps ? "FirFilter>FftFilter>RationalResampler>QuadratureDemod"
@@ -1335,6 +1358,15 @@ FmChain::FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, f
         if (!poly->build(ct.data(), 1, f->L, (size_t)D, false, stream)) poly.reset();
     }
     for (auto& b : last_r) { b.reserve(1); RR_HIP(hipMemsetAsync(b.p, 0, sizeof(cf), stream)); }
+    if (chain_nf_wanted(u8, I, D, f->nsamples)) {
+        std::vector<rr_c32> ct(f->L);
+        if (fir_taps) ct = FftFilter::composite(fir_taps, fir_ntaps, taps, f->L - (fir_ntaps - 1));
+        else std::copy(taps, taps + f->L, ct.begin());
+        std::vector<cf> r(f->L);
+        reversed_taps(ct.data(), f->L, r.data());
+        nf.rev_c.upload(r.data(), r.size(), stream);
+        nf.init(stream);
+    }
     RR_HIP(hipStreamSynchronize(stream));
 }
 
@@ -1451,6 +1483,15 @@ int FmChain::work_blocks(const void* in, size_t in_len, float* out, size_t, size
             launch_head_demod(f->d_zhead.p, nz, f->d_t2.p, (int)L2, I, D, gain, mode, a.r_hi, out,
                               last_r[cur_lr ^ 1].p, s);
         }
+        if (nf.on && !iq8) {
+            // the smallest tile a kernel above may have used (decimate-first: 1024 - Ls output positions per tile)
+            const uint64_t Lsd = (f->L + (uint64_t)D - 1) / (uint64_t)D;
+            const long P_os = (long)((size_t)1 << (use_alt ? f->alt_log2f : use_half ? 11 : f->log2f)) - (long)f->L + 1;
+            const long P = use_poly ? (long)(1024 - Lsd) : chain_probe_stride(P_os, I, D);
+            launch_chain_blocks_nonfinite(src, out, 0, 1, a, (long)S, (long)f->hist, P, (int)f->L, (int)f->front, nf.rev_c.p, 0,
+                                          last_r[cur_lr].p, last_r[cur_lr ^ 1].p, nf.slots.p, nf.seq, (f->front && n1 == 0) ? 1 : 0, s);
+            nf.seq++;
+        }
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
     } else if (*consumed) {                        // nothing to filter yet: the window only joins the pending samples
         if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);
@@ -1482,6 +1523,12 @@ AudioChain::AudioChain(const float* taps, size_t ntaps, size_t interp, size_t de
     std::vector<rr_c32> ct(ntaps);
     for (size_t i = 0; i < ntaps; i++) ct[i] = rr_c32{taps[i], 0.0f};  // fft_filter.rs:398
     f.reset(new FftFilter(ct.data(), ntaps, false, 12, true));
+    if (chain_nf_wanted(false, I, D, f->nsamples)) {
+        std::vector<float> r(ntaps);
+        for (size_t j = 0; j < ntaps; j++) r[j] = taps[ntaps - 1 - j];
+        nf.rev_f.upload(r.data(), r.size(), stream);
+        nf.init(stream);
+    }
 }
 
 // Bookkeeping as FmChain's without the demodulator's one-sample lag: a call emits whole filter blocks and every resampled
@@ -1522,6 +1569,12 @@ int AudioChain::work_blocks(const void* in, size_t in_len, float* out, size_t, s
         prof_begin(s);
         launch_audio_chain(f->log2f, src, out, (int)f->L, f->d_tw.p, f->d_hpos.p, a, s);
         prof_end(s);
+        if (nf.on) {
+            const long P_y = (long)((size_t)1 << f->log2f) - (long)f->L + 1;       // one real segment of a tile
+            launch_chain_blocks_nonfinite(src, out, a, (long)S, (long)f->hist, chain_probe_stride(P_y, I, D), (int)f->L, nf.rev_f.p,
+                                          nf.slots.p, nf.seq, s);
+            nf.seq++;
+        }
     } else if (*consumed) {
         launch_vcopy_f32(src, (long)n_y, reinterpret_cast<float*>(f->prefix[f->cur ^ 1].p), (long)(f->hist + new_pend), s);
     }
@@ -1583,6 +1636,13 @@ FmMulti::FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, 
         }
     }
     for (auto& b : last_r) { b.reserve(C); RR_HIP(hipMemsetAsync(b.p, 0, C * sizeof(cf), stream)); }
+    chain->nf.on = false;
+    if (chain_nf_wanted(u8, chain->I, chain->D, chain->f->nsamples)) {
+        std::vector<cf> r(C * ntaps);
+        for (size_t c = 0; c < C; c++) reversed_taps(taps + c * ntaps, ntaps, r.data() + c * ntaps);
+        nf.rev_c.upload(r.data(), r.size(), stream);
+        nf.init(stream);
+    }
     RR_HIP(hipStreamSynchronize(stream));
 }
 
@@ -1651,6 +1711,14 @@ int FmMulti::work_blocks(const void* in, size_t in_len, float* out, size_t out_s
             launch_fm_multi(f->log2f, src, out, (long)out_stride, (int)f->L, f->d_tw.p, d_hpos_all.p,
                             (int)C, a, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, s);
         prof_end(s);
+        if (nf.on && !iq8) {
+            const uint64_t Lsd = (f->L + (uint64_t)D - 1) / (uint64_t)D;
+            const long P_os = (long)((size_t)1 << f->log2f) - (long)f->L + 1;
+            const long P = poly ? (long)(1024 - Lsd) : chain_probe_stride(P_os, I, D);
+            launch_chain_blocks_nonfinite(src, out, (long)out_stride, (int)C, a, (long)S, (long)f->hist, P, (int)f->L, 0, nf.rev_c.p,
+                                          (long)f->L, last_r[cur_lr].p, last_r[cur_lr ^ 1].p, nf.slots.p, nf.seq, 0, s);
+            nf.seq++;
+        }
         if (a.r_hi > a.r_lo) cur_lr ^= 1;
     } else if (*consumed) {
         if (packed) launch_vcopy_iq8(src8, (long)n_y, f->prefix[f->cur ^ 1].p, (long)(f->hist + new_pend), s);

@@ -339,6 +339,17 @@ int trickle_work(B& b, OutTail& t, size_t C, const void* in, size_t in_len, void
 // Fused FftFilter -> RationalResampler(interp:deci) -> QuadratureDemod (one kernel per call).
 // Whole-stream output = what the three reference blocks produce in sequence: after N input
 // samples, N1 = floor(N/nsamples)*nsamples filtered, N2 = ceil(N1*I/D) resampled, N2-1 demodulated.
+// The fused chains' non-finite pass (kernels_misc.hip k_chain_blocks_nonfinite, round 6): the reversed time-domain taps it folds
+// with, the three sequence-numbered verdict slots and the call counter.  on == false: no pass (RTL-SDR byte sources cannot carry
+// a non-finite sample; rr_build_opts.fft_nonfinite_tiles = 1; ratios beyond one reference block per output).
+struct ChainNf {
+    bool on = false;
+    DevBuf<cf> rev_c;                 // [channels][L]
+    DevBuf<float> rev_f;              // [L] (audio chain)
+    DevBuf<int> slots;                // [6]
+    int seq = 1;
+    void init(hipStream_t s);
+};
 struct FmChain : Block {
     std::unique_ptr<FftFilter> f;     // owns taps tables, history/pending prefix and tile choice
     int64_t I = 1, D = 1;
@@ -356,6 +367,7 @@ struct FmChain : Block {
     std::unique_ptr<PolyTables> poly; // interp 1, integer deci: decimate-first tiles (k_fm_chain_poly)
     bool window_aware = true;         // windows of too few tiles run on the 2048-point kernels (off when fm_poly is forced)
     OutTail tail;                     // one block's outputs the caller's window could not take yet
+    ChainNf nf;                       // non-finite samples on the reference's blocks (round 6)
     FmChain(const rr_c32* taps, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false,
             int max_log2f = 14, const rr_c32* fir_taps = nullptr, size_t fir_ntaps = 0);
     size_t next_block_outputs() const;
@@ -376,6 +388,7 @@ struct AudioChain : Block {
     float scale;
     uint64_t n1 = 0;                  // filtered samples emitted so far
     OutTail tail;
+    ChainNf nf;
     AudioChain(const float* taps, size_t ntaps, size_t interp, size_t deci, float scale);
     size_t next_block_outputs() const;
     int work_blocks(const void*, size_t, float*, size_t, size_t, size_t*, size_t*, size_t*, hipStream_t, uint64_t max_blocks);
@@ -401,6 +414,7 @@ struct FmMulti : Block {
     bool iq8 = false;
     DevBuf<cf> decoded;               // odd-addressed byte windows are decoded out of line
     OutTail tail;                     // [C] windows of one block's outputs
+    ChainNf nf;                       // (its own: every channel's taps; `chain->nf` stays off)
     FmMulti(const rr_c32* taps, size_t nchan, size_t ntaps, size_t interp, size_t deci, float gain, int mode, bool iq8 = false);
     size_t out_windows() const override { return C; }
     size_t next_block_outputs() const { return chain->next_block_outputs(); }

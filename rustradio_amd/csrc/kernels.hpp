@@ -201,6 +201,12 @@ void launch_hilbert_refold_nonfinite(VSrc<float> src, cf* out, long n_out, long 
 // FftFilter / FftFilterFloat: non-finite samples poison the REFERENCE's blocks, not the GPU's tiles (kernels_misc.hip)
 void launch_ref_blocks_nonfinite(VSrc<cf> src, cf* out, long n_out, long S, long P, long hist, int L, int front, const cf* rev, int* tail, int seq, bool force0, hipStream_t s);
 void launch_ref_blocks_nonfinite(VSrc<float> src, float* out, long n_out, long S, long P, long hist, int L, int front, const float* rev, int* tail, int seq, bool force0, hipStream_t s);
+// the fused FM / audio chains: the same through the resampler's index map and the demodulator's pair (kernels_misc.hip); slots = int[6]
+void launch_chain_blocks_nonfinite(VSrc<cf> src, float* out, long out_stride, int nchan, const FmChainArgs& a, long S, long hist, long P,
+                                   int L, int front, const cf* rev, long rev_stride, const cf* last_in, cf* last_out, int* slots, int seq, int force,
+                                   hipStream_t s);
+void launch_chain_blocks_nonfinite(VSrc<float> src, float* out, const AudioChainArgs& a, long S, long hist, long P, int L,
+                                   const float* rev, int* slots, int seq, hipStream_t s);
 // a CarryOut as its own launch (calls without a main kernel; launchers with nothing to launch)
 void launch_carry(VSrc<cf> src, const CarryOut& c, hipStream_t s);
 void launch_carry(VSrcIQ8 src, const CarryOut& c, hipStream_t s);

@@ -323,6 +323,172 @@ void launch_ref_blocks_nonfinite(VSrc<float> src, float* out, long n_out, long S
     launch_ref_blocks<float>(src, out, n_out, S, P, hist, L, front, rev, tail, seq, force0, s);
 }
 
+// ---- fused FM / audio chains: non-finite samples on the REFERENCE's blocks (round 6) ------------------------------------
+// FftFilter -> RationalResampler -> QuadratureDemod (and FftFilterFloat -> RationalResampler -> MultiplyConst) in the
+// reference: the FftFilter stage poisons the filtered samples y[b S, (b + 1) S + Lf) of a block that holds a non-finite input
+// (fft_filter.rs:326-347), the resampler picks r[u] = y[floor(u D / I)] (rational_resampler.rs:183-198), the demodulator
+// pairs them, out[u - 1] = gain atan2(conj(r[u - 1]) r[u]) (quadrature_demod.rs:65-109): an output is NaN iff one of the (two)
+// filtered samples it reads lies in a poisoned stretch — and nothing else is.  The fused kernels work on tiles of another size
+// on another grid: a tile that read a NaN has no finite output.  This pass, behind the chain kernel of a call, puts the
+// reference's set in place exactly like k_ref_blocks_nonfinite does for the FftFilter block:
+//   * probe: one output every P (<= the outputs of the smallest tile of the call) over a workgroup's blocks and the two before
+//     them — clean: every workgroup returns (the steady state);
+//   * otherwise, per block: scan the INPUT of the block and the two before it, write NaN where the reference does, and
+//     recompute what only the tile had smeared: y at the one or two positions an output reads by the reference-order fold
+//     (nan_fix.hpp nf_fold_cc / nf_fold_ff), then the reference's own conj-multiply and atan2 (k_quaddemod's code).
+// The verdicts a later call needs (was the last / second-to-last block poisoned, was the carried r) sit in three sequence-
+// numbered slots like k_ref_blocks_nonfinite's tail.  NaN only: what an Inf turns into inside rustfft (Inf or NaN, bin by
+// bin) is not defined by anything this repository holds, and atan2 of two infinities is finite — stated in DESIGN.md.
+// RTL-SDR byte sources cannot carry a non-finite sample ((b - 127) * 0.008): those chains never launch this.
+struct ChainBlocksCtx {
+    const void* prefix; long plen; const void* in; long in_len;     // the call's virtual stream: y[m] reads [m, m + L) of it
+    float* out; long out_stride; int nchan;                          // channel c writes out + c * out_stride
+    long A, n_y, r_lo, r_hi, o_base, I, D;                           // FmChainArgs / AudioChainArgs (o_base = r_lo for the audio chain)
+    long S, hist, P;                                                 // block b reads [hist + b S, hist + (b + 1) S + front); probe stride
+    int L, front;
+    const void* rev; long rev_stride;                                // reversed taps per channel (cf / float)
+    float gain; int mode;                                            // demodulator: RR_ATAN2_*; audio: gain = scale
+    const cf* last_in;                                               // [nchan] r[r_lo - 1] (demodulator only)
+    cf* last_out;                                                    // [nchan] r[r_hi - 1] as the chain kernel left it for the next call
+    int* slots; int seq;                                             // slots[2 k + (q & 1)] == q: k = 0 last block, 1 second-to-last, 2 carried r — of call q
+    long nb, bpw;                                                    // blocks of the call, blocks per workgroup
+    int force;                                                       // 1: block 0 regardless (head fix), 2: every block (a call without outputs)
+};
+__device__ __forceinline__ long chain_n2(long y, long I, long D) { return (long)(((__int128)y * I + D - 1) / D); }   // first r index whose source is >= y
+template <class T, bool DEMOD, bool WIDE>
+__global__ __launch_bounds__(256) void k_chain_blocks_nonfinite(ChainBlocksCtx c) {
+    const VSrc<T> src{static_cast<const T*>(c.prefix), c.plen, static_cast<const T*>(c.in), c.in_len};
+    const int ch = (int)blockIdx.y;
+    float* out = c.out + (long)ch * c.out_stride;
+    const long b0 = (long)blockIdx.x * c.bpw, b1 = b0 + c.bpw < c.nb ? b0 + c.bpw : c.nb;
+    if (b0 >= b1) return;
+    const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6, nw = (int)(blockDim.x >> 6);
+    auto slot = [&](int k) { return c.slots[2 * k + ((c.seq - 1) & 1)] == c.seq - 1; };
+    const bool tail1 = slot(0), tail2 = slot(1), lastr = slot(2);
+    // outputs: index o <-> u = o + o_base + (DEMOD ? 1 : 0), the newest filtered sample it reads is y[floor(u D / I)]
+    // (WIDE: stream positions times the ratio beyond 2^62 — 128-bit products; otherwise plain 64-bit divisions: the 128-bit
+    //  ones are a few hundred instructions each, and six of them per thread were 11 of this pass's 14 us behind a 24e6-sample call)
+    const long u_min = DEMOD ? (c.r_lo > 1 ? c.r_lo : 1) : c.r_lo;
+    auto n2 = [&](long y) { return WIDE ? chain_n2(y, c.I, c.D) : (y * c.I + c.D - 1) / c.D; };   // first r index whose source is >= y
+    auto src_of = [&](long u) { return WIDE ? (long)(((__int128)u * c.D) / c.I) : (u * c.D) / c.I; };
+    auto u_of_block = [&](long b) { long u = n2(c.A + b * c.S); return u < u_min ? u_min : u; };   // first u of block b (b may be nb)
+    auto o_of = [&](long u) { return u - c.o_base - (DEMOD ? 1 : 0); };
+    auto probe = [&](long ulo, long uhi, int ln, int lanes) {
+        bool bad = false;
+        if (uhi <= ulo) return false;
+        for (long u = ulo + (long)ln * c.P; u < uhi; u += (long)lanes * c.P) bad |= nf_bad(out[o_of(u)]);
+        if (ln == 0) bad |= nf_bad(out[o_of(uhi - 1)]);
+        return bad;
+    };
+    {   // (own blocks and the two before them as separate lattices: the others' are being rewritten by another workgroup meanwhile,
+        //  and a lattice that started there could step over what the same tile left here)
+        const long bp = b0 >= 2 ? b0 - 2 : 0;
+        const long u0 = u_of_block(b0);
+        const bool hit = c.force == 2 || probe(u0, u_of_block(b1), t, (int)blockDim.x) ||
+                         (b0 > 0 && probe(u_of_block(bp), u0, t, (int)blockDim.x));
+        if (!__syncthreads_or((int)hit | (int)(b0 <= 1 && (tail1 || tail2 || lastr)) | (int)(b0 == 0 && c.force))) return;
+    }
+    auto any64 = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; };
+    auto scan = [&](long b) {                                       // a non-finite INPUT sample in block b?  (wave-cooperative)
+        if (b == -1) return tail1;
+        if (b < -1) return tail2;
+        bool bad = false;
+        const long v0 = c.hist + b * c.S, len = c.S + c.front;
+        for (long i0 = 0; i0 < len; i0 += 512) {
+            T x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = src.load(v0 + i0 + 64 * k + lane);
+#pragma unroll
+            for (int k = 0; k < 8; k++) bad |= i0 + 64 * k + lane < len && nf_bad(x[k]);
+            if (any64(bad)) break;
+        }
+        return any64(bad);
+    };
+    const long Lf = (long)(c.L - c.front);
+    const float nanv = __builtin_nanf("");
+    for (long b = b0 + wave; b < b1; b += nw) {                     // one wave per block
+        const long ulo = u_of_block(b), uhi = u_of_block(b + 1);
+        const bool first = b == 0, last = b == c.nb - 1;
+        bool hit = c.force == 2 || probe(ulo, uhi, lane, 64);
+        if (b >= 1) hit |= probe(u_of_block(b - 1), ulo, lane, 64);
+        if (b >= 2) hit |= probe(u_of_block(b - 2), u_of_block(b - 1), lane, 64);
+        if (!any64(hit) && !(b <= 1 && (tail1 || tail2 || lastr)) && !(first && c.force)) continue;
+        const bool bad0 = scan(b), bad1 = scan(b - 1), bad2 = scan(b - 2);
+        auto poisoned = [&](long yl) {                               // filtered sample A + yl, in block b or b - 1 (or carried: yl < 0)
+            if (yl < 0) return lastr;
+            const long bb = yl / c.S, off = yl - bb * c.S;
+            const bool cur = bb == b ? bad0 : bad1, prv = bb == b ? bad1 : bad2;
+            return cur || (prv && off < Lf);
+        };
+        for (long u = ulo + lane; u < uhi; u += 64) {
+            const long yb = src_of(u) - c.A;
+            const long o = o_of(u);
+            if constexpr (DEMOD) {
+                const long ya = src_of(u - 1) - c.A;
+                if (poisoned(ya) || poisoned(yb)) { out[o] = nanv; continue; }
+                if (!nf_bad(out[o])) continue;
+                const cf* rev = static_cast<const cf*>(c.rev) + (long)ch * c.rev_stride;
+                const cf a = ya < 0 ? c.last_in[ch] : nf_fold_cc(src, rev, c.L, ya);
+                const cf bq = nf_fold_cc(src, rev, c.L, yb);
+                const float na = -a.y;                               // conj(a) * b, num-complex order, un-contracted (k_quaddemod)
+                const float re = sub_rn(mul_rn(a.x, bq.x), mul_rn(na, bq.y));
+                const float im = add_rn(mul_rn(a.x, bq.y), mul_rn(na, bq.x));
+                out[o] = mul_rn(c.gain, c.mode == 0 ? atan2f(im, re) : fm_atan2(im, re));
+            } else {
+                if (poisoned(yb)) { out[o] = nanv; continue; }
+                if (!nf_bad(out[o])) continue;
+                const float* rev = static_cast<const float*>(c.rev) + (long)ch * c.rev_stride;
+                out[o] = mul_rn(nf_fold_ff(src, rev, c.L, yb), c.gain);      // MultiplyConst: sample * val (multiply_const.rs)
+            }
+        }
+        if constexpr (DEMOD) {
+            // the sample the chain kernel carried to the next call comes out of the same tile: poisoned -> NaN, smeared -> refolded
+            if (last && lane == 0 && c.r_hi > c.r_lo) {
+                const long yl = src_of(c.r_hi - 1) - c.A;
+                cf* lo = c.last_out + ch;
+                if (poisoned(yl)) *lo = mkcf(nanv, nanv);
+                else if (nf_bad(*lo)) *lo = nf_fold_cc(src, static_cast<const cf*>(c.rev) + (long)ch * c.rev_stride, c.L, yl);
+            }
+        }
+        if (last && ch == 0 && lane == 0) {                          // what the next call needs (every channel would write the same)
+            c.slots[0 + (c.seq & 1)] = bad0 ? c.seq : -1;
+            c.slots[2 + (c.seq & 1)] = bad1 ? c.seq : -1;
+            long ylast = -1;                                         // the filtered sample the carried r[r_hi - 1] is
+            if (c.r_hi > c.r_lo) ylast = src_of(c.r_hi - 1) - c.A;
+            c.slots[4 + (c.seq & 1)] = (c.r_hi > c.r_lo ? poisoned(ylast) : lastr) ? c.seq : -1;
+        }
+    }
+}
+template <class T, bool DEMOD>
+static void launch_chain_blocks(ChainBlocksCtx c, hipStream_t s) {
+    if (c.n_y <= 0 || c.nchan <= 0) return;
+    c.nb = c.n_y / c.S;
+    if (c.P < 1) c.P = 1;
+    if (c.r_hi <= (DEMOD ? (c.r_lo > 1 ? c.r_lo : 1) : c.r_lo)) c.force = 2;      // no output to probe: the verdicts come from the input
+    // ~2 workgroups per CU over all channel rows (a workgroup has four waves: at least four blocks each)
+    const long per_row = std::max<long>(1, 512 / c.nchan);
+    c.bpw = std::max<long>(4, (c.nb + per_row - 1) / per_row);
+    const long gx = (c.nb + c.bpw - 1) / c.bpw;
+    const __int128 lim = (__int128)1 << 62;
+    const bool wide = (__int128)(c.A + c.n_y + 1) * c.I >= lim || (__int128)(c.r_hi + 1) * c.D >= lim;
+    if (wide) hipLaunchKernelGGL((k_chain_blocks_nonfinite<T, DEMOD, true>), dim3((unsigned)gx, (unsigned)c.nchan), dim3(256), 0, s, c);
+    else hipLaunchKernelGGL((k_chain_blocks_nonfinite<T, DEMOD, false>), dim3((unsigned)gx, (unsigned)c.nchan), dim3(256), 0, s, c);
+    RR_HIP(hipGetLastError());
+}
+void launch_chain_blocks_nonfinite(VSrc<cf> src, float* out, long out_stride, int nchan, const FmChainArgs& a, long S, long hist, long P,
+                                   int L, int front, const cf* rev, long rev_stride, const cf* last_in, cf* last_out, int* slots, int seq, int force,
+                                   hipStream_t s) {
+    ChainBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, out_stride, nchan, a.A, a.n_y, a.r_lo, a.r_hi, a.o_base, a.I, a.D,
+                     S, hist, P, L, front, rev, rev_stride, a.gain, a.mode, last_in, last_out, slots, seq, 0, 0, force};
+    launch_chain_blocks<cf, true>(c, s);
+}
+void launch_chain_blocks_nonfinite(VSrc<float> src, float* out, const AudioChainArgs& a, long S, long hist, long P, int L,
+                                   const float* rev, int* slots, int seq, hipStream_t s) {
+    ChainBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, 0, 1, a.A, a.n_y, a.r_lo, a.r_hi, a.r_lo, a.I, a.D,
+                     S, hist, P, L, 0, rev, 0, a.scale, 0, nullptr, nullptr, slots, seq, 0, 0, 0};
+    launch_chain_blocks<float, false>(c, s);
+}
+
 // ---- Hilbert on transform tiles: the reference's locality for non-finite samples (round 5) -------------------
 // k_fftfilt_real<.., HILB> runs at its register limit and carries no nan_fix.hpp hooks (a transformer of 200 ... 3584 taps
 // on large windows): one non-finite input sample makes the imaginary part of its tile's 2 S outputs non-finite, where the
