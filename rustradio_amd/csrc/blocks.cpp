@@ -1273,10 +1273,9 @@ void ChainNf::init(hipStream_t s) {
     slots.upload(none, 6, s);
     on = true;
 }
-// whether a chain of this shape gets the pass: not with rr_build_opts.fft_nonfinite_tiles = 1, not from RTL-SDR bytes (always
-// finite), and only while an output's two filtered samples lie in one reference block or two neighbours (ceil(D / I) <= S)
-static bool chain_nf_wanted(bool u8, int64_t I, int64_t D, size_t S) {
-    return !u8 && build_opts().fft_nonfinite_tiles != 1 && (D + I - 1) / I <= (int64_t)S;
+// whether a chain gets the pass: not with rr_build_opts.fft_nonfinite_tiles = 1, not from RTL-SDR bytes (always finite)
+static bool chain_nf_wanted(bool u8, int64_t, int64_t, size_t) {
+    return !u8 && build_opts().fft_nonfinite_tiles != 1;
 }
 static void reversed_taps(const rr_c32* t, size_t L, cf* dst) {
     for (size_t j = 0; j < L; j++) dst[j] = mkcf(t[L - 1 - j].re, t[L - 1 - j].im);

@@ -353,6 +353,7 @@ struct ChainBlocksCtx {
     int* slots; int seq;                                             // slots[2 k + (q & 1)] == q: k = 0 last block, 1 second-to-last, 2 carried r — of call q
     long nb, bpw;                                                    // blocks of the call, blocks per workgroup
     int force;                                                       // 1: block 0 regardless (head fix), 2: every block (a call without outputs)
+    int sparse;                                                      // ceil(D / I) > S: at most one output per reference block
 };
 __device__ __forceinline__ long chain_n2(long y, long I, long D) { return (long)(((__int128)y * I + D - 1) / D); }   // first r index whose source is >= y
 template <class T, bool DEMOD, bool WIDE>
@@ -420,7 +421,38 @@ __global__ __launch_bounds__(256) void k_chain_blocks_nonfinite(ChainBlocksCtx c
             const bool cur = bb == b ? bad0 : bad1, prv = bb == b ? bad1 : bad2;
             return cur || (prv && off < Lf);
         };
-        for (long u = ulo + lane; u < uhi; u += 64) {
+        // (more than one reference block per output — ceil(D / I) > S, tiny filters under huge decimations: the lower sample of a
+        //  pair may lie any number of blocks back.  Then a block has at most one output: verdicts by uniform scans, lane 0 writes.)
+        const bool sparse = c.sparse != 0;
+        auto poisoned_any = [&](long yl) {                           // wave-uniform yl
+            if (yl < 0) return lastr;
+            const long bb = yl / c.S, off = yl - bb * c.S;
+            return scan(bb) || (off < Lf && scan(bb - 1));
+        };
+        for (long u = ulo; sparse && u < uhi; u++) {
+            const long yb = src_of(u) - c.A, o = o_of(u);
+            if constexpr (DEMOD) {
+                const long ya = src_of(u - 1) - c.A;
+                const bool p = poisoned_any(ya) || poisoned_any(yb);
+                if (lane != 0) continue;
+                if (p) { out[o] = nanv; continue; }
+                if (!nf_bad(out[o])) continue;
+                const cf* rev = static_cast<const cf*>(c.rev) + (long)ch * c.rev_stride;
+                const cf a = ya < 0 ? c.last_in[ch] : nf_fold_cc(src, rev, c.L, ya);
+                const cf bq = nf_fold_cc(src, rev, c.L, yb);
+                const float na = -a.y;
+                const float re = sub_rn(mul_rn(a.x, bq.x), mul_rn(na, bq.y));
+                const float im = add_rn(mul_rn(a.x, bq.y), mul_rn(na, bq.x));
+                out[o] = mul_rn(c.gain, c.mode == 0 ? atan2f(im, re) : fm_atan2(im, re));
+            } else {
+                const bool p = poisoned_any(yb);
+                if (lane != 0) continue;
+                if (p) { out[o] = nanv; continue; }
+                if (!nf_bad(out[o])) continue;
+                out[o] = mul_rn(nf_fold_ff(src, static_cast<const float*>(c.rev) + (long)ch * c.rev_stride, c.L, yb), c.gain);
+            }
+        }
+        for (long u = ulo + lane; !sparse && u < uhi; u += 64) {
             const long yb = src_of(u) - c.A;
             const long o = o_of(u);
             if constexpr (DEMOD) {
@@ -441,12 +473,14 @@ __global__ __launch_bounds__(256) void k_chain_blocks_nonfinite(ChainBlocksCtx c
                 out[o] = mul_rn(nf_fold_ff(src, rev, c.L, yb), c.gain);      // MultiplyConst: sample * val (multiply_const.rs)
             }
         }
+        bool carried_bad = false;                                    // (sparse: a wave-uniform verdict on r[r_hi - 1], all lanes take part)
+        if (sparse && last && c.r_hi > c.r_lo) carried_bad = poisoned_any(src_of(c.r_hi - 1) - c.A);
         if constexpr (DEMOD) {
             // the sample the chain kernel carried to the next call comes out of the same tile: poisoned -> NaN, smeared -> refolded
             if (last && lane == 0 && c.r_hi > c.r_lo) {
                 const long yl = src_of(c.r_hi - 1) - c.A;
                 cf* lo = c.last_out + ch;
-                if (poisoned(yl)) *lo = mkcf(nanv, nanv);
+                if (sparse ? carried_bad : poisoned(yl)) *lo = mkcf(nanv, nanv);
                 else if (nf_bad(*lo)) *lo = nf_fold_cc(src, static_cast<const cf*>(c.rev) + (long)ch * c.rev_stride, c.L, yl);
             }
         }
@@ -455,7 +489,7 @@ __global__ __launch_bounds__(256) void k_chain_blocks_nonfinite(ChainBlocksCtx c
             c.slots[2 + (c.seq & 1)] = bad1 ? c.seq : -1;
             long ylast = -1;                                         // the filtered sample the carried r[r_hi - 1] is
             if (c.r_hi > c.r_lo) ylast = src_of(c.r_hi - 1) - c.A;
-            c.slots[4 + (c.seq & 1)] = (c.r_hi > c.r_lo ? poisoned(ylast) : lastr) ? c.seq : -1;
+            c.slots[4 + (c.seq & 1)] = (c.r_hi > c.r_lo ? (sparse ? carried_bad : poisoned(ylast)) : lastr) ? c.seq : -1;
         }
     }
 }
@@ -465,6 +499,8 @@ static void launch_chain_blocks(ChainBlocksCtx c, hipStream_t s) {
     c.nb = c.n_y / c.S;
     if (c.P < 1) c.P = 1;
     if (c.r_hi <= (DEMOD ? (c.r_lo > 1 ? c.r_lo : 1) : c.r_lo)) c.force = 2;      // no output to probe: the verdicts come from the input
+    c.sparse = (c.D + c.I - 1) / c.I > c.S ? 1 : 0;
+    if (c.sparse) c.force = 2;          // (a tile's NaN run may be shorter than a block's span in outputs: every block looks at its input)
     // ~2 workgroups per CU over all channel rows (a workgroup has four waves: at least four blocks each)
     const long per_row = std::max<long>(1, 512 / c.nchan);
     c.bpw = std::max<long>(4, (c.nb + per_row - 1) / per_row);
@@ -479,13 +515,13 @@ void launch_chain_blocks_nonfinite(VSrc<cf> src, float* out, long out_stride, in
                                    int L, int front, const cf* rev, long rev_stride, const cf* last_in, cf* last_out, int* slots, int seq, int force,
                                    hipStream_t s) {
     ChainBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, out_stride, nchan, a.A, a.n_y, a.r_lo, a.r_hi, a.o_base, a.I, a.D,
-                     S, hist, P, L, front, rev, rev_stride, a.gain, a.mode, last_in, last_out, slots, seq, 0, 0, force};
+                     S, hist, P, L, front, rev, rev_stride, a.gain, a.mode, last_in, last_out, slots, seq, 0, 0, force, 0};
     launch_chain_blocks<cf, true>(c, s);
 }
 void launch_chain_blocks_nonfinite(VSrc<float> src, float* out, const AudioChainArgs& a, long S, long hist, long P, int L,
                                    const float* rev, int* slots, int seq, hipStream_t s) {
     ChainBlocksCtx c{src.prefix, src.plen, src.in, src.in_len, out, 0, 1, a.A, a.n_y, a.r_lo, a.r_hi, a.r_lo, a.I, a.D,
-                     S, hist, P, L, 0, rev, 0, a.scale, 0, nullptr, nullptr, slots, seq, 0, 0, 0};
+                     S, hist, P, L, 0, rev, 0, a.scale, 0, nullptr, nullptr, slots, seq, 0, 0, 0, 0};
     launch_chain_blocks<float, false>(c, s);
 }
 

@@ -626,3 +626,68 @@ def test_fuzz_nonfinite_sets(rr, seed):
         assert np.array_equal(go, gg), (kind, L, n, d, ring, sorted(pos)[:6], np.flatnonzero(go != gg)[:6])
         if go.any():
             assert max_norm_err(yg[go], yo[go]) <= TOL, (kind, L, n, ring)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_chain_nan_sets(rr, seed):
+    """Round 6: the fused chains (FmChain, FirFmChain, FmMulti, AudioChain) on random filters, ratios, stream lengths, ring sizes
+    and NaN positions (isolated, clustered, at the ends, either side of block boundaries, none at all; whole samples and
+    single components) — the outputs that are NaN are EXACTLY those of the reference's three blocks (FftFilter's blocks through
+    the resampler's index map and the demodulator's pair, across work() calls), everything else within the chain tolerance."""
+    from harness import angle_parity
+    rng = np.random.default_rng(11000 + seed)
+    for _ in range(3):
+        kind = int(rng.integers(0, 4))                  # 0 FmChain, 1 FirFmChain, 2 FmMulti, 3 AudioChain
+        L = int(rng.choice([2, 17, 64, 127, 128, 463, 1000, 2467]))
+        I, D = [(1, 6), (1, 4), (1, 10), (2, 3), (3, 2), (25, 128), (1, 1), (1, 17)][int(rng.integers(0, 8))]
+        n = int(rng.integers(6 * L + 2_000, 6 * L + int(rng.choice([20_000, 120_000, 400_000]))))
+        Sref = (1 << int(np.ceil(np.log2(max(2 * L, 4))))) - L + 1        # (about the reference's nsamples: where block boundaries are)
+        nbad = int(rng.choice([0, 1, 2, 5, 12]))
+        pos = [int(p) for p in rng.integers(0, n, nbad)]
+        if nbad and rng.integers(0, 2):
+            pos += [0, n - 1, min(n - 1, pos[0] + 1), min(n - 1, (pos[0] // Sref + 1) * Sref), max(0, (pos[0] // Sref) * Sref - 1)]
+        block = 4 * (1 << int(np.ceil(np.log2(max(L, 2)))))
+        if kind == 3:
+            x = rng.uniform(-1, 1, n).astype(np.float32)
+            for p in pos:
+                x[p] = np.nan
+            tf = (rng.uniform(-1, 1, L) / max(1, L // 4)).astype(np.float32)
+            ring = int(rng.choice([4_096_000, 4 * (block + int(rng.integers(64, 20_000)))]))
+            yo = run_chain([orc.FftFilterFloat(tf), orc.RationalResampler(I, D, np.float32), orc.MultiplyConst(0.5)], x, stream_bytes=ring)
+            yg = run_chain([rr.AudioChain(tf, I, D, 0.5)], x, stream_bytes=ring)
+            assert len(yo) == len(yg), (kind, L, I, D, n, ring)
+            bo, bg = ~np.isfinite(yo), ~np.isfinite(yg)
+            assert np.array_equal(bo, bg), (kind, L, I, D, n, ring, sorted(pos)[:6], np.flatnonzero(bo != bg)[:6])
+            if (~bo).any():
+                assert max_norm_err(yg[~bo], yo[~bo]) <= TOL, (kind, L, I, D, n, ring)
+            continue
+        ph = np.cumsum(0.2 * np.sin(2 * np.pi * 1e-3 * np.arange(n)))
+        x = (np.exp(1j * ph) + 0.02 * _c(rng, n)).astype(np.complex64)        # |r| away from 0: the plain bound nearly everywhere
+        for p in pos:
+            x[p] = [complex(np.nan, 0.5), complex(0.25, np.nan), complex(np.nan, np.nan)][int(rng.integers(0, 3))]
+        k = np.arange(L)
+        tc = (np.hamming(L) * np.sinc((k - (L - 1) / 2) * 0.2) * 0.2).astype(np.complex64)    # a low-pass: the carrier passes
+        t1 = (_c(rng, int(rng.choice([1, 2, 9, 33]))) / 4).astype(np.complex64)
+        ring = int(rng.choice([4_096_000, 8 * (block + int(rng.integers(64, 20_000)))]))
+        if kind == 2:
+            t3 = np.stack([tc, (tc * np.exp(1j * 0.05 * k)).astype(np.complex64)])
+            blk = rr.FmMulti(t3, I, D, 1.0)
+            cap = ring // 8
+            yg2, _ = drive_pageable(blk, x, cap, cap)
+            chans = [(None, t3[c], yg2[c]) for c in range(2)]
+        else:
+            blk = rr.FmChain(tc, I, D, 1.0) if kind == 0 else rr.FirFmChain(t1, tc, I, D, 1.0)
+            chans = [(t1 if kind == 1 else None, tc, run_chain([blk], x, stream_bytes=ring))]
+        for front, t, got in chans:
+            pre = [] if front is None else [orc.FirFilter(front)]
+            want = run_chain(pre + [orc.FftFilter(t), orc.RationalResampler(I, D), orc.QuadratureDemod(1.0)], x, stream_bytes=ring)
+            ro = run_chain(pre + [orc.FftFilter(t), orc.RationalResampler(I, D)], x, stream_bytes=ring)
+            assert len(want) >= len(got) and (len(got) == len(want) or kind == 2), (kind, L, I, D, n, ring, len(want), len(got))
+            if len(got) == 0:
+                continue
+            want, ro = want[:len(got)], ro[:len(got) + 1]
+            bo, bg = ~np.isfinite(want), ~np.isfinite(got)
+            assert np.array_equal(bo, bg), (kind, L, I, D, n, ring, sorted(pos)[:6], int(bo.sum()), int(bg.sum()), np.flatnonzero(bo != bg)[:6])
+            ro_ok = np.where(np.isfinite(ro.real) & np.isfinite(ro.imag), ro, 1.0)
+            par = angle_parity(np.where(bo, 0.0, got), np.where(bo, 0.0, want), ro_ok)
+            assert par["used"] <= 1.0, (kind, L, I, D, n, ring, par)

@@ -9,7 +9,7 @@ OUT=gpurun_out/pmc_stalls/raw_$TAG; mkdir -p "$OUT"; i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout 120 rocprofv3 --pmc $line --output-format csv -d "$OUT/pass$i" -o p -- python3 bench.py --workload $W --steps 3 --warmup 1 --no-others --no-cpu $EXTRA > "$OUT/pass$i.log" 2>&1
+  timeout 120 rocprofv3 --pmc $line --output-format csv -d "$OUT/pass$i" -o p -- python3 bench.py --workload $W --steps 3 --warmup 1 --no-others --no-cpu --no-verify $EXTRA > "$OUT/pass$i.log" 2>&1
 done <<'PASSES'
 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS

@@ -1,8 +1,8 @@
 #!/bin/bash
-# GPU box: everything profiles/r05_* is made of, on the tree's final sources (run through gpurun; ~25 min of box time).
-#   bash tools/r5_all.sh [tag]   then locally: python tools/r5_collect.py <tag>; cp gpurun_out/pmc_stalls/<tag>_*.txt profiles/
-TAG=${1:-r05}
-bash tools/r5_profiles.sh $TAG
+# GPU box: everything profiles/<tag>_* is made of, on the tree's final sources (run through gpurun; ~25 min of box time).
+#   bash tools/round_all.sh [tag]   then locally: python tools/round_collect.py <tag>; cp gpurun_out/pmc_stalls/<tag>_*.txt profiles/
+TAG=${1:-r06}
+bash tools/round_profiles.sh $TAG
 for w in fftfilter fm_chain fm_multi channelizer rtl_fm_example fir_1e8 fir_float; do
   bash tools/pmc_stalls.sh $w ${TAG}_${w}_stall_counters --no-dropin > /dev/null 2>&1
   mv gpurun_out/pmc_stalls/${TAG}_${w}_stall_counters.txt gpurun_out/prof_$TAG/${w}_stall_counters.txt

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""After tools/r5_all.sh <tag> ran on the GPU box: copy its summaries from gpurun_out/prof_<tag>/ into profiles/
-(tracked) as <tag>_*.  Usage: python tools/r5_collect.py <tag>"""
+"""After tools/round_all.sh <tag> ran on the GPU box: copy its summaries from gpurun_out/prof_<tag>/ into profiles/
+(tracked) as <tag>_*.  Usage: python tools/round_collect.py <tag>"""
 import os, shutil, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
