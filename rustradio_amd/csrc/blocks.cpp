@@ -1093,7 +1093,7 @@ void FftFilter::ref_blocks_on(const rr_c32* taps) {
     if (build_opts().fft_nonfinite_tiles == 1) return;
     // 3: the pass inside the tile kernel's tail (nan_fix.hpp rb_finish, round 6): ONE launch per work(), but every workgroup
     // must release its outputs to the device before the last one may overwrite some of them — on this part that is a write-back
-    // of the XCD's L2 per workgroup.  Measured on one box, FftFilter 401 taps (tools/r6_gpu3.sh): 1e8 samples 0.360 ms against
+    // of the XCD's L2 per workgroup.  Measured on one box, FftFilter 401 taps (tools/ab_nonfinite_pass.sh): 1e8 samples 0.360 ms against
     // 0.332 with the pass as its own launch (0.325 without any pass); a 512,000-sample call 22.2 us against 17.1 (12.9).  The
     // launch it saves costs less than the releases it needs: opt-in, for the record.
     rb_in_kernel = build_opts().fft_nonfinite_tiles == 3;

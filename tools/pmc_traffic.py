@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the PMC passes of tools/pmc_run.sh / tools/r5_profiles.sh.
+"""profiles/traffic.json from the PMC passes of tools/pmc_run.sh / tools/round_profiles.sh.
 HBM bytes per launch = FETCH_SIZE[KB] * 1024 * f_read + WRITE_SIZE[KB] * 1024 * f_write with the factors CALIBRATED on this
 part for the tile kernels' own access shapes (profiles/fetch_calibration.json, tools/fetchcal.sh: known byte counts read
 2 / 4 / 8 / 16 B per lane, lane-consecutive and tile-strided -> f_read = 2.000 for every width, f_write = 1.000; the
