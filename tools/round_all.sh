@@ -16,5 +16,6 @@ timeout 120 ./tools/micro/pcie_inplace.bin > gpurun_out/prof_$TAG/pcie_inplace.t
 (timeout 60 ./tools/micro/rotor_rate.bin; timeout 200 python3 tools/replay_rate.py 2>/dev/null | grep -v amdgpu) > gpurun_out/prof_$TAG/rotor_rate.txt 2>&1
 python3 tools/chain_tile_probe.py 2>/dev/null | grep -v amdgpu > gpurun_out/prof_$TAG/rtl_fm_tiles.txt
 python3 tools/clock_probe.py channelizer > gpurun_out/prof_$TAG/clocks.txt 2>&1
-python3 bench.py > "gpurun_out/prof_$TAG/bench_default.json" 2> "gpurun_out/prof_$TAG/bench_default.log"
+bash tools/ab_nonfinite_pass.sh 2>&1 | grep -v amdgpu > gpurun_out/prof_$TAG/ab_nonfinite_pass.txt
+python3 bench.py --detail-out "gpurun_out/prof_$TAG/bench_detail.json" > "gpurun_out/prof_$TAG/bench_default.json" 2> "gpurun_out/prof_$TAG/bench_default.log"
 tail -c 300 "gpurun_out/prof_$TAG/bench_default.log"; ls gpurun_out/prof_$TAG | head -60

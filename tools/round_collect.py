@@ -8,7 +8,7 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 n = 0
 for f in sorted(os.listdir(src)):
-    if f.endswith(("_kernel_stats.txt", "_traffic_pmc.txt", "_stall_counters.txt")) or f in ("bench_default.json", "pcie_inplace.txt", "rtl_fm_tiles.txt", "clocks.txt", "rotor_rate.txt"):
+    if f.endswith(("_kernel_stats.txt", "_traffic_pmc.txt", "_stall_counters.txt")) or f in ("bench_default.json", "bench_detail.json", "pcie_inplace.txt", "rtl_fm_tiles.txt", "clocks.txt", "rotor_rate.txt", "ab_nonfinite_pass.txt"):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}")); n += 1
     if f in ("traffic.json", "parity_allowance.json"):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f)); n += 1
