@@ -210,6 +210,7 @@ int Block::work_host(const void* in, size_t in_len, void* out, size_t out_cap, s
     // (polling an event from the calling thread instead was measured and changes nothing: 154 -> 158 us per reference-sized
     //  window; the call sits on the link — tools/micro/pcie_inplace.hip: a kernel moves 4,096,000 bytes each way in 128-145 us)
     RR_HIP(hipStreamSynchronize(stream));
+    if (hstage_) hstage_->quiesced();
     if (host_out) {
         const void* h = host_out;
         host_out = nullptr;

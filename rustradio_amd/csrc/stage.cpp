@@ -106,11 +106,13 @@ void stage_upload_sync(void* dst_dev, const void* src_host, size_t bytes, hipStr
     std::lock_guard<std::mutex> g(g_stage_m);
     global_stage().h2d(dst_dev, src_host, bytes, s);
     RR_HIP(hipStreamSynchronize(s));
+    global_stage().quiesced();
 }
 void stage_download_sync(void* dst_host, const void* src_dev, size_t bytes, hipStream_t s) {
     if (!bytes) return;
     std::lock_guard<std::mutex> g(g_stage_m);
     global_stage().d2h(dst_host, src_dev, bytes, s);
+    global_stage().quiesced();               // (d2h waited for every piece)
 }
 
 }  // namespace rr

@@ -33,6 +33,11 @@ struct HostStage {
     void d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t s);
     // rows x row_bytes out of a pitched device buffer into a pitched host buffer
     void d2h_2d(void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t row_bytes, size_t rows, hipStream_t s);
+    // the caller has just synchronised the stream(s) every pending chunk was enqueued on: nothing to wait for any more.  (Events
+    // are never waited on across calls otherwise either — the stream an event was last recorded on may be gone by then, and
+    // hipEventSynchronize on such an event fails: "operation not permitted on an event last recorded in a capturing stream",
+    // six of fifteen suite runs in the multi-threaded resident-graph test before this.)
+    void quiesced() { pending[0] = pending[1] = false; }
 
 private:
     void init();
