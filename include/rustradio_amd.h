@@ -320,8 +320,11 @@ int         rr_block_sync(rr_block *b);
  * rr_dstream_copy_in/out on such windows run as copy KERNELS on the range's device view (55 GB/s either way; hipMemcpyAsync
  * gets 16-18 GB/s up and 50 down out of a registered range here: profiles/r05_pcie_inplace.txt).  Windows
  * that are not WHOLLY inside a range registered here (pageable memory, memory the caller page-locked by
- * other means) are staged through device memory as before.  Optional; unregister before the memory is
- * unmapped, and not while a work call on one of its windows is running.
+ * other means) are staged through device memory — and since round 6 through pinned chunks the library owns,
+ * copied by the CPU: no GPU engine is ever pointed at memory the caller did not register (csrc/stage.hpp: the
+ * runtime's own pinning of a recycled pageable address was the abort() of rounds 4-5).  Expect one host core's
+ * memcpy rate there.  Optional; unregister before the memory is unmapped, and not while a work call on one of
+ * its windows is running.
  * Zero-copy is granted only to a range whose base and size are multiples of the SYSTEM page size (sysconf(_SC_PAGESIZE)) and none of
  * whose pages is, or ever was, part of another registration in this process — the reference's ring qualifies
  * (one page-aligned mmap, registered once).  Any other range is still page-locked (its staged copies run as
