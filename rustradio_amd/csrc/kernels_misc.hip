@@ -260,7 +260,9 @@ __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
     {
         bool bad = probe(b0 * c.S, b1 * c.S, t, (int)blockDim.x);
         if (b0 > 0) bad |= probe((b0 - 1) * c.S, b0 * c.S, t, (int)blockDim.x);
-        if (!__syncthreads_or((int)bad | (int)(b0 == 0 && (tail_bad || c.force0)))) return;
+        // (force0: the head fix cut the poisoned tile's run of non-finite outputs short of P, so neither block 0's lattice nor —
+        //  for the tail the block before it leaves — block 1's may find it: both look at their input.  Found by the soak, seed 10074.)
+        if (!__syncthreads_or((int)bad | (int)(b0 == 0 && tail_bad) | (int)(b0 <= 1 && c.force0))) return;
     }
     const int lane = t & 63, wave = t >> 6, nw = (int)(blockDim.x >> 6);
     auto any64 = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; };
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void k_ref_blocks_nonfinite(RefBlocksCtx c) {
         bool hit = probe(b * c.S, (b + 1) * c.S, lane, 64);
         if (sub > 1) hit |= probe(b * c.S + i0, b * c.S + i1, lane, 64);
         if (!first) hit |= probe((b - 1) * c.S, b * c.S, lane, 64);
-        if (!any64(hit) && !(first && (tail_bad || c.force0))) continue;
+        if (!any64(hit) && !(first && tail_bad) && !(b <= 1 && c.force0)) continue;
         const bool bad_prev = first ? tail_bad : scan(b - 1);
         const bool bad_cur = scan(b);
         for (long i = i0 + lane; i < i1; i += 64) {
@@ -370,8 +372,20 @@ __global__ __launch_bounds__(256) void k_chain_blocks_nonfinite(ChainBlocksCtx c
     // (WIDE: stream positions times the ratio beyond 2^62 — 128-bit products; otherwise plain 64-bit divisions: the 128-bit
     //  ones are a few hundred instructions each, and six of them per thread were 11 of this pass's 14 us behind a 24e6-sample call)
     const long u_min = DEMOD ? (c.r_lo > 1 ? c.r_lo : 1) : c.r_lo;
-    auto n2 = [&](long y) { return WIDE ? chain_n2(y, c.I, c.D) : (y * c.I + c.D - 1) / c.D; };   // first r index whose source is >= y
-    auto src_of = [&](long u) { return WIDE ? (long)(((__int128)u * c.D) / c.I) : (u * c.D) / c.I; };
+    // (a software 64-bit division is ~150 instructions and four of them stood in front of every workgroup's probes; below 2^52
+    //  the quotient comes out of one f64 division and a fix-up of at most one either way)
+    auto qdiv = [](long x, long d) {
+        if (x < ((long)1 << 52)) {
+            long q = (long)((double)x / (double)d);
+            long r = x - q * d;
+            if (r < 0) { q--; r += d; }
+            if (r >= d) q++;
+            return q;
+        }
+        return x / d;
+    };
+    auto n2 = [&](long y) { return WIDE ? chain_n2(y, c.I, c.D) : qdiv(y * c.I + c.D - 1, c.D); };   // first r index whose source is >= y
+    auto src_of = [&](long u) { return WIDE ? (long)(((__int128)u * c.D) / c.I) : qdiv(u * c.D, c.I); };
     auto u_of_block = [&](long b) { long u = n2(c.A + b * c.S); return u < u_min ? u_min : u; };   // first u of block b (b may be nb)
     auto o_of = [&](long u) { return u - c.o_base - (DEMOD ? 1 : 0); };
     auto probe = [&](long ulo, long uhi, int ln, int lanes) {
@@ -381,39 +395,76 @@ __global__ __launch_bounds__(256) void k_chain_blocks_nonfinite(ChainBlocksCtx c
         if (ln == 0) bad |= nf_bad(out[o_of(uhi - 1)]);
         return bad;
     };
-    {   // (own blocks and the two before them as separate lattices: the others' are being rewritten by another workgroup meanwhile,
-        //  and a lattice that started there could step over what the same tile left here)
-        const long bp = b0 >= 2 ? b0 - 2 : 0;
-        const long u0 = u_of_block(b0);
-        const bool hit = c.force == 2 || probe(u0, u_of_block(b1), t, (int)blockDim.x) ||
-                         (b0 > 0 && probe(u_of_block(bp), u0, t, (int)blockDim.x));
-        if (!__syncthreads_or((int)hit | (int)(b0 <= 1 && (tail1 || tail2 || lastr)) | (int)(b0 == 0 && c.force))) return;
-    }
+    // Where the evidence of a poisoned block b lies: the tile that read the sample has no finite output, and the outputs nearest
+    // to the sample belong to block b, to b - 1 (the one just before it) or — when no output of block b reads a filtered sample
+    // at or behind it — to block b + 1 (found by the soak: a 17-tap filter under 1:17, the sample three from its block's end).
+    // Nearest to a sample at the very END of a call there may be no output at all yet: the call's last block always looks at
+    // its input (one wave, S samples).
     auto any64 = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; };
     auto scan = [&](long b) {                                       // a non-finite INPUT sample in block b?  (wave-cooperative)
         if (b == -1) return tail1;
         if (b < -1) return tail2;
         bool bad = false;
         const long v0 = c.hist + b * c.S, len = c.S + c.front;
-        for (long i0 = 0; i0 < len; i0 += 512) {
-            T x[8];
+        for (long i0 = 0; i0 < len; i0 += 1024) {                   // (sixteen loads in flight: one round trip for a block of up to 1024 samples)
+            T x[16];
 #pragma unroll
-            for (int k = 0; k < 8; k++) x[k] = src.load(v0 + i0 + 64 * k + lane);
+            for (int k = 0; k < 16; k++) x[k] = src.load(v0 + i0 + 64 * k + lane);
 #pragma unroll
-            for (int k = 0; k < 8; k++) bad |= i0 + 64 * k + lane < len && nf_bad(x[k]);
+            for (int k = 0; k < 16; k++) bad |= i0 + 64 * k + lane < len && nf_bad(x[k]);
             if (any64(bad)) break;
         }
         return any64(bad);
     };
+    // A bad sample within ceil(D / I) of the call's END has no output at or behind it yet, and the tile that read it may hold none
+    // in front of it either: no evidence anywhere.  So the wave that owns the call's last block always looks at those last few
+    // input samples itself — ONE load per lane, issued here and looked at after the workgroup's probes (a scan of the whole block
+    // in front of them was 5 of this pass's 11 us in the steady state; behind them, still 3).
+    const bool owns_last = b1 == c.nb && (int)((c.nb - 1 - b0) % nw) == wave;
+    T tail_x[4];
+    long tail_n = 0;
+    if (owns_last) {
+        const long G = (c.D + c.I - 1) / c.I;
+        tail_n = (G < c.S ? G : c.S) + c.front;                      // samples [hist + n_y - min(G, S), hist + n_y + front)
+        if (tail_n > 256) tail_n = -1;                               // (a ratio beyond 256: the whole block, below)
+        const long v0 = c.hist + c.n_y + c.front - tail_n;
+#pragma unroll
+        for (int k = 0; k < 4; k++) tail_x[k] = tail_n > 0 && 64 * k + lane < tail_n ? src.load(v0 + 64 * k + lane) : T{};
+    }
+    bool wg_hit;
+    {   // (own blocks, the two before them and the one after as separate lattices: the others' are being rewritten by another
+        //  workgroup meanwhile, and a lattice that started there could step over what the same tile left here)
+        const long bp = b0 >= 2 ? b0 - 2 : 0, bn = b1 + 1 < c.nb ? b1 + 1 : c.nb;
+        const long u0 = u_of_block(b0), u1 = u_of_block(b1);
+        const bool hit = c.force == 2 || probe(u0, u1, t, (int)blockDim.x) ||
+                         (b0 > 0 && probe(u_of_block(bp), u0, t, (int)blockDim.x)) || (b1 < c.nb && probe(u1, u_of_block(bn), t, (int)blockDim.x));
+        wg_hit = __syncthreads_or((int)hit | (int)(b0 <= 1 && (tail1 || tail2 || lastr)) | (int)(b0 <= 1 && c.force)) != 0;
+        if (!wg_hit && b1 != c.nb) return;
+    }
     const long Lf = (long)(c.L - c.front);
     const float nanv = __builtin_nanf("");
-    for (long b = b0 + wave; b < b1; b += nw) {                     // one wave per block
+    // Nothing on any lattice of this workgroup: only the call's last block goes on, and only if its input holds a bad sample.
+    // (No loop over the other blocks then: the compiler hoists the index arithmetic of the loop body above an early `continue`,
+    //  and 67 iterations of it per wave were 12 us behind a 32-channel call.)
+    bool last_bad = false;
+    if (owns_last) {
+        if (tail_n < 0) last_bad = scan(c.nb - 1);
+        else {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) bad |= nf_bad(tail_x[k]);
+            last_bad = any64(bad);
+        }
+    }
+    if (!wg_hit && !last_bad) return;
+    for (long b = wg_hit ? b0 + wave : c.nb - 1; b < b1; b += nw) {   // one wave per block
+        const bool last = b == c.nb - 1;
         const long ulo = u_of_block(b), uhi = u_of_block(b + 1);
-        const bool first = b == 0, last = b == c.nb - 1;
         bool hit = c.force == 2 || probe(ulo, uhi, lane, 64);
         if (b >= 1) hit |= probe(u_of_block(b - 1), ulo, lane, 64);
         if (b >= 2) hit |= probe(u_of_block(b - 2), u_of_block(b - 1), lane, 64);
-        if (!any64(hit) && !(b <= 1 && (tail1 || tail2 || lastr)) && !(first && c.force)) continue;
+        if (b + 1 < c.nb) hit |= probe(uhi, u_of_block(b + 2 < c.nb ? b + 2 : c.nb), lane, 64);
+        if (!any64(hit) && !(b <= 1 && (tail1 || tail2 || lastr)) && !(b <= 1 && c.force) && !last) continue;
         const bool bad0 = scan(b), bad1 = scan(b - 1), bad2 = scan(b - 2);
         auto poisoned = [&](long yl) {                               // filtered sample A + yl, in block b or b - 1 (or carried: yl < 0)
             if (yl < 0) return lastr;
@@ -501,8 +552,9 @@ static void launch_chain_blocks(ChainBlocksCtx c, hipStream_t s) {
     if (c.r_hi <= (DEMOD ? (c.r_lo > 1 ? c.r_lo : 1) : c.r_lo)) c.force = 2;      // no output to probe: the verdicts come from the input
     c.sparse = (c.D + c.I - 1) / c.I > c.S ? 1 : 0;
     if (c.sparse) c.force = 2;          // (a tile's NaN run may be shorter than a block's span in outputs: every block looks at its input)
-    // ~2 workgroups per CU over all channel rows (a workgroup has four waves: at least four blocks each)
-    const long per_row = std::max<long>(1, 512 / c.nchan);
+    // ~1 workgroup per CU over all channel rows (a workgroup has four waves: at least four blocks each; 128 / 256 / 512 workgroups
+    // measure 5.96 / 6.2 / 6.43 us in the steady state, an EMPTY kernel of this shape 4.8)
+    const long per_row = std::max<long>(1, 256 / c.nchan);
     c.bpw = std::max<long>(4, (c.nb + per_row - 1) / per_row);
     const long gx = (c.nb + c.bpw - 1) / c.bpw;
     const __int128 lim = (__int128)1 << 62;

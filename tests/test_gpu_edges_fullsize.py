@@ -637,7 +637,10 @@ def test_a_window_of_nans_through_a_long_filter_is_not_a_throughput_collapse(rr)
     blk = rr.FirFilter(taps)
     blk.work(clean, n)                                       # (first call: tables, allocations)
     t0 = time.perf_counter(); st, c, p, need, y0 = blk.work(clean, n); t_clean = time.perf_counter() - t0
-    t0 = time.perf_counter(); st, c, p, need, y1 = blk.work(bad, n); t_bad = time.perf_counter() - t0
+    t_bad = float("inf")
+    for _ in range(3):          # (the best of three: one call in a few hundred stalls for tens of ms on this pool whatever it runs —
+        #  seen once in 27 suite runs, 81 ms against the usual 0.45; a collapse would be every call)
+        t0 = time.perf_counter(); st, c, p, need, y1 = blk.work(bad, n); t_bad = min(t_bad, time.perf_counter() - t0)
     assert p == len(y1) > 300_000 and np.all(np.isnan(y1.real)) and np.all(np.isnan(y1.imag))
     assert t_bad < 20 * t_clean + 0.05, (t_clean, t_bad)
 
@@ -664,9 +667,11 @@ def test_decimating_fir_near_the_top_of_the_tile_range(rr, L, deci):
     blk = rr.FirFilter(taps, deci=deci)
     s = torch.cuda.current_stream().cuda_stream
     blk.work_dev(dx.data_ptr(), n, dy.data_ptr(), n // deci + 8, s); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    st, c, p, need = blk.work_dev(dx.data_ptr(), n, dy.data_ptr(), n // deci + 8, s); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = float("inf")
+    for _ in range(3):          # (best of three, as above)
+        t0 = time.perf_counter()
+        st, c, p, need = blk.work_dev(dx.data_ptr(), n, dy.data_ptr(), n // deci + 8, s); torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
     assert p == (n - L + 1) // deci and c == p * deci
     assert dt < 0.05, dt          # (any-size frames: a few ms per 1e7 samples; the 16384-point tiles took 0.3 s at 16380 taps)
     # spot check at full size against f64
