@@ -1377,3 +1377,23 @@ def test_tag_rule_of_every_constructor(rr):
         if param is not None:
             assert p.value == param, (blk.name, p.value)
     assert rr.lib().rr_block_tag_rule(None, None) == -1
+
+
+@pytest.mark.parametrize("nbytes", [1, 4095, 2 << 20, (2 << 20) + 1, (6 << 20) + 12345, 21_000_003])
+def test_pageable_copies_go_through_the_librarys_pinned_chunks(rr, nbytes):
+    """Round 6 (csrc/stage.*): rr_dstream_copy_in / _out and rr_block_work on memory the caller did not register never hand the
+    pointer to a GPU engine — the CPU copies it through two pinned 2 MB chunks.  Any size, chunk boundaries included, byte for
+    byte; and a block on the same kind of window."""
+    rng = np.random.default_rng(nbytes)
+    x = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    assert not rr.host_window_in_place(x)
+    s = rr.DeviceStream(np.uint8, max(nbytes, 4096))
+    assert s.push(x) == nbytes
+    x_copy = x.copy()
+    x[:] = 0                                                   # (the source is the caller's again as soon as push returns)
+    assert np.array_equal(s.pop(), x_copy)
+    n = max(1, nbytes // 8)
+    z = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    st, c, p, need, y = rr.MultiplyConst(0.5 - 2j, np.complex64).work(z, n)
+    st2, c2, p2, need2, yo = orc.MultiplyConst(0.5 - 2j, np.complex64).work(z, n)
+    assert (st, c, p, need) == (st2, c2, p2, need2) and (c, p) == (n, n) and np.array_equal(y, yo)
