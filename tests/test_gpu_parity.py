@@ -1397,3 +1397,29 @@ def test_pageable_copies_go_through_the_librarys_pinned_chunks(rr, nbytes):
     st, c, p, need, y = rr.MultiplyConst(0.5 - 2j, np.complex64).work(z, n)
     st2, c2, p2, need2, yo = orc.MultiplyConst(0.5 - 2j, np.complex64).work(z, n)
     assert (st, c, p, need) == (st2, c2, p2, need2) and (c, p) == (n, n) and np.array_equal(y, yo)
+
+
+def test_zz_fm_multi_per_channel_create_work_destroy_soak(rr):
+    """500 create -> work -> destroy cycles of FmMulti beyond 4094 taps (the per-channel `Parallel`
+    composition: N chains on a pool of forked streams joined by events, csrc/compose.cpp) on PAGEABLE windows, at the end of this
+    file's run in the same process — the shape the abort() of rounds 4-5 was last seen in.  Every cycle's output must equal the
+    first's (same input, fresh handles): a stale copy or a missed join shows as a different sample."""
+    fs, n, L = 2.4e6, 40_000, 5000
+    x = fm_signal(n, fs, 0.0, 77)
+    proto = (rnd_c(L, L + 1) / (L // 4)).astype(np.complex64)
+    k = np.arange(L, dtype=np.float64)
+    taps = np.stack([(proto.astype(np.complex128) * np.exp(2j * np.pi * c * 30e3 * k / fs)).astype(np.complex64) for c in range(3)])
+    first = None
+    for cycle in range(500):
+        blk = rr.FmMulti(taps, 1, 6, 1.0)
+        xin = x.copy()                                          # a fresh pageable window every cycle (recycled addresses)
+        st, c, p, need, out = blk.work(xin, 100_000)
+        assert p > 1000
+        if first is None:
+            first = out.copy()
+            yo = run_chain([orc.FftFilter(taps[1]), orc.RationalResampler(1, 6), orc.QuadratureDemod(1.0)], x)
+            ro = run_chain([orc.FftFilter(taps[1]), orc.RationalResampler(1, 6)], x)
+            _demod_close(out.reshape(3, -1)[1][:p], yo[:p], ro[:p + 1])
+        else:
+            assert np.array_equal(out, first), cycle
+        del blk, xin, out
